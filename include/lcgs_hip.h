@@ -1,0 +1,270 @@
+/*
+ * lcgs_hip.h -- C ABI of liblcgs_hip.so: the MI355X-native (gfx950) implementation of the
+ * LuisaComputeGaussianSplatting hot path (SH colour -> 3D->2D projection -> tile keys -> sort ->
+ * per-tile alpha compositing, plus the matching backward).
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the reference
+ * repository).  The reference's operator API is three exported C++ classes taking POD "proxy"
+ * structs of non-owning device buffer views (lcgs/include/lcgs/proxy.h:21-73); here the same
+ * contract is expressed as plain pointers + sizes:
+ *   - all `d_` pointers are DEVICE pointers owned by the caller, laid out exactly as the
+ *     reference's flat float buffers (AoS-packed: xyz xyz..., rxyz rxyz..., SH (P,16,3));
+ *   - all structs are POD and passed by pointer, copied before the call returns;
+ *   - every function returns an lcgs_status; no exceptions cross the boundary
+ *     (the reference is `noexcept` + abort);
+ *   - one lcgs_context per (GPU, stream); a context is not thread-safe, like the reference's
+ *     operator objects (mutable num_rendered / temp buffers, gs_tile_splatter.h:23,50-55).
+ */
+#ifndef LCGS_HIP_H
+#define LCGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define LCGS_API __declspec(dllexport)
+#else
+#define LCGS_API __attribute__((visibility("default")))
+#endif
+
+typedef enum lcgs_status {
+    LCGS_OK                = 0,
+    LCGS_ERR_INVALID_ARG   = 1,
+    LCGS_ERR_HIP           = 2, /* a HIP runtime call failed; see lcgs_last_error() */
+    LCGS_ERR_NO_DEVICE     = 3,
+    LCGS_ERR_OUT_OF_MEMORY = 4,
+    LCGS_ERR_CAPACITY      = 5, /* caller-provided pair buffers too small (the reference does not check, app/main.cpp:245) */
+    LCGS_ERR_IO            = 6,
+    LCGS_ERR_FORMAT        = 7,
+    LCGS_ERR_STATE         = 8  /* e.g. backward without a preceding forward */
+} lcgs_status;
+
+typedef struct lcgs_context lcgs_context;
+
+/* lcgs/include/lcgs/util/camera.h:15-25 (struct Camera) */
+typedef struct lcgs_camera {
+    float position[3];
+    float front[3];
+    float up[3];
+    float right[3];
+    float fov;          /* vertical field of view, degrees (default 60) */
+    float aspect_ratio; /* width / height */
+    int   width;
+    int   height;
+} lcgs_camera;
+
+/* ------------------------------------------------------------------------------------------
+ * Library / context
+ * ------------------------------------------------------------------------------------------ */
+LCGS_API const char* lcgs_version(void);
+/* Thread-local message of the last failing call on this thread. */
+LCGS_API const char* lcgs_last_error(void);
+
+/* Replaces Context::create_device + Device::create_stream (app/main.cpp:162-163) and the three
+ * `create(Device&)` calls (sh_preprocessor.cpp:16, gs_projector/impl.cpp:14, gs_tile_splatter/impl.cpp:25).
+ * `stream` is a hipStream_t (NULL = the device's null stream); kernels are precompiled for gfx950,
+ * nothing is JIT-compiled here. */
+LCGS_API lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx);
+LCGS_API lcgs_status lcgs_destroy(lcgs_context* ctx);
+LCGS_API lcgs_status lcgs_set_stream(lcgs_context* ctx, void* stream);
+/* Stream::synchronize (app/main.cpp:223,315) */
+LCGS_API lcgs_status lcgs_synchronize(lcgs_context* ctx);
+
+/* ------------------------------------------------------------------------------------------
+ * Host camera helpers -- lcgs/include/lcgs/util/camera.h
+ * Matrices are column-major float[16], m[c*4+r], like luisa::float4x4.
+ * ------------------------------------------------------------------------------------------ */
+/* get_lookat_cam, camera.h:74-82 (fov/aspect/width/height get the struct defaults 60/1/512/512) */
+LCGS_API void lcgs_get_lookat_cam(const float pos[3], const float target[3], const float world_up[3],
+                                  lcgs_camera* out_cam);
+/* local_to_world_matrix, camera.h:27-36 */
+LCGS_API void lcgs_local_to_world_matrix(const lcgs_camera* cam, float m[16]);
+/* world_to_local_matrix, camera.h:38-51 */
+LCGS_API void lcgs_world_to_local_matrix(const lcgs_camera* cam, float m[16]);
+/* projection_matrix, camera.h:54-72 (reference defaults znear=0.1, zfar=100) */
+LCGS_API void lcgs_projection_matrix(float tanfovx, float tanfovy, float znear, float zfar, float m[16]);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage-level operators: one call per reference class method, on raw device pointers with the
+ * reference's buffer layouts, so each stage can be swapped in (and parity-tested) alone.
+ * ------------------------------------------------------------------------------------------ */
+
+/* SHProcessor::process (lcgs/include/lcgs/sh_preprocessor.h:30-37, lcgs/src/sh_preprocessor.cpp:169-188).
+ * d_pos[3P], d_sh[P*(level+1)^2*3] -> d_color[3P] = clamp(SH(dir) + 0.5, 0, 1). */
+LCGS_API lcgs_status lcgs_sh_process(lcgs_context* ctx, int num_points, const float* d_pos,
+                                     const lcgs_camera* camera, const float* d_sh, float* d_color,
+                                     int level, int channel);
+
+/* GSProjector::forward (lcgs/include/lcgs/gs_projector.h:37-43, lcgs/src/gs_projector/impl.cpp:26-93).
+ * Input proxy {num, pos[3P], scale[3P], rotq[4P] (r,x,y,z), scale_modifier} (gs_projector.h:16-22),
+ * output proxy {means_2d[2P] NDC, covs_2d[3P], depth[P]} (gs_projector.h:24-28).
+ * Splats with view-space z < 0.2 are left unwritten, as in the reference (gs_projector/shader.cpp:121). */
+LCGS_API lcgs_status lcgs_project_forward(lcgs_context* ctx, int num_gaussians, const float* d_pos,
+                                          const float* d_scale, const float* d_rotq, float scale_modifier,
+                                          float* d_means_2d, float* d_covs_2d, float* d_depth,
+                                          const lcgs_camera* camera, int use_focal);
+
+/* GSTileSplatterAccelProxy (lcgs/include/lcgs/proxy.h:56-64) + the pair capacity the app fixes at
+ * 20M (app/main.cpp:245). */
+typedef struct lcgs_tile_accel {
+    uint32_t* tiles_touched;            /* P */
+    uint32_t* point_offsets;            /* P */
+    uint64_t* point_list_keys_unsorted; /* capacity */
+    uint32_t* point_list_unsorted;      /* capacity */
+    uint64_t* point_list_keys;          /* capacity */
+    uint32_t* point_list;               /* capacity */
+    uint32_t* ranges;                   /* 2 * ceil(W/16) * ceil(H/16) */
+    int64_t   capacity;                 /* number of (tile,splat) pairs the four pair buffers hold */
+} lcgs_tile_accel;
+
+/* GSTileSplatterInputProxy (proxy.h:43-54).  means_2d and conic are read AND overwritten in place
+ * (NDC -> pixel, cov -> conic), exactly like the reference (gs_tile_splatter/shader.cpp:160-161). */
+typedef struct lcgs_tile_input {
+    int          num_gaussians;
+    float        bg_color[3];
+    float*       means_2d;         /* 2P */
+    const float* depth_features;   /* P  */
+    float*       conic;            /* 3P */
+    const float* color_features;   /* 3P */
+    const float* opacity_features; /* P  */
+} lcgs_tile_input;
+
+/* GSSplatForwardOutputProxy (proxy.h:66-71).  target_img is written planar CHW
+ * (gs_tile_splatter/shader.cpp:279-286).  final_T / n_contrib are optional extras (NULL to skip):
+ * the state a backward pass needs, which the reference computes and drops (shader.cpp:219-220). */
+typedef struct lcgs_tile_output {
+    int       height;
+    int       width;
+    float*    target_img; /* 3*H*W */
+    int32_t*  radii;      /* P */
+    float*    final_T;    /* H*W, optional */
+    uint32_t* n_contrib;  /* H*W, optional */
+} lcgs_tile_output;
+
+/* GSTileSplatter::forward (lcgs/include/lcgs/gs_tile_splatter.h:28-35, lcgs/src/gs_tile_splatter/impl.cpp:63-180).
+ * *num_rendered receives the reference's return value; 0 means nothing was drawn and the image is
+ * left untouched (impl.cpp:109). */
+LCGS_API lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* accel,
+                                             const lcgs_tile_input* input, const lcgs_tile_output* output,
+                                             int use_focal, int* num_rendered);
+
+/* The two external parallel primitives the splatter borrows (lcpp, absent from the reference tree):
+ * DeviceScan<>::InclusiveSum (call site gs_tile_splatter/impl.cpp:104) and
+ * DeviceRadixSort<>::SortPairs<ulong,uint> (call site impl.cpp:135-143).  Temp storage is owned by
+ * the context (the reference keeps it in the splatter, gs_tile_splatter.h:50-55). */
+LCGS_API lcgs_status lcgs_inclusive_sum_u32(lcgs_context* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n);
+LCGS_API lcgs_status lcgs_sort_pairs_u64_u32(lcgs_context* ctx, const uint64_t* d_keys_in, uint64_t* d_keys_out,
+                                             const uint32_t* d_vals_in, uint32_t* d_vals_out, int64_t n,
+                                             int begin_bit, int end_bit);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused path: what app/main.cpp:266-308 does per frame (process + forward + forward), as one
+ * stream submission with no host round trip.  Numerically identical to the three stage calls.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Bind caller-owned device arrays (the five buffers of app/main.cpp:180-186 after the upload at
+ * :216-223).  Activations are already applied (app/gaussians.cpp:140-168). */
+LCGS_API lcgs_status lcgs_scene_bind(lcgs_context* ctx, int num_gaussians, int sh_degree, const float* d_pos,
+                                     const float* d_scale, const float* d_rotq, const float* d_sh,
+                                     const float* d_opacity);
+/* Same from host arrays: allocates device copies owned by the context (app/main.cpp:180-186,216-223). */
+LCGS_API lcgs_status lcgs_scene_upload(lcgs_context* ctx, int num_gaussians, int sh_degree, const float* h_pos,
+                                       const float* h_scale, const float* h_rotq, const float* h_sh,
+                                       const float* h_opacity);
+
+/* One frame.  d_img: 3*H*W floats, CHW.  d_radii: P ints or NULL.  If num_rendered is non-NULL the call
+ * synchronises the stream and stores the reference's num_rendered (sum of tiles touched); if NULL the
+ * call only enqueues work.  keep_state != 0 keeps what lcgs_render_backward needs. */
+LCGS_API lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, const float bg_color[3],
+                                         float scale_modifier, float* d_img, int32_t* d_radii,
+                                         int keep_state, int* num_rendered);
+
+/* Per-stage device time of the last lcgs_render_forward / lcgs_render_backward in milliseconds
+ * (hipEvent pairs on the context's stream).  Enable with lcgs_set_profiling(ctx, 1). */
+#define LCGS_MAX_STAGES 16
+typedef struct lcgs_stage_times {
+    int         count;
+    const char* name[LCGS_MAX_STAGES];
+    float       ms[LCGS_MAX_STAGES];
+} lcgs_stage_times;
+LCGS_API lcgs_status lcgs_set_profiling(lcgs_context* ctx, int enabled);
+LCGS_API lcgs_status lcgs_get_stage_times(lcgs_context* ctx, lcgs_stage_times* out);
+
+/* Counters of the last frame (valid after a synchronising call): P, visible splats (radius>0 and
+ * >=1 tile), reference num_rendered, pairs actually sorted, tiles. */
+typedef struct lcgs_frame_stats {
+    int64_t num_gaussians;
+    int64_t num_visible;
+    int64_t num_rendered;
+    int64_t num_pairs;
+    int64_t num_tiles;
+} lcgs_frame_stats;
+LCGS_API lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* out);
+
+/* Diagnostics: the sorted per-tile lists of the last fused frame expressed in ORIGINAL splat indices
+ * (what the reference's accel.point_list holds after GSTileSplatter::forward, proxy.h:62) and the tile
+ * ranges (proxy.h:63).  d_list: num_pairs entries; d_ranges: 2 * tiles.  Either may be NULL.  Synchronises. */
+LCGS_API lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t* d_ranges);
+
+/* Backward of the last lcgs_render_forward(keep_state=1) -- no counterpart in the reference
+ * (README.md:70); specified in DESIGN.md.  All outputs are device pointers, overwritten:
+ * dL/dpos[3P], dL/dscale[3P] (activated scale), dL/drotq[4P] (r,x,y,z, as stored),
+ * dL/dsh[P*(deg+1)^2*3], dL/dopacity[P] (activated). */
+typedef struct lcgs_grads {
+    float* d_dL_dpos;
+    float* d_dL_dscale;
+    float* d_dL_drotq;
+    float* d_dL_dsh;
+    float* d_dL_dopacity;
+} lcgs_grads;
+LCGS_API lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads);
+
+/* ------------------------------------------------------------------------------------------
+ * Scene ingest / image egress (host side of `render(ply, camera) -> image`)
+ * ------------------------------------------------------------------------------------------ */
+
+/* GaussiansData (app/gaussians.h:15-35) after read_gs_ply (app/gaussians.cpp:75-171): activated,
+ * repacked host arrays.  Free with lcgs_scene_host_free. */
+typedef struct lcgs_scene_host {
+    int    num_gaussians;
+    int    sh_degree; /* 3 */
+    float* pos;       /* 3P */
+    float* feature;   /* P*16*3, [j*48 + k*3 + c] */
+    float* opacity;   /* P, sigmoid applied */
+    float* scale;     /* 3P, exp applied */
+    float* rotq;      /* 4P, (r,x,y,z) normalised */
+} lcgs_scene_host;
+
+/* read_gs_ply (app/gaussians.cpp:75-171): binary-little-endian or ascii PLY, properties looked up by
+ * name (x y z f_dc_0..2 f_rest_0..44 opacity scale_0..2 rot_0..3), other properties ignored. */
+LCGS_API lcgs_status lcgs_ply_read(const char* path, lcgs_scene_host* out);
+/* Inverse (raw, un-activated values in, INRIA property order with nx ny nz = 0) -- used to write the
+ * synthetic stand-in scenes; no counterpart in the reference. */
+LCGS_API lcgs_status lcgs_ply_write_raw(const char* path, int num_gaussians, const float* pos,
+                                        const float* f_dc /*3P*/, const float* f_rest /*45P, channel-major*/,
+                                        const float* opacity_logit, const float* log_scale, const float* rot);
+LCGS_API void lcgs_scene_host_free(lcgs_scene_host* scene);
+
+/* Deterministic synthetic stand-ins for the four BASELINE scenes: kind 0 = "synth_object"
+ * (lego/chair-like), kind 1 = "synth_unbounded" (bicycle/garden-like).  Counter-based RNG, so any
+ * sub-range [first, first+count) can be generated independently.  Outputs are ACTIVATED arrays in the
+ * layout of lcgs_scene_host (caller-allocated, count*{3,48,1,3,4} floats). */
+LCGS_API lcgs_status lcgs_synth_scene(int kind, uint64_t seed, int64_t first, int64_t count, float* pos,
+                                      float* feature, float* opacity, float* scale, float* rotq);
+
+/* app/main.cpp:323-335: CHW float -> HWC uint8, vertical flip, truncating *255.  Host buffers. */
+LCGS_API void lcgs_image_to_rgb8(int width, int height, const float* h_img_chw, uint8_t* h_rgb);
+/* Same on the device (d_img CHW float -> d_rgb HWC uint8), enqueued on the context's stream. */
+LCGS_API lcgs_status lcgs_image_to_rgb8_device(lcgs_context* ctx, int width, int height, const float* d_img_chw,
+                                               uint8_t* d_rgb);
+/* stbi_write_png(name, w, h, 3, data, 0) (app/main.cpp:339): 8-bit RGB PNG (stored deflate blocks). */
+LCGS_API lcgs_status lcgs_write_png(const char* path, int width, int height, const uint8_t* h_rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCGS_HIP_H */

@@ -1,0 +1,507 @@
+"""ctypes binding of liblcgs_hip.so + the Python mirror of the reference's operator classes.
+
+Reference interfaces mirrored here (paths relative to the reference repository):
+  * ``Camera`` / ``get_lookat_cam`` ...............  lcgs/include/lcgs/util/camera.h:15-82
+  * ``SHProcessor.process`` .......................  lcgs/include/lcgs/sh_preprocessor.h:30-37
+  * ``GSProjector.forward`` + its two proxies .....  lcgs/include/lcgs/gs_projector.h:16-43
+  * ``GSTileSplatter.forward`` + its three proxies   lcgs/include/lcgs/gs_tile_splatter.h:28-35, proxy.h:43-71
+  * ``read_gs_ply`` ...............................  app/gaussians.cpp:75-171
+  * ``Renderer`` (the per-frame loop body) ........  app/main.cpp:266-308
+
+Device buffers are torch CUDA(=HIP) tensors; only their ``data_ptr()`` crosses the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "liblcgs_hip.so"
+_lib = None
+
+
+class LcgsError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"lcgs status {status}: {message}")
+        self.status = status
+
+
+def library_path() -> str:
+    return os.path.join(_PKG_DIR, _LIB_NAME)
+
+
+def build_library(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into liblcgs_hip.so (in-tree).  Works without a GPU."""
+    args = ["make", "-C", os.path.join(_PKG_DIR, "csrc"), "-j8"]
+    if force:
+        subprocess.check_call(args + ["clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return library_path()
+
+
+class Camera(C.Structure):
+    """struct Camera, lcgs/include/lcgs/util/camera.h:15-25"""
+
+    _fields_ = [
+        ("position", C.c_float * 3),
+        ("front", C.c_float * 3),
+        ("up", C.c_float * 3),
+        ("right", C.c_float * 3),
+        ("fov", C.c_float),
+        ("aspect_ratio", C.c_float),
+        ("width", C.c_int),
+        ("height", C.c_int),
+    ]
+
+    def to_dict(self):
+        return {
+            "position": list(self.position), "front": list(self.front), "up": list(self.up),
+            "right": list(self.right), "fov": float(self.fov), "aspect_ratio": float(self.aspect_ratio),
+            "width": int(self.width), "height": int(self.height),
+        }
+
+    @staticmethod
+    def from_dict(d) -> "Camera":
+        cam = Camera()
+        for k in ("position", "front", "up", "right"):
+            for i in range(3):
+                getattr(cam, k)[i] = float(d[k][i])
+        cam.fov = float(d["fov"])
+        cam.aspect_ratio = float(d["aspect_ratio"])
+        cam.width = int(d["width"])
+        cam.height = int(d["height"])
+        return cam
+
+
+class _TileAccel(C.Structure):
+    _fields_ = [
+        ("tiles_touched", C.c_void_p), ("point_offsets", C.c_void_p), ("point_list_keys_unsorted", C.c_void_p),
+        ("point_list_unsorted", C.c_void_p), ("point_list_keys", C.c_void_p), ("point_list", C.c_void_p),
+        ("ranges", C.c_void_p), ("capacity", C.c_int64),
+    ]
+
+
+class _TileInput(C.Structure):
+    _fields_ = [
+        ("num_gaussians", C.c_int), ("bg_color", C.c_float * 3), ("means_2d", C.c_void_p),
+        ("depth_features", C.c_void_p), ("conic", C.c_void_p), ("color_features", C.c_void_p),
+        ("opacity_features", C.c_void_p),
+    ]
+
+
+class _TileOutput(C.Structure):
+    _fields_ = [
+        ("height", C.c_int), ("width", C.c_int), ("target_img", C.c_void_p), ("radii", C.c_void_p),
+        ("final_T", C.c_void_p), ("n_contrib", C.c_void_p),
+    ]
+
+
+class _StageTimes(C.Structure):
+    _fields_ = [("count", C.c_int), ("name", C.c_char_p * 16), ("ms", C.c_float * 16)]
+
+
+class _FrameStats(C.Structure):
+    _fields_ = [("num_gaussians", C.c_int64), ("num_visible", C.c_int64), ("num_rendered", C.c_int64),
+                ("num_pairs", C.c_int64), ("num_tiles", C.c_int64)]
+
+
+class _Grads(C.Structure):
+    _fields_ = [("d_dL_dpos", C.c_void_p), ("d_dL_dscale", C.c_void_p), ("d_dL_drotq", C.c_void_p),
+                ("d_dL_dsh", C.c_void_p), ("d_dL_dopacity", C.c_void_p)]
+
+
+class _SceneHost(C.Structure):
+    _fields_ = [("num_gaussians", C.c_int), ("sh_degree", C.c_int), ("pos", C.POINTER(C.c_float)),
+                ("feature", C.POINTER(C.c_float)), ("opacity", C.POINTER(C.c_float)),
+                ("scale", C.POINTER(C.c_float)), ("rotq", C.POINTER(C.c_float))]
+
+
+# every symbol include/lcgs_hip.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = [
+    "lcgs_version", "lcgs_last_error", "lcgs_create", "lcgs_destroy", "lcgs_set_stream", "lcgs_synchronize",
+    "lcgs_get_lookat_cam", "lcgs_local_to_world_matrix", "lcgs_world_to_local_matrix", "lcgs_projection_matrix",
+    "lcgs_sh_process", "lcgs_project_forward", "lcgs_tile_splat_forward", "lcgs_inclusive_sum_u32",
+    "lcgs_sort_pairs_u64_u32", "lcgs_scene_bind", "lcgs_scene_upload", "lcgs_render_forward",
+    "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists",
+    "lcgs_render_backward", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
+    "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png",
+]
+
+
+def load_library():
+    """dlopen liblcgs_hip.so.  Raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise LcgsError(-1, f"{path} is missing: run luisacomputegaussiansplatting_amd.build_library() "
+                            f"(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(path)
+    lib.lcgs_version.restype = C.c_char_p
+    lib.lcgs_last_error.restype = C.c_char_p
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("lcgs_version", "lcgs_last_error", "lcgs_get_lookat_cam", "lcgs_local_to_world_matrix",
+                        "lcgs_world_to_local_matrix", "lcgs_projection_matrix", "lcgs_scene_host_free",
+                        "lcgs_image_to_rgb8"):
+            fn.restype = C.c_int
+    lib.lcgs_get_lookat_cam.restype = None
+    lib.lcgs_local_to_world_matrix.restype = None
+    lib.lcgs_world_to_local_matrix.restype = None
+    lib.lcgs_projection_matrix.restype = None
+    lib.lcgs_scene_host_free.restype = None
+    lib.lcgs_image_to_rgb8.restype = None
+    lib.lcgs_projection_matrix.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    _lib = lib
+    return lib
+
+
+def _check(status: int):
+    if status != 0:
+        raise LcgsError(status, load_library().lcgs_last_error().decode(errors="replace"))
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _ptr(t) -> C.c_void_p:
+    """device (or host) pointer of a torch tensor / numpy array / int / None"""
+    if t is None:
+        return C.c_void_p(0)
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    if hasattr(t, "data_ptr"):
+        assert t.is_contiguous(), "buffers crossing the C ABI must be contiguous"
+        return C.c_void_p(t.data_ptr())
+    if isinstance(t, np.ndarray):
+        assert t.flags["C_CONTIGUOUS"]
+        return C.c_void_p(t.ctypes.data)
+    raise TypeError(type(t))
+
+
+# ---------------------------------------------------------------------------------------------- camera
+def get_lookat_cam(pos, target, world_up, width: Optional[int] = None, height: Optional[int] = None,
+                   fov: Optional[float] = None) -> Camera:
+    """get_lookat_cam (camera.h:74-82); width/height additionally apply app/main.cpp:204-207."""
+    cam = Camera()
+    load_library().lcgs_get_lookat_cam(_f3(pos), _f3(target), _f3(world_up), C.byref(cam))
+    if width is not None:
+        cam.width, cam.height = int(width), int(height)
+        cam.aspect_ratio = float(np.float32(width) / np.float32(height))
+    if fov is not None:
+        cam.fov = float(fov)
+    return cam
+
+
+def _mat(fn, *args) -> np.ndarray:
+    m = (C.c_float * 16)()
+    fn(*args, m)
+    return np.array(m, dtype=np.float32).reshape(4, 4).T.copy()  # (row, col) indexing
+
+
+def local_to_world_matrix(cam: Camera) -> np.ndarray:
+    return _mat(load_library().lcgs_local_to_world_matrix, C.byref(cam))
+
+
+def world_to_local_matrix(cam: Camera) -> np.ndarray:
+    return _mat(load_library().lcgs_world_to_local_matrix, C.byref(cam))
+
+
+def projection_matrix(tanfovx: float, tanfovy: float, znear: float = 0.1, zfar: float = 100.0) -> np.ndarray:
+    return _mat(load_library().lcgs_projection_matrix, C.c_float(tanfovx), C.c_float(tanfovy), C.c_float(znear),
+                C.c_float(zfar))
+
+
+# ---------------------------------------------------------------------------------------------- context
+class Context:
+    """One (GPU, stream) pair: Context::create_device + create_stream of app/main.cpp:162-163."""
+
+    def __init__(self, device_id: int = 0, stream: Optional[int] = None):
+        lib = load_library()
+        if stream is None:
+            try:
+                import torch
+
+                if torch.cuda.is_available():
+                    stream = torch.cuda.current_stream(device_id).cuda_stream
+            except ImportError:
+                stream = 0
+        self._h = C.c_void_p(0)
+        _check(lib.lcgs_create(C.c_int(device_id), C.c_void_p(stream or 0), C.byref(self._h)))
+        self.device_id = device_id
+
+    def close(self):
+        if self._h:
+            load_library().lcgs_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(load_library().lcgs_synchronize(self._h))
+
+    def set_stream(self, stream: int):
+        _check(load_library().lcgs_set_stream(self._h, C.c_void_p(stream)))
+
+    # lcpp primitives
+    def inclusive_sum(self, d_in, d_out, n: int):
+        _check(load_library().lcgs_inclusive_sum_u32(self._h, _ptr(d_in), _ptr(d_out), C.c_int64(n)))
+
+    def sort_pairs(self, keys_in, keys_out, vals_in, vals_out, n: int, begin_bit: int = 0, end_bit: int = 64):
+        _check(load_library().lcgs_sort_pairs_u64_u32(self._h, _ptr(keys_in), _ptr(keys_out), _ptr(vals_in),
+                                                      _ptr(vals_out), C.c_int64(n), C.c_int(begin_bit),
+                                                      C.c_int(end_bit)))
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# ---------------------------------------------------------------------------------------------- proxies
+@dataclass
+class GPUPointsProxy:  # sh_preprocessor.h:16-20
+    N: int = 0
+    stride: int = 3
+    pos: object = None
+
+
+@dataclass
+class GSProjectorInputProxy:  # gs_projector.h:16-22
+    num_gaussians: int
+    pos: object
+    scale: object
+    rotq: object
+    scale_modifier: float = 1.0
+
+
+@dataclass
+class GSProjectorOutputProxy:  # gs_projector.h:24-28
+    means_2d: object
+    covs_2d: object
+    depth: object
+
+
+@dataclass
+class GSTileSplatterInputProxy:  # proxy.h:43-54
+    num_gaussians: int
+    bg_color: tuple
+    means_2d: object
+    depth_features: object
+    conic: object
+    color_features: object
+    opacity_features: object
+
+
+@dataclass
+class GSTileSplatterAccelProxy:  # proxy.h:56-64
+    tiles_touched: object
+    point_offsets: object
+    point_list_keys_unsorted: object
+    point_list_unsorted: object
+    point_list_keys: object
+    point_list: object
+    ranges: object
+
+
+@dataclass
+class GSSplatForwardOutputProxy:  # proxy.h:66-71
+    height: int
+    width: int
+    target_img: object
+    radii: object
+    final_T: object = None
+    n_contrib: object = None
+
+
+# ---------------------------------------------------------------------------------------------- operators
+class SHProcessor:
+    """lcgs::SHProcessor (sh_preprocessor.h:22-57)."""
+
+    def __init__(self):
+        self.ctx: Optional[Context] = None
+
+    def create(self, ctx: Optional[Context] = None):
+        self.ctx = ctx or default_context()
+
+    def process(self, proxy: GPUPointsProxy, camera: Camera, sh, color, channel: int = 3, level: int = 3):
+        if self.ctx is None:
+            raise LcgsError(-1, "SHProcessor.create() was not called")
+        _check(load_library().lcgs_sh_process(self.ctx._h, C.c_int(proxy.N), _ptr(proxy.pos), C.byref(camera),
+                                              _ptr(sh), _ptr(color), C.c_int(level), C.c_int(channel)))
+
+
+class GSProjector:
+    """lcgs::GSProjector (gs_projector.h:30-87)."""
+
+    def __init__(self):
+        self.ctx: Optional[Context] = None
+
+    def create(self, ctx: Optional[Context] = None):
+        self.ctx = ctx or default_context()
+
+    def forward(self, input: GSProjectorInputProxy, output: GSProjectorOutputProxy, cam: Camera,
+                use_focal: bool = True):
+        if self.ctx is None:
+            raise LcgsError(-1, "GSProjector.create() was not called")
+        _check(load_library().lcgs_project_forward(
+            self.ctx._h, C.c_int(input.num_gaussians), _ptr(input.pos), _ptr(input.scale), _ptr(input.rotq),
+            C.c_float(input.scale_modifier), _ptr(output.means_2d), _ptr(output.covs_2d), _ptr(output.depth),
+            C.byref(cam), C.c_int(1 if use_focal else 0)))
+
+
+class GSTileSplatter:
+    """lcgs::GSTileSplatter (gs_tile_splatter.h:19-106)."""
+
+    m_blocks = (16, 16)  # module.h:17
+
+    def __init__(self):
+        self.ctx: Optional[Context] = None
+        self.num_rendered = 0  # gs_tile_splatter.h:23
+
+    def create(self, ctx: Optional[Context] = None):
+        self.ctx = ctx or default_context()
+
+    def forward(self, accel: GSTileSplatterAccelProxy, input: GSTileSplatterInputProxy,
+                output: GSSplatForwardOutputProxy, use_focal: bool = True) -> int:
+        if self.ctx is None:
+            raise LcgsError(-1, "GSTileSplatter.create() was not called")
+        cap = int(accel.point_list.numel()) if hasattr(accel.point_list, "numel") else int(accel.point_list.size)
+        a = _TileAccel(_ptr(accel.tiles_touched), _ptr(accel.point_offsets), _ptr(accel.point_list_keys_unsorted),
+                       _ptr(accel.point_list_unsorted), _ptr(accel.point_list_keys), _ptr(accel.point_list),
+                       _ptr(accel.ranges), cap)
+        i = _TileInput(int(input.num_gaussians), _f3(input.bg_color), _ptr(input.means_2d),
+                       _ptr(input.depth_features), _ptr(input.conic), _ptr(input.color_features),
+                       _ptr(input.opacity_features))
+        o = _TileOutput(int(output.height), int(output.width), _ptr(output.target_img), _ptr(output.radii),
+                        _ptr(output.final_T), _ptr(output.n_contrib))
+        n = C.c_int(0)
+        _check(load_library().lcgs_tile_splat_forward(self.ctx._h, C.byref(a), C.byref(i), C.byref(o),
+                                                      C.c_int(1 if use_focal else 0), C.byref(n)))
+        self.num_rendered = n.value
+        return n.value
+
+
+class Renderer:
+    """The fused per-frame path: what app/main.cpp:266-308 does (SHProcessor.process + GSProjector.forward +
+    GSTileSplatter.forward) as one stream submission."""
+
+    def __init__(self, ctx: Optional[Context] = None):
+        self.ctx = ctx or default_context()
+        self._keep = []  # keeps bound tensors alive
+        self.P = 0
+        self.sh_degree = 3
+
+    def bind_scene(self, pos, scale, rotq, sh, opacity, sh_degree: int = 3):
+        P = int(pos.shape[0])
+        self._keep = [pos, scale, rotq, sh, opacity]
+        self.P, self.sh_degree = P, sh_degree
+        _check(load_library().lcgs_scene_bind(self.ctx._h, C.c_int(P), C.c_int(sh_degree), _ptr(pos), _ptr(scale),
+                                              _ptr(rotq), _ptr(sh), _ptr(opacity)))
+
+    def upload_scene(self, scene: dict, sh_degree: int = 3):
+        arrs = [np.ascontiguousarray(scene[k], dtype=np.float32) for k in ("pos", "scale", "rotq", "sh", "opacity")]
+        P = int(arrs[0].reshape(-1, 3).shape[0])
+        self.P, self.sh_degree = P, sh_degree
+        _check(load_library().lcgs_scene_upload(self.ctx._h, C.c_int(P), C.c_int(sh_degree), *[_ptr(a) for a in arrs]))
+
+    def forward(self, cam: Camera, img, bg=(0.0, 0.0, 0.0), scale_modifier: float = 1.0, radii=None,
+                keep_state: bool = False, sync: bool = True) -> Optional[int]:
+        n = C.c_int(0)
+        _check(load_library().lcgs_render_forward(self.ctx._h, C.byref(cam), _f3(bg), C.c_float(scale_modifier),
+                                                  _ptr(img), _ptr(radii), C.c_int(1 if keep_state else 0),
+                                                  C.byref(n) if sync else None))
+        return n.value if sync else None
+
+    def backward(self, dL_dimg, dpos, dscale, drotq, dsh, dopacity):
+        g = _Grads(_ptr(dpos), _ptr(dscale), _ptr(drotq), _ptr(dsh), _ptr(dopacity))
+        _check(load_library().lcgs_render_backward(self.ctx._h, _ptr(dL_dimg), C.byref(g)))
+
+    def set_profiling(self, enabled: bool):
+        _check(load_library().lcgs_set_profiling(self.ctx._h, C.c_int(1 if enabled else 0)))
+
+    def stage_times(self) -> dict:
+        t = _StageTimes()
+        _check(load_library().lcgs_get_stage_times(self.ctx._h, C.byref(t)))
+        return {t.name[i].decode(): float(t.ms[i]) for i in range(t.count)}
+
+    def frame_stats(self) -> dict:
+        s = _FrameStats()
+        _check(load_library().lcgs_get_frame_stats(self.ctx._h, C.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in _FrameStats._fields_}
+
+    def last_lists(self, d_list, d_ranges):
+        _check(load_library().lcgs_debug_last_lists(self.ctx._h, _ptr(d_list), _ptr(d_ranges)))
+
+
+# ---------------------------------------------------------------------------------------------- host io
+def read_gs_ply(path: str) -> dict:
+    """read_gs_ply (app/gaussians.cpp:75-171): activated, repacked host arrays."""
+    lib = load_library()
+    s = _SceneHost()
+    _check(lib.lcgs_ply_read(path.encode(), C.byref(s)))
+    try:
+        P = s.num_gaussians
+
+        def grab(p, n, shape):
+            if P == 0:
+                return np.zeros(shape, dtype=np.float32)
+            return np.ctypeslib.as_array(p, shape=(n,)).reshape(shape).copy()
+
+        return {
+            "pos": grab(s.pos, P * 3, (P, 3)), "sh": grab(s.feature, P * 48, (P, 48)),
+            "opacity": grab(s.opacity, P, (P,)), "scale": grab(s.scale, P * 3, (P, 3)),
+            "rotq": grab(s.rotq, P * 4, (P, 4)), "sh_degree": int(s.sh_degree),
+        }
+    finally:
+        lib.lcgs_scene_host_free(C.byref(s))
+
+
+def write_ply_raw(path: str, pos, f_dc, f_rest, opacity_logit, log_scale, rot):
+    a = [np.ascontiguousarray(x, dtype=np.float32) for x in (pos, f_dc, f_rest, opacity_logit, log_scale, rot)]
+    P = int(a[0].reshape(-1, 3).shape[0])
+    _check(load_library().lcgs_ply_write_raw(path.encode(), C.c_int(P), *[_ptr(x) for x in a]))
+
+
+def synth_scene(kind: int, seed: int, count: int, first: int = 0) -> dict:
+    """Deterministic synthetic stand-in scene: kind 0 object-like, 1 unbounded-like."""
+    out = {
+        "pos": np.empty((count, 3), np.float32), "sh": np.empty((count, 48), np.float32),
+        "opacity": np.empty((count,), np.float32), "scale": np.empty((count, 3), np.float32),
+        "rotq": np.empty((count, 4), np.float32),
+    }
+    _check(load_library().lcgs_synth_scene(C.c_int(kind), C.c_uint64(seed), C.c_int64(first), C.c_int64(count),
+                                           _ptr(out["pos"]), _ptr(out["sh"]), _ptr(out["opacity"]),
+                                           _ptr(out["scale"]), _ptr(out["rotq"])))
+    return out
+
+
+def image_to_rgb8(img_chw: np.ndarray) -> np.ndarray:
+    """app/main.cpp:323-335"""
+    img = np.ascontiguousarray(img_chw, dtype=np.float32)
+    _, H, W = img.shape
+    out = np.empty((H, W, 3), np.uint8)
+    load_library().lcgs_image_to_rgb8(C.c_int(W), C.c_int(H), _ptr(img), _ptr(out))
+    return out
+
+
+def write_png(path: str, rgb: np.ndarray):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    H, W, _ = rgb.shape
+    _check(load_library().lcgs_write_png(path.encode(), C.c_int(W), C.c_int(H), _ptr(rgb)))

@@ -1,0 +1,267 @@
+// gs_math.hpp -- per-splat math of the lcgs hot path, written once for every kernel that needs it.
+//
+// Each function states the reference lines it implements (paths relative to the reference repo).
+// The arithmetic is spelled out term by term in the reference's evaluation order and every
+// translation unit that includes this header is compiled with -ffp-contract=off, so the per-splat
+// outputs (colour, NDC/pixel mean, depth, cov/conic, radius, rect, tile count) are reproducible
+// bit for bit -- which is what makes the integer half of the pipeline (keys, sorted lists, ranges)
+// exactly comparable with a CPU restatement.
+//
+// LuisaCompute conventions assumed (LC source is not part of the reference tree):
+//   column-major matrices, M*v summed left to right over columns, zero-initialised locals,
+//   clamp(v,lo,hi) = min(max(v,lo),hi), saturating float->int conversion.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LCGS_HD __host__ __device__ __forceinline__
+
+namespace lcgs
+{
+
+constexpr uint32_t kBlockX = 16u; // lcgs/include/lcgs/module.h:17  (m_blocks = {16,16})
+constexpr uint32_t kBlockY = 16u;
+
+// lcgs/include/lcgs/util/sh.hpp:12-28
+constexpr float SH_C0    = 0.28209479177387814f;
+constexpr float SH_C1    = 0.4886025119029199f;
+constexpr float SH_C2_0  = 1.0925484305920792f;
+constexpr float SH_C2_1  = -1.0925484305920792f;
+constexpr float SH_C2_2  = 0.31539156525252005f;
+constexpr float SH_C2_3  = -1.0925484305920792f;
+constexpr float SH_C2_4  = 0.5462742152960396f;
+constexpr float SH_C3_0  = -0.5900435899266435f;
+constexpr float SH_C3_1  = 2.890611442640554f;
+constexpr float SH_C3_2  = -0.4570457994644658f;
+constexpr float SH_C3_3  = 0.3731763325901154f;
+constexpr float SH_C3_4  = -0.4570457994644658f;
+constexpr float SH_C3_5  = 1.445305721320277f;
+constexpr float SH_C3_6  = -0.5900435899266435f;
+
+// Per-frame camera constants, computed once on the host exactly as
+// lcgs/src/gs_projector/impl.cpp:34-42 does and passed to kernels by value.
+struct CamParams {
+    float campos[3];
+    float right[3], up[3], front[3]; // rows of the view rotation (camera.h:38-51)
+    float tx, ty, tz;                // view translation: -dot(position, axis)
+    float inv_tanx, inv_tany;        // projection_matrix fx, fy (camera.h:58-59)
+    float tanfovx, tanfovy;
+    float focalx, focaly;
+    uint32_t width, height;
+    uint32_t grid_x, grid_y;
+};
+
+LCGS_HD float fmin_(float a, float b) { return a < b ? a : b; }
+LCGS_HD float fmax_(float a, float b) { return a > b ? a : b; }
+LCGS_HD float clamp_(float v, float lo, float hi) { return fmin_(fmax_(v, lo), hi); }
+
+// float -> u32 / i32 with the saturating semantics of cvt.rzi / v_cvt_*32_f32 (NaN -> 0)
+LCGS_HD uint32_t f2u_sat(float x)
+{
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+LCGS_HD int32_t f2i_sat(float x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return (int32_t)(-2147483647 - 1);
+    return (int32_t)x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SH colour: lcgs/src/sh_preprocessor.cpp:27-157 with util/sh.hpp:31-34,43-50,68-84,120-138.
+// `sh` points at this splat's (deg+1)^2 x 3 coefficients; sh_at(k, c) abstracts the fetch so the
+// caller can feed registers, LDS or global memory.
+// ---------------------------------------------------------------------------------------------
+template <typename ShAt>
+LCGS_HD void sh_to_color(int deg, const float campos[3], float px, float py, float pz, ShAt sh_at,
+                         float out_raw[3])
+{
+    float result[3] = { sh_at(0, 0), sh_at(0, 1), sh_at(0, 2) };
+    if (deg > -1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) result[c] = sh_at(0, c) * SH_C0;
+        if (deg > 0) {
+            float dx = px - campos[0], dy = py - campos[1], dz = pz - campos[2];
+            float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+            float x = dx * inv, y = dy * inv, z = dz * inv;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                result[c] = result[c] + (-SH_C1) * (sh_at(1, c) * y - sh_at(2, c) * z + sh_at(3, c) * x);
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, yz = y * z, zz = z * z, zx = z * x, xy = x * y;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    result[c] = result[c] +
+                                (SH_C2_0 * xy * sh_at(4, c) + SH_C2_1 * yz * sh_at(5, c) +
+                                 SH_C2_2 * (2.0f * zz - xx - yy) * sh_at(6, c) + SH_C2_3 * zx * sh_at(7, c) +
+                                 SH_C2_4 * (xx - yy) * sh_at(8, c));
+                if (deg > 2) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        result[c] = result[c] +
+                                    (SH_C3_0 * y * (3.0f * xx - yy) * sh_at(9, c) + SH_C3_1 * xy * z * sh_at(10, c) +
+                                     SH_C3_2 * y * (4.0f * zz - xx - yy) * sh_at(11, c) +
+                                     SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh_at(12, c) +
+                                     SH_C3_4 * x * (4.0f * zz - xx - yy) * sh_at(13, c) +
+                                     SH_C3_5 * z * (xx - yy) * sh_at(14, c) +
+                                     SH_C3_6 * x * (xx - 3.0f * yy) * sh_at(15, c));
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) result[c] = result[c] + 0.5f;
+    }
+    out_raw[0] = result[0];
+    out_raw[1] = result[1];
+    out_raw[2] = result[2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// View / projection: lcgs/src/gs_projector/shader.cpp:107-121 with the matrices of
+// util/camera.h:38-72.  view = [right up front]^T | t ; proj = diag(fx, fy, a) with w = z.
+// Terms multiplied by the matrices' structural zeros are dropped (they add +-0).
+// ---------------------------------------------------------------------------------------------
+LCGS_HD void view_transform(const CamParams& cp, float px, float py, float pz, float v[3])
+{
+    v[0] = cp.right[0] * px + cp.right[1] * py + cp.right[2] * pz + cp.tx;
+    v[1] = cp.up[0] * px + cp.up[1] * py + cp.up[2] * pz + cp.ty;
+    v[2] = cp.front[0] * px + cp.front[1] * py + cp.front[2] * pz + cp.tz;
+}
+
+LCGS_HD void ndc_from_view(const CamParams& cp, const float v[3], float ndc[2])
+{
+    float p_w = 1.0f / (v[2] + 1e-6f); // p_proj_hom.w = v.z (camera.h:69, zsign = 1)
+    ndc[0]    = (cp.inv_tanx * v[0]) * p_w;
+    ndc[1]    = (cp.inv_tany * v[1]) * p_w;
+}
+
+// R_from_qvec (util/transform.hpp:188-212), q = (x,y,z,w); calc_cov (util/gaussian.hpp:15-28):
+// M = R * diag(s), Sigma = M * M^T.  Column-major: M[c][r] = R[c][r] * s[c].
+LCGS_HD void cov3d_from_scale_rot(const float s[3], float qx, float qy, float qz, float qw, float Sig[3][3] /*[c][r]*/)
+{
+    float x = qx, y = qy, z = qz, w = qw;
+    float R[3][3];
+    R[0][0] = 1.0f - 2.0f * y * y - 2.0f * z * z;
+    R[0][1] = 2.0f * x * y + 2.0f * z * w;
+    R[0][2] = 2.0f * x * z - 2.0f * y * w;
+    R[1][0] = 2.0f * x * y - 2.0f * z * w;
+    R[1][1] = 1.0f - 2.0f * x * x - 2.0f * z * z;
+    R[1][2] = 2.0f * y * z + 2.0f * x * w;
+    R[2][0] = 2.0f * x * z + 2.0f * y * w;
+    R[2][1] = 2.0f * y * z - 2.0f * x * w;
+    R[2][2] = 1.0f - 2.0f * x * x - 2.0f * y * y;
+    float M[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) M[c][r] = R[c][r] * s[c];
+        // Sigma[c][r] = M[0][r]*M[0][c] + M[1][r]*M[1][c] + M[2][r]*M[2][c]
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Sig[c][r] = M[0][r] * M[0][c] + M[1][r] * M[1][c] + M[2][r] * M[2][c];
+}
+
+// mp_cam_clamp (gs_projector/shader.cpp:146-158)
+LCGS_HD void cam_clamp(const CamParams& cp, const float v[3], float t[3])
+{
+    float limx = 1.3f * cp.tanfovx;
+    float limy = 1.3f * cp.tanfovy;
+    float txtz = v[0] / v[2];
+    float tytz = v[1] / v[2];
+    t[0]       = clamp_(txtz, -limx, limx) * v[2];
+    t[1]       = clamp_(tytz, -limy, limy) * v[2];
+    t[2]       = v[2];
+}
+
+// ewasplat_cov_focal / ewasplat_cov (util/gaussian.hpp:52-70 / :31-49): T = W^T... with
+// J (column-major) J[0]=(j00,0,j02), J[1]=(0,j11,j12), J[2]=0 and W columns = right, up, front:
+//   T[0] = right*j00 + front*j02,  T[1] = up*j11 + front*j12,  T[2] = 0
+//   A[c][r] = dot(T[r], Sigma[c]),  cov[c][r] = A[0][r]*T[c][0] + A[1][r]*T[c][1] + A[2][r]*T[c][2]
+// Output (cov[0][0], cov[0][1], cov[1][1]).
+LCGS_HD void ewa_cov2d(const CamParams& cp, const float Sig[3][3], const float t[3], bool use_focal, float cov2d[3])
+{
+    float j00, j11, j02, j12;
+    if (use_focal) {
+        j00 = cp.focalx / t[2];
+        j11 = cp.focaly / t[2];
+        j02 = (-cp.focalx * t[0]) / (t[2] * t[2]);
+        j12 = (-cp.focaly * t[1]) / (t[2] * t[2]);
+    } else {
+        j00 = 1.0f / t[2];
+        j11 = 1.0f / t[2];
+        j02 = (-t[0]) / (t[2] * t[2]);
+        j12 = (-t[1]) / (t[2] * t[2]);
+    }
+    float T0[3], T1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        T0[r] = cp.right[r] * j00 + cp.front[r] * j02;
+        T1[r] = cp.up[r] * j11 + cp.front[r] * j12;
+    }
+    // A[c][0] = dot(T0, Sig[c]); A[c][1] = dot(T1, Sig[c])
+    float A0[3], A1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        A0[c] = T0[0] * Sig[c][0] + T0[1] * Sig[c][1] + T0[2] * Sig[c][2];
+        A1[c] = T1[0] * Sig[c][0] + T1[1] * Sig[c][1] + T1[2] * Sig[c][2];
+    }
+    cov2d[0] = A0[0] * T0[0] + A0[1] * T0[1] + A0[2] * T0[2]; // cov[0][0]
+    cov2d[1] = A1[0] * T0[0] + A1[1] * T0[1] + A1[2] * T0[2]; // cov[0][1]
+    cov2d[2] = A1[0] * T1[0] + A1[1] * T1[1] + A1[2] * T1[2]; // cov[1][1]
+    if (!use_focal) { // gs_projector/shader.cpp:73-76
+        cov2d[0] = cov2d[0] * 1.0f / (cp.tanfovx * cp.tanfovx);
+        cov2d[1] = cov2d[1] * 1.0f / (cp.tanfovx * cp.tanfovy);
+        cov2d[2] = cov2d[2] * 1.0f / (cp.tanfovy * cp.tanfovy);
+    }
+}
+
+// mp_ndc2pix (lcgs/src/module.cpp:18-20)
+LCGS_HD float ndc2pix(float v, uint32_t S) { return ((v + 1.0f) * (float)S - 1.0f) * 0.5f; }
+
+// mp_get_rect (lcgs/src/module.cpp:22-36): both ends clamped to [0, grids-1] -- the last tile
+// row/column never receives splats; this is reference behaviour and is reproduced.
+LCGS_HD void get_rect(float px, float py, int32_t max_radius, uint32_t grid_x, uint32_t grid_y, uint32_t rmin[2],
+                      uint32_t rmax[2])
+{
+    float    r  = (float)max_radius;
+    uint32_t ax = f2u_sat((px - r) / (float)kBlockX);
+    uint32_t ay = f2u_sat((py - r) / (float)kBlockY);
+    uint32_t bx = f2u_sat(px + r + (float)kBlockX - 1.0f) / kBlockX;
+    uint32_t by = f2u_sat(py + r + (float)kBlockY - 1.0f) / kBlockY;
+    uint32_t hx = grid_x - 1u, hy = grid_y - 1u;
+    rmin[0]     = ax < hx ? ax : hx;
+    rmin[1]     = ay < hy ? ay : hy;
+    rmax[0]     = bx < hx ? bx : hx;
+    rmax[1]     = by < hy ? by : hy;
+}
+
+// shad_allocate_tiles body (gs_tile_splatter/shader.cpp:123-157): low-pass, conic, radius.
+// `cov` is (xx, xy, yy) as produced by the projector; for use_focal == false the caller's
+// resolution scaling of shader.cpp:130-135 (including the res.y*res.x factor on yy) is applied.
+LCGS_HD void conic_and_radius(float cx, float cy, float cz, bool use_focal, uint32_t res_x, uint32_t res_y,
+                              float conic[3], int32_t& radius)
+{
+    if (!use_focal) {
+        cx = cx * (float)res_x * (float)res_x * 0.25f;
+        cy = cy * (float)res_x * (float)res_y * 0.25f;
+        cz = cz * (float)res_y * (float)res_x * 0.25f;
+    }
+    cx += 0.3f;
+    cz += 0.3f;
+    float det     = cx * cz - cy * cy;
+    float inv_det = 1.0f / (det + 1e-6f);
+    conic[0]      = inv_det * cz;
+    conic[1]      = inv_det * (-cy);
+    conic[2]      = inv_det * cx;
+    float mid     = 0.5f * (cx + cz);
+    float lambda1 = mid + sqrtf(fmax_(0.1f, mid * mid - det));
+    float lambda2 = mid - sqrtf(fmax_(0.1f, mid * mid - det));
+    radius        = f2i_sat(ceilf(3.0f * sqrtf(fmax_(lambda1, lambda2))));
+}
+
+} // namespace lcgs

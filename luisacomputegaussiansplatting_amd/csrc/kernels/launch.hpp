@@ -1,0 +1,99 @@
+// launch.hpp -- host-callable launchers of every HIP kernel in the library.
+// All launchers only enqueue work on `stream`; none allocates or synchronises.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gs_math.hpp"
+
+namespace lcgs
+{
+
+// ---- stage_kernels.hip : one kernel per reference shader (buffers in the reference's layouts) ----
+void launch_sh_process(int P, int deg, const CamParams& cp, const float* pos, const float* sh, float* color,
+                       hipStream_t stream);
+void launch_project(int P, const CamParams& cp, bool use_focal, const float* pos, const float* scale,
+                    const float* rotq, float scale_modifier, float* means_2d, float* depth, float* covs_2d,
+                    hipStream_t stream);
+void launch_allocate_tiles(int P, const CamParams& cp, bool use_focal, const float* depth, float* means_2d,
+                           float* covs_2d, uint32_t* tiles_touched, int32_t* radii, hipStream_t stream);
+void launch_copy_with_keys(int P, const CamParams& cp, const float* means_2d, const uint32_t* offsets,
+                           const int32_t* radii, const float* depth, uint64_t* keys, uint32_t* values,
+                           hipStream_t stream);
+void launch_get_ranges_u64(int64_t L, const uint64_t* keys, uint32_t* ranges, hipStream_t stream);
+
+// ---- scan.hip : DeviceScan::InclusiveSum<uint> ----
+size_t scan_temp_bytes(int64_t n);
+void   launch_inclusive_sum_u32(const uint32_t* in, uint32_t* out, int64_t n, void* temp, hipStream_t stream);
+// element count read from device memory (*d_n <= n_cap)
+void   launch_inclusive_sum_u32_dyn(const uint32_t* in, uint32_t* out, int64_t n_cap, const uint32_t* d_n, void* temp,
+                                    hipStream_t stream);
+
+// ---- radix_sort.hip : stable LSD radix sort of (key, u32 value) pairs over key bits [begin, end) ----
+// Result always lands in keys_out/vals_out.  keys_in/vals_in are clobbered when more than one pass runs
+// (they serve as the ping-pong partner); pass tmp buffers of n elements to keep the inputs intact.
+size_t sort_temp_bytes(int64_t n);
+void   launch_sort_pairs_u64(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, int64_t n,
+                             int begin_bit, int end_bit, void* temp, hipStream_t stream);
+void   launch_sort_pairs_u32(uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, int64_t n,
+                             int begin_bit, int end_bit, void* temp, hipStream_t stream);
+// Variants whose element count lives in device memory (*d_n <= n_cap): the whole frame can be
+// enqueued without a host round trip.
+void launch_sort_pairs_u32_dyn(uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
+                               const uint32_t* d_n, int64_t n_cap, int begin_bit, int end_bit, void* temp,
+                               hipStream_t stream);
+
+// Input-preserving form (inputs must not alias out/tmp); the last pass lands in (keys_out, vals_out).
+void launch_sort_pairs_u64_preserve(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
+                                    uint32_t* vals_out, uint64_t* keys_tmp, uint32_t* vals_tmp, int64_t n, int begin_bit,
+                                    int end_bit, void* temp, hipStream_t stream);
+
+// Ping-pong form: passes alternate a -> b -> a ...; returns 0 if the result ended in (keys_a, vals_a), 1 if in b.
+int launch_sort_pairs_u32_pingpong(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                                   const uint32_t* d_n, int64_t n_cap, int begin_bit, int end_bit, void* temp,
+                                   hipStream_t stream);
+
+// ---- render.hip : per-tile front-to-back compositing (gs_tile_splatter/shader.cpp:171-288) ----
+// Reference-layout inputs (means_2d[2P] pixel, conic[3P], opacity[P], color[3P]).
+void launch_render_forward_aos(const CamParams& cp, const float bg[3], const uint32_t* ranges,
+                               const uint32_t* point_list, const float* means_2d, const float* conic,
+                               const float* opacity, const float* color, float* img, float* final_T,
+                               uint32_t* n_contrib, hipStream_t stream);
+
+// ---- fused_forward.hip : the one-submission frame ----
+// Packed per-visible-splat record written by the fused preprocess and gathered by the renderer.
+struct __attribute__((aligned(16))) SplatRecord {
+    float    mx, my;   // pixel mean                       (float4 #0)
+    float    ca, cb;   // conic xx, xy
+    float    cc, opac; // conic yy, opacity                (float4 #1)
+    float    r, g;     // colour
+    float    b;        //                                  (float4 #2)
+    float    depth;    // view-space z
+    uint32_t rect_xy;  // rect_min.x | rect_min.y << 16    (tile units)
+    uint32_t rect_wh;  // width | height << 16             (tile units); tiles touched = w * h
+};
+static_assert(sizeof(SplatRecord) == 48, "SplatRecord must be 48 bytes");
+
+size_t fused_scan_state_bytes(int P);
+// d_counts: [0] V (splats touching >= 1 tile), [1] reference num_rendered, [2] pairs emitted, [3] overflow flag
+void launch_fused_preprocess(int P, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
+                             const float* scale, const float* rotq, const float* sh, const float* opacity,
+                             int32_t* radii, SplatRecord* recs, uint32_t* sort_keys, uint32_t* sort_vals,
+                             uint32_t* vis_index, uint64_t* scan_state, uint32_t* d_counts, hipStream_t stream);
+void launch_gather_tiles(int P_cap, const uint32_t* d_counts, const uint32_t* order, const SplatRecord* recs,
+                         uint32_t* tiles_sorted, hipStream_t stream);
+void launch_finalize_counts(uint32_t* d_counts, uint32_t capacity, hipStream_t stream);
+void launch_expand_pairs(int P_cap, const uint32_t* d_counts, uint32_t grid_x, const uint32_t* order,
+                         const uint32_t* offsets_incl, const SplatRecord* recs, uint32_t* pair_keys,
+                         uint32_t* pair_vals, uint32_t capacity, hipStream_t stream);
+void launch_get_ranges_u32(int64_t L_cap, const uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
+                           hipStream_t stream);
+void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t* list_vid, const uint32_t* vis_index,
+                         uint32_t* list_idx, hipStream_t stream);
+
+void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
+                               const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
+                               uint32_t* n_contrib, const uint32_t* d_counts, hipStream_t stream);
+
+} // namespace lcgs

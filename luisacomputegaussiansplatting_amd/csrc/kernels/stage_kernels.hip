@@ -1,0 +1,211 @@
+// stage_kernels.hip -- one HIP kernel per reference "shader", operating on the reference's own
+// buffer layouts (AoS-packed flat float arrays, lcgs/include/lcgs/proxy.h:21-73).  These back the
+// stage-level C-ABI entry points (lcgs_sh_process / lcgs_project_forward / lcgs_tile_splat_forward)
+// so that each reference operator can be swapped for its MI355X counterpart on its own.  The fused
+// one-submission frame lives in fused_forward.hip and shares gs_math.hpp with these kernels.
+//
+// All kernels here are HBM-streaming, one splat per lane, 256 lanes per block (4 wave64s).
+#include "launch.hpp"
+
+namespace lcgs
+{
+namespace
+{
+
+constexpr int kThreads = 256;
+
+// shad_sh_process (lcgs/src/sh_preprocessor.cpp:159-166) + mp_compute_color_from_sh (:27-157)
+__global__ void __launch_bounds__(kThreads) k_sh_process(int P, int deg, CamParams cp, const float* __restrict__ pos,
+                                                           const float* __restrict__ sh, float* __restrict__ color)
+{
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= P) return;
+    const int    feat_dim = (deg + 1) * (deg + 1);
+    const float* s        = sh + (size_t)idx * feat_dim * 3;
+    const float  px = pos[3 * (size_t)idx + 0], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
+    float        raw[3];
+    sh_to_color(deg, cp.campos, px, py, pz, [&](int k, int c) { return s[k * 3 + c]; }, raw);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) color[3 * (size_t)idx + c] = clamp_(raw[c], 0.0f, 1.0f); // :153
+}
+
+// shad_project_gs_focal / shad_project_gs (lcgs/src/gs_projector/shader.cpp:82-139 / :20-80)
+__global__ void __launch_bounds__(kThreads) k_project(int P, CamParams cp, bool use_focal,
+                                                        const float* __restrict__ pos, const float* __restrict__ scale,
+                                                        const float* __restrict__ rotq, float scale_modifier,
+                                                        float* __restrict__ means_2d, float* __restrict__ depth,
+                                                        float* __restrict__ covs_2d)
+{
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= P) return;
+    const float px = pos[3 * (size_t)idx + 0], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
+    float       v[3], ndc[2];
+    view_transform(cp, px, py, pz, v);
+    ndc_from_view(cp, v, ndc);
+    if (v[2] < 0.2f) return; // :121 -- no writes for near-culled splats
+    depth[idx]                    = v[2];
+    means_2d[2 * (size_t)idx + 0] = ndc[0];
+    means_2d[2 * (size_t)idx + 1] = ndc[1];
+    float s[3] = { scale_modifier * scale[3 * (size_t)idx + 0], scale_modifier * scale[3 * (size_t)idx + 1],
+                   scale_modifier * scale[3 * (size_t)idx + 2] };
+    // stored (r,x,y,z) -> (x,y,z,w) via .yzwx() (:130)
+    const float qr = rotq[4 * (size_t)idx + 0], qx = rotq[4 * (size_t)idx + 1], qy = rotq[4 * (size_t)idx + 2],
+                qz = rotq[4 * (size_t)idx + 3];
+    float Sig[3][3], t[3], cov2d[3];
+    cov3d_from_scale_rot(s, qx, qy, qz, qr, Sig);
+    cam_clamp(cp, v, t);
+    ewa_cov2d(cp, Sig, t, use_focal, cov2d);
+    covs_2d[3 * (size_t)idx + 0] = cov2d[0];
+    covs_2d[3 * (size_t)idx + 1] = cov2d[1];
+    covs_2d[3 * (size_t)idx + 2] = cov2d[2];
+}
+
+// shad_allocate_tiles (lcgs/src/gs_tile_splatter/shader.cpp:102-163)
+__global__ void __launch_bounds__(kThreads) k_allocate_tiles(int P, CamParams cp, bool use_focal,
+                                                               const float* __restrict__ depth,
+                                                               float* __restrict__ means_2d,
+                                                               float* __restrict__ covs_2d,
+                                                               uint32_t* __restrict__ tiles_touched,
+                                                               int32_t* __restrict__ radii)
+{
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= P) return;
+    if (depth[idx] < 0.2f) { // :120-121
+        radii[idx]         = 0;
+        tiles_touched[idx] = 0u;
+        return;
+    }
+    const float ndc_x = means_2d[2 * (size_t)idx + 0], ndc_y = means_2d[2 * (size_t)idx + 1];
+    float       conic[3];
+    int32_t     radius;
+    conic_and_radius(covs_2d[3 * (size_t)idx + 0], covs_2d[3 * (size_t)idx + 1], covs_2d[3 * (size_t)idx + 2],
+                     use_focal, cp.width, cp.height, conic, radius);
+    const float pix_x = ndc2pix(ndc_x, cp.width), pix_y = ndc2pix(ndc_y, cp.height);
+    uint32_t    rmin[2], rmax[2];
+    get_rect(pix_x, pix_y, radius, cp.grid_x, cp.grid_y, rmin, rmax);
+    radii[idx]                    = radius;
+    tiles_touched[idx]            = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
+    covs_2d[3 * (size_t)idx + 0]  = conic[0];
+    covs_2d[3 * (size_t)idx + 1]  = conic[1];
+    covs_2d[3 * (size_t)idx + 2]  = conic[2];
+    means_2d[2 * (size_t)idx + 0] = pix_x;
+    means_2d[2 * (size_t)idx + 1] = pix_y;
+}
+
+// shad_copy_with_keys (lcgs/src/gs_tile_splatter/shader.cpp:26-69).  The reference walks each
+// splat's rect with one thread; here the 64 lanes of a wave first handle the small rects one per
+// lane, and rects with more than 32 tiles are expanded cooperatively by the whole wave (64
+// consecutive pairs per step, coalesced 8-byte and 4-byte stores).
+__global__ void __launch_bounds__(kThreads) k_copy_with_keys(int P, CamParams cp, const float* __restrict__ means_2d,
+                                                               const uint32_t* __restrict__ offsets,
+                                                               const int32_t* __restrict__ radii,
+                                                               const float* __restrict__ depth,
+                                                               uint64_t* __restrict__ keys,
+                                                               uint32_t* __restrict__ values)
+{
+    const int idx  = blockIdx.x * kThreads + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t  rmin[2] = { 0, 0 }, rmax[2] = { 0, 0 };
+    uint32_t  off = 0, dbits = 0, w = 0, count = 0;
+    if (idx < P) {
+        const int32_t radius = radii[idx];
+        if (radius > 0) {
+            off = idx >= 1 ? offsets[idx - 1] : 0u;
+            get_rect(means_2d[2 * (size_t)idx + 0], means_2d[2 * (size_t)idx + 1], radius, cp.grid_x, cp.grid_y, rmin,
+                     rmax);
+            w     = rmax[0] - rmin[0];
+            count = w * (rmax[1] - rmin[1]);
+            dbits = __float_as_uint(depth[idx]);
+        }
+    }
+    const bool big = count > 32u;
+    if (count > 0 && !big) {
+        for (uint32_t j = rmin[1]; j < rmax[1]; ++j)
+            for (uint32_t i = rmin[0]; i < rmax[0]; ++i) {
+                keys[off]   = ((uint64_t)(i + j * cp.grid_x) << 32) | (uint64_t)dbits;
+                values[off] = (uint32_t)idx;
+                off         = off + 1u;
+            }
+    }
+    unsigned long long big_mask = __ballot(big);
+    while (big_mask) {
+        const int      src    = __ffsll((long long)big_mask) - 1;
+        big_mask &= big_mask - 1;
+        const uint32_t b_off   = __shfl(off, src, 64);
+        const uint32_t b_count = __shfl(count, src, 64);
+        const uint32_t b_w     = __shfl(w, src, 64);
+        const uint32_t b_x0    = __shfl(rmin[0], src, 64);
+        const uint32_t b_y0    = __shfl(rmin[1], src, 64);
+        const uint32_t b_dbits = __shfl(dbits, src, 64);
+        const uint32_t b_idx   = (uint32_t)(idx - lane + src);
+        for (uint32_t k = lane; k < b_count; k += 64) {
+            const uint32_t j = b_y0 + k / b_w, i = b_x0 + k % b_w;
+            keys[b_off + k]   = ((uint64_t)(i + j * cp.grid_x) << 32) | (uint64_t)b_dbits;
+            values[b_off + k] = b_idx;
+        }
+    }
+}
+
+// shad_get_ranges (lcgs/src/gs_tile_splatter/shader.cpp:71-100); ranges zero-filled by the caller (impl.cpp:147)
+__global__ void __launch_bounds__(kThreads) k_get_ranges_u64(int64_t L, const uint64_t* __restrict__ keys,
+                                                               uint32_t* __restrict__ ranges)
+{
+    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= L) return;
+    const uint32_t curr_tile = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0) {
+        ranges[2 * (size_t)curr_tile + 0] = 0u;
+    } else {
+        const uint32_t prev_tile = (uint32_t)(keys[idx - 1] >> 32);
+        if (curr_tile != prev_tile) {
+            ranges[2 * (size_t)prev_tile + 1] = (uint32_t)idx;
+            ranges[2 * (size_t)curr_tile + 0] = (uint32_t)idx;
+        }
+    }
+    if (idx == L - 1) ranges[2 * (size_t)curr_tile + 1] = (uint32_t)L;
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
+
+} // namespace
+
+void launch_sh_process(int P, int deg, const CamParams& cp, const float* pos, const float* sh, float* color,
+                       hipStream_t stream)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_sh_process, dim3(blocks_for(P)), dim3(kThreads), 0, stream, P, deg, cp, pos, sh, color);
+}
+
+void launch_project(int P, const CamParams& cp, bool use_focal, const float* pos, const float* scale,
+                    const float* rotq, float scale_modifier, float* means_2d, float* depth, float* covs_2d,
+                    hipStream_t stream)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_project, dim3(blocks_for(P)), dim3(kThreads), 0, stream, P, cp, use_focal, pos, scale, rotq,
+                       scale_modifier, means_2d, depth, covs_2d);
+}
+
+void launch_allocate_tiles(int P, const CamParams& cp, bool use_focal, const float* depth, float* means_2d,
+                           float* covs_2d, uint32_t* tiles_touched, int32_t* radii, hipStream_t stream)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_allocate_tiles, dim3(blocks_for(P)), dim3(kThreads), 0, stream, P, cp, use_focal, depth,
+                       means_2d, covs_2d, tiles_touched, radii);
+}
+
+void launch_copy_with_keys(int P, const CamParams& cp, const float* means_2d, const uint32_t* offsets,
+                           const int32_t* radii, const float* depth, uint64_t* keys, uint32_t* values,
+                           hipStream_t stream)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_copy_with_keys, dim3(blocks_for(P)), dim3(kThreads), 0, stream, P, cp, means_2d, offsets,
+                       radii, depth, keys, values);
+}
+
+void launch_get_ranges_u64(int64_t L, const uint64_t* keys, uint32_t* ranges, hipStream_t stream)
+{
+    if (L <= 0) return;
+    hipLaunchKernelGGL(k_get_ranges_u64, dim3(blocks_for(L)), dim3(kThreads), 0, stream, L, keys, ranges);
+}
+
+} // namespace lcgs

@@ -1,0 +1,582 @@
+// lcgs_abi.cpp -- the C ABI of liblcgs_hip.so (include/lcgs_hip.h): context, workspace management and
+// the host-side orchestration of the HIP kernels.  No compute happens on the host; if there is no GPU
+// lcgs_create fails with LCGS_ERR_NO_DEVICE -- there is no CPU fallback.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+
+#include "common.hpp"
+#include "kernels/launch.hpp"
+
+namespace lcgs
+{
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+
+lcgs_status hip_fail(hipError_t e, const char* what, const char* file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d in `%s`", (int)e, hipGetErrorString(e), file, line, what);
+    g_last_error = buf;
+    if (e == hipErrorOutOfMemory) return LCGS_ERR_OUT_OF_MEMORY;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return LCGS_ERR_NO_DEVICE;
+    return LCGS_ERR_HIP;
+}
+
+lcgs_status DeviceBuffer::ensure(size_t need)
+{
+    if (need <= bytes) return LCGS_OK;
+    // geometric growth, like ensure_*_temp_buffer (lcgs/src/gs_tile_splatter/impl.cpp:38-41)
+    size_t new_bytes = bytes == 0 ? need : std::max(need, bytes * 2);
+    new_bytes        = (new_bytes + 255) & ~(size_t)255;
+    if (ptr) {
+        LCGS_HIP_CHECK(hipFree(ptr));
+        ptr   = nullptr;
+        bytes = 0;
+    }
+    LCGS_HIP_CHECK(hipMalloc(&ptr, new_bytes));
+    bytes = new_bytes;
+    return LCGS_OK;
+}
+
+void DeviceBuffer::release()
+{
+    if (ptr) (void)hipFree(ptr);
+    ptr   = nullptr;
+    bytes = 0;
+}
+
+} // namespace lcgs
+
+using namespace lcgs;
+
+namespace
+{
+constexpr int kMaxEvents = LCGS_MAX_STAGES + 1;
+
+inline int ceil_log2_u32(uint32_t v)
+{
+    int b = 0;
+    while ((1ull << b) < v) ++b;
+    return b;
+}
+} // namespace
+
+struct lcgs_context {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+
+    // scene (lcgs_scene_bind / lcgs_scene_upload)
+    int          P = 0, sh_deg = 3;
+    const float *pos = nullptr, *scale = nullptr, *rotq = nullptr, *sh = nullptr, *opacity = nullptr;
+    DeviceBuffer owned[5];
+
+    // workspace of the fused frame
+    DeviceBuffer recs, sortk[2], sortv[2], vis_index, tiles_sorted, offsets, pairk[2], pairv[2], ranges, scan_state,
+        counts, sort_temp, scan_temp, final_T, n_contrib, list_idx;
+    // workspace of the stage-level path / primitives
+    DeviceBuffer st_keys_tmp, st_vals_tmp, st_sort_temp, st_scan_temp, st_scalar;
+    uint32_t     pair_capacity = 0;
+    uint32_t*    h_counts      = nullptr; // pinned, 8 x u32
+
+    // state of the last forward (for backward and stats)
+    struct {
+        bool      valid = false;
+        bool      has_state = false;
+        CamParams cp;
+        float     bg[3];
+        float     scale_modifier;
+        int       list_buf = 0; // pairv[list_buf] holds the sorted per-tile lists (dense ids)
+    } last;
+    lcgs_frame_stats stats{};
+
+    // per-stage timing
+    bool             profiling = false;
+    hipEvent_t       events[kMaxEvents]{};
+    bool             events_created = false;
+    int              n_marks        = 0;
+    const char*      mark_names[kMaxEvents]{};
+    lcgs_stage_times times{};
+};
+
+namespace lcgs
+{
+hipStream_t context_stream(lcgs_context* ctx) { return ctx->stream; }
+} // namespace lcgs
+
+namespace
+{
+
+lcgs_status mark(lcgs_context* ctx, const char* name)
+{
+    if (!ctx->profiling) return LCGS_OK;
+    if (!ctx->events_created) {
+        for (int i = 0; i < kMaxEvents; ++i) LCGS_HIP_CHECK(hipEventCreate(&ctx->events[i]));
+        ctx->events_created = true;
+    }
+    if (ctx->n_marks >= kMaxEvents) return LCGS_OK;
+    ctx->mark_names[ctx->n_marks] = name;
+    LCGS_HIP_CHECK(hipEventRecord(ctx->events[ctx->n_marks], ctx->stream));
+    ctx->n_marks++;
+    return LCGS_OK;
+}
+
+lcgs_status collect_marks(lcgs_context* ctx)
+{
+    ctx->times.count = 0;
+    if (!ctx->profiling || ctx->n_marks < 2) return LCGS_OK;
+    LCGS_HIP_CHECK(hipEventSynchronize(ctx->events[ctx->n_marks - 1]));
+    for (int i = 1; i < ctx->n_marks; ++i) {
+        float ms = 0;
+        LCGS_HIP_CHECK(hipEventElapsedTime(&ms, ctx->events[i - 1], ctx->events[i]));
+        ctx->times.name[i - 1] = ctx->mark_names[i];
+        ctx->times.ms[i - 1]   = ms;
+    }
+    ctx->times.count = ctx->n_marks - 1;
+    return LCGS_OK;
+}
+
+lcgs_status check_camera(const lcgs_camera* cam)
+{
+    LCGS_REQUIRE(cam != nullptr, "camera is NULL");
+    LCGS_REQUIRE(cam->width > 0 && cam->height > 0, "camera width/height must be positive");
+    LCGS_REQUIRE(cam->width <= 65535 * 16 && cam->height <= 65535 * 16, "resolution too large");
+    LCGS_REQUIRE(cam->fov > 0.0f && cam->fov < 180.0f, "camera fov must be in (0,180) degrees");
+    LCGS_REQUIRE(cam->aspect_ratio > 0.0f, "camera aspect_ratio must be positive");
+    return LCGS_OK;
+}
+
+#define LCGS_TRY(expr)                    \
+    do {                                  \
+        lcgs_status _s = (expr);          \
+        if (_s != LCGS_OK) return _s;     \
+    } while (0)
+
+lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool keep_state)
+{
+    const size_t P = (size_t)ctx->P;
+    LCGS_TRY(ctx->recs.ensure(P * sizeof(SplatRecord)));
+    for (int i = 0; i < 2; ++i) {
+        LCGS_TRY(ctx->sortk[i].ensure(P * 4));
+        LCGS_TRY(ctx->sortv[i].ensure(P * 4));
+    }
+    LCGS_TRY(ctx->vis_index.ensure(P * 4));
+    LCGS_TRY(ctx->tiles_sorted.ensure(P * 4));
+    LCGS_TRY(ctx->offsets.ensure(P * 4));
+    if (ctx->pair_capacity == 0) {
+        // generous default: 288 GB of HBM makes over-provisioning the pair buffers free
+        uint64_t cap       = std::max<uint64_t>((uint64_t)4 * P, (uint64_t)1 << 22);
+        ctx->pair_capacity = (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFull);
+    }
+    for (int i = 0; i < 2; ++i) {
+        LCGS_TRY(ctx->pairk[i].ensure((size_t)ctx->pair_capacity * 4));
+        LCGS_TRY(ctx->pairv[i].ensure((size_t)ctx->pair_capacity * 4));
+    }
+    const size_t G = (size_t)cp.grid_x * cp.grid_y;
+    LCGS_TRY(ctx->ranges.ensure(G * 2 * 4));
+    LCGS_TRY(ctx->scan_state.ensure(fused_scan_state_bytes((int)P)));
+    LCGS_TRY(ctx->counts.ensure(64));
+    LCGS_TRY(ctx->sort_temp.ensure(sort_temp_bytes(std::max<int64_t>((int64_t)P, (int64_t)ctx->pair_capacity))));
+    LCGS_TRY(ctx->scan_temp.ensure(scan_temp_bytes((int64_t)P)));
+    if (keep_state) {
+        LCGS_TRY(ctx->final_T.ensure((size_t)cp.width * cp.height * 4));
+        LCGS_TRY(ctx->n_contrib.ensure((size_t)cp.width * cp.height * 4));
+    }
+    if (!ctx->h_counts) LCGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counts), 64, hipHostMallocDefault));
+    return LCGS_OK;
+}
+
+// enqueue one fused forward frame (no synchronisation)
+lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float bg[3], float scale_modifier,
+                            float* d_img, int32_t* d_radii, bool keep_state)
+{
+    hipStream_t  st       = ctx->stream;
+    uint32_t*    d_counts = ctx->counts.as<uint32_t>();
+    const int    P        = ctx->P;
+    SplatRecord* recs     = ctx->recs.as<SplatRecord>();
+    ctx->n_marks          = 0;
+    LCGS_TRY(mark(ctx, "begin"));
+
+    launch_fused_preprocess(P, ctx->sh_deg, cp, scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity,
+                            d_radii, recs, ctx->sortk[0].as<uint32_t>(), ctx->sortv[0].as<uint32_t>(),
+                            ctx->vis_index.as<uint32_t>(), ctx->scan_state.as<uint64_t>(), d_counts, st);
+    LCGS_TRY(mark(ctx, "preprocess"));
+
+    // depth bits of a float >= 0.2 never use bit 31
+    const int where = launch_sort_pairs_u32_pingpong(ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
+                                                     ctx->sortv[0].as<uint32_t>(), ctx->sortv[1].as<uint32_t>(),
+                                                     d_counts + 0, P, 0, 32, ctx->sort_temp.ptr, st);
+    const uint32_t* order = ctx->sortv[where].as<uint32_t>();
+    LCGS_TRY(mark(ctx, "depth_sort"));
+
+    launch_gather_tiles(P, d_counts, order, recs, ctx->tiles_sorted.as<uint32_t>(), st);
+    launch_inclusive_sum_u32_dyn(ctx->tiles_sorted.as<uint32_t>(), ctx->offsets.as<uint32_t>(), P, d_counts + 0,
+                                 ctx->scan_temp.ptr, st);
+    launch_finalize_counts(d_counts, ctx->pair_capacity, st);
+    launch_expand_pairs(P, d_counts, cp.grid_x, order, ctx->offsets.as<uint32_t>(), recs, ctx->pairk[0].as<uint32_t>(),
+                        ctx->pairv[0].as<uint32_t>(), ctx->pair_capacity, st);
+    LCGS_TRY(mark(ctx, "expand"));
+
+    const int tile_bits = std::max(1, ceil_log2_u32(cp.grid_x * cp.grid_y));
+    const int where2 = launch_sort_pairs_u32_pingpong(ctx->pairk[0].as<uint32_t>(), ctx->pairk[1].as<uint32_t>(),
+                                                      ctx->pairv[0].as<uint32_t>(), ctx->pairv[1].as<uint32_t>(),
+                                                      d_counts + 2, ctx->pair_capacity, 0, tile_bits,
+                                                      ctx->sort_temp.ptr, st);
+    LCGS_TRY(mark(ctx, "tile_sort"));
+
+    const size_t G = (size_t)cp.grid_x * cp.grid_y;
+    LCGS_HIP_CHECK(hipMemsetAsync(ctx->ranges.ptr, 0, G * 2 * 4, st)); // gs_tile_splatter/impl.cpp:147
+    launch_get_ranges_u32(ctx->pair_capacity, d_counts, ctx->pairk[where2].as<uint32_t>(), ctx->ranges.as<uint32_t>(),
+                          st);
+    LCGS_TRY(mark(ctx, "ranges"));
+
+    launch_render_forward_rec(cp, bg, ctx->ranges.as<uint32_t>(), ctx->pairv[where2].as<uint32_t>(), recs, d_img,
+                              keep_state ? ctx->final_T.as<float>() : nullptr,
+                              keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, st);
+    LCGS_TRY(mark(ctx, "render"));
+
+    LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, d_counts, 16, hipMemcpyDeviceToHost, st));
+    ctx->last.valid          = true;
+    ctx->last.has_state      = keep_state;
+    ctx->last.cp             = cp;
+    ctx->last.scale_modifier = scale_modifier;
+    ctx->last.list_buf       = where2;
+    memcpy(ctx->last.bg, bg, sizeof(float) * 3);
+    return LCGS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* lcgs_version(void) { return "lcgs-hip 0.1 (gfx950)"; }
+const char* lcgs_last_error(void) { return g_last_error.c_str(); }
+
+lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx)
+{
+    LCGS_REQUIRE(out_ctx != nullptr, "out_ctx is NULL");
+    *out_ctx  = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_last_error("no HIP device available: liblcgs_hip has no CPU path");
+        return LCGS_ERR_NO_DEVICE;
+    }
+    LCGS_REQUIRE(device_id >= 0 && device_id < count, "device_id out of range");
+    LCGS_HIP_CHECK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    LCGS_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_last_error(std::string("liblcgs_hip is built for gfx950 only; device reports ") + prop.gcnArchName);
+        return LCGS_ERR_NO_DEVICE;
+    }
+    lcgs_context* ctx = new (std::nothrow) lcgs_context();
+    if (!ctx) return LCGS_ERR_OUT_OF_MEMORY;
+    ctx->device = device_id;
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    *out_ctx    = ctx;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_destroy(lcgs_context* ctx)
+{
+    if (!ctx) return LCGS_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DeviceBuffer* bufs[] = { &ctx->recs, &ctx->sortk[0], &ctx->sortk[1], &ctx->sortv[0], &ctx->sortv[1], &ctx->vis_index,
+                             &ctx->tiles_sorted, &ctx->offsets, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
+                             &ctx->pairv[1], &ctx->ranges, &ctx->scan_state, &ctx->counts, &ctx->sort_temp,
+                             &ctx->scan_temp, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->st_keys_tmp,
+                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar };
+    for (DeviceBuffer* b : bufs) b->release();
+    for (auto& b : ctx->owned) b.release();
+    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    if (ctx->events_created)
+        for (auto& ev : ctx->events) (void)hipEventDestroy(ev);
+    delete ctx;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_set_stream(lcgs_context* ctx, void* stream)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_synchronize(lcgs_context* ctx)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return LCGS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- stages
+
+lcgs_status lcgs_sh_process(lcgs_context* ctx, int num_points, const float* d_pos, const lcgs_camera* camera,
+                            const float* d_sh, float* d_color, int level, int channel)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(num_points >= 0, "num_points < 0");
+    LCGS_REQUIRE(camera != nullptr, "camera is NULL");
+    LCGS_REQUIRE(level >= -1 && level <= 3, "SH level must be in [-1,3]");
+    LCGS_REQUIRE(channel == 3, "only 3 colour channels are supported (as in the reference)");
+    if (num_points == 0) return LCGS_OK;
+    LCGS_REQUIRE(d_pos && d_sh && d_color, "NULL device pointer");
+    CamParams cp{};
+    for (int i = 0; i < 3; ++i) cp.campos[i] = camera->position[i];
+    launch_sh_process(num_points, level, cp, d_pos, d_sh, d_color, ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_project_forward(lcgs_context* ctx, int num_gaussians, const float* d_pos, const float* d_scale,
+                                 const float* d_rotq, float scale_modifier, float* d_means_2d, float* d_covs_2d,
+                                 float* d_depth, const lcgs_camera* camera, int use_focal)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(num_gaussians >= 0, "num_gaussians < 0");
+    LCGS_TRY(check_camera(camera));
+    if (num_gaussians == 0) return LCGS_OK;
+    LCGS_REQUIRE(d_pos && d_scale && d_rotq && d_means_2d && d_covs_2d && d_depth, "NULL device pointer");
+    CamParams cp = make_cam_params(*camera);
+    launch_project(num_gaussians, cp, use_focal != 0, d_pos, d_scale, d_rotq, scale_modifier, d_means_2d, d_depth,
+                   d_covs_2d, ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_inclusive_sum_u32(lcgs_context* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "n out of range");
+    if (n == 0) return LCGS_OK;
+    LCGS_REQUIRE(d_in && d_out, "NULL device pointer");
+    LCGS_TRY(ctx->st_scan_temp.ensure(scan_temp_bytes(n)));
+    launch_inclusive_sum_u32(d_in, d_out, n, ctx->st_scan_temp.ptr, ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_sort_pairs_u64_u32(lcgs_context* ctx, const uint64_t* d_keys_in, uint64_t* d_keys_out,
+                                    const uint32_t* d_vals_in, uint32_t* d_vals_out, int64_t n, int begin_bit,
+                                    int end_bit)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(n >= 0 && n < ((int64_t)1 << 30), "n out of range");
+    LCGS_REQUIRE(begin_bit >= 0 && end_bit <= 64 && begin_bit <= end_bit, "bad bit range");
+    if (n == 0) return LCGS_OK;
+    LCGS_REQUIRE(d_keys_in && d_keys_out && d_vals_in && d_vals_out, "NULL device pointer");
+    LCGS_REQUIRE((const void*)d_keys_in != (const void*)d_keys_out && (const void*)d_vals_in != (const void*)d_vals_out,
+                 "in-place sort is not supported");
+    LCGS_TRY(ctx->st_keys_tmp.ensure((size_t)n * 8));
+    LCGS_TRY(ctx->st_vals_tmp.ensure((size_t)n * 4));
+    LCGS_TRY(ctx->st_sort_temp.ensure(sort_temp_bytes(n)));
+    launch_sort_pairs_u64_preserve(d_keys_in, d_vals_in, d_keys_out, d_vals_out, ctx->st_keys_tmp.as<uint64_t>(),
+                                   ctx->st_vals_tmp.as<uint32_t>(), n, begin_bit, end_bit, ctx->st_sort_temp.ptr,
+                                   ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    return LCGS_OK;
+}
+
+// GSTileSplatter::forward, lcgs/src/gs_tile_splatter/impl.cpp:63-180 -- same stage order, same buffers.
+lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* accel, const lcgs_tile_input* input,
+                                    const lcgs_tile_output* output, int use_focal, int* num_rendered)
+{
+    LCGS_REQUIRE(ctx && accel && input && output, "NULL argument");
+    if (num_rendered) *num_rendered = 0;
+    const int P = input->num_gaussians;
+    LCGS_REQUIRE(P >= 0, "num_gaussians < 0");
+    LCGS_REQUIRE(output->width > 0 && output->height > 0, "output size must be positive");
+    LCGS_REQUIRE(accel->tiles_touched && accel->point_offsets && accel->point_list_keys_unsorted &&
+                     accel->point_list_unsorted && accel->point_list_keys && accel->point_list && accel->ranges,
+                 "NULL accel buffer");
+    LCGS_REQUIRE(output->target_img && output->radii, "NULL output buffer");
+    if (P == 0) return LCGS_OK; // num_rendered = 0: nothing drawn, image untouched (impl.cpp:109)
+    LCGS_REQUIRE(input->means_2d && input->depth_features && input->conic && input->color_features &&
+                     input->opacity_features,
+                 "NULL input buffer");
+    hipStream_t st = ctx->stream;
+    CamParams   cp{};
+    cp.width  = (uint32_t)output->width;
+    cp.height = (uint32_t)output->height;
+    cp.grid_x = div_up(cp.width, kBlockX); // impl.cpp:76-79
+    cp.grid_y = div_up(cp.height, kBlockY);
+
+    launch_allocate_tiles(P, cp, use_focal != 0, input->depth_features, input->means_2d, input->conic,
+                          accel->tiles_touched, output->radii, st); // impl.cpp:87-99
+    LCGS_TRY(ctx->st_scan_temp.ensure(scan_temp_bytes(P)));
+    launch_inclusive_sum_u32(accel->tiles_touched, accel->point_offsets, P, ctx->st_scan_temp.ptr, st); // impl.cpp:104
+    int32_t L = 0;
+    LCGS_HIP_CHECK(hipMemcpyAsync(&L, accel->point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st)); // impl.cpp:106
+    LCGS_HIP_CHECK(hipStreamSynchronize(st));                                                        // impl.cpp:107
+    if (num_rendered) *num_rendered = L;
+    if (L <= 0) return LCGS_OK; // impl.cpp:109
+    if ((int64_t)L > accel->capacity) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "num_rendered = %d exceeds the pair buffer capacity %lld", L, (long long)accel->capacity);
+        set_last_error(buf);
+        return LCGS_ERR_CAPACITY;
+    }
+    LCGS_HIP_CHECK(hipMemsetAsync(accel->point_list_unsorted, 0, (size_t)L * 4, st));      // impl.cpp:117
+    LCGS_HIP_CHECK(hipMemsetAsync(accel->point_list_keys_unsorted, 0, (size_t)L * 8, st)); // impl.cpp:118
+    launch_copy_with_keys(P, cp, input->means_2d, accel->point_offsets, output->radii, input->depth_features,
+                          accel->point_list_keys_unsorted, accel->point_list_unsorted, st); // impl.cpp:120-130
+    // impl.cpp:135-143 sorts all 64 key bits; only 32 + ceil(log2 G) of them can differ
+    const int tile_bits = std::max(1, ceil_log2_u32(cp.grid_x * cp.grid_y));
+    LCGS_TRY(ctx->st_keys_tmp.ensure((size_t)L * 8));
+    LCGS_TRY(ctx->st_vals_tmp.ensure((size_t)L * 4));
+    LCGS_TRY(ctx->st_sort_temp.ensure(sort_temp_bytes(L)));
+    launch_sort_pairs_u64_preserve(accel->point_list_keys_unsorted, accel->point_list_unsorted, accel->point_list_keys,
+                                   accel->point_list, ctx->st_keys_tmp.as<uint64_t>(), ctx->st_vals_tmp.as<uint32_t>(),
+                                   L, 0, 32 + tile_bits, ctx->st_sort_temp.ptr, st);
+    const size_t G = (size_t)cp.grid_x * cp.grid_y;
+    LCGS_HIP_CHECK(hipMemsetAsync(accel->ranges, 0, G * 2 * 4, st)); // impl.cpp:147
+    launch_get_ranges_u64(L, accel->point_list_keys, accel->ranges, st); // impl.cpp:150-156
+    launch_render_forward_aos(cp, input->bg_color, accel->ranges, accel->point_list, input->means_2d, input->conic,
+                              input->opacity_features, input->color_features, output->target_img, output->final_T,
+                              output->n_contrib, st); // impl.cpp:159-174
+    LCGS_HIP_CHECK(hipGetLastError());
+    return LCGS_OK; // no sync, like impl.cpp:177
+}
+
+// ---------------------------------------------------------------------------------------------- fused
+
+lcgs_status lcgs_scene_bind(lcgs_context* ctx, int num_gaussians, int sh_degree, const float* d_pos,
+                            const float* d_scale, const float* d_rotq, const float* d_sh, const float* d_opacity)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(num_gaussians >= 0 && num_gaussians < (1 << 30), "num_gaussians out of range");
+    LCGS_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "sh_degree must be in [0,3]");
+    if (num_gaussians > 0) LCGS_REQUIRE(d_pos && d_scale && d_rotq && d_sh && d_opacity, "NULL device pointer");
+    LCGS_REQUIRE((reinterpret_cast<uintptr_t>(d_rotq) & 15) == 0, "rotq must be 16-byte aligned");
+    ctx->P       = num_gaussians;
+    ctx->sh_deg  = sh_degree;
+    ctx->pos     = d_pos;
+    ctx->scale   = d_scale;
+    ctx->rotq    = d_rotq;
+    ctx->sh      = d_sh;
+    ctx->opacity = d_opacity;
+    ctx->last.valid = false;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_scene_upload(lcgs_context* ctx, int num_gaussians, int sh_degree, const float* h_pos,
+                              const float* h_scale, const float* h_rotq, const float* h_sh, const float* h_opacity)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(num_gaussians >= 0 && num_gaussians < (1 << 30), "num_gaussians out of range");
+    LCGS_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "sh_degree must be in [0,3]");
+    if (num_gaussians > 0) LCGS_REQUIRE(h_pos && h_scale && h_rotq && h_sh && h_opacity, "NULL host pointer");
+    const size_t P        = (size_t)num_gaussians;
+    const size_t feat     = (size_t)(sh_degree + 1) * (sh_degree + 1) * 3;
+    const size_t sizes[5] = { P * 3 * 4, P * 3 * 4, P * 4 * 4, P * feat * 4, P * 4 };
+    const float* src[5]   = { h_pos, h_scale, h_rotq, h_sh, h_opacity };
+    for (int i = 0; i < 5; ++i) {
+        LCGS_TRY(ctx->owned[i].ensure(std::max<size_t>(sizes[i], 16)));
+        if (sizes[i])
+            LCGS_HIP_CHECK(hipMemcpyAsync(ctx->owned[i].ptr, src[i], sizes[i], hipMemcpyHostToDevice, ctx->stream));
+    }
+    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // app/main.cpp:223
+    return lcgs_scene_bind(ctx, num_gaussians, sh_degree, ctx->owned[0].as<float>(), ctx->owned[1].as<float>(),
+                           ctx->owned[2].as<float>(), ctx->owned[3].as<float>(), ctx->owned[4].as<float>());
+}
+
+lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, const float bg_color[3],
+                                float scale_modifier, float* d_img, int32_t* d_radii, int keep_state,
+                                int* num_rendered)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_TRY(check_camera(camera));
+    LCGS_REQUIRE(bg_color != nullptr, "bg_color is NULL");
+    LCGS_REQUIRE(d_img != nullptr, "d_img is NULL");
+    if (num_rendered) *num_rendered = 0;
+    if (ctx->P == 0) return LCGS_OK; // nothing to draw: image untouched, like gs_tile_splatter/impl.cpp:109
+    LCGS_REQUIRE(ctx->pos != nullptr, "no scene bound (call lcgs_scene_bind / lcgs_scene_upload first)");
+    const CamParams cp = make_cam_params(*camera);
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        LCGS_TRY(ensure_fused_workspace(ctx, cp, keep_state != 0));
+        LCGS_TRY(enqueue_forward(ctx, cp, bg_color, scale_modifier, d_img, d_radii, keep_state != 0));
+        LCGS_HIP_CHECK(hipGetLastError());
+        if (!num_rendered && !ctx->profiling) return LCGS_OK; // fully asynchronous frame
+        LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        LCGS_TRY(collect_marks(ctx));
+        ctx->stats.num_gaussians = ctx->P;
+        ctx->stats.num_visible   = ctx->h_counts[0];
+        ctx->stats.num_rendered  = ctx->h_counts[1];
+        ctx->stats.num_pairs     = ctx->h_counts[2];
+        ctx->stats.num_tiles     = (int64_t)cp.grid_x * cp.grid_y;
+        if (num_rendered) *num_rendered = (int)ctx->h_counts[1];
+        if (ctx->h_counts[3] == 0) return LCGS_OK;
+        // pair buffers were too small for this view: grow and redo the frame
+        uint64_t want = (uint64_t)ctx->h_counts[1] + ctx->h_counts[1] / 4;
+        if (want > 0x7FFFFFFFull) {
+            set_last_error("num_rendered exceeds 2^31 pairs");
+            return LCGS_ERR_CAPACITY;
+        }
+        ctx->pair_capacity = (uint32_t)want;
+    }
+    set_last_error("pair buffer growth did not converge");
+    return LCGS_ERR_CAPACITY;
+}
+
+lcgs_status lcgs_set_profiling(lcgs_context* ctx, int enabled)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->profiling = enabled != 0;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_get_stage_times(lcgs_context* ctx, lcgs_stage_times* out)
+{
+    LCGS_REQUIRE(ctx && out, "NULL argument");
+    *out = ctx->times;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* out)
+{
+    LCGS_REQUIRE(ctx && out, "NULL argument");
+    LCGS_REQUIRE(ctx->last.valid, "no frame rendered yet");
+    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->stats.num_gaussians = ctx->P;
+    ctx->stats.num_visible   = ctx->h_counts[0];
+    ctx->stats.num_rendered  = ctx->h_counts[1];
+    ctx->stats.num_pairs     = ctx->h_counts[2];
+    ctx->stats.num_tiles     = (int64_t)ctx->last.cp.grid_x * ctx->last.cp.grid_y;
+    *out                     = ctx->stats;
+    return LCGS_OK;
+}
+
+// Debug/parity hook: the sorted per-tile lists of the last fused frame in ORIGINAL splat indices (what the
+// reference's point_list holds) and the tile ranges.  d_list must hold num_pairs entries, d_ranges 2*G.
+lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t* d_ranges)
+{
+    LCGS_REQUIRE(ctx && ctx->last.valid, "no frame rendered yet");
+    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const uint32_t L = ctx->h_counts[2];
+    if (d_list && L)
+        launch_map_to_index(L, ctx->counts.as<uint32_t>(), ctx->pairv[ctx->last.list_buf].as<uint32_t>(),
+                            ctx->vis_index.as<uint32_t>(), d_list, ctx->stream);
+    if (d_ranges)
+        LCGS_HIP_CHECK(hipMemcpyAsync(d_ranges, ctx->ranges.ptr,
+                                      (size_t)ctx->last.cp.grid_x * ctx->last.cp.grid_y * 8, hipMemcpyDeviceToDevice,
+                                      ctx->stream));
+    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads)
+{
+    LCGS_REQUIRE(ctx && d_dL_dimg && grads, "NULL argument");
+    set_last_error("lcgs_render_backward: not implemented yet");
+    return LCGS_ERR_STATE;
+}
+
+} // extern "C"

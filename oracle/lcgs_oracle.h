@@ -1,0 +1,163 @@
+/*
+ * lcgs_oracle.h -- CPU restatement of the LuisaComputeGaussianSplatting forward path
+ * (plus the build-defined backward).  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file and everything under oracle/ is the checker: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product (luisacomputegaussiansplatting_amd/, liblcgs_hip.so) never links,
+ * imports or calls it.
+ *
+ * Pinning status ("parity unpinned" items are listed in DESIGN.md):
+ *   - camera math: pinned by the reference's own known-answer tests
+ *     (test/test_camera.cpp:48-144), restated in tests/test_oracle_camera.py.
+ *   - SH band evaluators: pinned against the reference's own header
+ *     lcgs/include/lcgs/util/sh.hpp compiled here into oracle/_ref (it has no
+ *     includes), see oracle/ref_wrap.cpp and tests/golden/.
+ *   - PLY parsing: pinned against the reference's vendored app/happly.h compiled
+ *     into oracle/_ref.
+ *   - projection / conic / radius / keys / blend: the reference cannot be built
+ *     here (LuisaCompute + lc_parallel_primitive are external and absent), so
+ *     these follow the reference source line by line but are PARITY UNPINNED.
+ *   - scan / sort: lcpp is absent; semantics = inclusive sum / stable ascending
+ *     sort.  PARITY UNPINNED.
+ *   - backward: the reference has none.  Pinned by fp64 finite differences.
+ *
+ * The library is compiled twice: REAL=float (liblcgs_oracle_f32.so, the parity
+ * oracle and CPU baseline) and REAL=double (liblcgs_oracle_f64.so, used for
+ * finite-difference gradient checks).  Symbol names are identical.
+ */
+#ifndef LCGS_ORACLE_H
+#define LCGS_ORACLE_H
+
+#include <stdint.h>
+
+#ifndef ORC_REAL
+#define ORC_REAL float
+#endif
+typedef ORC_REAL real;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* lcgs/include/lcgs/util/camera.h:15-25 */
+typedef struct orc_camera {
+    real position[3];
+    real front[3];
+    real up[3];
+    real right[3];
+    real fov;          /* degrees */
+    real aspect_ratio;
+    int  width;
+    int  height;
+} orc_camera;
+
+int  orc_sizeof_real(void);
+void orc_set_threads(int n); /* 0 = all cores */
+int  orc_get_threads(void);
+
+/* camera.h:74-82, 27-51, 54-72.  Matrices are column-major m[c*4+r]. */
+void orc_get_lookat_cam(const real pos[3], const real target[3], const real world_up[3], orc_camera* cam);
+void orc_local_to_world_matrix(const orc_camera* cam, real m[16]);
+void orc_world_to_local_matrix(const orc_camera* cam, real m[16]);
+void orc_projection_matrix(real tanfovx, real tanfovy, real znear, real zfar, real m[16]);
+void orc_mat4_mul_vec4(const real m[16], const real v[4], real out[4]);
+
+/* band sums for a given unit direction (sh.hpp:31-138 as composed by sh_preprocessor.cpp:49-147) */
+void orc_sh_eval_dir(int deg, const real dir[3], const real* shs, real result[3]);
+
+/* sh_preprocessor.cpp:27-166 + util/sh.hpp.  color_raw (nullable) receives the value before the
+ * final clamp (needed for the backward clamp mask). */
+void orc_sh_process(int P, int channel, int deg, const real campos[3],
+                    const real* xyz, const real* sh, real* color, real* color_raw);
+
+/* gs_projector/impl.cpp:26-93 + shader.cpp:20-158 + util/gaussian.hpp + util/transform.hpp:188-212.
+ * Culled splats (p_view.z < 0.2) are NOT written (reference semantics, shader.cpp:121). */
+void orc_project_gs(int P, const real* pos, const real* scale, const real* rotq, real scale_modifier,
+                    real* means_2d, real* depth, real* covs_2d,
+                    const orc_camera* cam, int use_focal);
+
+/* gs_tile_splatter/shader.cpp:102-163 + module.cpp:18-36.  Overwrites means_2d (NDC->pixel) and
+ * covs_2d (cov->conic) in place. */
+void orc_allocate_tiles(int P, int width, int height,
+                        const real* depth, real* means_2d, real* covs_2d,
+                        uint32_t* tiles_touched, int32_t* radii, int use_focal);
+
+/* lcpp DeviceScan::InclusiveSum (external); call site gs_tile_splatter/impl.cpp:104 */
+void orc_inclusive_sum(int n, const uint32_t* in, uint32_t* out);
+
+/* gs_tile_splatter/shader.cpp:26-69 */
+void orc_copy_with_keys(int P, int width, int height,
+                        const real* means_2d, const uint32_t* offsets, const int32_t* radii,
+                        const real* depth, uint64_t* keys, uint32_t* values);
+
+/* lcpp DeviceRadixSort::SortPairs<ulong,uint> (external); call site impl.cpp:135-143.  Stable. */
+void orc_sort_pairs(int64_t n, const uint64_t* keys_in, const uint32_t* vals_in,
+                    uint64_t* keys_out, uint32_t* vals_out);
+
+/* gs_tile_splatter/shader.cpp:71-100.  ranges[2*G] must be zero-filled by the caller
+ * (impl.cpp:147). */
+void orc_get_ranges(int64_t L, const uint64_t* keys, uint32_t* ranges);
+
+/* gs_tile_splatter/shader.cpp:171-288.  Optional outputs (nullable):
+ *   final_T[H*W], n_contrib[H*W]  -- state needed by the backward
+ *   ambig[H*W]                    -- 1 where any threshold comparison of the pixel was within
+ *                                    ambig_eps (relative) of flipping. */
+void orc_render_forward(int width, int height, const real bg[3],
+                        const uint32_t* ranges, const uint32_t* point_list,
+                        const real* means_2d, const real* conic, const real* opacity, const real* color,
+                        real* img, real* final_T, uint32_t* n_contrib,
+                        uint8_t* ambig, real ambig_eps);
+
+/* gs_tile_splatter/impl.cpp:63-180: allocate_tiles -> scan -> keys -> sort -> ranges -> render.
+ * Buffers sized L_cap for keys/lists.  Returns num_rendered, or -1 if L_cap is too small. */
+int64_t orc_tile_splatter_forward(int P, int width, int height, const real bg[3],
+                                  real* means_2d, const real* depth, real* covs_2d,
+                                  const real* color, const real* opacity,
+                                  uint32_t* tiles_touched, uint32_t* point_offsets,
+                                  uint64_t* keys_unsorted, uint32_t* list_unsorted,
+                                  uint64_t* keys, uint32_t* list, uint32_t* ranges,
+                                  int64_t L_cap,
+                                  real* img, int32_t* radii, int use_focal,
+                                  real* final_T, uint32_t* n_contrib, uint8_t* ambig, real ambig_eps);
+
+/* app/main.cpp:266-308 in one call with clean semantics (intermediates zero-initialised).
+ * Returns num_rendered (or -1 on allocation failure).  img is CHW, 3*H*W. */
+int64_t orc_render(int P, int sh_deg, const real* pos, const real* scale, const real* rotq,
+                   const real* sh, const real* opacity,
+                   const orc_camera* cam, const real bg[3], real scale_modifier,
+                   real* img, int32_t* radii, real* final_T, uint32_t* n_contrib,
+                   uint8_t* ambig, real ambig_eps);
+
+/* app/main.cpp:323-335: CHW float -> HWC uint8 with vertical flip and truncating *255. */
+void orc_image_to_rgb8(int width, int height, const real* img_chw, uint8_t* rgb);
+
+/* ---- backward (build-defined) ---- */
+/* render-backward over the same sorted lists.  Outputs are accumulated into zero-initialised
+ * arrays: dL_dmean2d[2P] (pixel units), dL_dconic[3P], dL_dopacity[P], dL_dcolor[3P]. */
+void orc_render_backward(int width, int height, const real bg[3],
+                         const uint32_t* ranges, const uint32_t* point_list,
+                         const real* means_2d, const real* conic, const real* opacity, const real* color,
+                         const real* final_T, const uint32_t* n_contrib,
+                         const real* dL_dimg,
+                         real* dL_dmean2d, real* dL_dconic, real* dL_dopacity, real* dL_dcolor);
+
+/* preprocess-backward: 2-D grads -> dL/d{pos, scale, rotq, sh}.  dL_dopacity passes through. */
+void orc_preprocess_backward(int P, int sh_deg, const real* pos, const real* scale, const real* rotq,
+                             const real* sh, const orc_camera* cam, real scale_modifier,
+                             const int32_t* radii,
+                             const real* dL_dmean2d, const real* dL_dconic, const real* dL_dcolor,
+                             real* dL_dpos, real* dL_dscale, real* dL_drotq, real* dL_dsh);
+
+/* forward + backward for one view.  grads are overwritten. Returns num_rendered. */
+int64_t orc_render_backward_full(int P, int sh_deg, const real* pos, const real* scale, const real* rotq,
+                                 const real* sh, const real* opacity,
+                                 const orc_camera* cam, const real bg[3], real scale_modifier,
+                                 const real* dL_dimg, real* img,
+                                 real* dL_dpos, real* dL_dscale, real* dL_drotq, real* dL_dsh,
+                                 real* dL_dopacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,79 @@
+"""pytest configuration: the `gpu` marker and shared fixtures.
+
+`-m "not gpu"` runs here (no GPU): oracle vs golden vectors, host logic, ABI surface, gloo multi-process.
+`-m gpu` runs on an MI355X: parity of the HIP path against the oracle, through the C ABI.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device")
+
+
+def _has_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this environment")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import Oracle
+
+    return Oracle("f32")
+
+
+@pytest.fixture(scope="session")
+def oracle64():
+    from oracle import Oracle
+
+    return Oracle("f64")
+
+
+@pytest.fixture(scope="session")
+def lcgs():
+    import luisacomputegaussiansplatting_amd as L
+
+    if not os.path.exists(L.library_path()):
+        L.build_library()
+    L.load_library()
+    return L
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+def make_scene(rng, P, spread=0.6, center=(0.0, 0.0, 0.5), log_scale=(-3.8, 0.6)):
+    """Small random scene in the activated layout of read_gs_ply (tests only)."""
+    pos = (rng.normal(0, spread, (P, 3)) + np.asarray(center)).astype(np.float32)
+    scale = np.exp(rng.normal(log_scale[0], log_scale[1], (P, 3))).astype(np.float32)
+    rotq = rng.normal(size=(P, 4)).astype(np.float32)
+    rotq /= np.linalg.norm(rotq, axis=1, keepdims=True)
+    sh = rng.normal(0, 0.3, (P, 48)).astype(np.float32)
+    sh[:, :3] += 0.5
+    opacity = (1 / (1 + np.exp(-rng.normal(0, 2, P)))).astype(np.float32)
+    return {"pos": pos, "scale": scale, "rotq": rotq.astype(np.float32), "sh": sh, "opacity": opacity}

@@ -1,0 +1,125 @@
+"""`-m gpu`: the fused one-submission frame (lcgs_render_forward) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_scene
+from gpu_util import DEV, assert_image_parity, dev, upload_scene
+
+pytestmark = pytest.mark.gpu
+
+POSE = ([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1])
+
+
+def _render_both(lcgs, oracle, scene, W, H, bg=(0.1, 0.2, 0.3), pose=POSE, scale_modifier=1.0, check_lists=True):
+    P = scene["pos"].shape[0]
+    cam = lcgs.get_lookat_cam(*pose, width=W, height=H)
+    ocam = oracle.lookat(*pose, width=W, height=H)
+    r = lcgs.Renderer(lcgs.Context(0))
+    d = upload_scene(scene)
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    img = torch.full((3, H, W), -1.0, device=DEV)
+    radii = torch.full((P,), -7, dtype=torch.int32, device=DEV)
+    n = r.forward(cam, img, bg=bg, scale_modifier=scale_modifier, radii=radii, keep_state=False, sync=True)
+    orc = oracle.render(scene, ocam, bg=bg, scale_modifier=scale_modifier, ambig_eps=1e-5)
+    assert n == orc["num_rendered"]
+    if P:
+        assert np.array_equal(radii.cpu().numpy(), orc["radii"])
+    if n == 0:
+        assert (img == -1.0).all()  # image untouched, gs_tile_splatter/impl.cpp:109
+        return r, orc, None
+    st = r.frame_stats()
+    assert st["num_rendered"] == n and st["num_pairs"] == n
+    if check_lists:
+        # the per-tile lists are bit-identical to a stable sort on the reference's (tile<<32|depth) key
+        m, dd, c = oracle.project(scene["pos"], scene["scale"], scene["rotq"], ocam, scale_modifier=scale_modifier)
+        mp, conic, tiles, rad = oracle.allocate_tiles(W, H, dd, m, c)
+        offs = oracle.inclusive_sum(tiles)
+        k, v = oracle.copy_with_keys(W, H, mp, offs, rad, dd)
+        ks, vs = oracle.sort_pairs(k, v)
+        G = ((W + 15) // 16) * ((H + 15) // 16)
+        ranges = oracle.get_ranges(ks, G)
+        d_list = torch.zeros(n, dtype=torch.int32, device=DEV)
+        d_ranges = torch.zeros(2 * G, dtype=torch.int32, device=DEV)
+        r.last_lists(d_list, d_ranges)
+        assert st["num_visible"] == int((tiles > 0).sum())
+        assert np.array_equal(d_ranges.cpu().numpy().view(np.uint32).reshape(G, 2), ranges)
+        assert np.array_equal(d_list.cpu().numpy().view(np.uint32), vs)
+    stats = assert_image_parity(img.cpu().numpy(), orc)
+    return r, orc, stats
+
+
+@pytest.mark.parametrize("P,res", [(1, (64, 64)), (255, (64, 64)), (256, (100, 72)), (257, (333, 201)),
+                                   (30011, (800, 800)), (120000, (1920, 1080))])
+def test_fused_forward_matches_oracle(lcgs, oracle, P, res):
+    rng = np.random.default_rng(P)
+    scene = make_scene(rng, P, log_scale=(-4.2, 0.8))
+    if P > 1000:
+        scene["pos"][:100] = rng.normal(0, 0.3, (100, 3)) + POSE[0]
+        scene["scale"][100:110] *= 60.0
+    _render_both(lcgs, oracle, scene, res[0], res[1])
+
+
+def test_fused_equal_depth_ties_keep_index_order(lcgs, oracle):
+    """Duplicate splats (identical depth bits) must stay in splat-index order inside every tile."""
+    rng = np.random.default_rng(3)
+    scene = make_scene(rng, 2000, log_scale=(-3.5, 0.5))
+    for k in ("pos", "scale", "rotq"):
+        scene[k][1000:] = scene[k][:1000]  # geometry duplicated, colours/opacities differ
+    _render_both(lcgs, oracle, scene, 160, 120)
+
+
+def test_fused_all_culled_and_empty(lcgs, oracle):
+    rng = np.random.default_rng(9)
+    scene = make_scene(rng, 500)
+    scene["pos"][:] = np.array(POSE[0]) - 3.0 * (np.array(POSE[1]) - np.array(POSE[0]))
+    _render_both(lcgs, oracle, scene, 64, 48)
+    empty = {k: v[:0] for k, v in scene.items()}
+    r = lcgs.Renderer(lcgs.Context(0))
+    d = upload_scene(empty)
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    img = torch.full((3, 48, 64), -1.0, device=DEV)
+    assert r.forward(lcgs.get_lookat_cam(*POSE, width=64, height=48), img) == 0
+    assert (img == -1.0).all()
+
+
+def test_fused_scale_modifier_and_colmap_pose(lcgs, oracle):
+    rng = np.random.default_rng(12)
+    scene = make_scene(rng, 20000, log_scale=(-4.4, 0.8))
+    pose = ([-3, -0.5, 3.3], [0, 3, 0.5], [0, -1, -1])  # the garden pose of app/main.cpp:191-193
+    _render_both(lcgs, oracle, scene, 640, 360, bg=(0, 0, 0), pose=pose, scale_modifier=0.7)
+
+
+def test_fused_pair_buffer_growth(lcgs, oracle):
+    """Pairs beyond the workspace capacity: the frame is redone with larger buffers (the reference has a
+    fixed 20M-pair buffer and no check, app/main.cpp:245)."""
+    rng = np.random.default_rng(13)
+    scene = make_scene(rng, 3000, log_scale=(-2.0, 0.3))  # big splats: L >> 4 * P
+    _, orc, _ = _render_both(lcgs, oracle, scene, 1920, 1080)
+    assert orc["num_rendered"] > (1 << 22)
+
+
+def test_fused_is_deterministic_and_reentrant(lcgs, oracle):
+    rng = np.random.default_rng(14)
+    scene = make_scene(rng, 50000, log_scale=(-4.2, 0.8))
+    r = lcgs.Renderer(lcgs.Context(0))
+    d = upload_scene(scene)
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    imgs = []
+    for k in range(4):
+        ang = 0.3 * (k % 2)
+        cam = lcgs.get_lookat_cam([-3 * np.cos(ang), -0.5 + 3 * np.sin(ang), 2.3], [0, 0, 0.5], [0, 0, 1], width=640,
+                                  height=480)
+        img = torch.zeros(3, 480, 640, device=DEV)
+        r.forward(cam, img, sync=(k < 2))
+        imgs.append(img)
+    r.ctx.synchronize()
+    assert torch.equal(imgs[0], imgs[2]) and torch.equal(imgs[1], imgs[3])
+    assert not torch.equal(imgs[0], imgs[1])
+
+
+def test_synth_stand_in_scenes(lcgs, oracle):
+    """BASELINE config 2 stand-in (chair-like, 300k splats, 800x800) -- whole-image parity."""
+    scene = lcgs.synth_scene(0, 1002, 300000)
+    _, orc, stats = _render_both(lcgs, oracle, scene, 800, 800, bg=(0, 0, 0), check_lists=True)
+    assert orc["num_rendered"] > 1_000_000

@@ -1,0 +1,181 @@
+"""`-m gpu`: each stage-level C-ABI entry point (one per reference operator method) against the oracle.
+Per-splat stages and all integer work are compared BIT FOR BIT; images within 1e-4 L-inf."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_scene
+from gpu_util import DEV, assert_image_parity, dev
+
+pytestmark = pytest.mark.gpu
+
+POSE = ([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1])
+
+
+@pytest.fixture(scope="module")
+def ops(lcgs):
+    ctx = lcgs.Context(0)
+    sh, pr, ts = lcgs.SHProcessor(), lcgs.GSProjector(), lcgs.GSTileSplatter()
+    sh.create(ctx)
+    pr.create(ctx)
+    ts.create(ctx)
+    return ctx, sh, pr, ts
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_processor(lcgs, oracle, ops, deg):
+    ctx, sh, _, _ = ops
+    rng = np.random.default_rng(deg)
+    P = 100003
+    scene = make_scene(rng, P)
+    feat = (deg + 1) ** 2 * 3
+    cam = lcgs.get_lookat_cam(*POSE, width=800, height=800)
+    d_color = torch.zeros(P, 3, device=DEV)
+    shs = np.ascontiguousarray(scene["sh"][:, :feat])
+    sh.process(lcgs.GPUPointsProxy(P, 3, dev(scene["pos"])), cam, dev(shs), d_color, 3, deg)
+    ctx.synchronize()
+    expect = oracle.sh_process(np.array(cam.position, np.float32), scene["pos"], shs, deg=deg)
+    assert np.array_equal(d_color.cpu().numpy(), expect)
+
+
+@pytest.mark.parametrize("use_focal", [True, False])
+def test_projector(lcgs, oracle, ops, use_focal):
+    ctx, _, pr, _ = ops
+    rng = np.random.default_rng(5)
+    P = 70001
+    scene = make_scene(rng, P, spread=1.5, log_scale=(-4.0, 1.0))
+    scene["pos"][:300] = rng.normal(0, 0.4, (300, 3)) + POSE[0]
+    cam = lcgs.get_lookat_cam(*POSE, width=1920, height=1080)
+    ocam = oracle.lookat(*POSE, width=1920, height=1080)
+    # sentinel-filled outputs: culled splats must stay untouched (gs_projector/shader.cpp:121)
+    means = torch.full((P, 2), 7.0, device=DEV)
+    covs = torch.full((P, 3), 5.0, device=DEV)
+    depth = torch.full((P,), 9.0, device=DEV)
+    pr.forward(lcgs.GSProjectorInputProxy(P, dev(scene["pos"]), dev(scene["scale"]), dev(scene["rotq"]), 1.5),
+               lcgs.GSProjectorOutputProxy(means, covs, depth), cam, use_focal)
+    ctx.synchronize()
+    init = (np.full((P, 2), 7, np.float32), np.full(P, 9, np.float32), np.full((P, 3), 5, np.float32))
+    m, d, c = oracle.project(scene["pos"], scene["scale"], scene["rotq"], ocam, scale_modifier=1.5,
+                             use_focal=use_focal, init=init)
+    assert (d == 9).any() and (d != 9).any()
+    assert np.array_equal(means.cpu().numpy(), m)
+    assert np.array_equal(depth.cpu().numpy(), d)
+    assert np.array_equal(covs.cpu().numpy(), c)
+
+
+def _tile_splat(lcgs, oracle, ops, scene, W, H, bg, use_focal=True, cap_slack=1.0):
+    ctx, sh, pr, ts = ops
+    P = scene["pos"].shape[0]
+    cam = lcgs.get_lookat_cam(*POSE, width=W, height=H)
+    ocam = oracle.lookat(*POSE, width=W, height=H)
+    d = {k: dev(v) for k, v in scene.items()}
+    color = torch.zeros(P, 3, device=DEV)
+    means = torch.zeros(P, 2, device=DEV)
+    covs = torch.zeros(P, 3, device=DEV)
+    depth = torch.zeros(P, device=DEV)
+    sh.process(lcgs.GPUPointsProxy(P, 3, d["pos"]), cam, d["sh"], color, 3, 3)
+    pr.forward(lcgs.GSProjectorInputProxy(P, d["pos"], d["scale"], d["rotq"], 1.0),
+               lcgs.GSProjectorOutputProxy(means, covs, depth), cam, use_focal)
+    # oracle side
+    o_color = oracle.sh_process(np.array(cam.position, np.float32), scene["pos"], scene["sh"])
+    m, dd, c = oracle.project(scene["pos"], scene["scale"], scene["rotq"], ocam, use_focal=use_focal)
+    mp, conic, tiles, radii = oracle.allocate_tiles(W, H, dd, m, c, use_focal=use_focal)
+    offs = oracle.inclusive_sum(tiles)
+    keys, vals = oracle.copy_with_keys(W, H, mp, offs, radii, dd)
+    ks, vs = oracle.sort_pairs(keys, vals)
+    G = ((W + 15) // 16) * ((H + 15) // 16)
+    ranges = oracle.get_ranges(ks, G)
+    img, fT, nc, amb = oracle.render_forward(W, H, bg, ranges, vs, mp, conic, scene["opacity"], o_color, ambig_eps=1e-5)
+    L = int(offs[-1]) if P else 0
+    cap = max(1, int(L * cap_slack) + 7)
+    i64 = lambda n: torch.zeros(n, dtype=torch.int64, device=DEV)
+    i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=DEV)
+    accel = lcgs.GSTileSplatterAccelProxy(i32(P), i32(P), i64(cap), i32(cap), i64(cap), i32(cap), i32(2 * G))
+    target = torch.full((3, H, W), -1.0, device=DEV)
+    out = lcgs.GSSplatForwardOutputProxy(H, W, target, i32(P), torch.zeros(H, W, device=DEV), i32(H * W))
+    inp = lcgs.GSTileSplatterInputProxy(P, tuple(bg), means, depth, covs, color, d["opacity"])
+    n = ts.forward(accel, inp, out, use_focal)
+    ctx.synchronize()
+    assert n == L and ts.num_rendered == L
+    u32 = lambda t: t.cpu().numpy().view(np.uint32)
+    assert np.array_equal(u32(accel.tiles_touched), tiles)
+    assert np.array_equal(u32(accel.point_offsets), offs)
+    assert np.array_equal(out.radii.cpu().numpy(), radii)
+    vis = dd >= np.float32(0.2)
+    assert np.array_equal(means.cpu().numpy()[vis], mp[vis])   # NDC -> pixel, in place
+    assert np.array_equal(covs.cpu().numpy()[vis], conic[vis])  # cov -> conic, in place
+    if L > 0:
+        assert np.array_equal(accel.point_list_keys_unsorted.cpu().numpy().view(np.uint64)[:L], keys)
+        assert np.array_equal(u32(accel.point_list_unsorted)[:L], vals)
+        assert np.array_equal(accel.point_list_keys.cpu().numpy().view(np.uint64)[:L], ks)
+        assert np.array_equal(u32(accel.point_list)[:L], vs)
+        assert np.array_equal(u32(accel.ranges).reshape(G, 2), ranges)
+        assert_image_parity(target.cpu().numpy(), {"img": img, "ambig": amb})
+        assert np.array_equal(u32(out.n_contrib).reshape(H, W)[amb == 0], nc[amb == 0])
+        assert np.allclose(out.final_T.cpu().numpy()[amb == 0], fT[amb == 0], atol=1e-5)
+    else:
+        assert (target == -1.0).all()  # image untouched (impl.cpp:109)
+    return L
+
+
+@pytest.mark.parametrize("res", [(800, 800), (100, 72), (333, 201), (16, 16)])
+def test_tile_splatter_chain(lcgs, oracle, ops, res):
+    rng = np.random.default_rng(res[0])
+    scene = make_scene(rng, 30011, log_scale=(-4.2, 0.8))
+    scene["pos"][:100] = rng.normal(0, 0.3, (100, 3)) + POSE[0]
+    scene["scale"][100:110] *= 60.0  # rects that cover the whole grid
+    L = _tile_splat(lcgs, oracle, ops, scene, res[0], res[1], (0.1, 0.2, 0.3))
+    assert L > 0 or res == (16, 16)
+
+
+def test_tile_splatter_nonfocal(lcgs, oracle, ops):
+    rng = np.random.default_rng(77)
+    scene = make_scene(rng, 5000, log_scale=(-4.0, 0.7))
+    _tile_splat(lcgs, oracle, ops, scene, 320, 240, (0, 0, 0), use_focal=False)
+
+
+def test_tile_splatter_all_culled_and_capacity(lcgs, oracle, ops):
+    rng = np.random.default_rng(8)
+    scene = make_scene(rng, 1000)
+    scene["pos"][:, :] = np.array(POSE[0]) - 3.0 * (np.array(POSE[1]) - np.array(POSE[0]))  # behind the camera
+    assert _tile_splat(lcgs, oracle, ops, scene, 64, 64, (0.5, 0.5, 0.5)) == 0
+    scene = make_scene(rng, 4000)
+    with pytest.raises(lcgs.LcgsError) as e:
+        _tile_splat(lcgs, oracle, ops, scene, 256, 256, (0, 0, 0), cap_slack=0.5)
+    assert e.value.status == 5  # LCGS_ERR_CAPACITY (the reference silently overruns, app/main.cpp:245)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 1024, 1025, 4097, 1_000_003])
+def test_inclusive_sum(lcgs, oracle, ops, n):
+    ctx = ops[0]
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 50, n).astype(np.uint32)
+    if n > 10:
+        x[3] = 2**31  # u32 wrap-around
+        x[7] = 2**31
+    d_in = dev(x.view(np.int32)) if n else torch.zeros(0, dtype=torch.int32, device=DEV)
+    d_out = torch.zeros(n, dtype=torch.int32, device=DEV)
+    ctx.inclusive_sum(d_in, d_out, n)
+    ctx.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint32), oracle.inclusive_sum(x))
+
+
+@pytest.mark.parametrize("n,bits", [(0, 64), (1, 64), (4095, 64), (4096, 64), (4097, 45), (300_007, 45), (2_000_003, 64),
+                                    (100_000, 13), (100_000, 8), (100_000, 1)])
+def test_sort_pairs(lcgs, oracle, ops, n, bits):
+    ctx = ops[0]
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, 2**63, n, dtype=np.uint64)
+    if bits < 64:
+        keys &= np.uint64((1 << bits) - 1)
+    if n > 100:
+        keys[: n // 3] = keys[n // 3: 2 * (n // 3)]  # duplicates: stability matters
+    vals = np.arange(n, dtype=np.uint32)
+    dk, dv = dev(keys.view(np.int64)), dev(vals.view(np.int32))
+    ok, ov = torch.zeros(n, dtype=torch.int64, device=DEV), torch.zeros(n, dtype=torch.int32, device=DEV)
+    ctx.sort_pairs(dk, ok, dv, ov, n, 0, bits)
+    ctx.synchronize()
+    ks, vs = oracle.sort_pairs(keys, vals)
+    assert np.array_equal(ok.cpu().numpy().view(np.uint64), ks)
+    assert np.array_equal(ov.cpu().numpy().view(np.uint32), vs)
+    assert np.array_equal(dk.cpu().numpy().view(np.uint64), keys), "inputs must be preserved"
