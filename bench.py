@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- forward fps @1080p on the mip360_bicycle stand-in (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one view: the fused forward frame (SH colour -> projection ->
+tile keys -> sort -> per-tile compositing) of a 6,131,954-splat scene at 1920x1080, scene resident in HBM.
+With N > 1 every rank renders its own view of the (replicated) scene -- the path shards across views with no
+data-path collective (weak scaling); `value` = frames all ranks rendered / max-over-ranks time.
+
+The real mip360_bicycle_30000.ply is a GitHub release asset of the reference and is not available offline;
+the workload is the deterministic synthetic stand-in `synth_unbounded` (seed 2001) with the same splat count
+unless --ply points at the real file.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+P_BICYCLE = 6_131_954
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def view_pose(k: int):
+    """C5 views: the lego/bicycle pose of app/main.cpp:195-197 rotated about world-up (colmap: (0,-1,0)) by k*45 deg."""
+    pos = np.array([-3.0, -0.5, 2.3])
+    tgt = np.array([0.0, 0.0, 0.5])
+    up = np.array([0.0, -1.0, 0.0])
+    a = math.radians(45.0 * k)
+    c, s = math.cos(a), math.sin(a)
+    # rotation about the y axis (world-up is -y)
+    R = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    return (R @ pos).tolist(), (R @ tgt).tolist(), up.tolist()
+
+
+def algorithmic_bytes(P, V, L, G, W, H):
+    """Per-frame algorithmic HBM bytes, SURVEY 8(d) / BASELINE.md 3 (n = radix passes over the live key bits)."""
+    b = 32 + max(1, math.ceil(math.log2(max(G, 2))))
+    n = math.ceil(b / 8)
+    return (236 * P + 48 * V + 8 * P + (8 * P + 12 * L) + (8 + 24 * n) * L + (8 * L + 8 * G) + 40 * L + 12 * W * H)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--splats", type=int, default=P_BICYCLE)
+    ap.add_argument("--res", type=str, default="1920x1080")
+    ap.add_argument("--ply", type=str, default=os.environ.get("LCGS_BICYCLE_PLY", ""))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import luisacomputegaussiansplatting_amd as L
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        # launched without torchrun: start the N ranks as children and exit with their code
+        import subprocess
+
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"), __file__] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: liblcgs_hip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    W, H = (int(x) for x in args.res.lower().split("x"))
+    dev = torch.device("cuda", local_rank)
+
+    # ---- scene (replicated on every GPU)
+    data = "synthetic"
+    if args.ply and os.path.exists(args.ply):
+        scene = L.read_gs_ply(args.ply)
+        scene.pop("sh_degree", None)
+        workload = os.path.basename(args.ply)
+        data = "real"
+    else:
+        scene = L.synth_scene(1, 2001, args.splats)
+        workload = f"mip360_bicycle stand-in: synth_unbounded(seed=2001, P={args.splats})"
+    P = scene["pos"].shape[0]
+    d = {k: torch.from_numpy(scene[k]).to(dev) for k in ("pos", "scale", "rotq", "sh", "opacity")}
+    ctx = L.Context(local_rank, torch.cuda.current_stream(dev).cuda_stream)
+    r = L.Renderer(ctx)
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    cam = L.get_lookat_cam(*view_pose(rank), width=W, height=H)
+    img = torch.zeros(3, H, W, device=dev)
+
+    # first frame synchronises: sizes the pair buffers for this view
+    n_rendered = r.forward(cam, img, sync=True)
+    stats = r.frame_stats()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        r.forward(cam, img, sync=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r.forward(cam, img, sync=False)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * args.steps / elapsed
+
+    # ---- per-stage device times (HIP events on the context's stream), outside the timed region
+    r.set_profiling(True)
+    acc = {}
+    reps = 10
+    for _ in range(reps):
+        r.forward(cam, img, sync=True)
+        for k, v in r.stage_times().items():
+            acc[k] = acc.get(k, 0.0) + v / reps
+    r.set_profiling(False)
+    V, Lp, G = stats["num_visible"], stats["num_rendered"], stats["num_tiles"]
+    dominant = max(acc, key=acc.get) if acc else "render"
+    stage_bytes = {
+        # algorithmic bytes per launch of each stage (DESIGN.md "Kernels"): per-unit figure x units
+        "preprocess": 12 * P + 224 * V + 4 * P + 48 * V + 12 * V,
+        "depth_sort": 4 * (4 + 8 + 8) * V,
+        "expand": (4 + 8) * V + 12 * V + 8 * Lp,
+        "tile_sort": 2 * (4 + 8 + 8) * Lp,
+        "ranges": 4 * Lp + 8 * G,
+        "render": 40 * Lp + 12 * W * H,
+    }
+    dom_ms = acc.get(dominant, float("nan"))
+    achieved = stage_bytes.get(dominant, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": stage_bytes.get(dominant, 0), "avg_launch_ms": round(dom_ms, 4)}
+    frame_bytes = algorithmic_bytes(P, V, Lp, G, W, H)
+    frame_gbs = frame_bytes / (ms_per_step * 1e-3) / 1e9
+
+    out = {
+        "metric": "forward fps @1080p, mip360_bicycle", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": data,
+        "config": {"workload": workload, "resolution": f"{W}x{H}", "splats": P, "visible_splats": V,
+                   "tile_pairs": Lp, "views_per_gpu": 1, "parallelism": f"view-parallel x{world}"},
+        "roofline": roofline,
+        "frame_roofline": {"algorithmic_bytes": frame_bytes, "achieved": round(frame_gbs, 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(frame_gbs / HBM_PEAK_GBS, 4)},
+        "stages_ms": {k: round(v, 4) for k, v in acc.items()},
+    }
+
+    # ---- CPU baseline: the oracle (CPU restatement of the reference) on this box's host cores, rank 0, N = 1 only
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import Oracle
+
+        o = Oracle("f32")
+        o.set_threads(0)
+        ocam = o.lookat(*view_pose(0), width=W, height=H)
+        t0 = time.perf_counter()
+        frames = 0
+        while True:
+            ref = o.render(scene, ocam)
+            frames += 1
+            el = time.perf_counter() - t0
+            if el > 12.0 or frames >= 8:
+                break
+        out["cpu_baseline"] = {"value": round(frames / el, 4), "unit": "frames/s", "cores": o.get_threads(), "kind": "port",
+                               "sample": f"{frames} full frame(s) of the same workload ({P} splats, {W}x{H}) in {el:.1f} s"}
+        gi = img.cpu().numpy()
+        diff = np.abs(gi - ref["img"]).max(axis=0)
+        out["parity"] = {"num_rendered_equal": bool(ref["num_rendered"] == n_rendered),
+                         "pixels_over_1e-4": int((diff > 1e-4).sum()), "max_abs_diff": float(diff.max())}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -94,7 +94,7 @@ def test_fused_pair_buffer_growth(lcgs, oracle):
     """Pairs beyond the workspace capacity: the frame is redone with larger buffers (the reference has a
     fixed 20M-pair buffer and no check, app/main.cpp:245)."""
     rng = np.random.default_rng(13)
-    scene = make_scene(rng, 3000, log_scale=(-2.0, 0.3))  # big splats: L >> 4 * P
+    scene = make_scene(rng, 6000, log_scale=(-1.0, 0.2))  # big splats: L >> max(4 * P, 2^22)
     _, orc, _ = _render_both(lcgs, oracle, scene, 1920, 1080)
     assert orc["num_rendered"] > (1 << 22)
 
