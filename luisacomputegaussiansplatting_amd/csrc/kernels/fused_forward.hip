@@ -6,11 +6,12 @@
 // all L (tile,splat) pairs and five stream synchronisations.  What this file does instead, with
 // bit-identical per-tile lists:
 //
-//   k_fused_preprocess   one pass over the splats: view transform, near cull, covariance projection,
-//                        conic/radius/rect, and -- only for splats that touch >= 1 tile -- the 192-byte
-//                        SH fetch and colour.  Survivors are compacted IN INDEX ORDER into dense 48-byte
-//                        records through a single-pass chained scan (decoupled look-back across
-//                        workgroups, 8-byte self-validating status words).
+//   k_cull_compact       one pass over ALL splats: view transform, near cull, covariance projection,
+//                        conic/radius/rect and the exact opacity-aware pruning of the rect; the indices of
+//                        the survivors are compacted IN INDEX ORDER through a single-pass chained scan
+//                        (decoupled look-back across workgroups, 8-byte self-validating status words).
+//   k_build_records      one DENSE pass over the V survivors: 192-byte SH fetch + colour (the dominant
+//                        stream, paid only for splats that reach the screen) -> packed 48-byte records.
 //   depth sort           32-bit radix sort of the V survivors by depth bits (radix_sort.hip) -- the low
 //                        32 bits of the reference's 64-bit key, sorted BEFORE duplication, on V ~ L/5 items.
 //   k_gather_tiles + scan   per-splat tile counts in depth order -> pair offsets.
@@ -69,81 +70,124 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t& total)
     return inc - v;
 }
 
-// scan_state: [0] ticket counter (u32 in the low half), [1] error flag, [2..] per-workgroup status words
+// Everything the projector + allocate_tiles compute for one splat (gs_projector/shader.cpp:107-137,
+// gs_tile_splatter/shader.cpp:117-157), plus the pruned rect of gs_math.hpp tight_rect.
+struct Projected {
+    bool     visible;   // emits >= 1 pair after pruning
+    int32_t  radius;    // reference radius (0 if near-culled)
+    uint32_t ref_tiles; // reference tiles_touched
+    float    pix_x, pix_y, depth, conic[3];
+    uint32_t rmin[2], rw, rh; // pruned rect: origin + size in tiles
+};
+
+__device__ __forceinline__ Projected project_splat(const CamParams& cp, float scale_modifier, int idx,
+                                                   float px, float py, float pz, const float* __restrict__ scale,
+                                                   const float* __restrict__ rotq, const float* __restrict__ opacity)
+{
+    Projected r;
+    r.visible   = false;
+    r.radius    = 0;
+    r.ref_tiles = 0;
+    r.pix_x = r.pix_y = r.depth = 0.0f;
+    r.conic[0] = r.conic[1] = r.conic[2] = 0.0f;
+    r.rmin[0] = r.rmin[1] = r.rw = r.rh = 0;
+    float v[3], ndc[2];
+    view_transform(cp, px, py, pz, v);
+    if (v[2] < 0.2f) return r; // gs_projector/shader.cpp:121
+    ndc_from_view(cp, v, ndc);
+    r.depth    = v[2];
+    float s[3] = { scale_modifier * scale[3 * (size_t)idx + 0], scale_modifier * scale[3 * (size_t)idx + 1],
+                   scale_modifier * scale[3 * (size_t)idx + 2] };
+    const float4 q = *reinterpret_cast<const float4*>(rotq + 4 * (size_t)idx); // stored (r,x,y,z)
+    float        Sig[3][3], t[3], cov2d[3], filt[3];
+    cov3d_from_scale_rot(s, q.y, q.z, q.w, q.x, Sig);
+    cam_clamp(cp, v, t);
+    ewa_cov2d(cp, Sig, t, true, cov2d);
+    conic_and_radius(cov2d[0], cov2d[1], cov2d[2], true, cp.width, cp.height, r.conic, r.radius, filt);
+    r.pix_x = ndc2pix(ndc[0], cp.width);
+    r.pix_y = ndc2pix(ndc[1], cp.height);
+    uint32_t fmin[2], fmax[2], tmin[2], tmax[2];
+    get_rect(r.pix_x, r.pix_y, r.radius, cp.grid_x, cp.grid_y, fmin, fmax);
+    r.ref_tiles = (fmax[0] - fmin[0]) * (fmax[1] - fmin[1]);
+    if (r.radius <= 0) r.ref_tiles = 0; // radius <= 0 never emits pairs (gs_tile_splatter/shader.cpp:41-42)
+    if (r.ref_tiles == 0) return r;
+    tight_rect(r.pix_x, r.pix_y, filt[0], filt[1], filt[2], opacity[idx], fmin, fmax, tmin, tmax);
+    r.rmin[0] = tmin[0];
+    r.rmin[1] = tmin[1];
+    r.rw      = tmax[0] - tmin[0];
+    r.rh      = tmax[1] - tmin[1];
+    r.visible = r.rw * r.rh > 0u;
+    return r;
+}
+
+// Pass A over ALL splats: project, cull, and compact the survivors' indices IN INDEX ORDER through a
+// single-pass chained scan (decoupled look-back across workgroups).  Reads 12 B per splat, +32 B for the
+// ones in front of the near plane; writes radii (4 B/splat) and 12 B per survivor.
+// A workgroup owns a chunk of kCullItems x 256 consecutive splats (lane t takes splats t, t+256, ... of the
+// chunk: coalesced) and takes ONE ticket per chunk -- tickets are handed out in start order, so every
+// predecessor a workgroup waits on is already running, whatever the dispatch order or XCD placement; one
+// returning atomic per 2048 splats keeps the single ticket word far below its ~88 ops/us saturation.
+// scan_state: [0] ticket counter (u32 in the low half), [1] error flag, [2..] per-chunk status words
+constexpr int kCullItems = 8;
+constexpr int kCullChunk = kThreads * kCullItems;
+
 __global__ void __launch_bounds__(kThreads)
-k_fused_preprocess(int P, int sh_deg, CamParams cp, float scale_modifier, const float* __restrict__ pos,
-                   const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ sh,
-                   const float* __restrict__ opacity, int32_t* __restrict__ radii, SplatRecord* __restrict__ recs,
-                   uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals,
-                   uint32_t* __restrict__ vis_index, uint64_t* __restrict__ scan_state,
-                   uint32_t* __restrict__ d_counts)
+k_cull_compact(int P, CamParams cp, float scale_modifier, const float* __restrict__ pos,
+               const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ opacity,
+               int32_t* __restrict__ radii, uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals,
+               uint32_t* __restrict__ vis_index, uint64_t* __restrict__ scan_state, uint32_t* __restrict__ d_counts)
 {
     __shared__ uint32_t s_ticket;
-    __shared__ uint32_t s_wave_vis[4], s_wave_tiles[4];
-    __shared__ uint32_t s_prefix_vis, s_prefix_tiles;
+    __shared__ uint32_t s_wave_vis[kCullItems][4];
+    __shared__ uint32_t s_wave_tiles[4];
+    __shared__ uint32_t s_prefix_vis;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ticket = atomicAdd(reinterpret_cast<uint32_t*>(scan_state), 1u);
     __syncthreads();
-    const uint32_t bid     = s_ticket; // tickets are handed out in start order: every predecessor is running
-    const uint32_t nblocks = gridDim.x;
+    const uint32_t bid     = s_ticket;
+    const uint32_t nchunks = gridDim.x;
     uint64_t*      states  = scan_state + 2;
-    const int      idx     = (int)(bid * kThreads + tid);
+    const int64_t  base    = (int64_t)bid * kCullChunk;
 
-    // ---- per-splat projection (gs_projector/shader.cpp:107-137, gs_tile_splatter/shader.cpp:117-157)
-    bool     visible = false;
-    uint32_t tiles   = 0;
-    int32_t  radius  = 0;
-    float    pix_x = 0, pix_y = 0, depth = 0, conic[3] = { 0, 0, 0 };
-    float    px = 0, py = 0, pz = 0;
-    uint32_t rmin[2] = { 0, 0 }, rmax[2] = { 0, 0 };
-    if (idx < P) {
-        px = pos[3 * (size_t)idx + 0];
-        py = pos[3 * (size_t)idx + 1];
-        pz = pos[3 * (size_t)idx + 2];
-        float v[3], ndc[2];
-        view_transform(cp, px, py, pz, v);
-        if (!(v[2] < 0.2f)) {
-            ndc_from_view(cp, v, ndc);
-            depth      = v[2];
-            float s[3] = { scale_modifier * scale[3 * (size_t)idx + 0], scale_modifier * scale[3 * (size_t)idx + 1],
-                           scale_modifier * scale[3 * (size_t)idx + 2] };
-            const float4 q = *reinterpret_cast<const float4*>(rotq + 4 * (size_t)idx); // (r,x,y,z)
-            float        Sig[3][3], t[3], cov2d[3];
-            cov3d_from_scale_rot(s, q.y, q.z, q.w, q.x, Sig);
-            cam_clamp(cp, v, t);
-            ewa_cov2d(cp, Sig, t, true, cov2d);
-            conic_and_radius(cov2d[0], cov2d[1], cov2d[2], true, cp.width, cp.height, conic, radius);
-            pix_x = ndc2pix(ndc[0], cp.width);
-            pix_y = ndc2pix(ndc[1], cp.height);
-            get_rect(pix_x, pix_y, radius, cp.grid_x, cp.grid_y, rmin, rmax);
-            tiles   = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
-            // radius <= 0 never emits pairs (gs_tile_splatter/shader.cpp:41-42)
-            if (radius <= 0) tiles = 0;
-            visible = tiles > 0u;
-        }
-        if (radii) radii[idx] = radius;
-    }
-
-    // ---- block-local exclusive scan of (visible, tiles)
-    uint32_t wv_total, wt_total;
-    const uint32_t lv = wave_excl_scan(visible ? 1u : 0u, wv_total);
-    const uint32_t lt = wave_excl_scan(tiles, wt_total);
-    if (lane == 0) {
-        s_wave_vis[wave]   = wv_total;
-        s_wave_tiles[wave] = wt_total;
-    }
-    __syncthreads();
-    uint32_t bv = 0, bt = 0, cv = 0, ct = 0;
+    uint32_t vis_mask = 0;        // bit k: splat k of this lane survives
+    uint32_t lv[kCullItems];      // exclusive rank of the survivor inside its wave, per round
+    float    depth[kCullItems];
+    uint32_t tiles_sum = 0;       // reference tiles_touched (for num_rendered)
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        if (w < wave) {
-            cv += s_wave_vis[w];
-            ct += s_wave_tiles[w];
+    for (int k = 0; k < kCullItems; ++k) {
+        const int64_t idx = base + (int64_t)k * kThreads + tid;
+        bool          visible = false;
+        depth[k]              = 0.0f;
+        if (idx < P) {
+            const Projected pr = project_splat(cp, scale_modifier, (int)idx, pos[3 * (size_t)idx + 0],
+                                               pos[3 * (size_t)idx + 1], pos[3 * (size_t)idx + 2], scale, rotq, opacity);
+            visible  = pr.visible;
+            depth[k] = pr.depth;
+            tiles_sum += pr.ref_tiles;
+            if (radii) radii[idx] = pr.radius;
         }
-        bv += s_wave_vis[w];
-        bt += s_wave_tiles[w];
+        const unsigned long long m = __ballot(visible);
+        lv[k] = __popcll(m & ((1ull << lane) - 1ull));
+        if (visible) vis_mask |= 1u << k;
+        if (lane == 0) s_wave_vis[k][wave] = __popcll(m);
     }
+    uint32_t wt_total;
+    (void)wave_excl_scan(tiles_sum, wt_total);
+    if (lane == 0) s_wave_tiles[wave] = wt_total;
+    __syncthreads();
+    // index order inside the chunk: round k first, then wave, then lane
+    uint32_t bv = 0, bt = 0, my_base[kCullItems];
+#pragma unroll
+    for (int k = 0; k < kCullItems; ++k) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w == wave) my_base[k] = bv;
+            bv += s_wave_vis[k][w];
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) bt += s_wave_tiles[w];
 
     // ---- chained scan across workgroups (decoupled look-back), done by wave 0
     if (wave == 0) {
@@ -152,8 +196,8 @@ k_fused_preprocess(int P, int sh_deg, CamParams cp, float scale_modifier, const 
             if (lane == 0) state_store(&states[0], pack_state(kStatusInclusive, bv, bt));
         } else {
             if (lane == 0) state_store(&states[bid], pack_state(kStatusAggregate, bv, bt));
-            int64_t look = (int64_t)bid - 1;
-            bool    found = false;
+            int64_t  look  = (int64_t)bid - 1;
+            bool     found = false;
             uint32_t spins = 0;
             while (!found) {
                 const int64_t j = look - lane;
@@ -187,41 +231,94 @@ k_fused_preprocess(int P, int sh_deg, CamParams cp, float scale_modifier, const 
             if (lane == 0) state_store(&states[bid], pack_state(kStatusInclusive, ex_v + bv, ex_t + bt));
         }
         if (lane == 0) {
-            s_prefix_vis   = ex_v;
-            s_prefix_tiles = ex_t;
-            if (bid == nblocks - 1) {
-                d_counts[0] = ex_v + bv; // V: splats that touch >= 1 tile
+            s_prefix_vis = ex_v;
+            if (bid == nchunks - 1) {
+                d_counts[0] = ex_v + bv; // V: splats that emit >= 1 pair
                 d_counts[1] = ex_t + bt; // the reference's num_rendered (gs_tile_splatter/impl.cpp:106)
             }
         }
     }
     __syncthreads();
 
-    if (!visible) return;
-    const uint32_t vid = s_prefix_vis + cv + lv;
+    const uint32_t prefix = s_prefix_vis;
+#pragma unroll
+    for (int k = 0; k < kCullItems; ++k) {
+        if (!((vis_mask >> k) & 1u)) continue;
+        const uint32_t vid = prefix + my_base[k] + lv[k];
+        sort_keys[vid]     = __float_as_uint(depth[k]);
+        sort_vals[vid]     = vid;
+        vis_index[vid]     = (uint32_t)(base + (int64_t)k * kThreads + tid);
+    }
+}
 
-    // ---- colour: only survivors pay for the 192-byte SH fetch (sh_preprocessor.cpp:27-157)
-    const int    feat_dim = (sh_deg + 1) * (sh_deg + 1);
-    const float* s        = sh + (size_t)idx * feat_dim * 3;
-    float        raw[3];
-    if (sh_deg == 3 && ((reinterpret_cast<uintptr_t>(s) & 15) == 0)) {
+// Pass B over the V survivors only (dense: every lane does useful work): re-project (40 B), evaluate the SH
+// colour (192 B -- the dominant stream, read only for splats that reach the screen) and write the packed
+// 48-byte record the expander and the renderer gather.
+// The SH block of a splat is 192 contiguous bytes; a lane-per-splat float4 walk would touch 64 different
+// cache lines per wave instruction.  Instead the wave loads its 64 splats' 768 float4 chunks cooperatively --
+// 12 consecutive lanes cover one splat's 192 B, so an instruction touches ~8 lines -- parks them in LDS with a
+// 13-float4 row pitch (208 B: conflict-free for the per-lane ds_read_b128 that follows) and each lane then
+// reads its own 48 coefficients back.
+__global__ void __launch_bounds__(kThreads)
+k_build_records(int sh_deg, CamParams cp, float scale_modifier, const float* __restrict__ pos,
+                const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ sh,
+                const float* __restrict__ opacity, const uint32_t* __restrict__ vis_index,
+                const uint32_t* __restrict__ d_counts, SplatRecord* __restrict__ recs)
+{
+    __shared__ float4 s_sh[kThreads / 64][64 * 13];
+
+    const uint32_t V = d_counts[0];
+    if (blockIdx.x * kThreads >= V) return;
+    const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t vid   = blockIdx.x * kThreads + threadIdx.x;
+    const bool     valid = vid < V;
+    const int      idx   = (int)vis_index[valid ? vid : V - 1];
+    const bool     staged = sh_deg == 3 && ((reinterpret_cast<uintptr_t>(sh) & 15) == 0);
+
+    if (staged) {
+        const uint32_t wave_first = blockIdx.x * kThreads + wave * 64;
+        const uint32_t nvalid     = wave_first < V ? ((V - wave_first) < 64u ? (V - wave_first) : 64u) : 0u;
+        float4         q[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const uint32_t c    = (uint32_t)i * 64u + lane;
+            const uint32_t slot = c / 12u, part = c - slot * 12u;
+            const int      sidx = __shfl(idx, (int)slot, 64);
+            q[i]                = make_float4(0, 0, 0, 0);
+            if (slot < nvalid) q[i] = reinterpret_cast<const float4*>(sh + (size_t)sidx * 48)[part];
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const uint32_t c    = (uint32_t)i * 64u + lane;
+            const uint32_t slot = c / 12u, part = c - slot * 12u;
+            s_sh[wave][slot * 13u + part] = q[i];
+        }
+    }
+    __syncthreads();
+    if (!valid) return;
+
+    const float px = pos[3 * (size_t)idx + 0], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
+    const Projected pr = project_splat(cp, scale_modifier, idx, px, py, pz, scale, rotq, opacity);
+
+    // colour (sh_preprocessor.cpp:27-157)
+    float raw[3];
+    if (staged) {
         float4 q[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) q[k] = reinterpret_cast<const float4*>(s)[k];
+        for (int k = 0; k < 12; ++k) q[k] = s_sh[wave][lane * 13 + k];
         const float* f = reinterpret_cast<const float*>(q);
         sh_to_color(3, cp.campos, px, py, pz, [&](int k, int c) { return f[k * 3 + c]; }, raw);
     } else {
+        const int    feat_dim = (sh_deg + 1) * (sh_deg + 1);
+        const float* s        = sh + (size_t)idx * feat_dim * 3;
         sh_to_color(sh_deg, cp.campos, px, py, pz, [&](int k, int c) { return s[k * 3 + c]; }, raw);
     }
 
     float4* out = reinterpret_cast<float4*>(recs + vid);
-    out[0]      = make_float4(pix_x, pix_y, conic[0], conic[1]);
-    out[1]      = make_float4(conic[2], opacity[idx], clamp_(raw[0], 0.0f, 1.0f), clamp_(raw[1], 0.0f, 1.0f));
-    out[2]      = make_float4(clamp_(raw[2], 0.0f, 1.0f), depth, __uint_as_float(rmin[0] | (rmin[1] << 16)),
-                              __uint_as_float((rmax[0] - rmin[0]) | ((rmax[1] - rmin[1]) << 16)));
-    sort_keys[vid] = __float_as_uint(depth);
-    sort_vals[vid] = vid;
-    vis_index[vid] = (uint32_t)idx;
+    out[0]      = make_float4(pr.pix_x, pr.pix_y, pr.conic[0], pr.conic[1]);
+    out[1]      = make_float4(pr.conic[2], opacity[idx], clamp_(raw[0], 0.0f, 1.0f), clamp_(raw[1], 0.0f, 1.0f));
+    out[2]      = make_float4(clamp_(raw[2], 0.0f, 1.0f), pr.depth, __uint_as_float(pr.rmin[0] | (pr.rmin[1] << 16)),
+                              __uint_as_float(pr.rw | (pr.rh << 16)));
 }
 
 // tile counts of the survivors in depth order
@@ -237,10 +334,14 @@ __global__ void __launch_bounds__(kThreads) k_gather_tiles(const uint32_t* __res
     tiles_sorted[k]   = (wh & 0xFFFFu) * (wh >> 16);
 }
 
-// clamp the pair count to the workspace capacity; d_counts[2] = pairs actually emitted, [3] = overflow flag
-__global__ void k_finalize_counts(uint32_t* __restrict__ d_counts, uint32_t capacity)
+// pairs wanted = inclusive offset of the last depth-ordered survivor; clamp to the workspace capacity:
+// d_counts[2] = pairs actually emitted, [3] = overflow flag, [4] = pairs wanted
+__global__ void k_finalize_counts(uint32_t* __restrict__ d_counts, const uint32_t* __restrict__ offsets_incl,
+                                  uint32_t capacity)
 {
-    const uint32_t L = d_counts[1];
+    const uint32_t V = d_counts[0];
+    const uint32_t L = V ? offsets_incl[V - 1] : 0u;
+    d_counts[4]      = L;
     d_counts[2]      = L < capacity ? L : capacity;
     d_counts[3]      = L > capacity ? 1u : 0u;
 }
@@ -343,17 +444,25 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kThreads - 1) / k
 
 } // namespace
 
-size_t fused_scan_state_bytes(int P) { return (size_t)(blocks_for(P) + 2) * sizeof(uint64_t); }
+inline unsigned chunks_for(int64_t n) { return (unsigned)((n + kCullChunk - 1) / kCullChunk); }
+size_t fused_scan_state_bytes(int P) { return (size_t)(chunks_for(P) + 2) * sizeof(uint64_t); }
 
-void launch_fused_preprocess(int P, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
-                             const float* scale, const float* rotq, const float* sh, const float* opacity,
-                             int32_t* radii, SplatRecord* recs, uint32_t* sort_keys, uint32_t* sort_vals,
-                             uint32_t* vis_index, uint64_t* scan_state, uint32_t* d_counts, hipStream_t stream)
+void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const float* pos, const float* scale,
+                         const float* rotq, const float* opacity, int32_t* radii, uint32_t* sort_keys,
+                         uint32_t* sort_vals, uint32_t* vis_index, uint64_t* scan_state, uint32_t* d_counts,
+                         hipStream_t stream)
 {
-    hipMemsetAsync(scan_state, 0, fused_scan_state_bytes(P), stream);
-    hipLaunchKernelGGL(k_fused_preprocess, dim3(blocks_for(P)), dim3(kThreads), 0, stream, P, sh_deg, cp,
-                       scale_modifier, pos, scale, rotq, sh, opacity, radii, recs, sort_keys, sort_vals, vis_index,
-                       scan_state, d_counts);
+    (void)hipMemsetAsync(scan_state, 0, fused_scan_state_bytes(P), stream);
+    hipLaunchKernelGGL(k_cull_compact, dim3(chunks_for(P)), dim3(kThreads), 0, stream, P, cp, scale_modifier, pos,
+                       scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index, scan_state, d_counts);
+}
+
+void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
+                          const float* scale, const float* rotq, const float* sh, const float* opacity,
+                          const uint32_t* vis_index, const uint32_t* d_counts, SplatRecord* recs, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_build_records, dim3(blocks_for(P_cap)), dim3(kThreads), 0, stream, sh_deg, cp,
+                       scale_modifier, pos, scale, rotq, sh, opacity, vis_index, d_counts, recs);
 }
 
 void launch_gather_tiles(int P_cap, const uint32_t* d_counts, const uint32_t* order, const SplatRecord* recs,
@@ -363,9 +472,9 @@ void launch_gather_tiles(int P_cap, const uint32_t* d_counts, const uint32_t* or
                        tiles_sorted);
 }
 
-void launch_finalize_counts(uint32_t* d_counts, uint32_t capacity, hipStream_t stream)
+void launch_finalize_counts(uint32_t* d_counts, const uint32_t* offsets_incl, uint32_t capacity, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_finalize_counts, dim3(1), dim3(1), 0, stream, d_counts, capacity);
+    hipLaunchKernelGGL(k_finalize_counts, dim3(1), dim3(1), 0, stream, d_counts, offsets_incl, capacity);
 }
 
 void launch_expand_pairs(int P_cap, const uint32_t* d_counts, uint32_t grid_x, const uint32_t* order,

@@ -244,7 +244,7 @@ LCGS_HD void get_rect(float px, float py, int32_t max_radius, uint32_t grid_x, u
 // `cov` is (xx, xy, yy) as produced by the projector; for use_focal == false the caller's
 // resolution scaling of shader.cpp:130-135 (including the res.y*res.x factor on yy) is applied.
 LCGS_HD void conic_and_radius(float cx, float cy, float cz, bool use_focal, uint32_t res_x, uint32_t res_y,
-                              float conic[3], int32_t& radius)
+                              float conic[3], int32_t& radius, float* filtered = nullptr)
 {
     if (!use_focal) {
         cx = cx * (float)res_x * (float)res_x * 0.25f;
@@ -253,6 +253,11 @@ LCGS_HD void conic_and_radius(float cx, float cy, float cz, bool use_focal, uint
     }
     cx += 0.3f;
     cz += 0.3f;
+    if (filtered) {
+        filtered[0] = cx;
+        filtered[1] = cy;
+        filtered[2] = cz;
+    }
     float det     = cx * cz - cy * cy;
     float inv_det = 1.0f / (det + 1e-6f);
     conic[0]      = inv_det * cz;
@@ -262,6 +267,54 @@ LCGS_HD void conic_and_radius(float cx, float cy, float cz, bool use_focal, uint
     float lambda1 = mid + sqrtf(fmax_(0.1f, mid * mid - det));
     float lambda2 = mid - sqrtf(fmax_(0.1f, mid * mid - det));
     radius        = f2i_sat(ceilf(3.0f * sqrtf(fmax_(lambda1, lambda2))));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Opacity-aware tight tile rect (NOT in the reference; an exact pruning of its pair list).
+// The reference emits a (tile, splat) pair for every tile of the square rect of half-width
+// radius = ceil(3 sqrt(lambda_max)).  A pixel can only receive a contribution from the splat if
+// alpha = min(0.99, o exp(power)) >= 1/255 (gs_tile_splatter/shader.cpp:257-259), i.e. if
+// q(d) = d^T Q d <= t = 2 ln(255 o) with Q the conic.  The axis-aligned extent of that ellipse is
+// |dx| <= sqrt(t * Qyy / det Q), |dy| <= sqrt(t * Qxx / det Q); with Q = (cz, -cy, cx) / (det_f + 1e-6)
+// built from the filtered covariance (cx, cy, cz) this is sqrt(t * cx * (det_f + 1e-6) / det) -- computed
+// with explicit slack for the cancellation in det, the rounding of log/exp and the pixel grid.  Tiles of
+// the reference rect outside this box cannot contain a contributing pixel, so dropping their pairs leaves
+// every pixel's blend sequence -- and therefore the image -- bit-identical.  Returns the pruned rect
+// (subset of [rmin, rmax)); an empty rect means the splat contributes nowhere (e.g. opacity <= 1/255).
+// ---------------------------------------------------------------------------------------------
+LCGS_HD void tight_rect(float pix_x, float pix_y, float cx, float cy, float cz /* filtered cov */, float opacity,
+                        const uint32_t rmin[2], const uint32_t rmax[2], uint32_t tmin[2], uint32_t tmax[2])
+{
+    tmin[0] = rmin[0]; tmin[1] = rmin[1]; tmax[0] = rmax[0]; tmax[1] = rmax[1];
+    const float t0 = 2.0f * logf(255.0f * opacity);
+    if (!(t0 == t0)) return;                 // NaN opacity: keep the reference rect
+    const float t = t0 * 1.0001f + 2e-4f;    // same margin as the renderer's per-tile test
+    if (!(t > 0.0f)) {                       // alpha < 1/255 everywhere
+        tmax[0] = tmin[0];
+        tmax[1] = tmin[1];
+        return;
+    }
+    const float det  = cx * cz - cy * cy;
+    const float err  = 4e-7f * (fabsf(cx * cz) + cy * cy); // rounding of the two products that cancel in det
+    const float dlow = det - err;
+    if (!(dlow > 1e-12f)) return;            // ill-conditioned / non-finite: keep the reference rect
+    const float s  = (det + 1e-6f + err) / dlow;
+    const float hx = sqrtf(t * cx * s) * 1.0001f + 0.01f;
+    const float hy = sqrtf(t * cz * s) * 1.0001f + 0.01f;
+    if (!(hx == hx) || !(hy == hy)) return;
+    // tiles whose pixel span [16 tx, 16 tx + 15] meets [m - h, m + h]:
+    //   16 tx + 15 >= m - h  <=>  tx >= ceil((m - h - 15) / 16);   16 tx <= m + h  <=>  tx <= floor((m + h) / 16)
+    const uint32_t ax = f2u_sat(ceilf((pix_x - hx - (float)(kBlockX - 1)) / (float)kBlockX));
+    const uint32_t ay = f2u_sat(ceilf((pix_y - hy - (float)(kBlockY - 1)) / (float)kBlockY));
+    const float    fx = floorf((pix_x + hx) / (float)kBlockX), fy = floorf((pix_y + hy) / (float)kBlockY);
+    const uint32_t bx = fx < 0.0f ? 0u : f2u_sat(fx + 1.0f); // exclusive
+    const uint32_t by = fy < 0.0f ? 0u : f2u_sat(fy + 1.0f);
+    tmin[0] = ax > rmin[0] ? ax : rmin[0];
+    tmin[1] = ay > rmin[1] ? ay : rmin[1];
+    tmax[0] = bx < rmax[0] ? bx : rmax[0];
+    tmax[1] = by < rmax[1] ? by : rmax[1];
+    if (tmax[0] < tmin[0]) tmax[0] = tmin[0];
+    if (tmax[1] < tmin[1]) tmax[1] = tmin[1];
 }
 
 } // namespace lcgs

@@ -76,14 +76,18 @@ struct __attribute__((aligned(16))) SplatRecord {
 static_assert(sizeof(SplatRecord) == 48, "SplatRecord must be 48 bytes");
 
 size_t fused_scan_state_bytes(int P);
-// d_counts: [0] V (splats touching >= 1 tile), [1] reference num_rendered, [2] pairs emitted, [3] overflow flag
-void launch_fused_preprocess(int P, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
-                             const float* scale, const float* rotq, const float* sh, const float* opacity,
-                             int32_t* radii, SplatRecord* recs, uint32_t* sort_keys, uint32_t* sort_vals,
-                             uint32_t* vis_index, uint64_t* scan_state, uint32_t* d_counts, hipStream_t stream);
+// d_counts: [0] V (splats emitting >= 1 pair), [1] reference num_rendered, [2] pairs emitted, [3] overflow flag,
+//           [4] pairs wanted (before clamping to the workspace capacity)
+void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const float* pos, const float* scale,
+                         const float* rotq, const float* opacity, int32_t* radii, uint32_t* sort_keys,
+                         uint32_t* sort_vals, uint32_t* vis_index, uint64_t* scan_state, uint32_t* d_counts,
+                         hipStream_t stream);
+void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
+                          const float* scale, const float* rotq, const float* sh, const float* opacity,
+                          const uint32_t* vis_index, const uint32_t* d_counts, SplatRecord* recs, hipStream_t stream);
 void launch_gather_tiles(int P_cap, const uint32_t* d_counts, const uint32_t* order, const SplatRecord* recs,
                          uint32_t* tiles_sorted, hipStream_t stream);
-void launch_finalize_counts(uint32_t* d_counts, uint32_t capacity, hipStream_t stream);
+void launch_finalize_counts(uint32_t* d_counts, const uint32_t* offsets_incl, uint32_t capacity, hipStream_t stream);
 void launch_expand_pairs(int P_cap, const uint32_t* d_counts, uint32_t grid_x, const uint32_t* order,
                          const uint32_t* offsets_incl, const SplatRecord* recs, uint32_t* pair_keys,
                          uint32_t* pair_vals, uint32_t capacity, hipStream_t stream);

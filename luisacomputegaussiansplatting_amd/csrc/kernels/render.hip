@@ -53,6 +53,47 @@ struct FetchRec {
 
 constexpr int kXcd = 8;
 
+// Conservative "can this splat reach any pixel of the rect?" test, exact up to a safety margin.
+// A pixel receives a contribution only if alpha = min(0.99, o * exp(power)) >= 1/255 with power <= 0
+// (shader.cpp:256-259), i.e. q(d) = ca dx^2 + 2 cb dx dy + cc dy^2 <= t = 2 ln(255 o).  The minimum of the convex
+// quadratic q over the pixel rect [x0,x1] x [y0,y1] is 0 if the mean is inside, else it lies on one of the four
+// edges (a clamped 1-D quadratic each).  `t` already carries its margin; the absolute rounding slack scales with
+// the magnitude of the terms that cancel in q.  Non-finite inputs keep the entry.
+__device__ __forceinline__ bool splat_may_touch_rect(float mx, float my, float ca, float cb, float cc, float t,
+                                                     float x0, float y0, float x1, float y1)
+{
+    if (!(t > 0.0f)) return false; // opacity <= 1/255: alpha < 1/255 everywhere
+    const float ex0 = x0 - mx, ex1 = x1 - mx, ey0 = y0 - my, ey1 = y1 - my; // rect relative to the mean
+    if (ex0 <= 0.0f && ex1 >= 0.0f && ey0 <= 0.0f && ey1 >= 0.0f) return true;
+    if (!(ca > 0.0f) || !(cc > 0.0f)) return true; // degenerate conic: keep
+    float best = 3.0e38f, slack = 0.0f;
+    // vertical edges dx = ex0 / ex1: dy* = -cb dx / cc clamped to [ey0, ey1]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float dx = s ? ex1 : ex0;
+        const float dy = fmin_(fmax_(-cb * dx / cc, ey0), ey1);
+        const float q1 = ca * dx * dx, q2 = 2.0f * cb * dx * dy, q3 = cc * dy * dy;
+        const float q  = q1 + q2 + q3;
+        if (q < best) {
+            best  = q;
+            slack = fabsf(q1) + fabsf(q2) + fabsf(q3);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float dy = s ? ey1 : ey0;
+        const float dx = fmin_(fmax_(-cb * dy / ca, ex0), ex1);
+        const float q1 = ca * dx * dx, q2 = 2.0f * cb * dx * dy, q3 = cc * dy * dy;
+        const float q  = q1 + q2 + q3;
+        if (q < best) {
+            best  = q;
+            slack = fabsf(q1) + fabsf(q2) + fabsf(q3);
+        }
+    }
+    if (!(best == best)) return true; // NaN: keep
+    return best - 1e-5f * slack <= t;
+}
+
 template <typename Fetch>
 __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, float bg1, float bg2,
                                                          const uint32_t* __restrict__ ranges,
@@ -61,9 +102,9 @@ __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, 
                                                          uint32_t* __restrict__ n_contrib,
                                                          const uint32_t* __restrict__ d_counts)
 {
-    __shared__ float4 s_a[64];
-    __shared__ float4 s_b[64];
-    __shared__ float  s_c[64];
+    __shared__ float4 s_a[64]; // mean.x, mean.y, conic.x, conic.y
+    __shared__ float4 s_b[64]; // conic.z, opacity, r, g
+    __shared__ float4 s_c[64]; // b, power floor (-t/2), list position + 1 (as bits), unused
 
     const uint32_t G    = cp.grid_x * cp.grid_y;
     const uint32_t per  = (G + kXcd - 1) / kXcd;
@@ -77,6 +118,8 @@ __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, 
     const uint32_t px  = tx * kBlockX + (lane & 15u);
     const uint32_t py0 = ty * kBlockY + (lane >> 4);
     const float    pxf = (float)px;
+    const float    rx0 = (float)(tx * kBlockX), ry0 = (float)(ty * kBlockY);
+    const float    rx1 = rx0 + (float)(kBlockX - 1), ry1 = ry0 + (float)(kBlockY - 1);
 
     float    pyf[4];
     bool     inside[4], done[4];
@@ -96,51 +139,64 @@ __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, 
     const uint32_t range_start = ranges[2 * (size_t)tile + 0];
     const uint32_t range_end   = ranges[2 * (size_t)tile + 1];
 
+    // software pipeline: the gather of round r+1 is in flight while round r is composited
+    float4 na = make_float4(0, 0, 0, 0), nb = make_float4(0, 0, 0, 0);
+    float  nc = 0.0f;
+    if (range_start + lane < range_end) fetch(point_list[range_start + lane], na, nb, nc);
+
     for (uint32_t base = range_start; base < range_end; base += 64u) {
         if (__all(done[0] && done[1] && done[2] && done[3])) break;
-        const uint32_t e = base + lane;
-        if (e < range_end) {
-            const uint32_t id = point_list[e];
-            float4         a, b;
-            float          c;
-            fetch(id, a, b, c);
-            s_a[lane] = a;
-            s_b[lane] = b;
-            s_c[lane] = c;
+        // ---- stage: cull against the tile rect, compact survivors into LDS in list order
+        const uint32_t e     = base + lane;
+        const bool     have  = e < range_end;
+        const float4   a = na, b = nb;
+        const float    c = nc;
+        // t = 2 ln(255 o) with a relative + absolute safety margin (exp/log rounding, 0.99 clamp irrelevant)
+        const float t    = have ? (2.0f * __logf(255.0f * b.y)) * 1.0001f + 2e-4f : -1.0f;
+        const bool  keep = have && splat_may_touch_rect(a.x, a.y, a.z, a.w, b.x, t, rx0, ry0, rx1, ry1);
+        const unsigned long long mask = __ballot(keep);
+        const uint32_t slot = __popcll(mask & ((1ull << lane) - 1ull));
+        const uint32_t cnt  = __popcll(mask);
+        __syncthreads(); // previous round's readers are done with the slab
+        if (keep) {
+            s_a[slot] = a;
+            s_b[slot] = b;
+            s_c[slot] = make_float4(c, -0.5f * t, __uint_as_float(e - range_start + 1u), 0.0f);
         }
+        const uint32_t en = e + 64u;
+        if (en < range_end) fetch(point_list[en], na, nb, nc);
         __syncthreads();
-        const uint32_t cnt = (range_end - base) < 64u ? (range_end - base) : 64u;
+
         for (uint32_t j = 0; j < cnt; ++j) {
             if (__all(done[0] && done[1] && done[2] && done[3])) break;
-            const float4   a           = s_a[j]; // mean.x, mean.y, conic.x, conic.y
-            const float4   b           = s_b[j]; // conic.z, opacity, r, g
-            const float    cb          = s_c[j]; // b
-            const uint32_t contributor = base - range_start + j + 1u;
-            const float    dx          = a.x - pxf;
-            const float    cxdxdx      = a.z * dx * dx; // con_o.x * d.x * d.x
-            const float    cydx        = a.w * dx;      // con_o.y * d.x
+            const float4   ea          = s_a[j];
+            const float4   eb          = s_b[j];
+            const float4   ec          = s_c[j];
+            const uint32_t contributor = __float_as_uint(ec.z);
+            const float    dx          = ea.x - pxf;
+            const float    cxdxdx      = ea.z * dx * dx; // con_o.x * d.x * d.x
+            const float    cydx        = ea.w * dx;      // con_o.y * d.x
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (done[k]) continue;
-                const float dy    = a.y - pyf[k];
-                const float power = -0.5f * (cxdxdx + b.x * dy * dy) - cydx * dy; // shader.cpp:256
-                if (power > 0.0f) continue;
-                const float alpha = fmin_(0.99f, b.y * __expf(power));
-                if (alpha < 1.0f / 255.0f) continue;
+                const float dy    = ea.y - pyf[k];
+                const float power = -0.5f * (cxdxdx + eb.x * dy * dy) - cydx * dy; // shader.cpp:256
+                // strip-level skip before the exp: no lane of this 16x4 strip can reach alpha >= 1/255
+                const bool cand = !done[k] && !(power > 0.0f) && (power >= ec.y);
+                if (!__any(cand)) continue;
+                const float alpha  = fmin_(0.99f, eb.y * __expf(power));
+                const bool  valid  = cand && !(alpha < 1.0f / 255.0f);
                 const float test_T = T[k] * (1.0f - alpha);
-                if (test_T < 0.0001f) {
-                    done[k] = true;
-                    continue;
-                }
-                const float w = T[k] * alpha;
-                Cr[k]         = Cr[k] + w * b.z;
-                Cg[k]         = Cg[k] + w * b.w;
-                Cb[k]         = Cb[k] + w * cb;
-                T[k]          = test_T;
-                last_contrib[k] = contributor;
+                const bool  sat    = valid && (test_T < 0.0001f);
+                const bool  upd    = valid && !sat;
+                done[k]            = done[k] || sat;
+                const float w      = upd ? T[k] * alpha : 0.0f;
+                Cr[k]              = Cr[k] + w * eb.z;
+                Cg[k]              = Cg[k] + w * eb.w;
+                Cb[k]              = Cb[k] + w * ec.x;
+                T[k]               = upd ? test_T : T[k];
+                last_contrib[k]    = upd ? contributor : last_contrib[k];
             }
         }
-        __syncthreads();
     }
 
     const size_t hw = (size_t)cp.width * cp.height;

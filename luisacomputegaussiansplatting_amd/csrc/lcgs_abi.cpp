@@ -203,10 +203,13 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     ctx->n_marks          = 0;
     LCGS_TRY(mark(ctx, "begin"));
 
-    launch_fused_preprocess(P, ctx->sh_deg, cp, scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity,
-                            d_radii, recs, ctx->sortk[0].as<uint32_t>(), ctx->sortv[0].as<uint32_t>(),
-                            ctx->vis_index.as<uint32_t>(), ctx->scan_state.as<uint64_t>(), d_counts, st);
-    LCGS_TRY(mark(ctx, "preprocess"));
+    launch_cull_compact(P, cp, scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->opacity, d_radii,
+                        ctx->sortk[0].as<uint32_t>(), ctx->sortv[0].as<uint32_t>(), ctx->vis_index.as<uint32_t>(),
+                        ctx->scan_state.as<uint64_t>(), d_counts, st);
+    LCGS_TRY(mark(ctx, "cull_compact"));
+    launch_build_records(P, ctx->sh_deg, cp, scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity,
+                         ctx->vis_index.as<uint32_t>(), d_counts, recs, st);
+    LCGS_TRY(mark(ctx, "build_records"));
 
     // depth bits of a float >= 0.2 never use bit 31
     const int where = launch_sort_pairs_u32_pingpong(ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
@@ -218,7 +221,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     launch_gather_tiles(P, d_counts, order, recs, ctx->tiles_sorted.as<uint32_t>(), st);
     launch_inclusive_sum_u32_dyn(ctx->tiles_sorted.as<uint32_t>(), ctx->offsets.as<uint32_t>(), P, d_counts + 0,
                                  ctx->scan_temp.ptr, st);
-    launch_finalize_counts(d_counts, ctx->pair_capacity, st);
+    launch_finalize_counts(d_counts, ctx->offsets.as<uint32_t>(), ctx->pair_capacity, st);
     launch_expand_pairs(P, d_counts, cp.grid_x, order, ctx->offsets.as<uint32_t>(), recs, ctx->pairk[0].as<uint32_t>(),
                         ctx->pairv[0].as<uint32_t>(), ctx->pair_capacity, st);
     LCGS_TRY(mark(ctx, "expand"));
@@ -241,7 +244,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
                               keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, st);
     LCGS_TRY(mark(ctx, "render"));
 
-    LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, d_counts, 16, hipMemcpyDeviceToHost, st));
+    LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, d_counts, 32, hipMemcpyDeviceToHost, st));
     ctx->last.valid          = true;
     ctx->last.has_state      = keep_state;
     ctx->last.cp             = cp;
@@ -515,7 +518,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
         if (num_rendered) *num_rendered = (int)ctx->h_counts[1];
         if (ctx->h_counts[3] == 0) return LCGS_OK;
         // pair buffers were too small for this view: grow and redo the frame
-        uint64_t want = (uint64_t)ctx->h_counts[1] + ctx->h_counts[1] / 4;
+        uint64_t want = (uint64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4;
         if (want > 0x7FFFFFFFull) {
             set_last_error("num_rendered exceeds 2^31 pairs");
             return LCGS_ERR_CAPACITY;

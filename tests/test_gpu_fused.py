@@ -29,22 +29,58 @@ def _render_both(lcgs, oracle, scene, W, H, bg=(0.1, 0.2, 0.3), pose=POSE, scale
         assert (img == -1.0).all()  # image untouched, gs_tile_splatter/impl.cpp:109
         return r, orc, None
     st = r.frame_stats()
-    assert st["num_rendered"] == n and st["num_pairs"] == n
+    assert st["num_rendered"] == n and 0 < st["num_pairs"] <= n
     if check_lists:
-        # the per-tile lists are bit-identical to a stable sort on the reference's (tile<<32|depth) key
+        # Per tile, the fused list is the reference list (stable sort on (tile<<32|depth), index-order ties) with
+        # only never-contributing entries pruned: same relative order, and every pruned (tile, splat) pair has
+        # alpha < 1/255 (or power > 0) at every pixel of the tile.
         m, dd, c = oracle.project(scene["pos"], scene["scale"], scene["rotq"], ocam, scale_modifier=scale_modifier)
         mp, conic, tiles, rad = oracle.allocate_tiles(W, H, dd, m, c)
         offs = oracle.inclusive_sum(tiles)
         k, v = oracle.copy_with_keys(W, H, mp, offs, rad, dd)
         ks, vs = oracle.sort_pairs(k, v)
-        G = ((W + 15) // 16) * ((H + 15) // 16)
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        G = gx * gy
         ranges = oracle.get_ranges(ks, G)
-        d_list = torch.zeros(n, dtype=torch.int32, device=DEV)
+        Lp = st["num_pairs"]
+        d_list = torch.zeros(Lp, dtype=torch.int32, device=DEV)
         d_ranges = torch.zeros(2 * G, dtype=torch.int32, device=DEV)
         r.last_lists(d_list, d_ranges)
-        assert st["num_visible"] == int((tiles > 0).sum())
-        assert np.array_equal(d_ranges.cpu().numpy().view(np.uint32).reshape(G, 2), ranges)
-        assert np.array_equal(d_list.cpu().numpy().view(np.uint32), vs)
+        fl = d_list.cpu().numpy().view(np.uint32)
+        fr = d_ranges.cpu().numpy().view(np.uint32).reshape(G, 2)
+        assert int((fr[:, 1] - fr[:, 0]).sum()) == Lp
+        removed = []
+        for t in range(G):
+            o_l = vs[ranges[t, 0]:ranges[t, 1]]
+            f_l = fl[fr[t, 0]:fr[t, 1]]
+            if f_l.size == 0:
+                if o_l.size:
+                    removed.append((np.full(o_l.size, t), o_l))
+                continue
+            sorter = np.argsort(o_l, kind="stable")
+            pos = sorter[np.clip(np.searchsorted(o_l, f_l, sorter=sorter), 0, o_l.size - 1)]
+            assert np.array_equal(o_l[pos], f_l), f"tile {t}: fused list has entries the reference list lacks"
+            assert (np.diff(pos.astype(np.int64)) > 0).all(), f"tile {t}: order differs from the reference"
+            keep = np.zeros(o_l.size, bool)
+            keep[pos] = True
+            if (~keep).any():
+                removed.append((np.full(int((~keep).sum()), t), o_l[~keep]))
+        if removed:
+            rt = np.concatenate([x[0] for x in removed])
+            rs = np.concatenate([x[1] for x in removed])
+            if rt.size > 20000:
+                sel = np.random.default_rng(0).choice(rt.size, 20000, replace=False)
+                rt, rs = rt[sel], rs[sel]
+            ys, xs = np.mgrid[0:16, 0:16]
+            pxs = (rt % gx)[:, None, None] * 16 + xs[None]
+            pys = (rt // gx)[:, None, None] * 16 + ys[None]
+            dx = mp[rs, 0][:, None, None] - pxs.astype(np.float32)
+            dy = mp[rs, 1][:, None, None] - pys.astype(np.float32)
+            cx, cy, cz = (conic[rs, i][:, None, None] for i in range(3))
+            power = np.float32(-0.5) * (cx * dx * dx + cz * dy * dy) - cy * dx * dy
+            alpha = np.minimum(np.float32(0.99), scene["opacity"][rs][:, None, None] * np.exp(power))
+            contributes = (power <= 0) & (alpha >= np.float32(1.0 / 255.0))
+            assert not contributes.any(), "a pruned (tile, splat) pair would have contributed"
     stats = assert_image_parity(img.cpu().numpy(), orc)
     return r, orc, stats
 
