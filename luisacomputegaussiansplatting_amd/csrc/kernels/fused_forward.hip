@@ -14,9 +14,9 @@
 //                        stream, paid only for splats that reach the screen) -> packed 48-byte records.
 //   depth sort           32-bit radix sort of the V survivors by depth bits (radix_sort.hip) -- the low
 //                        32 bits of the reference's 64-bit key, sorted BEFORE duplication, on V ~ L/5 items.
-//   k_gather_tiles + scan   per-splat tile counts in depth order -> pair offsets.
-//   k_expand_pairs       wave-cooperative, load-balanced duplication: every 64 consecutive output pairs
-//                        are written by 64 consecutive lanes (coalesced), whatever the splat sizes.
+//   k_expand_*           pruned tile counts in depth order -> pair offsets -> wave-cooperative, load-balanced
+//                        duplication: every 64 consecutive output pairs are written by 64 consecutive lanes
+//                        (coalesced), whatever the splat sizes.
 //   tile partition       stable radix passes over only the ceil(log2 G) tile-id bits (2 passes at 1080p).
 //                        LSD order (depth digits first, tile digits last) makes the result equal to a
 //                        stable sort on the reference's (tile << 32 | depth) key with index-order ties.
@@ -135,7 +135,8 @@ __global__ void __launch_bounds__(kThreads)
 k_cull_compact(int P, CamParams cp, float scale_modifier, const float* __restrict__ pos,
                const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ opacity,
                int32_t* __restrict__ radii, uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals,
-               uint32_t* __restrict__ vis_index, uint64_t* __restrict__ scan_state, uint32_t* __restrict__ d_counts)
+               uint32_t* __restrict__ vis_index, uint2* __restrict__ rects, uint64_t* __restrict__ scan_state,
+               uint32_t* __restrict__ d_counts)
 {
     __shared__ uint32_t s_ticket;
     __shared__ uint32_t s_wave_vis[kCullItems][4];
@@ -153,17 +154,20 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const float* __restric
     uint32_t vis_mask = 0;        // bit k: splat k of this lane survives
     uint32_t lv[kCullItems];      // exclusive rank of the survivor inside its wave, per round
     float    depth[kCullItems];
+    uint2    rect[kCullItems];    // pruned rect: x | y << 16, w | h << 16
     uint32_t tiles_sum = 0;       // reference tiles_touched (for num_rendered)
 #pragma unroll
     for (int k = 0; k < kCullItems; ++k) {
         const int64_t idx = base + (int64_t)k * kThreads + tid;
         bool          visible = false;
         depth[k]              = 0.0f;
+        rect[k]               = make_uint2(0u, 0u);
         if (idx < P) {
             const Projected pr = project_splat(cp, scale_modifier, (int)idx, pos[3 * (size_t)idx + 0],
                                                pos[3 * (size_t)idx + 1], pos[3 * (size_t)idx + 2], scale, rotq, opacity);
             visible  = pr.visible;
             depth[k] = pr.depth;
+            rect[k]  = make_uint2(pr.rmin[0] | (pr.rmin[1] << 16), pr.rw | (pr.rh << 16));
             tiles_sum += pr.ref_tiles;
             if (radii) radii[idx] = pr.radius;
         }
@@ -248,6 +252,7 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const float* __restric
         sort_keys[vid]     = __float_as_uint(depth[k]);
         sort_vals[vid]     = vid;
         vis_index[vid]     = (uint32_t)(base + (int64_t)k * kThreads + tid);
+        rects[vid]         = rect[k];
     }
 }
 
@@ -268,15 +273,15 @@ k_build_records(int sh_deg, CamParams cp, float scale_modifier, const float* __r
     __shared__ float4 s_sh[kThreads / 64][64 * 13];
 
     const uint32_t V = d_counts[0];
-    if (blockIdx.x * kThreads >= V) return;
     const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t vid   = blockIdx.x * kThreads + threadIdx.x;
+    for (uint32_t blk = blockIdx.x; blk * kThreads < V; blk += gridDim.x) {
+    const uint32_t vid   = blk * kThreads + threadIdx.x;
     const bool     valid = vid < V;
     const int      idx   = (int)vis_index[valid ? vid : V - 1];
     const bool     staged = sh_deg == 3 && ((reinterpret_cast<uintptr_t>(sh) & 15) == 0);
 
     if (staged) {
-        const uint32_t wave_first = blockIdx.x * kThreads + wave * 64;
+        const uint32_t wave_first = blk * kThreads + wave * 64;
         const uint32_t nvalid     = wave_first < V ? ((V - wave_first) < 64u ? (V - wave_first) : 64u) : 0u;
         float4         q[12];
 #pragma unroll
@@ -295,7 +300,7 @@ k_build_records(int sh_deg, CamParams cp, float scale_modifier, const float* __r
         }
     }
     __syncthreads();
-    if (!valid) return;
+    if (valid) {
 
     const float px = pos[3 * (size_t)idx + 0], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
     const Projected pr = project_splat(cp, scale_modifier, idx, px, py, pz, scale, rotq, opacity);
@@ -319,91 +324,187 @@ k_build_records(int sh_deg, CamParams cp, float scale_modifier, const float* __r
     out[1]      = make_float4(pr.conic[2], opacity[idx], clamp_(raw[0], 0.0f, 1.0f), clamp_(raw[1], 0.0f, 1.0f));
     out[2]      = make_float4(clamp_(raw[2], 0.0f, 1.0f), pr.depth, __uint_as_float(pr.rmin[0] | (pr.rmin[1] << 16)),
                               __uint_as_float(pr.rw | (pr.rh << 16)));
+    }
+    __syncthreads(); // the LDS slab is reused by the next iteration
+    }
 }
 
-// tile counts of the survivors in depth order
-__global__ void __launch_bounds__(kThreads) k_gather_tiles(const uint32_t* __restrict__ d_counts,
-                                                             const uint32_t* __restrict__ order,
-                                                             const SplatRecord* __restrict__ recs,
-                                                             uint32_t* __restrict__ tiles_sorted)
+// ---------------------------------------------------------------------------------------------
+// Duplication (gs_tile_splatter/shader.cpp:26-69 emits the same pairs, one thread per splat) in three launches:
+//   k_expand_reduce   per 1024 depth-ordered survivors: sum of their pruned tile counts
+//   k_expand_offsets  one workgroup: exclusive scan of those sums; publishes the pair totals
+//   k_expand_emit     re-derives the in-block offsets and writes the pairs, load-balanced: a wave owns 64
+//                     consecutive survivors whose pairs form one contiguous output run, written 64 pairs per step
+//                     (coalesced), each lane locating its source splat by a 6-step search over the wave's
+//                     exclusive offsets in LDS.  Order inside a splat is y-outer, x-inner like the reference.
+// ---------------------------------------------------------------------------------------------
+constexpr int kExpandSub   = 4;                      // 256-splat sub-chunks per workgroup
+constexpr int kExpandChunk = kThreads * kExpandSub;  // 1024 survivors
+
+__device__ __forceinline__ uint32_t rect_tiles(uint2 rc) { return (rc.y & 0xFFFFu) * (rc.y >> 16); }
+
+__global__ void __launch_bounds__(kThreads) k_expand_reduce(const uint32_t* __restrict__ d_counts,
+                                                              const uint32_t* __restrict__ order,
+                                                              const uint2* __restrict__ rects,
+                                                              uint2* __restrict__ rects_sorted,
+                                                              uint32_t* __restrict__ block_sums)
 {
-    const uint32_t V = d_counts[0];
-    const uint32_t k = blockIdx.x * kThreads + threadIdx.x;
-    if (k >= V) return;
-    const uint32_t wh = reinterpret_cast<const uint32_t*>(recs + order[k])[11];
-    tiles_sorted[k]   = (wh & 0xFFFFu) * (wh >> 16);
+    __shared__ uint32_t s_wave[4];
+    const uint32_t V  = d_counts[0];
+    const uint32_t nb = (V + kExpandChunk - 1) / kExpandChunk;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t chunk = blockIdx.x; chunk < nb; chunk += gridDim.x) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int s = 0; s < kExpandSub; ++s) {
+            const uint32_t k = chunk * kExpandChunk + s * kThreads + threadIdx.x;
+            if (k < V) {
+                const uint2 rc  = rects[order[k]]; // the one random gather; emit reads the sorted copy
+                rects_sorted[k] = rc;
+                sum += rect_tiles(rc);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (lane == 0) s_wave[wave] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) block_sums[chunk] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
 }
 
-// pairs wanted = inclusive offset of the last depth-ordered survivor; clamp to the workspace capacity:
-// d_counts[2] = pairs actually emitted, [3] = overflow flag, [4] = pairs wanted
-__global__ void k_finalize_counts(uint32_t* __restrict__ d_counts, const uint32_t* __restrict__ offsets_incl,
-                                  uint32_t capacity)
+// exclusive scan of the block sums in place by one workgroup; d_counts[4] = pairs wanted,
+// [2] = pairs emitted (clamped to the workspace capacity), [3] = overflow flag
+__global__ void __launch_bounds__(1024) k_expand_offsets(uint32_t* __restrict__ d_counts,
+                                                           uint32_t* __restrict__ block_sums, uint32_t capacity)
 {
-    const uint32_t V = d_counts[0];
-    const uint32_t L = V ? offsets_incl[V - 1] : 0u;
-    d_counts[4]      = L;
-    d_counts[2]      = L < capacity ? L : capacity;
-    d_counts[3]      = L > capacity ? 1u : 0u;
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t V  = d_counts[0];
+    const uint32_t nb = (V + kExpandChunk - 1) / kExpandChunk;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nb ? block_sums[i] : 0u;
+        uint32_t       inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t carry = s_carry;
+        for (int w = 0; w < wave; ++w) carry += s_wave[w];
+        if (i < nb) block_sums[i] = carry + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t L = s_carry;
+        d_counts[4]      = L;
+        d_counts[2]      = L < capacity ? L : capacity;
+        d_counts[3]      = L > capacity ? 1u : 0u;
+    }
 }
 
-// Load-balanced duplication (gs_tile_splatter/shader.cpp:26-69 emits the same pairs, one thread per
-// splat).  Wave w owns 64 consecutive depth-ordered splats; their pairs form one contiguous output run
-// that the wave writes 64 pairs per step, each lane locating its source splat by a 6-step search over
-// the wave's exclusive offsets in LDS.  Order inside a splat is y-outer, x-inner like the reference.
-__global__ void __launch_bounds__(kThreads) k_expand_pairs(const uint32_t* __restrict__ d_counts, uint32_t grid_x,
-                                                             const uint32_t* __restrict__ order,
-                                                             const uint32_t* __restrict__ offsets_incl,
-                                                             const SplatRecord* __restrict__ recs,
-                                                             uint32_t* __restrict__ pair_keys,
-                                                             uint32_t* __restrict__ pair_vals, uint32_t capacity)
+// Output-balanced emit.  In depth order the first survivors are the nearest -- and by far the largest -- splats
+// (hundreds of tiles each), so assigning splats to waves leaves a few waves with 100x the average work.  Instead a
+// workgroup owns a fixed window of 4096 OUTPUT pairs: it locates the 1024-survivor chunk(s) overlapping the window
+// by binary search over the chunk offsets, rebuilds each chunk's per-splat offsets in LDS (4 KiB scan), and every
+// lane finds its source splat by a 10-step search.  Stores stay fully coalesced.
+constexpr int kEmitWindow = 4096;
+
+__global__ void __launch_bounds__(kThreads) k_expand_emit(const uint32_t* __restrict__ d_counts, uint32_t grid_x,
+                                                            const uint32_t* __restrict__ order,
+                                                            const uint2* __restrict__ rects_sorted,
+                                                            const uint32_t* __restrict__ block_offsets,
+                                                            uint32_t* __restrict__ pair_keys,
+                                                            uint32_t* __restrict__ pair_vals)
 {
-    __shared__ uint32_t s_excl[4][64];
-    __shared__ uint32_t s_vid[4][64];
-    __shared__ uint32_t s_xy[4][64];
-    __shared__ uint32_t s_w[4][64];
+    __shared__ uint32_t s_off[kExpandChunk + 1];
+    __shared__ uint32_t s_vid[kExpandChunk];
+    __shared__ uint32_t s_xy[kExpandChunk];
+    __shared__ uint32_t s_w[kExpandChunk];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_c0;
 
     const uint32_t V    = d_counts[0];
-    const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t k    = blockIdx.x * kThreads + threadIdx.x;
-    if (blockIdx.x * kThreads >= V) return;
-
-    uint32_t vid = 0, xy = 0, w = 1, count = 0, incl = 0;
-    if (k < V) {
-        vid               = order[k];
-        const uint32_t* r = reinterpret_cast<const uint32_t*>(recs + vid);
-        xy                = r[10];
-        const uint32_t wh = r[11];
-        w                 = wh & 0xFFFFu;
-        count             = w * (wh >> 16);
-        incl              = offsets_incl[k];
-    }
-    uint32_t       total;
-    const uint32_t excl      = wave_excl_scan(count, total);
-    const uint32_t wave_base = __shfl(incl - count, 0, 64); // global offset of the wave's first pair
-    s_excl[wave][lane] = excl;
-    s_vid[wave][lane]  = vid;
-    s_xy[wave][lane]   = xy;
-    s_w[wave][lane]    = w;
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the wave's own LDS writes have landed
-
-    for (uint32_t p = lane; p < total; p += 64) {
-        // largest l with excl[l] <= p (zero-count splats share an offset with their successor: take the last)
-        int l = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1) {
-            const int cand = l + step;
-            if (cand < 64 && s_excl[wave][cand] <= p) l = cand;
+    const uint32_t L    = d_counts[2]; // pairs to emit (already clamped to the workspace capacity)
+    const uint32_t nb   = (V + kExpandChunk - 1) / kExpandChunk;
+    const uint32_t nwin = (L + kEmitWindow - 1) / kEmitWindow;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t win = blockIdx.x; win < nwin; win += gridDim.x) {
+        const uint32_t p0 = win * kEmitWindow;
+        const uint32_t p1 = (L - p0) < (uint32_t)kEmitWindow ? L : p0 + kEmitWindow;
+        if (tid == 0) { // largest chunk c with block_offsets[c] <= p0
+            uint32_t lo = 0, hi = nb;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (block_offsets[mid] <= p0) lo = mid;
+                else hi = mid;
+            }
+            s_c0 = lo;
         }
-        const uint32_t local = p - s_excl[wave][l];
-        const uint32_t ww    = s_w[wave][l];
-        const uint32_t xy0   = s_xy[wave][l];
-        const uint32_t ty    = (xy0 >> 16) + local / ww;
-        const uint32_t tx    = (xy0 & 0xFFFFu) + local % ww;
-        const uint32_t dst   = wave_base + p;
-        if (dst < capacity) {
-            pair_keys[dst] = ty * grid_x + tx;
-            pair_vals[dst] = s_vid[wave][l];
+        __syncthreads();
+        for (uint32_t c = s_c0; c < nb; ++c) {
+            const uint32_t base = block_offsets[c];
+            if (base >= p1) break;
+            // ---- per-splat exclusive offsets of chunk c (lane t owns survivors 4t .. 4t+3 of the chunk)
+            uint32_t cnt[4], run = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t j = tid * 4 + i, k = c * kExpandChunk + j;
+                uint32_t       count = 0;
+                if (k < V) {
+                    const uint2 rc = rects_sorted[k];
+                    s_vid[j]       = order[k];
+                    s_xy[j]        = rc.x;
+                    s_w[j]         = rc.y & 0xFFFFu;
+                    count          = (rc.y & 0xFFFFu) * (rc.y >> 16);
+                } else {
+                    s_w[j] = 1;
+                }
+                cnt[i] = run;
+                run += count;
+            }
+            uint32_t wtotal;
+            uint32_t excl = wave_excl_scan(run, wtotal);
+            if (lane == 0) s_wave[wave] = wtotal;
+            __syncthreads();
+            uint32_t carry = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                if (w < wave) carry += s_wave[w];
+            const uint32_t chunk_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_off[tid * 4 + i] = carry + excl + cnt[i];
+            if (tid == 0) s_off[kExpandChunk] = chunk_total;
+            __syncthreads();
+            // ---- pairs of this chunk that fall inside the window
+            const uint32_t lo = p0 > base ? p0 : base;
+            const uint32_t end = base + chunk_total;
+            const uint32_t hi = p1 < end ? p1 : end;
+            for (uint32_t p = lo + tid; p < hi; p += kThreads) {
+                const uint32_t rel = p - base;
+                // largest l with s_off[l] <= rel (zero-count padding entries share the offset of their successor;
+                // the search lands on the last of them, which is always a real survivor because rel < chunk_total)
+                uint32_t l = 0;
+#pragma unroll
+                for (uint32_t step = kExpandChunk / 2; step > 0; step >>= 1)
+                    if (s_off[l + step] <= rel) l += step;
+                const uint32_t local = rel - s_off[l];
+                const uint32_t ww    = s_w[l];
+                const uint32_t xy0   = s_xy[l];
+                const uint32_t ty    = (xy0 >> 16) + local / ww;
+                const uint32_t tx    = (xy0 & 0xFFFFu) + local % ww;
+                pair_keys[p]         = ty * grid_x + tx;
+                pair_vals[p]         = s_vid[l];
+            }
+            __syncthreads();
         }
     }
 }
@@ -413,20 +514,20 @@ __global__ void __launch_bounds__(kThreads) k_get_ranges_u32(const uint32_t* __r
                                                                const uint32_t* __restrict__ keys,
                                                                uint32_t* __restrict__ ranges)
 {
-    const uint32_t L   = d_counts[2];
-    const uint32_t idx = blockIdx.x * kThreads + threadIdx.x;
-    if (idx >= L) return;
-    const uint32_t curr_tile = keys[idx];
-    if (idx == 0) {
-        ranges[2 * (size_t)curr_tile + 0] = 0u;
-    } else {
-        const uint32_t prev_tile = keys[idx - 1];
-        if (curr_tile != prev_tile) {
-            ranges[2 * (size_t)prev_tile + 1] = idx;
-            ranges[2 * (size_t)curr_tile + 0] = idx;
+    const uint32_t L = d_counts[2];
+    for (uint32_t idx = blockIdx.x * kThreads + threadIdx.x; idx < L; idx += gridDim.x * kThreads) {
+        const uint32_t curr_tile = keys[idx];
+        if (idx == 0) {
+            ranges[2 * (size_t)curr_tile + 0] = 0u;
+        } else {
+            const uint32_t prev_tile = keys[idx - 1];
+            if (curr_tile != prev_tile) {
+                ranges[2 * (size_t)prev_tile + 1] = idx;
+                ranges[2 * (size_t)curr_tile + 0] = idx;
+            }
         }
+        if (idx == L - 1) ranges[2 * (size_t)curr_tile + 1] = L;
     }
-    if (idx == L - 1) ranges[2 * (size_t)curr_tile + 1] = L;
 }
 
 // point_list in original splat indices (what the reference's point_list holds), for parity checks
@@ -449,12 +550,11 @@ size_t fused_scan_state_bytes(int P) { return (size_t)(chunks_for(P) + 2) * size
 
 void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const float* pos, const float* scale,
                          const float* rotq, const float* opacity, int32_t* radii, uint32_t* sort_keys,
-                         uint32_t* sort_vals, uint32_t* vis_index, uint64_t* scan_state, uint32_t* d_counts,
-                         hipStream_t stream)
+                         uint32_t* sort_vals, uint32_t* vis_index, uint2* rects, uint64_t* scan_state,
+                         uint32_t* d_counts, hipStream_t stream)
 {
-    (void)hipMemsetAsync(scan_state, 0, fused_scan_state_bytes(P), stream);
     hipLaunchKernelGGL(k_cull_compact, dim3(chunks_for(P)), dim3(kThreads), 0, stream, P, cp, scale_modifier, pos,
-                       scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index, scan_state, d_counts);
+                       scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index, rects, scan_state, d_counts);
 }
 
 void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
@@ -465,30 +565,37 @@ void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scal
                        scale_modifier, pos, scale, rotq, sh, opacity, vis_index, d_counts, recs);
 }
 
-void launch_gather_tiles(int P_cap, const uint32_t* d_counts, const uint32_t* order, const SplatRecord* recs,
-                         uint32_t* tiles_sorted, hipStream_t stream)
-{
-    hipLaunchKernelGGL(k_gather_tiles, dim3(blocks_for(P_cap)), dim3(kThreads), 0, stream, d_counts, order, recs,
-                       tiles_sorted);
-}
 
-void launch_finalize_counts(uint32_t* d_counts, const uint32_t* offsets_incl, uint32_t capacity, hipStream_t stream)
-{
-    hipLaunchKernelGGL(k_finalize_counts, dim3(1), dim3(1), 0, stream, d_counts, offsets_incl, capacity);
-}
 
-void launch_expand_pairs(int P_cap, const uint32_t* d_counts, uint32_t grid_x, const uint32_t* order,
-                         const uint32_t* offsets_incl, const SplatRecord* recs, uint32_t* pair_keys,
-                         uint32_t* pair_vals, uint32_t capacity, hipStream_t stream)
+
+size_t expand_ws_bytes(int P_cap) { return (size_t)((P_cap + kExpandChunk - 1) / kExpandChunk + 4) * sizeof(uint32_t); }
+
+void launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts, uint32_t grid_x,
+                   const uint32_t* order, const uint2* rects, uint2* rects_sorted, uint32_t* pair_keys,
+                   uint32_t* pair_vals, uint32_t capacity, uint32_t* ws, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_expand_pairs, dim3(blocks_for(P_cap)), dim3(kThreads), 0, stream, d_counts, grid_x, order,
-                       offsets_incl, recs, pair_keys, pair_vals, capacity);
+    int64_t hint   = v_hint > 0 ? v_hint : P_cap;
+    int64_t blocks = (hint + kExpandChunk - 1) / kExpandChunk;
+    int64_t cap    = ((int64_t)P_cap + kExpandChunk - 1) / kExpandChunk;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_expand_reduce, dim3((unsigned)blocks), dim3(kThreads), 0, stream, d_counts, order, rects,
+                       rects_sorted, ws);
+    hipLaunchKernelGGL(k_expand_offsets, dim3(1), dim3(1024), 0, stream, d_counts, ws, capacity);
+    int64_t lh      = l_hint > 0 ? l_hint : capacity;
+    int64_t eblocks = (lh + kEmitWindow - 1) / kEmitWindow;
+    if (eblocks > 16384) eblocks = 16384;
+    if (eblocks < 1) eblocks = 1;
+    hipLaunchKernelGGL(k_expand_emit, dim3((unsigned)eblocks), dim3(kThreads), 0, stream, d_counts, grid_x, order,
+                       rects_sorted, ws, pair_keys, pair_vals);
 }
 
 void launch_get_ranges_u32(int64_t L_cap, const uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
                            hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_get_ranges_u32, dim3(blocks_for(L_cap)), dim3(kThreads), 0, stream, d_counts, keys, ranges);
+    unsigned blocks = blocks_for(L_cap);
+    if (blocks > 4096u) blocks = 4096u;
+    hipLaunchKernelGGL(k_get_ranges_u32, dim3(blocks), dim3(kThreads), 0, stream, d_counts, keys, ranges);
 }
 
 void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t* list_vid, const uint32_t* vis_index,

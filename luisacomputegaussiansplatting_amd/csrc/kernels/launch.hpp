@@ -80,17 +80,22 @@ size_t fused_scan_state_bytes(int P);
 //           [4] pairs wanted (before clamping to the workspace capacity)
 void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const float* pos, const float* scale,
                          const float* rotq, const float* opacity, int32_t* radii, uint32_t* sort_keys,
-                         uint32_t* sort_vals, uint32_t* vis_index, uint64_t* scan_state, uint32_t* d_counts,
-                         hipStream_t stream);
+                         uint32_t* sort_vals, uint32_t* vis_index, uint2* rects, uint64_t* scan_state,
+                         uint32_t* d_counts, hipStream_t stream);
+size_t expand_ws_bytes(int P_cap);
+// v_hint: expected survivor count (bounds the launch; larger live counts are handled by chunk striding)
+void launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts, uint32_t grid_x,
+                   const uint32_t* order, const uint2* rects, uint2* rects_sorted, uint32_t* pair_keys,
+                   uint32_t* pair_vals, uint32_t capacity, uint32_t* ws, hipStream_t stream);
+
+// ---- pair_sort.hip : stable radix sort of (u32 key, u32 value) pairs, count in device memory ----
+size_t pair_sort_ws_bytes(int64_t n_cap);
+// ping-pongs a -> b -> a ...; returns 0 if the result ended in (keys_a, vals_a), 1 if in (keys_b, vals_b)
+int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, const uint32_t* d_n,
+                         int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws, hipStream_t stream);
 void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
                           const float* scale, const float* rotq, const float* sh, const float* opacity,
                           const uint32_t* vis_index, const uint32_t* d_counts, SplatRecord* recs, hipStream_t stream);
-void launch_gather_tiles(int P_cap, const uint32_t* d_counts, const uint32_t* order, const SplatRecord* recs,
-                         uint32_t* tiles_sorted, hipStream_t stream);
-void launch_finalize_counts(uint32_t* d_counts, const uint32_t* offsets_incl, uint32_t capacity, hipStream_t stream);
-void launch_expand_pairs(int P_cap, const uint32_t* d_counts, uint32_t grid_x, const uint32_t* order,
-                         const uint32_t* offsets_incl, const SplatRecord* recs, uint32_t* pair_keys,
-                         uint32_t* pair_vals, uint32_t capacity, hipStream_t stream);
 void launch_get_ranges_u32(int64_t L_cap, const uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
                            hipStream_t stream);
 void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t* list_vid, const uint32_t* vis_index,

@@ -1,0 +1,240 @@
+// pair_sort.hip -- the stable LSD radix sort of (u32 key, u32 value) pairs used twice per fused frame
+// (survivors by depth bits; pairs by tile id).  Same role as radix_sort.hip (lcpp DeviceRadixSort, call site
+// lcgs/src/gs_tile_splatter/impl.cpp:135-143) but with the element count read from device memory and three
+// launches per digit instead of five:
+//   k_hist     per-chunk digit counts -> counts[digit][chunk]            (reads the keys)
+//   k_rowscan  one workgroup per digit: exclusive scan of its row + the row total
+//   k_scatter  wave64-ballot stable ranking, LDS staging into chunk-sorted order, coalesced runs out;
+//              the global digit bases are re-derived per workgroup from the 256 row totals
+// A decoupled-look-back single-pass variant was measured and rejected on this part: per-digit look-back chains
+// are latency-bound here (agent-scope sc1 loads are ~1 us each under load, one ticket atomic saturates at
+// ~88/us), 1.5-2x slower than these three plain launches at V ~ 2.4 M / L ~ 7.5 M.
+// Workgroups stride over chunks, so the grid is bounded (no launch of capacity-sized empty grids).
+#include "launch.hpp"
+
+namespace lcgs
+{
+namespace
+{
+
+constexpr int kThreads = 256;
+constexpr int kWaves   = kThreads / 64;
+constexpr int kItems   = 16;
+constexpr int kKPB     = kThreads * kItems; // 4096 keys per chunk
+constexpr int kRadix   = 256;
+
+__global__ void __launch_bounds__(kThreads) k_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
+                                                     int shift, uint32_t mask, uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t s_hist[kRadix];
+    const uint32_t n  = *d_n;
+    const uint32_t nb = (n + kKPB - 1) / kKPB;
+    for (uint32_t chunk = blockIdx.x; chunk < nb; chunk += gridDim.x) {
+        s_hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t base = chunk * kKPB;
+#pragma unroll 4
+        for (int r = 0; r < kItems; ++r) {
+            const uint32_t i = base + r * kThreads + threadIdx.x;
+            if (i < n) atomicAdd(&s_hist[(keys[i] >> shift) & mask], 1u);
+        }
+        __syncthreads();
+        counts[(size_t)threadIdx.x * nb + chunk] = s_hist[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// one workgroup per digit: counts[d][0..nb) -> exclusive prefix in place; totals[d] = row sum
+__global__ void __launch_bounds__(kThreads) k_rowscan(uint32_t* __restrict__ counts, const uint32_t* __restrict__ d_n,
+                                                        uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t s_wave[kWaves];
+    __shared__ uint32_t s_carry;
+    const uint32_t n    = *d_n;
+    const uint32_t nb   = (n + kKPB - 1) / kKPB;
+    uint32_t*      row  = counts + (size_t)blockIdx.x * nb;
+    const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += kThreads) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nb ? row[i] : 0u;
+        uint32_t       inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t carry = s_carry;
+        for (int w = 0; w < wave; ++w) carry += s_wave[w];
+        if (i < nb) row[i] = carry + inc - v;
+        __syncthreads();
+        if (threadIdx.x == kThreads - 1) s_carry = carry + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = s_carry;
+}
+
+__global__ void __launch_bounds__(kThreads) k_scatter(const uint32_t* __restrict__ keys_in,
+                                                        const uint32_t* __restrict__ vals_in,
+                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                        const uint32_t* __restrict__ d_n, int shift, uint32_t mask,
+                                                        int bits, const uint32_t* __restrict__ row_excl,
+                                                        const uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t s_wave_hist[kWaves][kRadix];
+    __shared__ uint32_t s_global_delta[kRadix];
+    __shared__ uint32_t s_digit_base[kRadix];
+    __shared__ uint32_t s_scan[kWaves];
+    __shared__ uint32_t s_keys[kKPB];
+    __shared__ uint32_t s_vals[kKPB];
+
+    const uint32_t n  = *d_n;
+    const uint32_t nb = (n + kKPB - 1) / kKPB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x >= nb) return;
+
+    // global exclusive base of each digit from the 256 row totals
+    {
+        const uint32_t own = totals[tid];
+        uint32_t       inc = own;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) s_scan[wave] = inc;
+        __syncthreads();
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w)
+            if (w < wave) carry += s_scan[w];
+        s_digit_base[tid] = carry + inc - own;
+        __syncthreads();
+    }
+
+    for (uint32_t chunk = blockIdx.x; chunk < nb; chunk += gridDim.x) {
+        const uint32_t block_base = chunk * kKPB;
+        const uint32_t wave_base  = block_base + wave * 64 * kItems;
+        const uint32_t in_block   = (n - block_base) < (uint32_t)kKPB ? (n - block_base) : (uint32_t)kKPB;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) s_wave_hist[w][tid] = 0;
+        __syncthreads();
+
+        uint32_t key[kItems], rank[kItems];
+        volatile uint32_t* my_hist = s_wave_hist[wave];
+        // ---- per-wave stable ranking, 64 keys per round in memory order
+#pragma unroll
+        for (int r = 0; r < kItems; ++r) {
+            const uint32_t i     = wave_base + r * 64 + lane;
+            const bool     valid = i < n;
+            key[r]               = valid ? keys_in[i] : 0u;
+            const uint32_t d     = (key[r] >> shift) & mask;
+            unsigned long long peers = __ballot(valid);
+            for (int b = 0; b < bits; ++b) {
+                const bool               bit = (d >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+            }
+            const uint32_t below = __popcll(peers & ((1ull << lane) - 1ull));
+            const uint32_t count = __popcll(peers);
+            uint32_t       prev  = 0;
+            if (valid) prev = my_hist[d];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && below == 0) my_hist[d] = prev + count;
+            __builtin_amdgcn_wave_barrier();
+            rank[r] = prev + below;
+        }
+        __syncthreads();
+
+        // ---- thread d owns digit d: combine the waves; chunk-local start; global position
+        uint32_t wave_off[kWaves];
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            wave_off[w] = total;
+            total += s_wave_hist[w][tid];
+        }
+        uint32_t inc = total;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) s_scan[wave] = inc;
+        __syncthreads();
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w)
+            if (w < wave) carry += s_scan[w];
+        const uint32_t start = carry + inc - total;
+        s_global_delta[tid]  = s_digit_base[tid] + row_excl[(size_t)tid * nb + chunk] - start;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) s_wave_hist[w][tid] = start + wave_off[w];
+        __syncthreads();
+
+        // ---- stage into chunk-sorted order in LDS, then scatter each digit's run coalesced
+#pragma unroll
+        for (int r = 0; r < kItems; ++r) {
+            const uint32_t i = wave_base + r * 64 + lane;
+            if (i < n) {
+                const uint32_t d   = (key[r] >> shift) & mask;
+                const uint32_t pos = s_wave_hist[wave][d] + rank[r];
+                s_keys[pos]        = key[r];
+                s_vals[pos]        = vals_in[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (uint32_t i = tid; i < in_block; i += kThreads) {
+            const uint32_t k   = s_keys[i];
+            const uint32_t dst = s_global_delta[(k >> shift) & mask] + i;
+            keys_out[dst]      = k;
+            vals_out[dst]      = s_vals[i];
+        }
+        __syncthreads();
+    }
+}
+
+} // namespace
+
+size_t pair_sort_ws_bytes(int64_t n_cap)
+{
+    const int64_t nb = (n_cap + kKPB - 1) / kKPB;
+    return (size_t)(nb * kRadix + kRadix + 64) * sizeof(uint32_t);
+}
+
+// Ping-pongs a -> b -> a ...; returns 0 if the result ended in (keys_a, vals_a), 1 if in (keys_b, vals_b).
+// grid_hint: expected element count (bounds the launch; larger live counts are handled by chunk striding).
+int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, const uint32_t* d_n,
+                         int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws_, hipStream_t stream)
+{
+    if (n_cap <= 0) return 0;
+    const int n_pass = (end_bit - begin_bit + 7) / 8;
+    if (n_pass <= 0) return 0;
+    const int64_t nb_cap = (n_cap + kKPB - 1) / kKPB;
+    uint32_t*     counts = reinterpret_cast<uint32_t*>(ws_);
+    uint32_t*     totals = counts + nb_cap * kRadix;
+    int64_t       hint   = grid_hint > 0 ? grid_hint : n_cap;
+    int64_t       blocks = (hint + kKPB - 1) / kKPB;
+    if (blocks > nb_cap) blocks = nb_cap;
+    if (blocks < 1) blocks = 1;
+    uint32_t* kb[2] = { keys_a, keys_b };
+    uint32_t* vb[2] = { vals_a, vals_b };
+    int       src = 0, shift = begin_bit;
+    for (int p = 0; p < n_pass; ++p) {
+        const int      bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+        const uint32_t mask = (1u << bits) - 1u;
+        hipLaunchKernelGGL(k_hist, dim3((unsigned)blocks), dim3(kThreads), 0, stream, kb[src], d_n, shift, mask, counts);
+        hipLaunchKernelGGL(k_rowscan, dim3(kRadix), dim3(kThreads), 0, stream, counts, d_n, totals);
+        hipLaunchKernelGGL(k_scatter, dim3((unsigned)blocks), dim3(kThreads), 0, stream, kb[src], vb[src], kb[src ^ 1],
+                           vb[src ^ 1], d_n, shift, mask, bits, counts, totals);
+        src ^= 1;
+        shift += bits;
+    }
+    return src;
+}
+
+} // namespace lcgs

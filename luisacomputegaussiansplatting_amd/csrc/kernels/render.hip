@@ -94,6 +94,32 @@ __device__ __forceinline__ bool splat_may_touch_rect(float mx, float my, float c
     return best - 1e-5f * slack <= t;
 }
 
+// Workgroup -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b lands on XCD b % 8,
+// and is that XCD's (b / 8)-th workgroup).  Tiles are grouped into blocks of 8 x 4 tiles (128 x 64 px: most
+// splats live inside one block, so its tiles share their records in one XCD's L2) and the blocks are dealt
+// round-robin to the XCDs, so every XCD gets an even mix of dense (image centre) and sparse (border) regions.
+// Speed only: any placement gives the same image.
+constexpr uint32_t kBlkW = 8, kBlkH = 4;
+
+__device__ __forceinline__ bool tile_of_workgroup(uint32_t b, uint32_t grid_x, uint32_t grid_y, uint32_t& tx,
+                                                  uint32_t& ty)
+{
+    const uint32_t xcd = b % kXcd, seq = b / kXcd;
+    const uint32_t bw = (grid_x + kBlkW - 1) / kBlkW;
+    const uint32_t blk = xcd + kXcd * (seq / (kBlkW * kBlkH));
+    const uint32_t in  = seq % (kBlkW * kBlkH);
+    tx = (blk % bw) * kBlkW + in % kBlkW;
+    ty = (blk / bw) * kBlkH + in / kBlkW;
+    return tx < grid_x && ty < grid_y;
+}
+
+__host__ __device__ inline uint32_t render_grid_size(uint32_t grid_x, uint32_t grid_y)
+{
+    const uint32_t bw = (grid_x + kBlkW - 1) / kBlkW, bh = (grid_y + kBlkH - 1) / kBlkH;
+    const uint32_t per_xcd = (bw * bh + kXcd - 1) / kXcd; // blocks per XCD
+    return per_xcd * kBlkW * kBlkH * kXcd;
+}
+
 template <typename Fetch>
 __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, float bg1, float bg2,
                                                          const uint32_t* __restrict__ ranges,
@@ -104,37 +130,40 @@ __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, 
 {
     __shared__ float4 s_a[64]; // mean.x, mean.y, conic.x, conic.y
     __shared__ float4 s_b[64]; // conic.z, opacity, r, g
-    __shared__ float4 s_c[64]; // b, power floor (-t/2), list position + 1 (as bits), unused
+    __shared__ float4 s_c[64]; // b, power floor (-t/2), list position + 1 (bits), strip mask (bits)
 
-    const uint32_t G    = cp.grid_x * cp.grid_y;
-    const uint32_t per  = (G + kXcd - 1) / kXcd;
-    const uint32_t tile = (blockIdx.x % kXcd) * per + blockIdx.x / kXcd;
-    if (tile >= G) return;
+    uint32_t tx, ty;
+    if (!tile_of_workgroup(blockIdx.x, cp.grid_x, cp.grid_y, tx, ty)) return;
+    const uint32_t tile = ty * cp.grid_x + tx;
     // num_rendered == 0: nothing is drawn and the image is left untouched (gs_tile_splatter/impl.cpp:109)
     if (d_counts && d_counts[1] == 0u) return;
 
     const uint32_t lane = threadIdx.x;
-    const uint32_t tx = tile % cp.grid_x, ty = tile / cp.grid_x;
     const uint32_t px  = tx * kBlockX + (lane & 15u);
     const uint32_t py0 = ty * kBlockY + (lane >> 4);
-    const float    pxf = (float)px;
+    float          pxf = (float)px;
     const float    rx0 = (float)(tx * kBlockX), ry0 = (float)(ty * kBlockY);
-    const float    rx1 = rx0 + (float)(kBlockX - 1), ry1 = ry0 + (float)(kBlockY - 1);
+    const float    rx1 = rx0 + (float)(kBlockX - 1);
 
-    float    pyf[4];
-    bool     inside[4], done[4];
-    float    T[4], Cr[4], Cg[4], Cb[4];
+    // T > 0: pixel live; T < 0: pixel finished (saturated or outside the image), |T| is its transmittance.
+    float    pyf[4], T[4], Cr[4], Cg[4], Cb[4];
     uint32_t last_contrib[4];
+    uint32_t live = 0;       // wave-uniform count of live pixels
+    uint32_t live_strips = 0; // wave-uniform: bit k set while strip k still has a live pixel
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t py = py0 + 4u * k;
         pyf[k]            = (float)py;
-        inside[k]         = (px < cp.width) && (py < cp.height);
-        done[k]           = !inside[k];
-        T[k]              = 1.0f;
+        const bool inside = (px < cp.width) && (py < cp.height);
+        T[k]              = inside ? 1.0f : -1.0f;
         Cr[k] = Cg[k] = Cb[k] = 0.0f;
         last_contrib[k]       = 0u;
+        const unsigned long long in_mask = __ballot(inside);
+        live += __popcll(in_mask);
+        if (in_mask) live_strips |= 1u << k;
+        asm volatile("" : "+v"(pyf[k])); // keep the converted coordinate in a register (no re-conversion per entry)
     }
+    asm volatile("" : "+v"(pxf));
 
     const uint32_t range_start = ranges[2 * (size_t)tile + 0];
     const uint32_t range_end   = ranges[2 * (size_t)tile + 1];
@@ -144,16 +173,23 @@ __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, 
     float  nc = 0.0f;
     if (range_start + lane < range_end) fetch(point_list[range_start + lane], na, nb, nc);
 
-    for (uint32_t base = range_start; base < range_end; base += 64u) {
-        if (__all(done[0] && done[1] && done[2] && done[3])) break;
-        // ---- stage: cull against the tile rect, compact survivors into LDS in list order
-        const uint32_t e     = base + lane;
-        const bool     have  = e < range_end;
+    for (uint32_t base = range_start; base < range_end && live != 0u; base += 64u) {
+        // ---- stage: test each entry against the four 16x4 strips of the tile, compact survivors in list order
+        const uint32_t e    = base + lane;
+        const bool     have = e < range_end;
         const float4   a = na, b = nb;
         const float    c = nc;
-        // t = 2 ln(255 o) with a relative + absolute safety margin (exp/log rounding, 0.99 clamp irrelevant)
-        const float t    = have ? (2.0f * __logf(255.0f * b.y)) * 1.0001f + 2e-4f : -1.0f;
-        const bool  keep = have && splat_may_touch_rect(a.x, a.y, a.z, a.w, b.x, t, rx0, ry0, rx1, ry1);
+        // t = 2 ln(255 o) with a relative + absolute safety margin (exp/log rounding)
+        const float t = have ? (2.0f * __logf(255.0f * b.y)) * 1.0001f + 2e-4f : -1.0f;
+        uint32_t    kmask = 0;
+        if (have) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float y0 = ry0 + 4.0f * k;
+                if (splat_may_touch_rect(a.x, a.y, a.z, a.w, b.x, t, rx0, y0, rx1, y0 + 3.0f)) kmask |= 1u << k;
+            }
+        }
+        const bool               keep = kmask != 0u;
         const unsigned long long mask = __ballot(keep);
         const uint32_t slot = __popcll(mask & ((1ull << lane) - 1ull));
         const uint32_t cnt  = __popcll(mask);
@@ -161,40 +197,47 @@ __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, 
         if (keep) {
             s_a[slot] = a;
             s_b[slot] = b;
-            s_c[slot] = make_float4(c, -0.5f * t, __uint_as_float(e - range_start + 1u), 0.0f);
+            s_c[slot] = make_float4(c, -0.5f * t, __uint_as_float(e - range_start + 1u), __uint_as_float(kmask));
         }
         const uint32_t en = e + 64u;
         if (en < range_end) fetch(point_list[en], na, nb, nc);
         __syncthreads();
 
-        for (uint32_t j = 0; j < cnt; ++j) {
-            if (__all(done[0] && done[1] && done[2] && done[3])) break;
-            const float4   ea          = s_a[j];
-            const float4   eb          = s_b[j];
-            const float4   ec          = s_c[j];
-            const uint32_t contributor = __float_as_uint(ec.z);
-            const float    dx          = ea.x - pxf;
-            const float    cxdxdx      = ea.z * dx * dx; // con_o.x * d.x * d.x
-            const float    cydx        = ea.w * dx;      // con_o.y * d.x
+        float4 ea = s_a[0], eb = s_b[0], ec = s_c[0];
+        for (uint32_t j = 0; j < cnt && live != 0u; ++j) {
+            const float4 ca = ea, cb4 = eb, cc4 = ec;
+            const uint32_t jn = (j + 1u < cnt) ? j + 1u : j;
+            ea = s_a[jn]; // LDS reads of the next entry overlap this entry's arithmetic
+            eb = s_b[jn];
+            ec = s_c[jn];
+            const uint32_t contributor = __float_as_uint(cc4.z);
+            const uint32_t strips      = __builtin_amdgcn_readfirstlane(__float_as_uint(cc4.w)) & live_strips;
+            const float    dx          = ca.x - pxf;
+            const float    cxdxdx      = ca.z * dx * dx; // con_o.x * d.x * d.x
+            const float    cydx        = ca.w * dx;      // con_o.y * d.x
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float dy    = ea.y - pyf[k];
-                const float power = -0.5f * (cxdxdx + eb.x * dy * dy) - cydx * dy; // shader.cpp:256
-                // strip-level skip before the exp: no lane of this 16x4 strip can reach alpha >= 1/255
-                const bool cand = !done[k] && !(power > 0.0f) && (power >= ec.y);
+                if (!((strips >> k) & 1u)) continue; // scalar: this 16x4 strip is out of the splat's reach
+                const float dy    = ca.y - pyf[k];
+                const float power = -0.5f * (cxdxdx + cb4.x * dy * dy) - cydx * dy; // shader.cpp:256
+                const bool  cand  = (T[k] > 0.0f) && !(power > 0.0f) && (power >= cc4.y);
                 if (!__any(cand)) continue;
-                const float alpha  = fmin_(0.99f, eb.y * __expf(power));
+                const float alpha  = fmin_(0.99f, cb4.y * __expf(power));
                 const bool  valid  = cand && !(alpha < 1.0f / 255.0f);
                 const float test_T = T[k] * (1.0f - alpha);
                 const bool  sat    = valid && (test_T < 0.0001f);
                 const bool  upd    = valid && !sat;
-                done[k]            = done[k] || sat;
                 const float w      = upd ? T[k] * alpha : 0.0f;
-                Cr[k]              = Cr[k] + w * eb.z;
-                Cg[k]              = Cg[k] + w * eb.w;
-                Cb[k]              = Cb[k] + w * ec.x;
-                T[k]               = upd ? test_T : T[k];
+                Cr[k]              = Cr[k] + w * cb4.z;
+                Cg[k]              = Cg[k] + w * cb4.w;
+                Cb[k]              = Cb[k] + w * cc4.x;
+                T[k]               = upd ? test_T : (sat ? -T[k] : T[k]);
                 last_contrib[k]    = upd ? contributor : last_contrib[k];
+                const unsigned long long sm = __ballot(sat);
+                if (sm) { // rare: some pixel of this strip just saturated
+                    live -= __popcll(sm);
+                    if (!__any(T[k] > 0.0f)) live_strips &= ~(1u << k); // the whole 16x4 strip is finished
+                }
             }
         }
     }
@@ -202,12 +245,14 @@ __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, 
     const size_t hw = (size_t)cp.width * cp.height;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (!inside[k]) continue;
-        const size_t pix = (size_t)px + (size_t)cp.width * (py0 + 4u * k);
-        img[pix]          = bg0 * T[k] + Cr[k]; // shader.cpp:279-286, planar CHW
-        img[pix + hw]     = bg1 * T[k] + Cg[k];
-        img[pix + 2 * hw] = bg2 * T[k] + Cb[k];
-        if (final_T) final_T[pix] = T[k];
+        const uint32_t py = py0 + 4u * k;
+        if (!((px < cp.width) && (py < cp.height))) continue;
+        const float  Tk  = fabsf(T[k]);
+        const size_t pix = (size_t)px + (size_t)cp.width * py;
+        img[pix]          = bg0 * Tk + Cr[k]; // shader.cpp:279-286, planar CHW
+        img[pix + hw]     = bg1 * Tk + Cg[k];
+        img[pix + 2 * hw] = bg2 * Tk + Cb[k];
+        if (final_T) final_T[pix] = Tk;
         if (n_contrib) n_contrib[pix] = last_contrib[k];
     }
 }
@@ -217,10 +262,8 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
                    Fetch fetch, float* img, float* final_T, uint32_t* n_contrib, const uint32_t* d_counts,
                    hipStream_t stream)
 {
-    const uint32_t G   = cp.grid_x * cp.grid_y;
-    const uint32_t per = (G + kXcd - 1) / kXcd;
-    if (G == 0) return;
-    hipLaunchKernelGGL(k_render_forward<Fetch>, dim3(per * kXcd), dim3(64), 0, stream, cp, bg[0], bg[1], bg[2], ranges,
+    if (cp.grid_x * cp.grid_y == 0) return;
+    hipLaunchKernelGGL(k_render_forward<Fetch>, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(64), 0, stream, cp, bg[0], bg[1], bg[2], ranges,
                        point_list, fetch, img, final_T, n_contrib, d_counts);
 }
 

@@ -78,8 +78,15 @@ struct lcgs_context {
     DeviceBuffer owned[5];
 
     // workspace of the fused frame
-    DeviceBuffer recs, sortk[2], sortv[2], vis_index, tiles_sorted, offsets, pairk[2], pairv[2], ranges, scan_state,
-        counts, sort_temp, scan_temp, final_T, n_contrib, list_idx;
+    DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws, counts, sort_ws, expand_ws,
+        final_T, n_contrib, list_idx;
+    // sub-allocations of zero_ws (one memset per frame): chained-scan states of the cull pass and the tile ranges
+    uint64_t* scan_state = nullptr;
+    uint32_t* ranges     = nullptr;
+    size_t    zero_bytes = 0;
+    // launch-size hints from the last synchronised frame (live counts stay on the device; larger counts are
+    // still handled correctly by chunk striding)
+    int64_t hint_V = 0, hint_L = 0;
     // workspace of the stage-level path / primitives
     DeviceBuffer st_keys_tmp, st_vals_tmp, st_sort_temp, st_scan_temp, st_scalar;
     uint32_t     pair_capacity = 0;
@@ -167,8 +174,8 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
         LCGS_TRY(ctx->sortv[i].ensure(P * 4));
     }
     LCGS_TRY(ctx->vis_index.ensure(P * 4));
-    LCGS_TRY(ctx->tiles_sorted.ensure(P * 4));
-    LCGS_TRY(ctx->offsets.ensure(P * 4));
+    LCGS_TRY(ctx->rects.ensure(P * 8));
+    LCGS_TRY(ctx->rects_sorted.ensure(P * 8));
     if (ctx->pair_capacity == 0) {
         // generous default: 288 GB of HBM makes over-provisioning the pair buffers free
         uint64_t cap       = std::max<uint64_t>((uint64_t)4 * P, (uint64_t)1 << 22);
@@ -179,11 +186,15 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
         LCGS_TRY(ctx->pairv[i].ensure((size_t)ctx->pair_capacity * 4));
     }
     const size_t G = (size_t)cp.grid_x * cp.grid_y;
-    LCGS_TRY(ctx->ranges.ensure(G * 2 * 4));
-    LCGS_TRY(ctx->scan_state.ensure(fused_scan_state_bytes((int)P)));
+    auto         al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b0 = al(fused_scan_state_bytes((int)P)), b1 = al(G * 2 * 4);
+    LCGS_TRY(ctx->zero_ws.ensure(b0 + b1));
+    ctx->scan_state = ctx->zero_ws.as<uint64_t>();
+    ctx->ranges     = reinterpret_cast<uint32_t*>(ctx->zero_ws.as<char>() + b0);
+    ctx->zero_bytes = b0 + b1;
     LCGS_TRY(ctx->counts.ensure(64));
-    LCGS_TRY(ctx->sort_temp.ensure(sort_temp_bytes(std::max<int64_t>((int64_t)P, (int64_t)ctx->pair_capacity))));
-    LCGS_TRY(ctx->scan_temp.ensure(scan_temp_bytes((int64_t)P)));
+    LCGS_TRY(ctx->sort_ws.ensure(pair_sort_ws_bytes(std::max<int64_t>((int64_t)P, (int64_t)ctx->pair_capacity))));
+    LCGS_TRY(ctx->expand_ws.ensure(expand_ws_bytes((int)P)));
     if (keep_state) {
         LCGS_TRY(ctx->final_T.ensure((size_t)cp.width * cp.height * 4));
         LCGS_TRY(ctx->n_contrib.ensure((size_t)cp.width * cp.height * 4));
@@ -203,43 +214,42 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     ctx->n_marks          = 0;
     LCGS_TRY(mark(ctx, "begin"));
 
+    // one memset per frame: scan states of the cull pass + tile ranges (the reference zero-fills ranges too,
+    // gs_tile_splatter/impl.cpp:147)
+    LCGS_HIP_CHECK(hipMemsetAsync(ctx->zero_ws.ptr, 0, ctx->zero_bytes, st));
     launch_cull_compact(P, cp, scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->opacity, d_radii,
                         ctx->sortk[0].as<uint32_t>(), ctx->sortv[0].as<uint32_t>(), ctx->vis_index.as<uint32_t>(),
-                        ctx->scan_state.as<uint64_t>(), d_counts, st);
+                        ctx->rects.as<uint2>(), ctx->scan_state, d_counts, st);
     LCGS_TRY(mark(ctx, "cull_compact"));
-    launch_build_records(P, ctx->sh_deg, cp, scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity,
-                         ctx->vis_index.as<uint32_t>(), d_counts, recs, st);
+    const int64_t hint_V = ctx->hint_V > 0 ? ctx->hint_V : P;
+    const int64_t hint_L = ctx->hint_L > 0 ? ctx->hint_L : ctx->pair_capacity;
+    launch_build_records((int)std::min<int64_t>(P, hint_V), ctx->sh_deg, cp, scale_modifier, ctx->pos, ctx->scale,
+                         ctx->rotq, ctx->sh, ctx->opacity, ctx->vis_index.as<uint32_t>(), d_counts, recs, st);
     LCGS_TRY(mark(ctx, "build_records"));
 
-    // depth bits of a float >= 0.2 never use bit 31
-    const int where = launch_sort_pairs_u32_pingpong(ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
-                                                     ctx->sortv[0].as<uint32_t>(), ctx->sortv[1].as<uint32_t>(),
-                                                     d_counts + 0, P, 0, 32, ctx->sort_temp.ptr, st);
+    // survivors by depth bits: the low 32 bits of the reference key, sorted before duplication
+    const int where = launch_pair_sort_u32(ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
+                                           ctx->sortv[0].as<uint32_t>(), ctx->sortv[1].as<uint32_t>(), d_counts + 0, P,
+                                           hint_V, 0, 32, ctx->sort_ws.ptr, st);
     const uint32_t* order = ctx->sortv[where].as<uint32_t>();
     LCGS_TRY(mark(ctx, "depth_sort"));
 
-    launch_gather_tiles(P, d_counts, order, recs, ctx->tiles_sorted.as<uint32_t>(), st);
-    launch_inclusive_sum_u32_dyn(ctx->tiles_sorted.as<uint32_t>(), ctx->offsets.as<uint32_t>(), P, d_counts + 0,
-                                 ctx->scan_temp.ptr, st);
-    launch_finalize_counts(d_counts, ctx->offsets.as<uint32_t>(), ctx->pair_capacity, st);
-    launch_expand_pairs(P, d_counts, cp.grid_x, order, ctx->offsets.as<uint32_t>(), recs, ctx->pairk[0].as<uint32_t>(),
-                        ctx->pairv[0].as<uint32_t>(), ctx->pair_capacity, st);
+    launch_expand(P, hint_V, hint_L, d_counts, cp.grid_x, order, ctx->rects.as<uint2>(), ctx->rects_sorted.as<uint2>(),
+                  ctx->pairk[0].as<uint32_t>(), ctx->pairv[0].as<uint32_t>(), ctx->pair_capacity,
+                  ctx->expand_ws.as<uint32_t>(), st);
     LCGS_TRY(mark(ctx, "expand"));
 
+    // stable partition by tile id: only ceil(log2 G) key bits are live
     const int tile_bits = std::max(1, ceil_log2_u32(cp.grid_x * cp.grid_y));
-    const int where2 = launch_sort_pairs_u32_pingpong(ctx->pairk[0].as<uint32_t>(), ctx->pairk[1].as<uint32_t>(),
-                                                      ctx->pairv[0].as<uint32_t>(), ctx->pairv[1].as<uint32_t>(),
-                                                      d_counts + 2, ctx->pair_capacity, 0, tile_bits,
-                                                      ctx->sort_temp.ptr, st);
+    const int where2 = launch_pair_sort_u32(ctx->pairk[0].as<uint32_t>(), ctx->pairk[1].as<uint32_t>(),
+                                            ctx->pairv[0].as<uint32_t>(), ctx->pairv[1].as<uint32_t>(), d_counts + 2,
+                                            ctx->pair_capacity, hint_L, 0, tile_bits, ctx->sort_ws.ptr, st);
     LCGS_TRY(mark(ctx, "tile_sort"));
 
-    const size_t G = (size_t)cp.grid_x * cp.grid_y;
-    LCGS_HIP_CHECK(hipMemsetAsync(ctx->ranges.ptr, 0, G * 2 * 4, st)); // gs_tile_splatter/impl.cpp:147
-    launch_get_ranges_u32(ctx->pair_capacity, d_counts, ctx->pairk[where2].as<uint32_t>(), ctx->ranges.as<uint32_t>(),
-                          st);
+    launch_get_ranges_u32(hint_L, d_counts, ctx->pairk[where2].as<uint32_t>(), ctx->ranges, st);
     LCGS_TRY(mark(ctx, "ranges"));
 
-    launch_render_forward_rec(cp, bg, ctx->ranges.as<uint32_t>(), ctx->pairv[where2].as<uint32_t>(), recs, d_img,
+    launch_render_forward_rec(cp, bg, ctx->ranges, ctx->pairv[where2].as<uint32_t>(), recs, d_img,
                               keep_state ? ctx->final_T.as<float>() : nullptr,
                               keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, st);
     LCGS_TRY(mark(ctx, "render"));
@@ -293,9 +303,9 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DeviceBuffer* bufs[] = { &ctx->recs, &ctx->sortk[0], &ctx->sortk[1], &ctx->sortv[0], &ctx->sortv[1], &ctx->vis_index,
-                             &ctx->tiles_sorted, &ctx->offsets, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
-                             &ctx->pairv[1], &ctx->ranges, &ctx->scan_state, &ctx->counts, &ctx->sort_temp,
-                             &ctx->scan_temp, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->st_keys_tmp,
+                             &ctx->rects, &ctx->rects_sorted, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
+                             &ctx->pairv[1], &ctx->zero_ws, &ctx->counts, &ctx->sort_ws,
+                             &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->st_keys_tmp,
                              &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& b : ctx->owned) b.release();
@@ -516,6 +526,9 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
         ctx->stats.num_pairs     = ctx->h_counts[2];
         ctx->stats.num_tiles     = (int64_t)cp.grid_x * cp.grid_y;
         if (num_rendered) *num_rendered = (int)ctx->h_counts[1];
+        // launch-size hints for the following asynchronous frames
+        ctx->hint_V = (int64_t)ctx->h_counts[0] + ctx->h_counts[0] / 4 + 4096;
+        ctx->hint_L = (int64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4 + 4096;
         if (ctx->h_counts[3] == 0) return LCGS_OK;
         // pair buffers were too small for this view: grow and redo the frame
         uint64_t want = (uint64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4;
@@ -568,7 +581,7 @@ lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t*
         launch_map_to_index(L, ctx->counts.as<uint32_t>(), ctx->pairv[ctx->last.list_buf].as<uint32_t>(),
                             ctx->vis_index.as<uint32_t>(), d_list, ctx->stream);
     if (d_ranges)
-        LCGS_HIP_CHECK(hipMemcpyAsync(d_ranges, ctx->ranges.ptr,
+        LCGS_HIP_CHECK(hipMemcpyAsync(d_ranges, ctx->ranges,
                                       (size_t)ctx->last.cp.grid_x * ctx->last.cp.grid_y * 8, hipMemcpyDeviceToDevice,
                                       ctx->stream));
     LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
