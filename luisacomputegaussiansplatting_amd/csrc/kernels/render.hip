@@ -19,6 +19,8 @@
 //     hit the same L2.
 // Numerics: the per-pixel expressions keep the reference's evaluation order with no FMA contraction
 // (-ffp-contract=off); exp() is the hardware v_exp_f32 path (__expf).
+#include <stdlib.h>
+
 #include "launch.hpp"
 
 namespace lcgs
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, 
             eb = s_b[jn];
             ec = s_c[jn];
             const uint32_t contributor = __float_as_uint(cc4.z);
-            const uint32_t strips      = __builtin_amdgcn_readfirstlane(__float_as_uint(cc4.w)) & live_strips;
+            const uint32_t strips      = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cc4.w)) & live_strips;
             const float    dx          = ca.x - pxf;
             const float    cxdxdx      = ca.z * dx * dx; // con_o.x * d.x * d.x
             const float    cydx        = ca.w * dx;      // con_o.y * d.x
@@ -257,12 +259,153 @@ __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Variant B: one workgroup (4 wave64s) per tile, wave k owns the 16x4 strip k, one pixel per lane.
+// The heaviest tiles set the kernel's critical path; splitting a tile over four waves shortens it 4x and gives
+// the dispatcher four times as many independent wave-sized work items to balance.  A round stages 256 list
+// entries: every lane fetches one entry, tests it against the four strips, and the per-strip ballots (one
+// 64-bit mask per staging wave and strip) go to LDS; wave k then walks the set bits of "its" four masks with
+// scalar bit-scan instructions -- entries irrelevant to a strip cost that strip nothing, order is preserved.
+// ---------------------------------------------------------------------------------------------
+template <typename Fetch>
+__global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg0, float bg1, float bg2,
+                                                            const uint32_t* __restrict__ ranges,
+                                                            const uint32_t* __restrict__ point_list, Fetch fetch,
+                                                            float* __restrict__ img, float* __restrict__ final_T,
+                                                            uint32_t* __restrict__ n_contrib,
+                                                            const uint32_t* __restrict__ d_counts)
+{
+    __shared__ float4             s_a[256]; // mean.x, mean.y, conic.x, conic.y
+    __shared__ float4             s_b[256]; // conic.z, opacity, r, g
+    __shared__ float2             s_c[256]; // b, power floor (-t/2)
+    __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
+    __shared__ uint32_t           s_live_waves;
+
+    uint32_t tx, ty;
+    if (!tile_of_workgroup(blockIdx.x, cp.grid_x, cp.grid_y, tx, ty)) return;
+    const uint32_t tile = ty * cp.grid_x + tx;
+    if (d_counts && d_counts[1] == 0u) return; // image untouched (gs_tile_splatter/impl.cpp:109)
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t px = tx * kBlockX + (lane & 15u);
+    const uint32_t py = ty * kBlockY + 4u * wave + (lane >> 4);
+    float          pxf = (float)px, pyf = (float)py;
+    asm volatile("" : "+v"(pxf), "+v"(pyf));
+    const float rx0 = (float)(tx * kBlockX), ry0 = (float)(ty * kBlockY), rx1 = rx0 + (float)(kBlockX - 1);
+    const bool  inside = (px < cp.width) && (py < cp.height);
+
+    float    T = inside ? 1.0f : -1.0f; // T < 0: finished, |T| is the transmittance
+    float    Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
+    uint32_t last_contrib = 0u;
+    uint32_t live = __popcll(__ballot(inside)); // wave-uniform
+    if (tid == 0) s_live_waves = 0u;
+    __syncthreads();
+    if (lane == 0 && live != 0u) atomicAdd(&s_live_waves, 1u);
+
+    const uint32_t range_start = ranges[2 * (size_t)tile + 0];
+    const uint32_t range_end   = ranges[2 * (size_t)tile + 1];
+
+    float4 na = make_float4(0, 0, 0, 0), nb = make_float4(0, 0, 0, 0);
+    float  nc = 0.0f;
+    if (range_start + tid < range_end) fetch(point_list[range_start + tid], na, nb, nc);
+    __syncthreads();
+
+    for (uint32_t base = range_start; base < range_end; base += 256u) {
+        if (s_live_waves == 0u) break; // every pixel of the tile is finished
+        // ---- stage 256 entries: strip tests, per-strip ballots, slab
+        const uint32_t e    = base + tid;
+        const bool     have = e < range_end;
+        const float4   a = na, b = nb;
+        const float    c = nc;
+        const float    t = have ? (2.0f * __logf(255.0f * b.y)) * 1.0001f + 2e-4f : -1.0f;
+        uint32_t       kmask = 0;
+        if (have) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float y0 = ry0 + 4.0f * k;
+                if (splat_may_touch_rect(a.x, a.y, a.z, a.w, b.x, t, rx0, y0, rx1, y0 + 3.0f)) kmask |= 1u << k;
+            }
+        }
+        __syncthreads(); // previous round's readers are done with the slab and the masks
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long m = __ballot((kmask >> k) & 1u);
+            if (lane == 0) s_mask[wave][k] = m;
+        }
+        if (kmask) {
+            s_a[tid] = a;
+            s_b[tid] = b;
+            s_c[tid] = make_float2(c, -0.5f * t);
+        }
+        const uint32_t en = e + 256u;
+        if (en < range_end) fetch(point_list[en], na, nb, nc);
+        __syncthreads();
+
+        if (live != 0u) {
+            for (uint32_t w = 0; w < 4u && live != 0u; ++w) {
+                unsigned long long m = s_mask[w][wave];
+                // readfirstlane returns int: cast through uint32_t so the low half is not sign-extended
+                m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) |
+                    (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+                while (m != 0ull && live != 0u) {
+                    const uint32_t l   = (uint32_t)__ffsll((long long)m) - 1u;
+                    m &= m - 1ull;
+                    const uint32_t idx = w * 64u + l;
+                    const float4   ea = s_a[idx], eb = s_b[idx];
+                    const float2   ec = s_c[idx];
+                    const uint32_t contributor = base - range_start + idx + 1u;
+                    const float dx    = ea.x - pxf;
+                    const float dy    = ea.y - pyf;
+                    const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy; // shader.cpp:256
+                    const bool  cand  = (T > 0.0f) && !(power > 0.0f) && (power >= ec.y);
+                    if (!__any(cand)) continue;
+                    const float alpha  = fmin_(0.99f, eb.y * __expf(power));
+                    const bool  valid  = cand && !(alpha < 1.0f / 255.0f);
+                    const float test_T = T * (1.0f - alpha);
+                    const bool  sat    = valid && (test_T < 0.0001f);
+                    const bool  upd    = valid && !sat;
+                    const float wgt    = upd ? T * alpha : 0.0f;
+                    Cr                 = Cr + wgt * eb.z;
+                    Cg                 = Cg + wgt * eb.w;
+                    Cb                 = Cb + wgt * ec.x;
+                    T                  = upd ? test_T : (sat ? -T : T);
+                    last_contrib       = upd ? contributor : last_contrib;
+                    const unsigned long long sm = __ballot(sat);
+                    if (sm) live -= __popcll(sm);
+                }
+            }
+            if (live == 0u && lane == 0) atomicSub(&s_live_waves, 1u);
+        }
+        __syncthreads();
+    }
+
+    if (inside) {
+        const size_t hw  = (size_t)cp.width * cp.height;
+        const float  Tk  = fabsf(T);
+        const size_t pix = (size_t)px + (size_t)cp.width * py;
+        img[pix]          = bg0 * Tk + Cr;
+        img[pix + hw]     = bg1 * Tk + Cg;
+        img[pix + 2 * hw] = bg2 * Tk + Cb;
+        if (final_T) final_T[pix] = Tk;
+        if (n_contrib) n_contrib[pix] = last_contrib;
+    }
+}
+
 template <typename Fetch>
 void launch_render(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                    Fetch fetch, float* img, float* final_T, uint32_t* n_contrib, const uint32_t* d_counts,
                    hipStream_t stream)
 {
     if (cp.grid_x * cp.grid_y == 0) return;
+    static const int variant = [] {
+        const char* v = getenv("LCGS_RENDER_VARIANT"); // tuning hook: "a" = wave per tile, default = workgroup per tile
+        return (v && v[0] == 'a') ? 0 : 1;
+    }();
+    if (variant == 1) {
+        hipLaunchKernelGGL(k_render_forward_b<Fetch>, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(256), 0, stream,
+                           cp, bg[0], bg[1], bg[2], ranges, point_list, fetch, img, final_T, n_contrib, d_counts);
+        return;
+    }
     hipLaunchKernelGGL(k_render_forward<Fetch>, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(64), 0, stream, cp, bg[0], bg[1], bg[2], ranges,
                        point_list, fetch, img, final_T, n_contrib, d_counts);
 }
