@@ -1,2 +1,528 @@
-// backward.hip -- render-backward and preprocess-backward kernels (filled in below).
+// backward.hip -- the backward of the fused forward frame.  The reference has no backward (README.md:70: "only
+// forward code"); its only backward artefacts are the unused per-band dL/dSH helpers of
+// lcgs/include/lcgs/util/sh.hpp:37-40,53-65,87-117,141-165.  What is differentiated here is exactly the forward of
+// render.hip / gs_math.hpp (= gs_tile_splatter/shader.cpp:171-288, gs_projector/shader.cpp:82-158,
+// sh_preprocessor.cpp:27-157); the specification is DESIGN.md "Backward" (SURVEY Appendix B).
+//
+//   k_render_backward      one workgroup per tile, wave k = 16x4 strip k, one pixel per lane (same geometry as the
+//                          forward renderer).  The tile list is walked BACK TO FRONT in rounds of 256 entries; per
+//                          entry a wave derives the per-pixel gradients w.r.t. {pixel mean, conic, opacity, rgb},
+//                          reduces them over its 64 lanes with DPP row shifts/broadcasts (no LDS traffic), and adds the
+//                          9 sums to a per-round LDS accumulator; after the round one lane per entry flushes the
+//                          workgroup's totals with global float atomics -- 9 atomics per (tile, splat) instead of per
+//                          (pixel, splat).  Global float atomics run at ~1.3 TB/s of added bytes chip-wide
+//                          (MI355X_MICROARCH "Global float atomics"); at ~6.5 M pairs x 36 B this is ~0.2 ms.
+//   k_preprocess_backward  one lane per surviving splat: 2-D gradients -> dL/d{pos, scale, rotq, sh, opacity};
+//                          the 192-byte SH gradient rows leave through LDS as coalesced 16-byte stores.
+// Thresholds are constants for the derivative: near cull, alpha < 1/255 skip, T < 1e-4 stop and power > 0 gate the
+// sums; the 0.99 alpha cap, the colour clamp and a saturated cam_clamp axis pass no gradient.
 #include "launch.hpp"
+
+namespace lcgs
+{
+
+// shared with render.hip (same translation-unit-local helper there); duplicated signature, defined below
+namespace
+{
+
+constexpr int      kXcd  = 8;
+constexpr uint32_t kBlkW = 8, kBlkH = 4;
+
+__device__ __forceinline__ bool tile_of_workgroup(uint32_t b, uint32_t grid_x, uint32_t grid_y, uint32_t& tx,
+                                                  uint32_t& ty)
+{
+    const uint32_t xcd = b % kXcd, seq = b / kXcd;
+    const uint32_t bw  = (grid_x + kBlkW - 1) / kBlkW;
+    const uint32_t blk = xcd + kXcd * (seq / (kBlkW * kBlkH));
+    const uint32_t in  = seq % (kBlkW * kBlkH);
+    tx = (blk % bw) * kBlkW + in % kBlkW;
+    ty = (blk / bw) * kBlkH + in / kBlkW;
+    return tx < grid_x && ty < grid_y;
+}
+
+inline uint32_t render_grid_size(uint32_t grid_x, uint32_t grid_y)
+{
+    const uint32_t bw = (grid_x + kBlkW - 1) / kBlkW, bh = (grid_y + kBlkH - 1) / kBlkH;
+    const uint32_t per_xcd = (bw * bh + kXcd - 1) / kXcd;
+    return per_xcd * kBlkW * kBlkH * kXcd;
+}
+
+// same conservative test as the forward renderer (render.hip): can the splat reach any pixel of the rect?
+__device__ __forceinline__ bool splat_may_touch_rect(float mx, float my, float ca, float cb, float cc, float t,
+                                                     float x0, float y0, float x1, float y1)
+{
+    if (!(t > 0.0f)) return false;
+    const float ex0 = x0 - mx, ex1 = x1 - mx, ey0 = y0 - my, ey1 = y1 - my;
+    if (ex0 <= 0.0f && ex1 >= 0.0f && ey0 <= 0.0f && ey1 >= 0.0f) return true;
+    if (!(ca > 0.0f) || !(cc > 0.0f)) return true;
+    float best = 3.0e38f, slack = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float dx = s ? ex1 : ex0;
+        const float dy = fmin_(fmax_(-cb * dx / cc, ey0), ey1);
+        const float q1 = ca * dx * dx, q2 = 2.0f * cb * dx * dy, q3 = cc * dy * dy;
+        const float q  = q1 + q2 + q3;
+        if (q < best) {
+            best  = q;
+            slack = fabsf(q1) + fabsf(q2) + fabsf(q3);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float dy = s ? ey1 : ey0;
+        const float dx = fmin_(fmax_(-cb * dy / ca, ex0), ex1);
+        const float q1 = ca * dx * dx, q2 = 2.0f * cb * dx * dy, q3 = cc * dy * dy;
+        const float q  = q1 + q2 + q3;
+        if (q < best) {
+            best  = q;
+            slack = fabsf(q1) + fabsf(q2) + fabsf(q3);
+        }
+    }
+    if (!(best == best)) return true;
+    return best - 1e-5f * slack <= t;
+}
+
+// sum over the 64 lanes of a wave, result valid in lane 63 (DPP row shifts + row broadcasts: no LDS)
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    int x = __float_as_int(v);
+#define LCGS_DPP_ADD(ctrl, row_mask, bank_mask)                                                                     \
+    x = __float_as_int(__int_as_float(x) +                                                                          \
+                       __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, row_mask, bank_mask, true)))
+    LCGS_DPP_ADD(0x111, 0xF, 0xF); // row_shr:1
+    LCGS_DPP_ADD(0x112, 0xF, 0xF); // row_shr:2
+    LCGS_DPP_ADD(0x114, 0xF, 0xE); // row_shr:4
+    LCGS_DPP_ADD(0x118, 0xF, 0xC); // row_shr:8  -> lane 15 of each row holds the row sum
+    LCGS_DPP_ADD(0x142, 0xA, 0xF); // row_bcast:15 into rows 1 and 3
+    LCGS_DPP_ADD(0x143, 0xC, 0xF); // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+#undef LCGS_DPP_ADD
+    return __int_as_float(x);
+}
+
+constexpr int kG2D = 12; // floats per splat in the 2-D gradient buffer: mean(2) conic(3) opacity(1) rgb(3) pad(3)
+
+__global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0, float bg1, float bg2,
+                                                           const uint32_t* __restrict__ ranges,
+                                                           const uint32_t* __restrict__ point_list,
+                                                           const SplatRecord* __restrict__ recs,
+                                                           const float* __restrict__ final_T,
+                                                           const uint32_t* __restrict__ n_contrib,
+                                                           const float* __restrict__ dL_dimg,
+                                                           float* __restrict__ grads2d)
+{
+    __shared__ float4             s_a[256]; // mean.x, mean.y, conic.x, conic.y
+    __shared__ float4             s_b[256]; // conic.z, opacity, r, g
+    __shared__ float2             s_c[256]; // b, power floor
+    __shared__ uint32_t           s_vid[256];
+    __shared__ float              s_grad[9][256];
+    __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
+    __shared__ uint32_t           s_max[4];
+
+    uint32_t tx, ty;
+    if (!tile_of_workgroup(blockIdx.x, cp.grid_x, cp.grid_y, tx, ty)) return;
+    const uint32_t tile = ty * cp.grid_x + tx;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t px = tx * kBlockX + (lane & 15u);
+    const uint32_t py = ty * kBlockY + 4u * wave + (lane >> 4);
+    const float    pxf = (float)px, pyf = (float)py;
+    const float    rx0 = (float)(tx * kBlockX), ry0 = (float)(ty * kBlockY), rx1 = rx0 + (float)(kBlockX - 1);
+    const bool     inside = (px < cp.width) && (py < cp.height);
+    const size_t   hw  = (size_t)cp.width * cp.height;
+    const size_t   pix = (size_t)px + (size_t)cp.width * py;
+
+    const uint32_t last    = inside ? n_contrib[pix] : 0u; // 1-based list position of the last contributor
+    const float    T_final = inside ? final_T[pix] : 0.0f;
+    float          dpr = 0.0f, dpg = 0.0f, dpb = 0.0f;
+    if (inside) {
+        dpr = dL_dimg[pix];
+        dpg = dL_dimg[pix + hw];
+        dpb = dL_dimg[pix + 2 * hw];
+    }
+    const float bg_dot = bg0 * dpr + bg1 * dpg + bg2 * dpb;
+
+    uint32_t wmax = last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(wmax, off, 64);
+        wmax             = o > wmax ? o : wmax;
+    }
+    if (lane == 0) s_max[wave] = wmax;
+    __syncthreads();
+    uint32_t hi = s_max[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) hi = s_max[w] > hi ? s_max[w] : hi;
+    const uint32_t range_start = ranges[2 * (size_t)tile + 0];
+
+    float T = T_final, acr = 0.0f, acg = 0.0f, acb = 0.0f, lcr = 0.0f, lcg = 0.0f, lcb = 0.0f, last_alpha = 0.0f;
+
+    while (hi > 0u) {
+        const uint32_t lo   = hi > 256u ? hi - 256u : 0u;
+        const uint32_t e    = lo + tid;
+        const bool     have = e < hi;
+        // ---- stage entries [lo, hi): strip tests, per-strip ballots, slab; clear the round's accumulators
+        float4   a = make_float4(0, 0, 0, 0), b = a;
+        float    c = 0.0f, t = -1.0f;
+        uint32_t vid = 0, kmask = 0;
+        if (have) {
+            vid             = point_list[range_start + e];
+            const float4* p = reinterpret_cast<const float4*>(recs + vid);
+            a = p[0];                                           // mx, my, ca, cb
+            b = p[1];                                           // cc, opacity, r, g
+            c = reinterpret_cast<const float*>(recs + vid)[8];  // b
+            t = (2.0f * __logf(255.0f * b.y)) * 1.0001f + 2e-4f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float y0 = ry0 + 4.0f * k;
+                if (splat_may_touch_rect(a.x, a.y, a.z, a.w, b.x, t, rx0, y0, rx1, y0 + 3.0f)) kmask |= 1u << k;
+            }
+        }
+        __syncthreads(); // previous round fully flushed
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long m = __ballot((kmask >> k) & 1u);
+            if (lane == 0) s_mask[wave][k] = m;
+        }
+        s_a[tid]   = a;
+        s_b[tid]   = b;
+        s_c[tid]   = make_float2(c, -0.5f * t);
+        s_vid[tid] = vid;
+#pragma unroll
+        for (int g = 0; g < 9; ++g) s_grad[g][tid] = 0.0f;
+        __syncthreads();
+
+        // ---- walk "my" strip's entries back to front
+        for (int w = 3; w >= 0; --w) {
+            unsigned long long m = s_mask[w][wave];
+            m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) |
+                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+            while (m != 0ull) {
+                const uint32_t l = 63u - (uint32_t)__clzll((long long)m);
+                m &= ~(1ull << l);
+                const uint32_t idx = (uint32_t)w * 64u + l;
+                const uint32_t pos = lo + idx; // 0-based list position
+                const float4   ea = s_a[idx], eb = s_b[idx];
+                const float2   ec = s_c[idx];
+                const float dx    = ea.x - pxf;
+                const float dy    = ea.y - pyf;
+                const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
+                const bool  cand  = (pos < last) && !(power > 0.0f) && (power >= ec.y);
+                if (!__any(cand)) continue;
+                const float G      = __expf(power);
+                const float oG     = eb.y * G;
+                const float alpha  = fmin_(0.99f, oG);
+                const bool  valid  = cand && !(alpha < 1.0f / 255.0f);
+                if (!__any(valid)) continue;
+                const float one_m  = 1.0f - alpha;
+                const float Tn     = valid ? T / one_m : T; // the forward's T before this splat
+                const float wgt    = valid ? alpha * Tn : 0.0f;
+                // running "colour behind this splat"
+                const float nar = last_alpha * lcr + (1.0f - last_alpha) * acr;
+                const float nag = last_alpha * lcg + (1.0f - last_alpha) * acg;
+                const float nab = last_alpha * lcb + (1.0f - last_alpha) * acb;
+                float dL_dalpha = ((eb.z - nar) * dpr + (eb.w - nag) * dpg + (ec.x - nab) * dpb) * Tn;
+                dL_dalpha += (-T_final / one_m) * bg_dot;
+                if (valid) {
+                    acr = nar; acg = nag; acb = nab;
+                    lcr = eb.z; lcg = eb.w; lcb = ec.x;
+                    last_alpha = alpha;
+                    T          = Tn;
+                }
+                const bool  live_g = valid && (oG < 0.99f); // the 0.99 cap passes no gradient
+                const float dL_dG  = live_g ? eb.y * dL_dalpha : 0.0f;
+                const float gdx = G * dx, gdy = G * dy;
+                float v[9];
+                v[0] = dL_dG * (-(gdx * ea.z + gdy * ea.w));
+                v[1] = dL_dG * (-(gdy * eb.x + gdx * ea.w));
+                v[2] = -0.5f * gdx * dx * dL_dG;
+                v[3] = -gdx * dy * dL_dG;
+                v[4] = -0.5f * gdy * dy * dL_dG;
+                v[5] = live_g ? G * dL_dalpha : 0.0f;
+                v[6] = wgt * dpr;
+                v[7] = wgt * dpg;
+                v[8] = wgt * dpb;
+#pragma unroll
+                for (int g = 0; g < 9; ++g) {
+                    const float s = wave_sum_to_lane63(v[g]);
+                    if (lane == 63u) atomicAdd(&s_grad[g][idx], s);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- flush the round: one lane per entry, 9 global float atomics for entries some strip touched
+        if (have && kmask != 0u) {
+            float* g2 = grads2d + (size_t)vid * kG2D;
+#pragma unroll
+            for (int g = 0; g < 9; ++g) {
+                const float s = s_grad[g][tid];
+                if (s != 0.0f) atomicAdd(&g2[g], s);
+            }
+        }
+        hi = lo;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2-D gradients -> parameter gradients, one lane per surviving splat.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float basis[16], float dbx[16],
+                                              float dby[16], float dbz[16])
+{
+#pragma unroll
+    for (int k = 0; k < 16; ++k) basis[k] = dbx[k] = dby[k] = dbz[k] = 0.0f;
+    basis[0] = SH_C0;
+    if (deg < 1) return;
+    basis[1] = -SH_C1 * y; dby[1] = -SH_C1;
+    basis[2] = SH_C1 * z;  dbz[2] = SH_C1;
+    basis[3] = -SH_C1 * x; dbx[3] = -SH_C1;
+    if (deg < 2) return;
+    const float xx = x * x, yy = y * y, zz = z * z;
+    basis[4] = SH_C2_0 * x * y; dbx[4] = SH_C2_0 * y; dby[4] = SH_C2_0 * x;
+    basis[5] = SH_C2_1 * y * z; dby[5] = SH_C2_1 * z; dbz[5] = SH_C2_1 * y;
+    basis[6] = SH_C2_2 * (2.0f * zz - xx - yy); dbx[6] = SH_C2_2 * (-2.0f * x); dby[6] = SH_C2_2 * (-2.0f * y); dbz[6] = SH_C2_2 * (4.0f * z);
+    basis[7] = SH_C2_3 * z * x; dbx[7] = SH_C2_3 * z; dbz[7] = SH_C2_3 * x;
+    basis[8] = SH_C2_4 * (xx - yy); dbx[8] = SH_C2_4 * 2.0f * x; dby[8] = SH_C2_4 * -2.0f * y;
+    if (deg < 3) return;
+    basis[9]  = SH_C3_0 * y * (3.0f * xx - yy); dbx[9] = SH_C3_0 * 6.0f * x * y; dby[9] = SH_C3_0 * (3.0f * xx - 3.0f * yy);
+    basis[10] = SH_C3_1 * x * y * z; dbx[10] = SH_C3_1 * y * z; dby[10] = SH_C3_1 * x * z; dbz[10] = SH_C3_1 * x * y;
+    basis[11] = SH_C3_2 * y * (4.0f * zz - xx - yy);
+    dbx[11] = SH_C3_2 * (-2.0f * x * y); dby[11] = SH_C3_2 * (4.0f * zz - xx - 3.0f * yy); dbz[11] = SH_C3_2 * 8.0f * y * z;
+    basis[12] = SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+    dbx[12] = SH_C3_3 * (-6.0f * x * z); dby[12] = SH_C3_3 * (-6.0f * y * z); dbz[12] = SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+    basis[13] = SH_C3_4 * x * (4.0f * zz - xx - yy);
+    dbx[13] = SH_C3_4 * (4.0f * zz - 3.0f * xx - yy); dby[13] = SH_C3_4 * (-2.0f * x * y); dbz[13] = SH_C3_4 * 8.0f * x * z;
+    basis[14] = SH_C3_5 * z * (xx - yy); dbx[14] = SH_C3_5 * 2.0f * x * z; dby[14] = SH_C3_5 * -2.0f * y * z; dbz[14] = SH_C3_5 * (xx - yy);
+    basis[15] = SH_C3_6 * x * (xx - 3.0f * yy); dbx[15] = SH_C3_6 * (3.0f * xx - 3.0f * yy); dby[15] = SH_C3_6 * (-6.0f * x * y);
+}
+
+__global__ void __launch_bounds__(256)
+k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const float* __restrict__ pos,
+                      const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ sh,
+                      const uint32_t* __restrict__ vis_index, const uint32_t* __restrict__ d_counts,
+                      const float* __restrict__ grads2d, float* __restrict__ dL_dpos, float* __restrict__ dL_dscale,
+                      float* __restrict__ dL_drotq, float* __restrict__ dL_dsh, float* __restrict__ dL_dopacity)
+{
+    __shared__ float4 s_sh[4][64 * 13];
+    const uint32_t V = d_counts[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int feat = (sh_deg + 1) * (sh_deg + 1);
+    for (uint32_t blk = blockIdx.x; blk * 256u < V; blk += gridDim.x) {
+        const uint32_t vid   = blk * 256u + threadIdx.x;
+        const bool     valid = vid < V;
+        const int      idx   = (int)vis_index[valid ? vid : V - 1];
+        float          gsh[48];
+#pragma unroll
+        for (int k = 0; k < 48; ++k) gsh[k] = 0.0f;
+        if (valid) {
+            const float* g2 = grads2d + (size_t)vid * kG2D;
+            const float4 q0 = reinterpret_cast<const float4*>(g2)[0], q1 = reinterpret_cast<const float4*>(g2)[1];
+            const float  gmx = q0.x, gmy = q0.y, gA = q0.z, gB = q0.w, gC = q1.x, gop = q1.y;
+            const float  gcol[3] = { q1.z, q1.w, g2[8] };
+            const float  px = pos[3 * (size_t)idx + 0], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
+            float        gp[3] = { 0.0f, 0.0f, 0.0f };
+
+            // ---- colour -> SH coefficients and position (through the view direction)
+            {
+                const float dx = px - cp.campos[0], dy = py - cp.campos[1], dz = pz - cp.campos[2];
+                const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+                const float dir[3] = { dx * inv, dy * inv, dz * inv };
+                float basis[16], dbx[16], dby[16], dbz[16];
+                sh_basis_grad(sh_deg, dir[0], dir[1], dir[2], basis, dbx, dby, dbz);
+                const float* s = sh + (size_t)idx * feat * 3;
+                float ddir[3] = { 0.0f, 0.0f, 0.0f };
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    float raw = 0.5f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        if (k < feat) {
+                            const float c = s[k * 3 + ch];
+                            raw += basis[k] * c;
+                            sx += c * dbx[k];
+                            sy += c * dby[k];
+                            sz += c * dbz[k];
+                        }
+                    }
+                    const bool  pass = raw > 0.0f && raw < 1.0f; // clamp(.,0,1) saturated otherwise
+                    const float g    = pass ? gcol[ch] : 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) gsh[k * 3 + ch] = (k < feat) ? basis[k] * g : 0.0f;
+                    ddir[0] += g * sx;
+                    ddir[1] += g * sy;
+                    ddir[2] += g * sz;
+                }
+                const float dd = dir[0] * ddir[0] + dir[1] * ddir[1] + dir[2] * ddir[2];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) gp[i] += (ddir[i] - dir[i] * dd) * inv;
+            }
+
+            // ---- geometry: recompute the forward quantities (gs_math.hpp order is irrelevant for the derivative)
+            float v[3];
+            view_transform(cp, px, py, pz, v);
+            const float limx = 1.3f * cp.tanfovx, limy = 1.3f * cp.tanfovy;
+            const float rx = v[0] / v[2], ry = v[1] / v[2];
+            const int   clx = (rx < -limx) ? -1 : (rx > limx ? 1 : 0);
+            const int   cly = (ry < -limy) ? -1 : (ry > limy ? 1 : 0);
+            const float tx = (clx ? (float)clx * limx : rx) * v[2];
+            const float ty = (cly ? (float)cly * limy : ry) * v[2];
+            const float tz = v[2];
+            const float sc[3] = { scale_modifier * scale[3 * (size_t)idx + 0], scale_modifier * scale[3 * (size_t)idx + 1],
+                                  scale_modifier * scale[3 * (size_t)idx + 2] };
+            const float4 q = *reinterpret_cast<const float4*>(rotq + 4 * (size_t)idx); // (r,x,y,z)
+            const float  x = q.y, y = q.z, z = q.w, w = q.x;
+            float R[3][3];
+            R[0][0] = 1.0f - 2.0f * y * y - 2.0f * z * z; R[0][1] = 2.0f * x * y - 2.0f * z * w; R[0][2] = 2.0f * x * z + 2.0f * y * w;
+            R[1][0] = 2.0f * x * y + 2.0f * z * w; R[1][1] = 1.0f - 2.0f * x * x - 2.0f * z * z; R[1][2] = 2.0f * y * z - 2.0f * x * w;
+            R[2][0] = 2.0f * x * z - 2.0f * y * w; R[2][1] = 2.0f * y * z + 2.0f * x * w; R[2][2] = 1.0f - 2.0f * x * x - 2.0f * y * y;
+            float M[3][3], Sig[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) M[r][k] = R[r][k] * sc[k];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) Sig[r][k] = M[r][0] * M[k][0] + M[r][1] * M[k][1] + M[r][2] * M[k][2];
+            const float j00 = cp.focalx / tz, j11 = cp.focaly / tz, j02 = -cp.focalx * tx / (tz * tz),
+                        j12 = -cp.focaly * ty / (tz * tz);
+            float T0[3], T1[3], ST0[3], ST1[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                T0[r] = cp.right[r] * j00 + cp.front[r] * j02;
+                T1[r] = cp.up[r] * j11 + cp.front[r] * j12;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                ST0[r] = Sig[r][0] * T0[0] + Sig[r][1] * T0[1] + Sig[r][2] * T0[2];
+                ST1[r] = Sig[r][0] * T1[0] + Sig[r][1] * T1[1] + Sig[r][2] * T1[2];
+            }
+            const float a = T0[0] * ST0[0] + T0[1] * ST0[1] + T0[2] * ST0[2] + 0.3f;
+            const float b = T1[0] * ST0[0] + T1[1] * ST0[1] + T1[2] * ST0[2];
+            const float c = T1[0] * ST1[0] + T1[1] * ST1[1] + T1[2] * ST1[2] + 0.3f;
+            const float D = a * c - b * b + 1e-6f;
+            const float iD2 = 1.0f / (D * D);
+            const float g00 = (-c * c * gA + b * c * gB + (D - a * c) * gC) * iD2;
+            const float g11 = ((D - a * c) * gA + a * b * gB - a * a * gC) * iD2;
+            const float g01 = (2.0f * b * c * gA - (D + 2.0f * b * b) * gB + 2.0f * a * b * gC) * iD2;
+            float Gm[3][3], dT0[3], dT1[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) Gm[r][k] = g00 * T0[r] * T0[k] + g01 * T1[r] * T0[k] + g11 * T1[r] * T1[k];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                dT0[r] = 2.0f * g00 * ST0[r] + g01 * ST1[r];
+                dT1[r] = 2.0f * g11 * ST1[r] + g01 * ST0[r];
+            }
+            const float dj00 = cp.right[0] * dT0[0] + cp.right[1] * dT0[1] + cp.right[2] * dT0[2];
+            const float dj02 = cp.front[0] * dT0[0] + cp.front[1] * dT0[1] + cp.front[2] * dT0[2];
+            const float dj11 = cp.up[0] * dT1[0] + cp.up[1] * dT1[1] + cp.up[2] * dT1[2];
+            const float dj12 = cp.front[0] * dT1[0] + cp.front[1] * dT1[1] + cp.front[2] * dT1[2];
+            const float itz2 = 1.0f / (tz * tz), itz3 = itz2 / tz;
+            const float dtx = dj02 * (-cp.focalx * itz2);
+            const float dty = dj12 * (-cp.focaly * itz2);
+            const float dtz = dj00 * (-cp.focalx * itz2) + dj11 * (-cp.focaly * itz2) + dj02 * (2.0f * cp.focalx * tx * itz3) +
+                              dj12 * (2.0f * cp.focaly * ty * itz3);
+            float dv[3];
+            dv[0] = clx ? 0.0f : dtx;
+            dv[1] = cly ? 0.0f : dty;
+            dv[2] = dtz + (clx ? dtx * (float)clx * limx : 0.0f) + (cly ? dty * (float)cly * limy : 0.0f);
+            const float pw = 1.0f / (v[2] + 1e-6f);
+            dv[0] += gmx * cp.focalx * pw;
+            dv[1] += gmy * cp.focaly * pw;
+            dv[2] += -(gmx * cp.focalx * v[0] + gmy * cp.focaly * v[1]) * pw * pw;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) gp[i] += cp.right[i] * dv[0] + cp.up[i] * dv[1] + cp.front[i] * dv[2];
+
+            float dM[3][3], dR[3][3], gs[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    dM[r][k] = (Gm[r][0] + Gm[0][r]) * M[0][k] + (Gm[r][1] + Gm[1][r]) * M[1][k] + (Gm[r][2] + Gm[2][r]) * M[2][k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                gs[k] = scale_modifier * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) dR[r][k] = dM[r][k] * sc[k];
+            }
+            const float gx_ = 2.0f * (y * (dR[0][1] + dR[1][0]) + z * (dR[0][2] + dR[2][0]) + w * (dR[2][1] - dR[1][2])) - 4.0f * x * (dR[1][1] + dR[2][2]);
+            const float gy_ = 2.0f * (x * (dR[0][1] + dR[1][0]) + z * (dR[1][2] + dR[2][1]) + w * (dR[0][2] - dR[2][0])) - 4.0f * y * (dR[0][0] + dR[2][2]);
+            const float gz_ = 2.0f * (x * (dR[0][2] + dR[2][0]) + y * (dR[1][2] + dR[2][1]) + w * (dR[1][0] - dR[0][1])) - 4.0f * z * (dR[0][0] + dR[1][1]);
+            const float gw_ = 2.0f * (z * (dR[1][0] - dR[0][1]) + y * (dR[0][2] - dR[2][0]) + x * (dR[2][1] - dR[1][2]));
+
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                dL_dpos[3 * (size_t)idx + i]   = gp[i];
+                dL_dscale[3 * (size_t)idx + i] = gs[i];
+            }
+            *reinterpret_cast<float4*>(dL_drotq + 4 * (size_t)idx) = make_float4(gw_, gx_, gy_, gz_); // (r,x,y,z)
+            dL_dopacity[idx] = gop;
+        }
+
+        // ---- SH gradient rows: through LDS, then 12 consecutive lanes write one splat's 192 contiguous bytes
+        if (sh_deg == 3 && ((reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0)) {
+            const uint32_t wave_first = blk * 256u + wave * 64u;
+            const uint32_t nvalid     = wave_first < V ? ((V - wave_first) < 64u ? (V - wave_first) : 64u) : 0u;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                s_sh[wave][lane * 13 + k] = make_float4(gsh[4 * k], gsh[4 * k + 1], gsh[4 * k + 2], gsh[4 * k + 3]);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const uint32_t cidx = (uint32_t)i * 64u + lane;
+                const uint32_t slot = cidx / 12u, part = cidx - slot * 12u;
+                const int      sidx = __shfl(idx, (int)slot, 64);
+                if (slot < nvalid) reinterpret_cast<float4*>(dL_dsh + (size_t)sidx * 48)[part] = s_sh[wave][slot * 13u + part];
+            }
+        } else if (valid) {
+            float* o = dL_dsh + (size_t)idx * feat * 3;
+#pragma unroll
+            for (int k = 0; k < 48; ++k)
+                if (k < feat * 3) o[k] = gsh[k];
+        }
+    }
+}
+
+} // namespace
+
+size_t grads2d_bytes(int64_t V_cap) { return (size_t)V_cap * kG2D * sizeof(float); }
+
+namespace
+{
+__global__ void __launch_bounds__(256) k_zero_grads2d(const uint32_t* __restrict__ d_counts, float4* __restrict__ g)
+{
+    const size_t n = (size_t)d_counts[0] * (kG2D / 4);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        g[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+} // namespace
+
+void launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_zero_grads2d, dim3(2048), dim3(256), 0, stream, d_counts, reinterpret_cast<float4*>(grads2d));
+}
+
+void launch_render_backward(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
+                            const SplatRecord* recs, const float* final_T, const uint32_t* n_contrib,
+                            const float* dL_dimg, float* grads2d, hipStream_t stream)
+{
+    if (cp.grid_x * cp.grid_y == 0) return;
+    hipLaunchKernelGGL(k_render_backward, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(256), 0, stream, cp, bg[0],
+                       bg[1], bg[2], ranges, point_list, recs, final_T, n_contrib, dL_dimg, grads2d);
+}
+
+void launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
+                                const float* scale, const float* rotq, const float* sh, const uint32_t* vis_index,
+                                const uint32_t* d_counts, const float* grads2d, float* dL_dpos, float* dL_dscale,
+                                float* dL_drotq, float* dL_dsh, float* dL_dopacity, hipStream_t stream)
+{
+    int64_t blocks = (v_hint + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_preprocess_backward, dim3((unsigned)blocks), dim3(256), 0, stream, sh_deg, cp, scale_modifier,
+                       pos, scale, rotq, sh, vis_index, d_counts, grads2d, dL_dpos, dL_dscale, dL_drotq, dL_dsh,
+                       dL_dopacity);
+}
+
+} // namespace lcgs

@@ -79,7 +79,7 @@ struct lcgs_context {
 
     // workspace of the fused frame
     DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws, counts, sort_ws, expand_ws,
-        final_T, n_contrib, list_idx;
+        final_T, n_contrib, list_idx, grads2d;
     // sub-allocations of zero_ws (one memset per frame): chained-scan states of the cull pass and the tile ranges
     uint64_t* scan_state = nullptr;
     uint32_t* ranges     = nullptr;
@@ -305,7 +305,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
     DeviceBuffer* bufs[] = { &ctx->recs, &ctx->sortk[0], &ctx->sortk[1], &ctx->sortv[0], &ctx->sortv[1], &ctx->vis_index,
                              &ctx->rects, &ctx->rects_sorted, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
                              &ctx->pairv[1], &ctx->zero_ws, &ctx->counts, &ctx->sort_ws,
-                             &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->st_keys_tmp,
+                             &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->st_keys_tmp,
                              &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& b : ctx->owned) b.release();
@@ -591,8 +591,43 @@ lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t*
 lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads)
 {
     LCGS_REQUIRE(ctx && d_dL_dimg && grads, "NULL argument");
-    set_last_error("lcgs_render_backward: not implemented yet");
-    return LCGS_ERR_STATE;
+    LCGS_REQUIRE(grads->d_dL_dpos && grads->d_dL_dscale && grads->d_dL_drotq && grads->d_dL_dsh && grads->d_dL_dopacity,
+                 "NULL gradient buffer");
+    if (!ctx->last.valid || !ctx->last.has_state) {
+        set_last_error("lcgs_render_backward needs a preceding lcgs_render_forward(..., keep_state = 1)");
+        return LCGS_ERR_STATE;
+    }
+    LCGS_REQUIRE((reinterpret_cast<uintptr_t>(grads->d_dL_drotq) & 15) == 0, "dL_drotq must be 16-byte aligned");
+    hipStream_t  st   = ctx->stream;
+    const size_t P    = (size_t)ctx->P;
+    const size_t feat = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3;
+    ctx->n_marks      = 0;
+    LCGS_TRY(mark(ctx, "begin"));
+    // dense per-splat gradients: splats that did not reach the screen get exact zeros
+    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dpos, 0, P * 3 * 4, st));
+    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dscale, 0, P * 3 * 4, st));
+    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_drotq, 0, P * 4 * 4, st));
+    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dsh, 0, P * feat * 4, st));
+    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dopacity, 0, P * 4, st));
+    LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)P)));
+    launch_zero_grads2d(ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(), st);
+    LCGS_TRY(mark(ctx, "zero_grads"));
+    launch_render_backward(ctx->last.cp, ctx->last.bg, ctx->ranges, ctx->pairv[ctx->last.list_buf].as<uint32_t>(),
+                           ctx->recs.as<SplatRecord>(), ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(),
+                           d_dL_dimg, ctx->grads2d.as<float>(), st);
+    LCGS_TRY(mark(ctx, "render_backward"));
+    launch_preprocess_backward(ctx->hint_V > 0 ? ctx->hint_V : (int64_t)P, ctx->sh_deg, ctx->last.cp,
+                               ctx->last.scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->sh,
+                               ctx->vis_index.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(),
+                               grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh,
+                               grads->d_dL_dopacity, st);
+    LCGS_TRY(mark(ctx, "preprocess_backward"));
+    LCGS_HIP_CHECK(hipGetLastError());
+    if (ctx->profiling) {
+        LCGS_HIP_CHECK(hipStreamSynchronize(st));
+        LCGS_TRY(collect_marks(ctx));
+    }
+    return LCGS_OK;
 }
 
 } // extern "C"

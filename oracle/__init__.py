@@ -82,6 +82,9 @@ class Oracle:
     def set_threads(self, n: int) -> None:
         self.lib.orc_set_threads(C.c_int(n))
 
+    def set_smooth(self, on: bool) -> None:
+        self.lib.orc_set_smooth(C.c_int(1 if on else 0))
+
     def get_threads(self) -> int:
         return int(self.lib.orc_get_threads())
 
@@ -269,6 +272,22 @@ class Oracle:
         return out
 
     # ------------------------------------------------------------------ backward
+    def preprocess_backward(self, scene, cam, radii, dL_dmean2d, dL_dconic, dL_dcolor, scale_modifier=1.0, sh_deg=3):
+        pos = self.arr(scene["pos"], (-1, 3))
+        P = pos.shape[0]
+        scale = self.arr(scene["scale"], (P, 3))
+        rotq = self.arr(scene["rotq"], (P, 4))
+        sh = self.arr(scene["sh"], (P, -1))
+        radii = np.ascontiguousarray(radii, dtype=np.int32)
+        gm, gc, gcol = self.arr(dL_dmean2d, (P, 2)), self.arr(dL_dconic, (P, 3)), self.arr(dL_dcolor, (P, 3))
+        g = {"pos": np.zeros((P, 3), self.dtype), "scale": np.zeros((P, 3), self.dtype),
+             "rotq": np.zeros((P, 4), self.dtype), "sh": np.zeros_like(sh)}
+        self.lib.orc_preprocess_backward(C.c_int(P), C.c_int(sh_deg), self.rp(pos), self.rp(scale), self.rp(rotq),
+                                         self.rp(sh), C.byref(cam), self.creal(scale_modifier), _ptr(radii, C.c_int32),
+                                         self.rp(gm), self.rp(gc), self.rp(gcol), self.rp(g["pos"]), self.rp(g["scale"]),
+                                         self.rp(g["rotq"]), self.rp(g["sh"]))
+        return g
+
     def render_backward_full(self, scene, cam, dL_dimg, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_deg=3):
         pos = self.arr(scene["pos"], (-1, 3))
         P = pos.shape[0]

@@ -38,6 +38,11 @@
 #define RC(x) ((real)(x))
 
 static int g_threads = 0;
+/* FD-validation aid: when non-zero the two hard blend thresholds (alpha < 1/255 skip, T < 1e-4 stop) are disabled in
+ * the forward AND the backward, which makes the image a smooth function of the parameters so that central
+ * differences of the f64 build validate the analytic gradients to ~1e-7.  Never set for parity work. */
+int orc_g_smooth = 0;
+void orc_set_smooth(int on) { orc_g_smooth = on; }
 
 int orc_sizeof_real(void) { return (int)sizeof(real); }
 
@@ -634,10 +639,10 @@ void orc_render_forward(int width, int height, const real bg[3], const uint32_t*
                     if (power > RC(0.0f)) continue;
                     real alpha = r_min(RC(0.99f), o * R_EXP(power));
                     if (ambig && near_rel(alpha, RC(1.0f) / RC(255.0f), ambig_eps)) amb = 1;
-                    if (alpha < RC(1.0f) / RC(255.0f)) continue;
+                    if (!orc_g_smooth && alpha < RC(1.0f) / RC(255.0f)) continue;
                     real test_T = T * (RC(1.0f) - alpha);
                     if (ambig && near_rel(test_T, RC(0.0001f), ambig_eps)) amb = 1;
-                    if (test_T < RC(0.0001f)) break; /* done = true; loop exits at next iteration, :261-265 */
+                    if (!orc_g_smooth && test_T < RC(0.0001f)) break; /* done = true; loop exits at next iteration, :261-265 */
                     for (int ch = 0; ch < 3; ++ch) C[ch] = C[ch] + T * alpha * color[3 * (size_t)id + ch];
                     T                = test_T;
                     last_contributor = contributor;

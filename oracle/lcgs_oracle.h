@@ -55,6 +55,8 @@ typedef struct orc_camera {
 int  orc_sizeof_real(void);
 void orc_set_threads(int n); /* 0 = all cores */
 int  orc_get_threads(void);
+/* FD-validation aid (see lcgs_oracle.c): disable the alpha < 1/255 skip and the T < 1e-4 stop */
+void orc_set_smooth(int on);
 
 /* camera.h:74-82, 27-51, 54-72.  Matrices are column-major m[c*4+r]. */
 void orc_get_lookat_cam(const real pos[3], const real target[3], const real world_up[3], orc_camera* cam);
