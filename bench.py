@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--res", type=str, default="1920x1080")
     ap.add_argument("--ply", type=str, default=os.environ.get("LCGS_BICYCLE_PLY", ""))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-backward", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -169,6 +170,45 @@ def main():
                            "unit": "GB/s", "frac": round(frame_gbs / HBM_PEAK_GBS, 4)},
         "stages_ms": {k: round(v, 4) for k, v in acc.items()},
     }
+
+    # ---- forward + backward (+ RCCL all-reduce of the dense per-splat gradients when N > 1): one training-style step
+    # per view; Msplats/s = splats x views / time.  Same barrier / max-over-ranks protocol.
+    if not args.no_backward:
+        gbuf = torch.zeros(59 * P, device=dev)  # pos 3 | scale 3 | rotq 4 | sh 48 | opacity 1, one flat buffer
+        o0 = 0
+        views = {}
+        for name, width in (("pos", 3), ("scale", 3), ("rotq", 4), ("sh", 48), ("opacity", 1)):
+            views[name] = gbuf[o0:o0 + width * P]
+            o0 += width * P
+        dL = torch.randn(3, H, W, device=dev)
+
+        def train_step():
+            r.forward(cam, img, keep_state=True, sync=False)
+            r.backward(dL, views["pos"], views["scale"], views["rotq"], views["sh"], views["opacity"])
+            if dist is not None:
+                dist.all_reduce(gbuf)  # sum of the per-view gradients over xGMI
+
+        for _ in range(max(1, args.warmup)):
+            train_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            train_step()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        r.set_profiling(True)
+        r.forward(cam, img, keep_state=True, sync=True)
+        r.backward(dL, views["pos"], views["scale"], views["rotq"], views["sh"], views["opacity"])
+        bwd_stages = r.stage_times()
+        r.set_profiling(False)
+        out["fwd_bwd"] = {"metric": "fwd+bwd Msplats/s", "value": round(world * P * args.steps / el / 1e6, 1),
+                          "unit": "Msplats/s", "ms_per_step": round(el * 1e3 / args.steps, 4),
+                          "grad_allreduce_bytes_per_gpu": 59 * 4 * P if world > 1 else 0,
+                          "backward_stages_ms": {k: round(v, 4) for k, v in bwd_stages.items()}}
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference) on this box's host cores, rank 0, N = 1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
