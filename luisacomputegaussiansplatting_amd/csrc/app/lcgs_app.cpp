@@ -1,0 +1,179 @@
+// lcgs-app -- CLI work-alike of the reference's app/main.cpp on the MI355X library.
+//   lcgs-app --ply <path> [--res WxH] [--out dir] [--world colmap|blender] [--exp_N N] [--backend hip]
+//            [--path fused|stage] [--synth kind:count:seed]
+// Same flags (app/main.cpp:52-124; `--key=value` and `--key value`, app/command_parser.hpp:5-79), the same
+// hard-coded look-at camera (app/main.cpp:191-207), the same frame loop (:266-308), the same output:
+// <out>/<ply stem>_<backend>.png, CHW float -> vertically flipped RGB8 with a truncating *255 (:323-339).
+// --display (ImGui window) is not available on a headless GPU box and is rejected.
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "lcgs/lcgs.hpp"
+
+namespace
+{
+[[noreturn]] void die(const std::string& m)
+{
+    fprintf(stderr, "lcgs-app: %s\n", m.c_str());
+    exit(1);
+}
+
+void usage(const char* argv0)
+{
+    printf("Usage: %s [options]\n", argv0);
+    printf("  --help / -h              Show this help message\n");
+    printf("  --res <width>x<height>   Set the resolution (default: 1600x1063)\n");
+    printf("  --ply <path>             Set the path to the PLY file (default: gsplat.ply)\n");
+    printf("  --backend <name>         Accepted for compatibility; the only backend is `hip` (gfx950)\n");
+    printf("  --out <dir>              Set the output directory (default: out)\n");
+    printf("  --world <type>           colmap or blender (default: colmap)\n");
+    printf("  --exp_N <N>              Number of frames to render (default: 1)\n");
+    printf("  --path <fused|stage>     One-submission fused frame (default) or the three stage-level operators\n");
+    printf("  --synth <kind:count:seed> Render a synthetic stand-in scene instead of --ply (kind 0 object, 1 unbounded)\n");
+    printf("  --display                Not supported (headless)\n");
+}
+
+template <typename T>
+lcgs::Buffer<T> upload(const T* h, size_t n)
+{
+    lcgs::Buffer<T> b(n);
+    if (n && hipMemcpy(b.data(), h, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) die("H2D copy failed");
+    return b;
+}
+} // namespace
+
+int main(int argc, char** argv)
+{
+    unsigned    W = 1600, H = 1063; // app/main.cpp:38
+    std::string ply_path = "gsplat.ply", backend = "hip", out_dir = "out", world = "colmap", path = "fused", synth;
+    int         exp_N = 1;
+    // parse_command (app/command_parser.hpp:5-79): strip leading dashes, `key=value` or `key value`
+    for (int i = 1; i < argc; ++i) {
+        std::string arg = argv[i];
+        size_t      k   = arg.find_first_not_of('-');
+        if (k == std::string::npos || k == 0) die("invalid argument: " + arg);
+        std::string kv = arg.substr(k), key = kv, value;
+        size_t      eq = kv.find('=');
+        if (eq != std::string::npos) {
+            key   = kv.substr(0, eq);
+            value = kv.substr(eq + 1);
+        } else if (i + 1 < argc) {
+            std::string next = argv[i + 1];
+            bool        flag = !next.empty() && next[0] == '-' && !(next.size() >= 2 && isdigit((unsigned char)next[1]));
+            if (!flag) {
+                value = next;
+                ++i;
+            }
+        }
+        if (key == "help" || key == "h") {
+            usage(argv[0]);
+            return 0;
+        } else if (key == "res") {
+            size_t x = value.find('x');
+            if (x == std::string::npos) die("Invalid resolution format: '" + value + "'. Expected <width>x<height>");
+            W = (unsigned)std::stoi(value.substr(0, x));
+            H = (unsigned)std::stoi(value.substr(x + 1));
+        } else if (key == "ply") ply_path = value;
+        else if (key == "backend") backend = value;
+        else if (key == "out") out_dir = value;
+        else if (key == "world") {
+            if (value == "colmap" || value.empty()) world = "colmap";
+            else if (value == "blender") world = "blender";
+            else die("Invalid world type: " + value);
+        } else if (key == "exp_N") {
+            if (value.empty()) die("--exp_N requires a value");
+            exp_N = std::stoi(value);
+        } else if (key == "path") path = value;
+        else if (key == "synth") synth = value;
+        else if (key == "display") die("--display needs a GUI; this build is headless");
+        else die("unknown option --" + key);
+    }
+    // ply stem (app/main.cpp:126-148)
+    std::string ply_name = ply_path;
+    size_t      sp       = ply_name.find_last_of("/\\");
+    if (sp != std::string::npos) ply_name = ply_name.substr(sp + 1);
+    size_t ep = ply_name.find_last_of('.');
+    if (ep != std::string::npos) ply_name = ply_name.substr(0, ep);
+    mkdir(out_dir.c_str(), 0755);
+
+    try {
+        lcgs::Device device(0);
+        // ---- scene: read_gs_ply (app/main.cpp:165-167) or a synthetic stand-in
+        lcgs_scene_host sc{};
+        std::vector<float> spos, sfeat, sop, sscale, srot;
+        int                P = 0;
+        if (!synth.empty()) {
+            int kind = 0; long long count = 0; unsigned long long seed = 0;
+            if (sscanf(synth.c_str(), "%d:%lld:%llu", &kind, &count, &seed) != 3) die("--synth expects kind:count:seed");
+            P = (int)count;
+            spos.resize((size_t)P * 3); sfeat.resize((size_t)P * 48); sop.resize(P); sscale.resize((size_t)P * 3); srot.resize((size_t)P * 4);
+            lcgs::check(lcgs_synth_scene(kind, seed, 0, count, spos.data(), sfeat.data(), sop.data(), sscale.data(), srot.data()));
+            sc = { P, 3, spos.data(), sfeat.data(), sop.data(), sscale.data(), srot.data() };
+            ply_name = "synth" + std::to_string(kind) + "_" + std::to_string(count);
+        } else {
+            lcgs::check(lcgs_ply_read(ply_path.c_str(), &sc));
+            P = sc.num_gaussians;
+        }
+        printf("num_gaussians: %d\n", P);
+        auto d_pos = upload(sc.pos, (size_t)P * 3), d_scale = upload(sc.scale, (size_t)P * 3),
+             d_rotq = upload(sc.rotq, (size_t)P * 4), d_sh = upload(sc.feature, (size_t)P * 48),
+             d_opacity = upload(sc.opacity, (size_t)P); // app/main.cpp:180-186, 216-223
+
+        // ---- camera (app/main.cpp:191-207)
+        float pos[3] = { -3.0f, -0.5f, 3.3f }, target[3] = { 0.0f, 3.0f, 0.5f }, up[3] = { 0.0f, -1.0f, -1.0f };
+        if (world == "blender") { up[0] = 0.0f; up[1] = 0.0f; up[2] = 1.0f; }
+        lcgs::Camera cam   = lcgs::get_lookat_cam(pos, target, up);
+        cam.aspect_ratio   = (float)W / (float)H;
+        cam.width          = (int)W;
+        cam.height         = (int)H;
+        const float bg[3]  = { 0.0f, 0.0f, 0.0f };
+        lcgs::Buffer<float> d_img((size_t)W * H * 3);
+        lcgs::Buffer<int>   d_radii((size_t)P);
+        int                 num_rendered = 0;
+        auto                t0 = std::chrono::steady_clock::now();
+        if (path == "stage") {
+            // the reference's own call sequence (app/main.cpp:227-308) on the stage-level operators
+            lcgs::SHProcessor sh_processor; lcgs::GSProjector projector; lcgs::GSTileSplatter tile_splatter;
+            sh_processor.create(device); projector.create(device); tile_splatter.create(device);
+            lcgs::Buffer<float> d_color((size_t)P * 3), d_means_2d((size_t)P * 2), d_depth((size_t)P), d_covs_2d((size_t)P * 3);
+            (void)hipMemset(d_means_2d.data(), 0, (size_t)P * 8); (void)hipMemset(d_depth.data(), 0, (size_t)P * 4); (void)hipMemset(d_covs_2d.data(), 0, (size_t)P * 12);
+            lcgs::Buffer<uint32_t> d_tiles((size_t)P), d_offsets((size_t)P);
+            const size_t L = 20000000; // app/main.cpp:245
+            lcgs::Buffer<uint64_t> d_ku(L), d_ks(L);
+            lcgs::Buffer<uint32_t> d_lu(L), d_ls(L), d_ranges((size_t)((W + 15) / 16) * ((H + 15) / 16) * 2);
+            for (int it = 0; it < exp_N; ++it) {
+                sh_processor.process({ P, 3, d_pos }, cam, d_sh, d_color, 3, 3);
+                projector.forward({ P, d_pos, d_scale, d_rotq, 1.0f }, { d_means_2d, d_covs_2d, d_depth }, cam);
+                num_rendered = tile_splatter.forward({ d_tiles, d_offsets, d_ku, d_lu, d_ks, d_ls, d_ranges },
+                                                     { P, { 0, 0, 0 }, d_means_2d, d_depth, d_covs_2d, d_color, d_opacity },
+                                                     { (int)H, (int)W, d_img, d_radii });
+            }
+        } else {
+            lcgs::check(lcgs_scene_bind(device.ctx(), P, 3, d_pos.data(), d_scale.data(), d_rotq.data(), d_sh.data(), d_opacity.data()));
+            for (int it = 0; it < exp_N; ++it)
+                lcgs::check(lcgs_render_forward(device.ctx(), &cam, bg, 1.0f, d_img.data(), d_radii.data(), 0,
+                                                it + 1 == exp_N ? &num_rendered : nullptr));
+        }
+        std::vector<float> h_img((size_t)W * H * 3);
+        device.synchronize();
+        if (hipMemcpy(h_img.data(), d_img.data(), h_img.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) die("D2H copy failed");
+        double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        printf("num_rendered: %d\nexp time: %.3f ms\nfps: %.2f with test N %d\n", num_rendered, ms, 1000.0 / (ms / exp_N), exp_N);
+        std::vector<uint8_t> rgb((size_t)W * H * 3);
+        lcgs_image_to_rgb8((int)W, (int)H, h_img.data(), rgb.data());
+        std::string img_name = out_dir + "/" + ply_name + "_" + backend + ".png";
+        lcgs::check(lcgs_write_png(img_name.c_str(), (int)W, (int)H, rgb.data()));
+        printf("result saved in %s\n", img_name.c_str());
+        if (synth.empty()) lcgs_scene_host_free(&sc);
+    } catch (const lcgs::Error& e) {
+        die(e.what());
+    }
+    return 0;
+}

@@ -1,0 +1,183 @@
+// lcgs.hpp -- C++ host-side mirror of the reference's operator API on top of the C ABI (include/lcgs_hip.h).
+// Same class names, method names, argument meaning and proxy structs as the reference's headers, so a caller
+// written against lcgs/include/lcgs/{sh_preprocessor,gs_projector,gs_tile_splatter,proxy}.h maps one to one:
+//   luisa::compute::Device / Stream      -> lcgs::Device (one lcgs_context = one GPU + one HIP stream)
+//   luisa::compute::BufferView<T>        -> lcgs::BufferView<T> (non-owning device pointer + element count)
+//   CommandList                          -> not needed: every call enqueues on the Device's stream
+// Errors: the reference is noexcept + LUISA_ERROR(abort); here a failing call throws lcgs::Error carrying the
+// lcgs_status and lcgs_last_error() text.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#include "lcgs_hip.h"
+
+namespace lcgs
+{
+
+struct Error : std::runtime_error {
+    lcgs_status status;
+    Error(lcgs_status s, const std::string& what) : std::runtime_error(what), status(s) {}
+};
+
+inline void check(lcgs_status s)
+{
+    if (s != LCGS_OK) throw Error(s, std::string("lcgs status ") + std::to_string((int)s) + ": " + lcgs_last_error());
+}
+
+template <typename T>
+struct BufferView {
+    T*     ptr  = nullptr;
+    size_t size = 0;
+    BufferView() = default;
+    BufferView(T* p, size_t n) : ptr(p), size(n) {}
+    BufferView subview(size_t offset, size_t n) const { return BufferView(ptr + offset, n); }
+};
+
+// owning device buffer (Device::create_buffer<T>, app/main.cpp:180-186)
+template <typename T>
+class Buffer
+{
+public:
+    Buffer() = default;
+    explicit Buffer(size_t n) : m_size(n)
+    {
+        if (hipMalloc(reinterpret_cast<void**>(&m_ptr), (n ? n : 1) * sizeof(T)) != hipSuccess)
+            throw Error(LCGS_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+    }
+    Buffer(const Buffer&)            = delete;
+    Buffer& operator=(const Buffer&) = delete;
+    Buffer(Buffer&& o) noexcept : m_ptr(o.m_ptr), m_size(o.m_size) { o.m_ptr = nullptr; }
+    ~Buffer()
+    {
+        if (m_ptr) (void)hipFree(m_ptr);
+    }
+    BufferView<T> view() const { return BufferView<T>(m_ptr, m_size); }
+    operator BufferView<T>() const { return view(); }
+    T*     data() const { return m_ptr; }
+    size_t size() const { return m_size; }
+
+private:
+    T*     m_ptr  = nullptr;
+    size_t m_size = 0;
+};
+
+// lcgs/include/lcgs/util/camera.h:15-25 -- the POD is shared with the C ABI
+using Camera = lcgs_camera;
+inline Camera get_lookat_cam(const float pos[3], const float target[3], const float world_up[3])
+{
+    Camera c;
+    lcgs_get_lookat_cam(pos, target, world_up, &c);
+    return c;
+}
+
+class Device
+{
+public:
+    explicit Device(int device_id = 0, hipStream_t stream = nullptr) { check(lcgs_create(device_id, stream, &m_ctx)); }
+    Device(const Device&)            = delete;
+    Device& operator=(const Device&) = delete;
+    ~Device() { lcgs_destroy(m_ctx); }
+    lcgs_context* ctx() const { return m_ctx; }
+    void          synchronize() { check(lcgs_synchronize(m_ctx)); }
+    template <typename T>
+    Buffer<T> create_buffer(size_t n) { return Buffer<T>(n); }
+
+private:
+    lcgs_context* m_ctx = nullptr;
+};
+
+// ---- proxies: lcgs/include/lcgs/sh_preprocessor.h:16-20, gs_projector.h:16-28, proxy.h:43-71 ----
+struct GPUPointsProxy {
+    int               N      = 0;
+    int               stride = 3;
+    BufferView<float> pos;
+};
+struct GSProjectorInputProxy {
+    int               num_gaussians;
+    BufferView<float> pos, scale, rotq;
+    float             scale_modifier;
+};
+struct GSProjectorOutputProxy {
+    BufferView<float> means_2d, covs_2d, depth;
+};
+struct GSTileSplatterInputProxy {
+    int               num_gaussians;
+    float             bg_color[3];
+    BufferView<float> means_2d, depth_features, conic, color_features, opacity_features;
+};
+struct GSTileSplatterAccelProxy {
+    BufferView<uint32_t> tiles_touched, point_offsets;
+    BufferView<uint64_t> point_list_keys_unsorted;
+    BufferView<uint32_t> point_list_unsorted;
+    BufferView<uint64_t> point_list_keys;
+    BufferView<uint32_t> point_list, ranges;
+};
+struct GSSplatForwardOutputProxy {
+    int               height, width;
+    BufferView<float> target_img; // written planar CHW (gs_tile_splatter/shader.cpp:279-286)
+    BufferView<int>   radii;
+};
+
+// lcgs::SHProcessor (sh_preprocessor.h:22-57)
+class SHProcessor
+{
+public:
+    void create(Device& device) noexcept { m_dev = &device; }
+    void process(GPUPointsProxy proxy, Camera& camera, BufferView<float> sh, BufferView<float> color, int channel = 3,
+                 int level = 3)
+    {
+        check(lcgs_sh_process(m_dev->ctx(), proxy.N, proxy.pos.ptr, &camera, sh.ptr, color.ptr, level, channel));
+    }
+
+private:
+    Device* m_dev = nullptr;
+};
+
+// lcgs::GSProjector (gs_projector.h:30-87)
+class GSProjector
+{
+public:
+    void create(Device& device) noexcept { m_dev = &device; }
+    void forward(GSProjectorInputProxy input, GSProjectorOutputProxy output, Camera& cam, bool use_focal = true)
+    {
+        check(lcgs_project_forward(m_dev->ctx(), input.num_gaussians, input.pos.ptr, input.scale.ptr, input.rotq.ptr,
+                                   input.scale_modifier, output.means_2d.ptr, output.covs_2d.ptr, output.depth.ptr, &cam,
+                                   use_focal ? 1 : 0));
+    }
+
+private:
+    Device* m_dev = nullptr;
+};
+
+// lcgs::GSTileSplatter (gs_tile_splatter.h:19-106).  The scan / radix-sort / filler objects the reference
+// borrows (set_device_scan etc.) are owned by the context here.
+class GSTileSplatter
+{
+public:
+    int      num_rendered = 0;            // gs_tile_splatter.h:23
+    uint32_t m_blocks[2]  = { 16u, 16u }; // module.h:17
+    void     create(Device& device) noexcept { m_dev = &device; }
+    int forward(GSTileSplatterAccelProxy accel, GSTileSplatterInputProxy input, GSSplatForwardOutputProxy output,
+                bool use_focal = true)
+    {
+        lcgs_tile_accel a{ accel.tiles_touched.ptr, accel.point_offsets.ptr, accel.point_list_keys_unsorted.ptr,
+                           accel.point_list_unsorted.ptr, accel.point_list_keys.ptr, accel.point_list.ptr,
+                           accel.ranges.ptr, (int64_t)accel.point_list.size };
+        lcgs_tile_input i{ input.num_gaussians, { input.bg_color[0], input.bg_color[1], input.bg_color[2] },
+                           input.means_2d.ptr, input.depth_features.ptr, input.conic.ptr, input.color_features.ptr,
+                           input.opacity_features.ptr };
+        lcgs_tile_output o{ output.height, output.width, output.target_img.ptr, output.radii.ptr, nullptr, nullptr };
+        check(lcgs_tile_splat_forward(m_dev->ctx(), &a, &i, &o, use_focal ? 1 : 0, &num_rendered));
+        return num_rendered;
+    }
+
+private:
+    Device* m_dev = nullptr;
+};
+
+} // namespace lcgs
