@@ -132,7 +132,8 @@ constexpr int kCullItems = 8;
 constexpr int kCullChunk = kThreads * kCullItems;
 
 __global__ void __launch_bounds__(kThreads)
-k_cull_compact(int P, CamParams cp, float scale_modifier, const float* __restrict__ pos,
+k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __restrict__ fpp,
+               const float* __restrict__ pos,
                const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ opacity,
                int32_t* __restrict__ radii, uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals,
                uint32_t* __restrict__ vis_index, uint2* __restrict__ rects, uint64_t* __restrict__ scan_state,
@@ -143,6 +144,10 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const float* __restric
     __shared__ uint32_t s_wave_tiles[4];
     __shared__ uint32_t s_prefix_vis;
 
+    if (fpp) { // graph replay: per-call parameters come from device memory
+        cp             = fpp->cp;
+        scale_modifier = fpp->scale_modifier;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ticket = atomicAdd(reinterpret_cast<uint32_t*>(scan_state), 1u);
     __syncthreads();
@@ -265,13 +270,18 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const float* __restric
 // 13-float4 row pitch (208 B: conflict-free for the per-lane ds_read_b128 that follows) and each lane then
 // reads its own 48 coefficients back.
 __global__ void __launch_bounds__(kThreads)
-k_build_records(int sh_deg, CamParams cp, float scale_modifier, const float* __restrict__ pos,
+k_build_records(int sh_deg, CamParams cp, float scale_modifier, const FrameParams* __restrict__ fpp,
+                const float* __restrict__ pos,
                 const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ sh,
                 const float* __restrict__ opacity, const uint32_t* __restrict__ vis_index,
                 const uint32_t* __restrict__ d_counts, SplatRecord* __restrict__ recs)
 {
     __shared__ float4 s_sh[kThreads / 64][64 * 13];
 
+    if (fpp) {
+        cp             = fpp->cp;
+        scale_modifier = fpp->scale_modifier;
+    }
     const uint32_t V = d_counts[0];
     const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t blk = blockIdx.x; blk * kThreads < V; blk += gridDim.x) {
@@ -548,21 +558,30 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kThreads - 1) / k
 inline unsigned chunks_for(int64_t n) { return (unsigned)((n + kCullChunk - 1) / kCullChunk); }
 size_t fused_scan_state_bytes(int P) { return (size_t)(chunks_for(P) + 2) * sizeof(uint64_t); }
 
-void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const float* pos, const float* scale,
+__global__ void k_set_frame_params(FrameParams fp, FrameParams* __restrict__ dst) { *dst = fp; }
+
+void launch_set_frame_params(const FrameParams& fp, FrameParams* d_fp, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_set_frame_params, dim3(1), dim3(1), 0, stream, fp, d_fp);
+}
+
+void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const FrameParams* d_fp, const float* pos,
+                         const float* scale,
                          const float* rotq, const float* opacity, int32_t* radii, uint32_t* sort_keys,
                          uint32_t* sort_vals, uint32_t* vis_index, uint2* rects, uint64_t* scan_state,
                          uint32_t* d_counts, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_cull_compact, dim3(chunks_for(P)), dim3(kThreads), 0, stream, P, cp, scale_modifier, pos,
+    hipLaunchKernelGGL(k_cull_compact, dim3(chunks_for(P)), dim3(kThreads), 0, stream, P, cp, scale_modifier, d_fp, pos,
                        scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index, rects, scan_state, d_counts);
 }
 
-void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
+void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const FrameParams* d_fp,
+                          const float* pos,
                           const float* scale, const float* rotq, const float* sh, const float* opacity,
                           const uint32_t* vis_index, const uint32_t* d_counts, SplatRecord* recs, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_build_records, dim3(blocks_for(P_cap)), dim3(kThreads), 0, stream, sh_deg, cp,
-                       scale_modifier, pos, scale, rotq, sh, opacity, vis_index, d_counts, recs);
+                       scale_modifier, d_fp, pos, scale, rotq, sh, opacity, vis_index, d_counts, recs);
 }
 
 

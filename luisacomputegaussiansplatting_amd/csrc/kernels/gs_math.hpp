@@ -52,6 +52,14 @@ struct CamParams {
     uint32_t grid_x, grid_y;
 };
 
+// Per-call parameters of the fused frame, kept in DEVICE memory so that a captured hipGraph of the frame stays
+// valid when the camera moves: one tiny eager kernel refreshes this block, then the whole frame replays.
+struct FrameParams {
+    CamParams cp;
+    float     bg[3];
+    float     scale_modifier;
+};
+
 LCGS_HD float fmin_(float a, float b) { return a < b ? a : b; }
 LCGS_HD float fmax_(float a, float b) { return a > b ? a : b; }
 LCGS_HD float clamp_(float v, float lo, float hi) { return fmin_(fmax_(v, lo), hi); }

@@ -78,7 +78,10 @@ static_assert(sizeof(SplatRecord) == 48, "SplatRecord must be 48 bytes");
 size_t fused_scan_state_bytes(int P);
 // d_counts: [0] V (splats emitting >= 1 pair), [1] reference num_rendered, [2] pairs emitted, [3] overflow flag,
 //           [4] pairs wanted (before clamping to the workspace capacity)
-void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const float* pos, const float* scale,
+void launch_set_frame_params(const FrameParams& fp, FrameParams* d_fp, hipStream_t stream);
+// d_fp (nullable): when non-NULL the kernels take camera / bg / scale_modifier from device memory (graph replay)
+void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const FrameParams* d_fp, const float* pos,
+                         const float* scale,
                          const float* rotq, const float* opacity, int32_t* radii, uint32_t* sort_keys,
                          uint32_t* sort_vals, uint32_t* vis_index, uint2* rects, uint64_t* scan_state,
                          uint32_t* d_counts, hipStream_t stream);
@@ -93,7 +96,8 @@ size_t pair_sort_ws_bytes(int64_t n_cap);
 // ping-pongs a -> b -> a ...; returns 0 if the result ended in (keys_a, vals_a), 1 if in (keys_b, vals_b)
 int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, const uint32_t* d_n,
                          int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws, hipStream_t stream);
-void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
+void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const FrameParams* d_fp,
+                          const float* pos,
                           const float* scale, const float* rotq, const float* sh, const float* opacity,
                           const uint32_t* vis_index, const uint32_t* d_counts, SplatRecord* recs, hipStream_t stream);
 void launch_get_ranges_u32(int64_t L_cap, const uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
@@ -103,7 +107,8 @@ void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t
 
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
-                               uint32_t* n_contrib, const uint32_t* d_counts, hipStream_t stream);
+                               uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,
+                               hipStream_t stream);
 
 // ---- backward.hip ----
 size_t grads2d_bytes(int64_t V_cap);

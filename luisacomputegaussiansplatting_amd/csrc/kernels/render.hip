@@ -124,6 +124,7 @@ __host__ __device__ inline uint32_t render_grid_size(uint32_t grid_x, uint32_t g
 
 template <typename Fetch>
 __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, float bg1, float bg2,
+                                                            const FrameParams* __restrict__ fpp,
                                                          const uint32_t* __restrict__ ranges,
                                                          const uint32_t* __restrict__ point_list, Fetch fetch,
                                                          float* __restrict__ img, float* __restrict__ final_T,
@@ -134,6 +135,12 @@ __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, 
     __shared__ float4 s_b[64]; // conic.z, opacity, r, g
     __shared__ float4 s_c[64]; // b, power floor (-t/2), list position + 1 (bits), strip mask (bits)
 
+    if (fpp) { // graph replay: per-call parameters come from device memory
+        cp  = fpp->cp;
+        bg0 = fpp->bg[0];
+        bg1 = fpp->bg[1];
+        bg2 = fpp->bg[2];
+    }
     uint32_t tx, ty;
     if (!tile_of_workgroup(blockIdx.x, cp.grid_x, cp.grid_y, tx, ty)) return;
     const uint32_t tile = ty * cp.grid_x + tx;
@@ -269,6 +276,7 @@ __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, 
 // ---------------------------------------------------------------------------------------------
 template <typename Fetch>
 __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg0, float bg1, float bg2,
+                                                            const FrameParams* __restrict__ fpp,
                                                             const uint32_t* __restrict__ ranges,
                                                             const uint32_t* __restrict__ point_list, Fetch fetch,
                                                             float* __restrict__ img, float* __restrict__ final_T,
@@ -281,6 +289,12 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
     __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
     __shared__ uint32_t           s_live_waves;
 
+    if (fpp) { // graph replay: per-call parameters come from device memory
+        cp  = fpp->cp;
+        bg0 = fpp->bg[0];
+        bg1 = fpp->bg[1];
+        bg2 = fpp->bg[2];
+    }
     uint32_t tx, ty;
     if (!tile_of_workgroup(blockIdx.x, cp.grid_x, cp.grid_y, tx, ty)) return;
     const uint32_t tile = ty * cp.grid_x + tx;
@@ -394,7 +408,7 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
 template <typename Fetch>
 void launch_render(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                    Fetch fetch, float* img, float* final_T, uint32_t* n_contrib, const uint32_t* d_counts,
-                   hipStream_t stream)
+                   const FrameParams* d_fp, hipStream_t stream)
 {
     if (cp.grid_x * cp.grid_y == 0) return;
     static const int variant = [] {
@@ -403,10 +417,10 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
     }();
     if (variant == 1) {
         hipLaunchKernelGGL(k_render_forward_b<Fetch>, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(256), 0, stream,
-                           cp, bg[0], bg[1], bg[2], ranges, point_list, fetch, img, final_T, n_contrib, d_counts);
+                           cp, bg[0], bg[1], bg[2], d_fp, ranges, point_list, fetch, img, final_T, n_contrib, d_counts);
         return;
     }
-    hipLaunchKernelGGL(k_render_forward<Fetch>, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(64), 0, stream, cp, bg[0], bg[1], bg[2], ranges,
+    hipLaunchKernelGGL(k_render_forward<Fetch>, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(64), 0, stream, cp, bg[0], bg[1], bg[2], d_fp, ranges,
                        point_list, fetch, img, final_T, n_contrib, d_counts);
 }
 
@@ -418,14 +432,15 @@ void launch_render_forward_aos(const CamParams& cp, const float bg[3], const uin
                                uint32_t* n_contrib, hipStream_t stream)
 {
     launch_render(cp, bg, ranges, point_list, FetchAoS{ means_2d, conic, opacity, color }, img, final_T, n_contrib,
-                  nullptr, stream);
+                  nullptr, nullptr, stream);
 }
 
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
-                               uint32_t* n_contrib, const uint32_t* d_counts, hipStream_t stream)
+                               uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,
+                               hipStream_t stream)
 {
-    launch_render(cp, bg, ranges, point_list, FetchRec{ recs }, img, final_T, n_contrib, d_counts, stream);
+    launch_render(cp, bg, ranges, point_list, FetchRec{ recs }, img, final_T, n_contrib, d_counts, d_fp, stream);
 }
 
 } // namespace lcgs

@@ -3,6 +3,7 @@
 // lcgs_create fails with LCGS_ERR_NO_DEVICE -- there is no CPU fallback.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -84,6 +85,26 @@ struct lcgs_context {
     uint64_t* scan_state = nullptr;
     uint32_t* ranges     = nullptr;
     size_t    zero_bytes = 0;
+    // device-resident per-call parameters + the captured frame graph (replayed while its key is unchanged)
+    DeviceBuffer   frame_params;
+    hipGraphExec_t graph_exec = nullptr;
+    struct GraphKey {
+        const void *pos = nullptr, *img = nullptr, *radii = nullptr;
+        int         P = -1, sh_deg = -1, width = 0, height = 0, keep_state = -1;
+        int64_t     hint_V = -1, hint_L = -1;
+        uint32_t    capacity = 0;
+        hipStream_t stream = nullptr;
+        bool        operator==(const GraphKey& o) const
+        {
+            return pos == o.pos && img == o.img && radii == o.radii && P == o.P && sh_deg == o.sh_deg && width == o.width &&
+                   height == o.height && keep_state == o.keep_state && hint_V == o.hint_V && hint_L == o.hint_L &&
+                   capacity == o.capacity && stream == o.stream;
+        }
+    } graph_key;
+    bool use_graph = false; // opt-in (LCGS_GRAPH=1): measured no gain on MI355X, the short kernels are GPU-latency-bound
+    // second stream: work that is independent of the sort chain (record building; gradient zero-fill) overlaps it
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
     // launch-size hints from the last synchronised frame (live counts stay on the device; larger counts are
     // still handled correctly by chunk striding)
     int64_t hint_V = 0, hint_L = 0;
@@ -204,8 +225,9 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
 }
 
 // enqueue one fused forward frame (no synchronisation)
+// d_fp: when non-NULL, camera / bg / scale_modifier are read from device memory by the kernels (graph replay)
 lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float bg[3], float scale_modifier,
-                            float* d_img, int32_t* d_radii, bool keep_state)
+                            float* d_img, int32_t* d_radii, bool keep_state, const FrameParams* d_fp)
 {
     hipStream_t  st       = ctx->stream;
     uint32_t*    d_counts = ctx->counts.as<uint32_t>();
@@ -217,14 +239,24 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     // one memset per frame: scan states of the cull pass + tile ranges (the reference zero-fills ranges too,
     // gs_tile_splatter/impl.cpp:147)
     LCGS_HIP_CHECK(hipMemsetAsync(ctx->zero_ws.ptr, 0, ctx->zero_bytes, st));
-    launch_cull_compact(P, cp, scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->opacity, d_radii,
+    launch_cull_compact(P, cp, scale_modifier, d_fp, ctx->pos, ctx->scale, ctx->rotq, ctx->opacity, d_radii,
                         ctx->sortk[0].as<uint32_t>(), ctx->sortv[0].as<uint32_t>(), ctx->vis_index.as<uint32_t>(),
                         ctx->rects.as<uint2>(), ctx->scan_state, d_counts, st);
     LCGS_TRY(mark(ctx, "cull_compact"));
     const int64_t hint_V = ctx->hint_V > 0 ? ctx->hint_V : P;
     const int64_t hint_L = ctx->hint_L > 0 ? ctx->hint_L : ctx->pair_capacity;
-    launch_build_records((int)std::min<int64_t>(P, hint_V), ctx->sh_deg, cp, scale_modifier, ctx->pos, ctx->scale,
-                         ctx->rotq, ctx->sh, ctx->opacity, ctx->vis_index.as<uint32_t>(), d_counts, recs, st);
+    // Record building (SH fetch + colour: bandwidth-bound) is independent of the sort chain (latency-bound short
+    // kernels): fork it onto the auxiliary stream so the two overlap; the renderer joins.  With per-stage
+    // profiling on, everything runs in order on the main stream so that stage times stay attributable.
+    const bool overlap = !ctx->profiling;
+    hipStream_t rec_stream = overlap ? ctx->aux_stream : st;
+    if (overlap) {
+        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+    }
+    launch_build_records((int)std::min<int64_t>(P, hint_V), ctx->sh_deg, cp, scale_modifier, d_fp, ctx->pos, ctx->scale,
+                         ctx->rotq, ctx->sh, ctx->opacity, ctx->vis_index.as<uint32_t>(), d_counts, recs, rec_stream);
+    if (overlap) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
     LCGS_TRY(mark(ctx, "build_records"));
 
     // survivors by depth bits: the low 32 bits of the reference key, sorted before duplication
@@ -249,9 +281,10 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     launch_get_ranges_u32(hint_L, d_counts, ctx->pairk[where2].as<uint32_t>(), ctx->ranges, st);
     LCGS_TRY(mark(ctx, "ranges"));
 
+    if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0)); // records are ready
     launch_render_forward_rec(cp, bg, ctx->ranges, ctx->pairv[where2].as<uint32_t>(), recs, d_img,
                               keep_state ? ctx->final_T.as<float>() : nullptr,
-                              keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, st);
+                              keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, d_fp, st);
     LCGS_TRY(mark(ctx, "render"));
 
     LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, d_counts, 32, hipMemcpyDeviceToHost, st));
@@ -293,6 +326,25 @@ lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx)
     if (!ctx) return LCGS_ERR_OUT_OF_MEMORY;
     ctx->device = device_id;
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    if (const char* e = getenv("LCGS_GRAPH")) ctx->use_graph = (e[0] == '1'); // tuning hook
+    // The auxiliary stream has the LOWEST dispatch priority: its bandwidth-bound workgroups fill the gaps the main
+    // stream's short, latency-bound kernels leave instead of competing with them.
+    hipError_t se;
+    {
+        int         lo = 0, hi = 0;
+        const char* m  = getenv("LCGS_AUX_PRIORITY"); // tuning hook: "low" (default), "same"
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = numerically greatest = lowest priority
+        const int prio = (m && m[0] == 's') ? 0 : lo;
+        se             = hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, prio);
+        if (se != hipSuccess) se = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
+    }
+    if (se == hipSuccess) se = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+    if (se == hipSuccess) se = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+    if (se != hipSuccess) {
+        lcgs_status s = hip_fail(se, "aux stream / events", __FILE__, __LINE__);
+        delete ctx;
+        return s;
+    }
     *out_ctx    = ctx;
     return LCGS_OK;
 }
@@ -309,6 +361,14 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
                              &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& b : ctx->owned) b.release();
+    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+    if (ctx->aux_stream) {
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    ctx->frame_params.release();
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->events_created)
         for (auto& ev : ctx->events) (void)hipEventDestroy(ev);
@@ -515,8 +575,47 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
     const CamParams cp = make_cam_params(*camera);
     for (int attempt = 0; attempt < 4; ++attempt) {
         LCGS_TRY(ensure_fused_workspace(ctx, cp, keep_state != 0));
-        LCGS_TRY(enqueue_forward(ctx, cp, bg_color, scale_modifier, d_img, d_radii, keep_state != 0));
-        LCGS_HIP_CHECK(hipGetLastError());
+        if (ctx->use_graph && !ctx->profiling && ctx->stream != nullptr) { // the legacy NULL stream cannot be captured
+            // refresh the device-resident parameters (one tiny eager launch), then replay the captured frame
+            LCGS_TRY(ctx->frame_params.ensure(sizeof(FrameParams)));
+            FrameParams fp;
+            fp.cp = cp;
+            memcpy(fp.bg, bg_color, sizeof(float) * 3);
+            fp.scale_modifier = scale_modifier;
+            launch_set_frame_params(fp, ctx->frame_params.as<FrameParams>(), ctx->stream);
+            lcgs_context::GraphKey key;
+            key.pos = ctx->pos; key.img = d_img; key.radii = d_radii; key.P = ctx->P; key.sh_deg = ctx->sh_deg;
+            key.width = camera->width; key.height = camera->height; key.keep_state = keep_state != 0;
+            key.hint_V = ctx->hint_V; key.hint_L = ctx->hint_L; key.capacity = ctx->pair_capacity; key.stream = ctx->stream;
+            if (!ctx->graph_exec || !(key == ctx->graph_key)) {
+                if (ctx->graph_exec) {
+                    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                    (void)hipGraphExecDestroy(ctx->graph_exec);
+                    ctx->graph_exec = nullptr;
+                }
+                hipGraph_t graph = nullptr;
+                LCGS_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                lcgs_status cs = enqueue_forward(ctx, cp, bg_color, scale_modifier, d_img, d_radii, keep_state != 0,
+                                                 ctx->frame_params.as<FrameParams>());
+                hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+                if (cs != LCGS_OK) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    return cs;
+                }
+                LCGS_HIP_CHECK(ce);
+                LCGS_HIP_CHECK(hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                ctx->graph_key = key;
+            }
+            LCGS_HIP_CHECK(hipGraphLaunch(ctx->graph_exec, ctx->stream));
+            ctx->last.valid          = true;
+            ctx->last.has_state      = keep_state != 0;
+            ctx->last.cp             = cp;
+            ctx->last.scale_modifier = scale_modifier;
+            memcpy(ctx->last.bg, bg_color, sizeof(float) * 3);
+        } else {
+            LCGS_TRY(enqueue_forward(ctx, cp, bg_color, scale_modifier, d_img, d_radii, keep_state != 0, nullptr));
+        }
         if (!num_rendered && !ctx->profiling) return LCGS_OK; // fully asynchronous frame
         LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         LCGS_TRY(collect_marks(ctx));
@@ -527,8 +626,11 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
         ctx->stats.num_tiles     = (int64_t)cp.grid_x * cp.grid_y;
         if (num_rendered) *num_rendered = (int)ctx->h_counts[1];
         // launch-size hints for the following asynchronous frames
-        ctx->hint_V = (int64_t)ctx->h_counts[0] + ctx->h_counts[0] / 4 + 4096;
-        ctx->hint_L = (int64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4 + 4096;
+        // (kept unless the live counts leave the [hint/2, hint] band, so a captured graph stays valid)
+        if ((int64_t)ctx->h_counts[0] > ctx->hint_V || (int64_t)ctx->h_counts[0] * 2 < ctx->hint_V)
+            ctx->hint_V = (int64_t)ctx->h_counts[0] + ctx->h_counts[0] / 4 + 4096;
+        if ((int64_t)ctx->h_counts[4] > ctx->hint_L || (int64_t)ctx->h_counts[4] * 2 < ctx->hint_L)
+            ctx->hint_L = (int64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4 + 4096;
         if (ctx->h_counts[3] == 0) return LCGS_OK;
         // pair buffers were too small for this view: grow and redo the frame
         uint64_t want = (uint64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4;
@@ -603,12 +705,20 @@ lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, cons
     const size_t feat = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3;
     ctx->n_marks      = 0;
     LCGS_TRY(mark(ctx, "begin"));
-    // dense per-splat gradients: splats that did not reach the screen get exact zeros
-    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dpos, 0, P * 3 * 4, st));
-    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dscale, 0, P * 3 * 4, st));
-    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_drotq, 0, P * 4 * 4, st));
-    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dsh, 0, P * feat * 4, st));
-    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dopacity, 0, P * 4, st));
+    // dense per-splat gradients: splats that did not reach the screen get exact zeros.  The 236 B/splat zero-fill
+    // is pure HBM writes and independent of the render-backward: it runs on the auxiliary stream beside it.
+    const bool  overlap = !ctx->profiling;
+    hipStream_t zs      = overlap ? ctx->aux_stream : st;
+    if (overlap) {
+        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+    }
+    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dpos, 0, P * 3 * 4, zs));
+    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dscale, 0, P * 3 * 4, zs));
+    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_drotq, 0, P * 4 * 4, zs));
+    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dsh, 0, P * feat * 4, zs));
+    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dopacity, 0, P * 4, zs));
+    if (overlap) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
     LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)P)));
     launch_zero_grads2d(ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(), st);
     LCGS_TRY(mark(ctx, "zero_grads"));
@@ -616,6 +726,7 @@ lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, cons
                            ctx->recs.as<SplatRecord>(), ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(),
                            d_dL_dimg, ctx->grads2d.as<float>(), st);
     LCGS_TRY(mark(ctx, "render_backward"));
+    if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     launch_preprocess_backward(ctx->hint_V > 0 ? ctx->hint_V : (int64_t)P, ctx->sh_deg, ctx->last.cp,
                                ctx->last.scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->sh,
                                ctx->vis_index.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(),
