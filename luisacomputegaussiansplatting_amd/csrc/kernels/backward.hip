@@ -108,7 +108,8 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
                                                            const float* __restrict__ final_T,
                                                            const uint32_t* __restrict__ n_contrib,
                                                            const float* __restrict__ dL_dimg,
-                                                           float* __restrict__ grads2d)
+                                                           float* __restrict__ grads2d,
+                                                           const uint32_t* __restrict__ tile_order)
 {
     __shared__ float4             s_a[256]; // mean.x, mean.y, conic.x, conic.y
     __shared__ float4             s_b[256]; // conic.z, opacity, r, g
@@ -119,7 +120,12 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
     __shared__ uint32_t           s_max[4];
 
     uint32_t tx, ty;
-    if (!tile_of_workgroup(blockIdx.x, cp.grid_x, cp.grid_y, tx, ty)) return;
+    if (tile_order) { // longest-list-first schedule of the forward (scheduling hint only)
+        if (blockIdx.x >= cp.grid_x * cp.grid_y) return;
+        const uint32_t t = tile_order[blockIdx.x];
+        tx = t % cp.grid_x;
+        ty = t / cp.grid_x;
+    } else if (!tile_of_workgroup(blockIdx.x, cp.grid_x, cp.grid_y, tx, ty)) return;
     const uint32_t tile = ty * cp.grid_x + tx;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t px = tx * kBlockX + (lane & 15u);
@@ -514,11 +520,11 @@ void launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t s
 
 void launch_render_backward(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                             const SplatRecord* recs, const float* final_T, const uint32_t* n_contrib,
-                            const float* dL_dimg, float* grads2d, hipStream_t stream)
+                            const float* dL_dimg, float* grads2d, const uint32_t* tile_order, hipStream_t stream)
 {
     if (cp.grid_x * cp.grid_y == 0) return;
     hipLaunchKernelGGL(k_render_backward, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(256), 0, stream, cp, bg[0],
-                       bg[1], bg[2], ranges, point_list, recs, final_T, n_contrib, dL_dimg, grads2d);
+                       bg[1], bg[2], ranges, point_list, recs, final_T, n_contrib, dL_dimg, grads2d, tile_order);
 }
 
 void launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,

@@ -105,17 +105,19 @@ void launch_get_ranges_u32(int64_t L_cap, const uint32_t* d_counts, const uint32
 void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t* list_vid, const uint32_t* vis_index,
                          uint32_t* list_idx, hipStream_t stream);
 
+// longest-list-first tile schedule for the renderers (order[G], a scheduling hint only)
+void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream);
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,
-                               hipStream_t stream);
+                               const uint32_t* tile_order, hipStream_t stream);
 
 // ---- backward.hip ----
 size_t grads2d_bytes(int64_t V_cap);
 void   launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t stream);
 void   launch_render_backward(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                               const SplatRecord* recs, const float* final_T, const uint32_t* n_contrib,
-                              const float* dL_dimg, float* grads2d, hipStream_t stream);
+                              const float* dL_dimg, float* grads2d, const uint32_t* tile_order, hipStream_t stream);
 void   launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
                                   const float* scale, const float* rotq, const float* sh, const uint32_t* vis_index,
                                   const uint32_t* d_counts, const float* grads2d, float* dL_dpos, float* dL_dscale,

@@ -281,7 +281,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                                                             const uint32_t* __restrict__ point_list, Fetch fetch,
                                                             float* __restrict__ img, float* __restrict__ final_T,
                                                             uint32_t* __restrict__ n_contrib,
-                                                            const uint32_t* __restrict__ d_counts)
+                                                            const uint32_t* __restrict__ d_counts,
+                                                            const uint32_t* __restrict__ tile_order)
 {
     __shared__ float4             s_a[256]; // mean.x, mean.y, conic.x, conic.y
     __shared__ float4             s_b[256]; // conic.z, opacity, r, g
@@ -296,7 +297,12 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         bg2 = fpp->bg[2];
     }
     uint32_t tx, ty;
-    if (!tile_of_workgroup(blockIdx.x, cp.grid_x, cp.grid_y, tx, ty)) return;
+    if (tile_order) { // scheduling hint only: which workgroup takes which tile never changes the image
+        if (blockIdx.x >= cp.grid_x * cp.grid_y) return;
+        const uint32_t t = tile_order[blockIdx.x];
+        tx = t % cp.grid_x;
+        ty = t / cp.grid_x;
+    } else if (!tile_of_workgroup(blockIdx.x, cp.grid_x, cp.grid_y, tx, ty)) return;
     const uint32_t tile = ty * cp.grid_x + tx;
     if (d_counts && d_counts[1] == 0u) return; // image untouched (gs_tile_splatter/impl.cpp:109)
 
@@ -405,10 +411,50 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
     }
 }
 
+// Longest-list-first tile schedule (a scheduling hint: any order gives the same image).  Tile work is roughly
+// proportional to list length and varies >10x across a frame; dispatching the long tiles first removes the tail in
+// which a few late heavy tiles keep the kernel alive (measured: -16 % renderer time on the bicycle stand-in).
+// One workgroup: counting sort of the tiles into 1024 length buckets (descending); order inside a bucket is
+// whatever the LDS atomics produce.
+__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ ranges, uint32_t G,
+                                                       uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t s_bucket[1024];
+    __shared__ uint32_t s_wave[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    s_bucket[tid] = 0;
+    __syncthreads();
+    for (uint32_t t = tid; t < G; t += 1024u) {
+        const uint32_t len = ranges[2 * (size_t)t + 1] - ranges[2 * (size_t)t];
+        const uint32_t b   = 1023u - ((len >> 3) < 1023u ? (len >> 3) : 1023u);
+        atomicAdd(&s_bucket[b], 1u);
+    }
+    __syncthreads();
+    const uint32_t own = s_bucket[tid];
+    uint32_t       inc = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < wave; ++w) carry += s_wave[w];
+    __syncthreads();
+    s_bucket[tid] = carry + inc - own; // exclusive start of the bucket
+    __syncthreads();
+    for (uint32_t t = tid; t < G; t += 1024u) {
+        const uint32_t len = ranges[2 * (size_t)t + 1] - ranges[2 * (size_t)t];
+        const uint32_t b   = 1023u - ((len >> 3) < 1023u ? (len >> 3) : 1023u);
+        order[atomicAdd(&s_bucket[b], 1u)] = t;
+    }
+}
+
 template <typename Fetch>
 void launch_render(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                    Fetch fetch, float* img, float* final_T, uint32_t* n_contrib, const uint32_t* d_counts,
-                   const FrameParams* d_fp, hipStream_t stream)
+                   const FrameParams* d_fp, const uint32_t* tile_order, hipStream_t stream)
 {
     if (cp.grid_x * cp.grid_y == 0) return;
     static const int variant = [] {
@@ -417,7 +463,8 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
     }();
     if (variant == 1) {
         hipLaunchKernelGGL(k_render_forward_b<Fetch>, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(256), 0, stream,
-                           cp, bg[0], bg[1], bg[2], d_fp, ranges, point_list, fetch, img, final_T, n_contrib, d_counts);
+                           cp, bg[0], bg[1], bg[2], d_fp, ranges, point_list, fetch, img, final_T, n_contrib, d_counts,
+                           tile_order);
         return;
     }
     hipLaunchKernelGGL(k_render_forward<Fetch>, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(64), 0, stream, cp, bg[0], bg[1], bg[2], d_fp, ranges,
@@ -426,21 +473,28 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
 
 } // namespace
 
+void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream)
+{
+    if (G == 0) return;
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, ranges, G, order);
+}
+
 void launch_render_forward_aos(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const float* means_2d, const float* conic,
                                const float* opacity, const float* color, float* img, float* final_T,
                                uint32_t* n_contrib, hipStream_t stream)
 {
     launch_render(cp, bg, ranges, point_list, FetchAoS{ means_2d, conic, opacity, color }, img, final_T, n_contrib,
-                  nullptr, nullptr, stream);
+                  nullptr, nullptr, nullptr, stream);
 }
 
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,
-                               hipStream_t stream)
+                               const uint32_t* tile_order, hipStream_t stream)
 {
-    launch_render(cp, bg, ranges, point_list, FetchRec{ recs }, img, final_T, n_contrib, d_counts, d_fp, stream);
+    launch_render(cp, bg, ranges, point_list, FetchRec{ recs }, img, final_T, n_contrib, d_counts, d_fp, tile_order,
+                  stream);
 }
 
 } // namespace lcgs

@@ -101,6 +101,7 @@ struct lcgs_context {
                    capacity == o.capacity && stream == o.stream;
         }
     } graph_key;
+    DeviceBuffer tile_order; // longest-list-first schedule of the last frame's tiles
     bool use_graph = false; // opt-in (LCGS_GRAPH=1): measured no gain on MI355X, the short kernels are GPU-latency-bound
     // second stream: work that is independent of the sort chain (record building; gradient zero-fill) overlaps it
     hipStream_t aux_stream = nullptr;
@@ -214,6 +215,7 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
     ctx->ranges     = reinterpret_cast<uint32_t*>(ctx->zero_ws.as<char>() + b0);
     ctx->zero_bytes = b0 + b1;
     LCGS_TRY(ctx->counts.ensure(64));
+    LCGS_TRY(ctx->tile_order.ensure(G * 4));
     LCGS_TRY(ctx->sort_ws.ensure(pair_sort_ws_bytes(std::max<int64_t>((int64_t)P, (int64_t)ctx->pair_capacity))));
     LCGS_TRY(ctx->expand_ws.ensure(expand_ws_bytes((int)P)));
     if (keep_state) {
@@ -279,12 +281,14 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     LCGS_TRY(mark(ctx, "tile_sort"));
 
     launch_get_ranges_u32(hint_L, d_counts, ctx->pairk[where2].as<uint32_t>(), ctx->ranges, st);
+    launch_tile_order(ctx->ranges, cp.grid_x * cp.grid_y, ctx->tile_order.as<uint32_t>(), st);
     LCGS_TRY(mark(ctx, "ranges"));
 
     if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0)); // records are ready
     launch_render_forward_rec(cp, bg, ctx->ranges, ctx->pairv[where2].as<uint32_t>(), recs, d_img,
                               keep_state ? ctx->final_T.as<float>() : nullptr,
-                              keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, d_fp, st);
+                              keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, d_fp,
+                              ctx->tile_order.as<uint32_t>(), st);
     LCGS_TRY(mark(ctx, "render"));
 
     LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, d_counts, 32, hipMemcpyDeviceToHost, st));
@@ -357,7 +361,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
     DeviceBuffer* bufs[] = { &ctx->recs, &ctx->sortk[0], &ctx->sortk[1], &ctx->sortv[0], &ctx->sortv[1], &ctx->vis_index,
                              &ctx->rects, &ctx->rects_sorted, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
                              &ctx->pairv[1], &ctx->zero_ws, &ctx->counts, &ctx->sort_ws,
-                             &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->st_keys_tmp,
+                             &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order, &ctx->st_keys_tmp,
                              &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& b : ctx->owned) b.release();
@@ -724,7 +728,7 @@ lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, cons
     LCGS_TRY(mark(ctx, "zero_grads"));
     launch_render_backward(ctx->last.cp, ctx->last.bg, ctx->ranges, ctx->pairv[ctx->last.list_buf].as<uint32_t>(),
                            ctx->recs.as<SplatRecord>(), ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(),
-                           d_dL_dimg, ctx->grads2d.as<float>(), st);
+                           d_dL_dimg, ctx->grads2d.as<float>(), ctx->tile_order.as<uint32_t>(), st);
     LCGS_TRY(mark(ctx, "render_backward"));
     if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     launch_preprocess_backward(ctx->hint_V > 0 ? ctx->hint_V : (int64_t)P, ctx->sh_deg, ctx->last.cp,
