@@ -294,7 +294,18 @@ LCGS_HD void tight_rect(float pix_x, float pix_y, float cx, float cy, float cz /
                         const uint32_t rmin[2], const uint32_t rmax[2], uint32_t tmin[2], uint32_t tmax[2])
 {
     tmin[0] = rmin[0]; tmin[1] = rmin[1]; tmax[0] = rmax[0]; tmax[1] = rmax[1];
-    const float t0 = 2.0f * logf(255.0f * opacity);
+    // This bound only has to be conservative (explicit slack below), so on the device the 1-ulp hardware
+    // log / sqrt / reciprocal replace the IEEE library forms.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LCGS_FAST_LOG(x) __logf(x)
+#define LCGS_FAST_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define LCGS_FAST_RCP(x) __builtin_amdgcn_rcpf(x)
+#else
+#define LCGS_FAST_LOG(x) logf(x)
+#define LCGS_FAST_SQRT(x) sqrtf(x)
+#define LCGS_FAST_RCP(x) (1.0f / (x))
+#endif
+    const float t0 = 2.0f * LCGS_FAST_LOG(255.0f * opacity);
     if (!(t0 == t0)) return;                 // NaN opacity: keep the reference rect
     const float t = t0 * 1.0001f + 2e-4f;    // same margin as the renderer's per-tile test
     if (!(t > 0.0f)) {                       // alpha < 1/255 everywhere
@@ -306,9 +317,12 @@ LCGS_HD void tight_rect(float pix_x, float pix_y, float cx, float cy, float cz /
     const float err  = 4e-7f * (fabsf(cx * cz) + cy * cy); // rounding of the two products that cancel in det
     const float dlow = det - err;
     if (!(dlow > 1e-12f)) return;            // ill-conditioned / non-finite: keep the reference rect
-    const float s  = (det + 1e-6f + err) / dlow;
-    const float hx = sqrtf(t * cx * s) * 1.0001f + 0.01f;
-    const float hy = sqrtf(t * cz * s) * 1.0001f + 0.01f;
+    const float s  = (det + 1e-6f + err) * LCGS_FAST_RCP(dlow);
+    const float hx = LCGS_FAST_SQRT(t * cx * s) * 1.0001f + 0.01f;
+    const float hy = LCGS_FAST_SQRT(t * cz * s) * 1.0001f + 0.01f;
+#undef LCGS_FAST_LOG
+#undef LCGS_FAST_SQRT
+#undef LCGS_FAST_RCP
     if (!(hx == hx) || !(hy == hy)) return;
     // tiles whose pixel span [16 tx, 16 tx + 15] meets [m - h, m + h]:
     //   16 tx + 15 >= m - h  <=>  tx >= ceil((m - h - 15) / 16);   16 tx <= m + h  <=>  tx <= floor((m + h) / 16)
