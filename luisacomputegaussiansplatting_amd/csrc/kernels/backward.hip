@@ -86,21 +86,34 @@ __device__ __forceinline__ bool splat_may_touch_rect(float mx, float my, float c
     return best - 1e-5f * slack <= t;
 }
 
-// sum over the 64 lanes of a wave, result valid in lane 63 (DPP row shifts + row broadcasts: no LDS)
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
+// Sums of nine values over the 64 lanes of a wave, results valid in lane 63.  DPP row shifts + row broadcasts (no
+// LDS).  The nine chains advance in lockstep, one DPP step each per round, so the 2-wait-state VALU-write -> DPP-read
+// hazard of a chain is covered by the eight other chains' instructions (hipcc pads nothing inside asm; the leading
+// s_nop covers the producers of v[]).  Lanes a step does not address (bank/row masks, shifted-in positions) keep
+// their value because the destination is the accumulator itself.
+__device__ __forceinline__ void wave_sum9_to_lane63(float v[9])
 {
-    int x = __float_as_int(v);
-#define LCGS_DPP_ADD(ctrl, row_mask, bank_mask)                                                                     \
-    x = __float_as_int(__int_as_float(x) +                                                                          \
-                       __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, row_mask, bank_mask, true)))
-    LCGS_DPP_ADD(0x111, 0xF, 0xF); // row_shr:1
-    LCGS_DPP_ADD(0x112, 0xF, 0xF); // row_shr:2
-    LCGS_DPP_ADD(0x114, 0xF, 0xE); // row_shr:4
-    LCGS_DPP_ADD(0x118, 0xF, 0xC); // row_shr:8  -> lane 15 of each row holds the row sum
-    LCGS_DPP_ADD(0x142, 0xA, 0xF); // row_bcast:15 into rows 1 and 3
-    LCGS_DPP_ADD(0x143, 0xC, 0xF); // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
-#undef LCGS_DPP_ADD
-    return __int_as_float(x);
+    asm volatile("s_nop 1" ::: "memory");
+#define LCGS_DPP_STEP(ctrl)                                                                                         \
+    asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl "\n\t"                                                             \
+                 "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t"                                                             \
+                 "v_add_f32_dpp %2, %2, %2 " ctrl "\n\t"                                                             \
+                 "v_add_f32_dpp %3, %3, %3 " ctrl "\n\t"                                                             \
+                 "v_add_f32_dpp %4, %4, %4 " ctrl "\n\t"                                                             \
+                 "v_add_f32_dpp %5, %5, %5 " ctrl "\n\t"                                                             \
+                 "v_add_f32_dpp %6, %6, %6 " ctrl "\n\t"                                                             \
+                 "v_add_f32_dpp %7, %7, %7 " ctrl "\n\t"                                                             \
+                 "v_add_f32_dpp %8, %8, %8 " ctrl                                                                    \
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),   \
+                   "+v"(v[8]))
+    LCGS_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf");
+    LCGS_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf");
+    LCGS_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xe");
+    LCGS_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xc"); // lane 15 of each row holds the row sum
+    LCGS_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    LCGS_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf"); // lane 63 holds the wave sum
+#undef LCGS_DPP_STEP
+    asm volatile("s_nop 1" ::: "memory");
 }
 
 constexpr int kG2D = 12; // floats per splat in the 2-D gradient buffer: mean(2) conic(3) opacity(1) rgb(3) pad(3)
@@ -253,11 +266,11 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
                 // lane 63 holds each wave sum; a raw ds_add_f32 (hipcc's atomic optimiser would wrap a C++ atomicAdd
                 // in a per-active-lane scan loop, ~15 extra instructions per value)
                 const uint32_t lds_addr = (uint32_t)(uintptr_t)&s_grad[0][idx];
+                wave_sum9_to_lane63(v);
+                if (lane == 63u) {
 #pragma unroll
-                for (int g = 0; g < 9; ++g) {
-                    const float s = wave_sum_to_lane63(v[g]);
-                    if (lane == 63u)
-                        asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(lds_addr), "v"(s), "n"(g * 256 * 4) : "memory");
+                    for (int g = 0; g < 9; ++g)
+                        asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(lds_addr), "v"(v[g]), "n"(g * 256 * 4) : "memory");
                 }
             }
         }
@@ -283,36 +296,33 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
 // ---------------------------------------------------------------------------------------------------------------
 // 2-D gradients -> parameter gradients, one lane per surviving splat.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float basis[16], float dbx[16],
-                                              float dby[16], float dbz[16])
-{
-#pragma unroll
-    for (int k = 0; k < 16; ++k) basis[k] = dbx[k] = dby[k] = dbz[k] = 0.0f;
-    basis[0] = SH_C0;
-    if (deg < 1) return;
-    basis[1] = -SH_C1 * y; dby[1] = -SH_C1;
-    basis[2] = SH_C1 * z;  dbz[2] = SH_C1;
-    basis[3] = -SH_C1 * x; dbx[3] = -SH_C1;
-    if (deg < 2) return;
-    const float xx = x * x, yy = y * y, zz = z * z;
-    basis[4] = SH_C2_0 * x * y; dbx[4] = SH_C2_0 * y; dby[4] = SH_C2_0 * x;
-    basis[5] = SH_C2_1 * y * z; dby[5] = SH_C2_1 * z; dbz[5] = SH_C2_1 * y;
-    basis[6] = SH_C2_2 * (2.0f * zz - xx - yy); dbx[6] = SH_C2_2 * (-2.0f * x); dby[6] = SH_C2_2 * (-2.0f * y); dbz[6] = SH_C2_2 * (4.0f * z);
-    basis[7] = SH_C2_3 * z * x; dbx[7] = SH_C2_3 * z; dbz[7] = SH_C2_3 * x;
-    basis[8] = SH_C2_4 * (xx - yy); dbx[8] = SH_C2_4 * 2.0f * x; dby[8] = SH_C2_4 * -2.0f * y;
-    if (deg < 3) return;
-    basis[9]  = SH_C3_0 * y * (3.0f * xx - yy); dbx[9] = SH_C3_0 * 6.0f * x * y; dby[9] = SH_C3_0 * (3.0f * xx - 3.0f * yy);
-    basis[10] = SH_C3_1 * x * y * z; dbx[10] = SH_C3_1 * y * z; dby[10] = SH_C3_1 * x * z; dbz[10] = SH_C3_1 * x * y;
-    basis[11] = SH_C3_2 * y * (4.0f * zz - xx - yy);
-    dbx[11] = SH_C3_2 * (-2.0f * x * y); dby[11] = SH_C3_2 * (4.0f * zz - xx - 3.0f * yy); dbz[11] = SH_C3_2 * 8.0f * y * z;
-    basis[12] = SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
-    dbx[12] = SH_C3_3 * (-6.0f * x * z); dby[12] = SH_C3_3 * (-6.0f * y * z); dbz[12] = SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
-    basis[13] = SH_C3_4 * x * (4.0f * zz - xx - yy);
-    dbx[13] = SH_C3_4 * (4.0f * zz - 3.0f * xx - yy); dby[13] = SH_C3_4 * (-2.0f * x * y); dbz[13] = SH_C3_4 * 8.0f * x * z;
-    basis[14] = SH_C3_5 * z * (xx - yy); dbx[14] = SH_C3_5 * 2.0f * x * z; dby[14] = SH_C3_5 * -2.0f * y * z; dbz[14] = SH_C3_5 * (xx - yy);
-    basis[15] = SH_C3_6 * x * (xx - 3.0f * yy); dbx[15] = SH_C3_6 * (3.0f * xx - 3.0f * yy); dby[15] = SH_C3_6 * (-6.0f * x * y);
-}
+// The 16 SH basis terms and their direction gradients, signs as composed by sh_preprocessor.cpp:49-147.
+// X(k, basis, d/dx, d/dy, d/dz) with x, y, z, xx, yy, zz in scope.
+#define LCGS_SH_TERMS(X)                                                                                              \
+    X(0, SH_C0, 0.0f, 0.0f, 0.0f)                                                                                     \
+    X(1, -SH_C1 * y, 0.0f, -SH_C1, 0.0f)                                                                              \
+    X(2, SH_C1 * z, 0.0f, 0.0f, SH_C1)                                                                                \
+    X(3, -SH_C1 * x, -SH_C1, 0.0f, 0.0f)                                                                              \
+    X(4, SH_C2_0 * x * y, SH_C2_0 * y, SH_C2_0 * x, 0.0f)                                                             \
+    X(5, SH_C2_1 * y * z, 0.0f, SH_C2_1 * z, SH_C2_1 * y)                                                             \
+    X(6, SH_C2_2 * (2.0f * zz - xx - yy), SH_C2_2 * (-2.0f * x), SH_C2_2 * (-2.0f * y), SH_C2_2 * (4.0f * z))         \
+    X(7, SH_C2_3 * z * x, SH_C2_3 * z, 0.0f, SH_C2_3 * x)                                                             \
+    X(8, SH_C2_4 * (xx - yy), SH_C2_4 * 2.0f * x, SH_C2_4 * -2.0f * y, 0.0f)                                          \
+    X(9, SH_C3_0 * y * (3.0f * xx - yy), SH_C3_0 * 6.0f * x * y, SH_C3_0 * (3.0f * xx - 3.0f * yy), 0.0f)             \
+    X(10, SH_C3_1 * x * y * z, SH_C3_1 * y * z, SH_C3_1 * x * z, SH_C3_1 * x * y)                                     \
+    X(11, SH_C3_2 * y * (4.0f * zz - xx - yy), SH_C3_2 * (-2.0f * x * y), SH_C3_2 * (4.0f * zz - xx - 3.0f * yy),     \
+      SH_C3_2 * 8.0f * y * z)                                                                                         \
+    X(12, SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), SH_C3_3 * (-6.0f * x * z), SH_C3_3 * (-6.0f * y * z),    \
+      SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy))                                                                  \
+    X(13, SH_C3_4 * x * (4.0f * zz - xx - yy), SH_C3_4 * (4.0f * zz - 3.0f * xx - yy), SH_C3_4 * (-2.0f * x * y),     \
+      SH_C3_4 * 8.0f * x * z)                                                                                         \
+    X(14, SH_C3_5 * z * (xx - yy), SH_C3_5 * 2.0f * x * z, SH_C3_5 * -2.0f * y * z, SH_C3_5 * (xx - yy))              \
+    X(15, SH_C3_6 * x * (xx - 3.0f * yy), SH_C3_6 * (3.0f * xx - 3.0f * yy), SH_C3_6 * (-6.0f * x * y), 0.0f)
 
+// One lane per surviving splat (dense ids).  The splat's 48 SH coefficients arrive through the wave's LDS slab
+// (cooperative 16-byte loads, 12 lanes per 192-byte row), the SH gradient row is written back IN PLACE into the
+// slab as it is produced (so it never lives in registers next to the geometry Jacobians) and leaves as coalesced
+// 16-byte stores.
 __global__ void __launch_bounds__(256)
 k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const float* __restrict__ pos,
                       const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ sh,
@@ -324,13 +334,32 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
     const uint32_t V = d_counts[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int feat = (sh_deg + 1) * (sh_deg + 1);
+    const bool staged = sh_deg == 3 && ((reinterpret_cast<uintptr_t>(sh) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0);
     for (uint32_t blk = blockIdx.x; blk * 256u < V; blk += gridDim.x) {
         const uint32_t vid   = blk * 256u + threadIdx.x;
         const bool     valid = vid < V;
         const int      idx   = (int)vis_index[valid ? vid : V - 1];
-        float          gsh[48];
+        const uint32_t wave_first = blk * 256u + wave * 64u;
+        const uint32_t nvalid     = wave_first < V ? ((V - wave_first) < 64u ? (V - wave_first) : 64u) : 0u;
+        float*         row = reinterpret_cast<float*>(&s_sh[wave][lane * 13]); // this lane's 48 floats (+4 pad)
+
+        // ---- stage the SH rows (coalesced), or fetch them lane-wise for other degrees
+        __syncthreads();
+        if (staged) {
 #pragma unroll
-        for (int k = 0; k < 48; ++k) gsh[k] = 0.0f;
+            for (int i = 0; i < 12; ++i) {
+                const uint32_t c    = (uint32_t)i * 64u + lane;
+                const uint32_t slot = c / 12u, part = c - slot * 12u;
+                const int      sidx = __shfl(idx, (int)slot, 64);
+                if (slot < nvalid) s_sh[wave][slot * 13u + part] = reinterpret_cast<const float4*>(sh + (size_t)sidx * 48)[part];
+            }
+        } else if (valid) {
+            const float* s = sh + (size_t)idx * feat * 3;
+            for (int k = 0; k < 48; ++k) row[k] = k < feat * 3 ? s[k] : 0.0f;
+        }
+        __syncthreads();
+
         if (valid) {
             const float* g2 = grads2d + (size_t)vid * kG2D;
             const float4 q0 = reinterpret_cast<const float4*>(g2)[0], q1 = reinterpret_cast<const float4*>(g2)[1];
@@ -343,35 +372,40 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
             {
                 const float dx = px - cp.campos[0], dy = py - cp.campos[1], dz = pz - cp.campos[2];
                 const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-                const float dir[3] = { dx * inv, dy * inv, dz * inv };
-                float basis[16], dbx[16], dby[16], dbz[16];
-                sh_basis_grad(sh_deg, dir[0], dir[1], dir[2], basis, dbx, dby, dbz);
-                const float* s = sh + (size_t)idx * feat * 3;
-                float ddir[3] = { 0.0f, 0.0f, 0.0f };
+                const float x = dx * inv, y = dy * inv, z = dz * inv;
+                const float xx = x * x, yy = y * y, zz = z * z;
+                float raw[3] = { 0.5f, 0.5f, 0.5f };
+#define LCGS_RAW(k, B, DX, DY, DZ)                                                                                    \
+    if (k < feat) {                                                                                                   \
+        const float bk = (B);                                                                                         \
+        raw[0] += bk * row[k * 3 + 0];                                                                                \
+        raw[1] += bk * row[k * 3 + 1];                                                                                \
+        raw[2] += bk * row[k * 3 + 2];                                                                                \
+    }
+                LCGS_SH_TERMS(LCGS_RAW)
+#undef LCGS_RAW
+                float g[3];
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    float raw = 0.5f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        if (k < feat) {
-                            const float c = s[k * 3 + ch];
-                            raw += basis[k] * c;
-                            sx += c * dbx[k];
-                            sy += c * dby[k];
-                            sz += c * dbz[k];
-                        }
-                    }
-                    const bool  pass = raw > 0.0f && raw < 1.0f; // clamp(.,0,1) saturated otherwise
-                    const float g    = pass ? gcol[ch] : 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) gsh[k * 3 + ch] = (k < feat) ? basis[k] * g : 0.0f;
-                    ddir[0] += g * sx;
-                    ddir[1] += g * sy;
-                    ddir[2] += g * sz;
-                }
-                const float dd = dir[0] * ddir[0] + dir[1] * ddir[1] + dir[2] * ddir[2];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) gp[i] += (ddir[i] - dir[i] * dd) * inv;
+                for (int ch = 0; ch < 3; ++ch) g[ch] = (raw[ch] > 0.0f && raw[ch] < 1.0f) ? gcol[ch] : 0.0f; // clamp mask
+                float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
+#define LCGS_GRAD(k, B, DX, DY, DZ)                                                                                   \
+    {                                                                                                                 \
+        const float c0 = row[k * 3 + 0], c1 = row[k * 3 + 1], c2 = row[k * 3 + 2];                                    \
+        const float bk = (k < feat) ? (B) : 0.0f;                                                                     \
+        const float wk = (k < feat) ? g[0] * c0 + g[1] * c1 + g[2] * c2 : 0.0f;                                       \
+        ddx += wk * (DX);                                                                                             \
+        ddy += wk * (DY);                                                                                             \
+        ddz += wk * (DZ);                                                                                             \
+        row[k * 3 + 0] = bk * g[0];                                                                                   \
+        row[k * 3 + 1] = bk * g[1];                                                                                   \
+        row[k * 3 + 2] = bk * g[2];                                                                                   \
+    }
+                LCGS_SH_TERMS(LCGS_GRAD)
+#undef LCGS_GRAD
+                const float dd = x * ddx + y * ddy + z * ddz;
+                gp[0] += (ddx - x * dd) * inv;
+                gp[1] += (ddy - y * dd) * inv;
+                gp[2] += (ddz - z * dd) * inv;
             }
 
             // ---- geometry: recompute the forward quantities (gs_math.hpp order is irrelevant for the derivative)
@@ -478,15 +512,9 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
             dL_dopacity[idx] = gop;
         }
 
-        // ---- SH gradient rows: through LDS, then 12 consecutive lanes write one splat's 192 contiguous bytes
-        if (sh_deg == 3 && ((reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0)) {
-            const uint32_t wave_first = blk * 256u + wave * 64u;
-            const uint32_t nvalid     = wave_first < V ? ((V - wave_first) < 64u ? (V - wave_first) : 64u) : 0u;
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 12; ++k)
-                s_sh[wave][lane * 13 + k] = make_float4(gsh[4 * k], gsh[4 * k + 1], gsh[4 * k + 2], gsh[4 * k + 3]);
-            __syncthreads();
+        // ---- SH gradient rows: 12 consecutive lanes write one splat's 192 contiguous bytes
+        __syncthreads();
+        if (staged) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 const uint32_t cidx = (uint32_t)i * 64u + lane;
@@ -496,9 +524,7 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
             }
         } else if (valid) {
             float* o = dL_dsh + (size_t)idx * feat * 3;
-#pragma unroll
-            for (int k = 0; k < 48; ++k)
-                if (k < feat * 3) o[k] = gsh[k];
+            for (int k = 0; k < feat * 3; ++k) o[k] = row[k];
         }
     }
 }

@@ -106,7 +106,8 @@ void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t
                          uint32_t* list_idx, hipStream_t stream);
 
 // longest-list-first tile schedule for the renderers (order[G], a scheduling hint only)
-void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream);
+void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, const uint32_t* scan_error_flag,
+                       uint32_t* d_counts, hipStream_t stream);
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,

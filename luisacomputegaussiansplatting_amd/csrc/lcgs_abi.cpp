@@ -171,6 +171,27 @@ lcgs_status collect_marks(lcgs_context* ctx)
     return LCGS_OK;
 }
 
+// after a stream synchronisation: problems the last (possibly asynchronous) frame reported through its counters
+lcgs_status check_frame_flags(lcgs_context* ctx)
+{
+    if (!ctx->last.valid || !ctx->h_counts) return LCGS_OK;
+    if (ctx->h_counts[5] != 0) {
+        set_last_error("chained scan timed out (bounded spin expired): the frame is invalid");
+        return LCGS_ERR_HIP;
+    }
+    if (ctx->h_counts[3] != 0) {
+        // the pair workspace was too small for that view: the lists were truncated.  Grow for the next frame.
+        uint64_t want = (uint64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4;
+        if (want > 0x7FFFFFFFull) want = 0x7FFFFFFFull;
+        ctx->pair_capacity = (uint32_t)want;
+        ctx->h_counts[3]   = 0;
+        set_last_error("the last asynchronous frame needed more (tile, splat) pairs than the workspace held; "
+                       "its image is truncated.  The workspace has been grown: render the frame again");
+        return LCGS_ERR_CAPACITY;
+    }
+    return LCGS_OK;
+}
+
 lcgs_status check_camera(const lcgs_camera* cam)
 {
     LCGS_REQUIRE(cam != nullptr, "camera is NULL");
@@ -281,7 +302,8 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     LCGS_TRY(mark(ctx, "tile_sort"));
 
     launch_get_ranges_u32(hint_L, d_counts, ctx->pairk[where2].as<uint32_t>(), ctx->ranges, st);
-    launch_tile_order(ctx->ranges, cp.grid_x * cp.grid_y, ctx->tile_order.as<uint32_t>(), st);
+    launch_tile_order(ctx->ranges, cp.grid_x * cp.grid_y, ctx->tile_order.as<uint32_t>(),
+                      reinterpret_cast<const uint32_t*>(ctx->scan_state + 1), d_counts, st);
     LCGS_TRY(mark(ctx, "ranges"));
 
     if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0)); // records are ready
@@ -391,7 +413,7 @@ lcgs_status lcgs_synchronize(lcgs_context* ctx)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
     LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return LCGS_OK;
+    return check_frame_flags(ctx);
 }
 
 // ---------------------------------------------------------------------------------------------- stages
@@ -629,6 +651,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
         ctx->stats.num_pairs     = ctx->h_counts[2];
         ctx->stats.num_tiles     = (int64_t)cp.grid_x * cp.grid_y;
         if (num_rendered) *num_rendered = (int)ctx->h_counts[1];
+        if (ctx->h_counts[5] != 0) return check_frame_flags(ctx);
         // launch-size hints for the following asynchronous frames
         // (kept unless the live counts leave the [hint/2, hint] band, so a captured graph stays valid)
         if ((int64_t)ctx->h_counts[0] > ctx->hint_V || (int64_t)ctx->h_counts[0] * 2 < ctx->hint_V)
