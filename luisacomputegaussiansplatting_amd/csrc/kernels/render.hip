@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
     float    T = inside ? 1.0f : -1.0f; // T < 0: finished, |T| is the transmittance
     float    Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
     uint32_t last_contrib = 0u;
-    uint32_t live = __popcll(__ballot(inside)); // wave-uniform
+    uint32_t live = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(inside))); // wave-uniform
     if (tid == 0) s_live_waves = 0u;
     __syncthreads();
     if (lane == 0 && live != 0u) atomicAdd(&s_live_waves, 1u);
@@ -365,36 +365,38 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         __syncthreads();
 
         if (live != 0u) {
-            for (uint32_t w = 0; w < 4u && live != 0u; ++w) {
+            for (uint32_t w = 0; w < 4u && __builtin_amdgcn_readfirstlane((int)live) != 0; ++w) {
                 unsigned long long m = s_mask[w][wave];
                 // readfirstlane returns int: cast through uint32_t so the low half is not sign-extended
                 m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) |
                     (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
-                while (m != 0ull && live != 0u) {
+                while (m != 0ull && __builtin_amdgcn_readfirstlane((int)live) != 0) { // scalar loop control
                     const uint32_t l   = (uint32_t)__ffsll((long long)m) - 1u;
                     m &= m - 1ull;
                     const uint32_t idx = w * 64u + l;
                     const float4   ea = s_a[idx], eb = s_b[idx];
-                    const float2   ec = s_c[idx];
+                    const float2   ec = s_c[idx]; // loaded with the rest: no conditional LDS read in the hot loop
                     const uint32_t contributor = base - range_start + idx + 1u;
                     const float dx    = ea.x - pxf;
                     const float dy    = ea.y - pyf;
                     const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy; // shader.cpp:256
-                    const bool  cand  = (T > 0.0f) && !(power > 0.0f) && (power >= ec.y);
-                    if (!__any(cand)) continue;
+                    const float floor_p = ec.y;
+                    const bool  cand  = (T > 0.0f) & !(power > 0.0f) & (power >= floor_p);
+                    if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue; // scalar test of the lane mask
                     const float alpha  = fmin_(0.99f, eb.y * __expf(power));
-                    const bool  valid  = cand && !(alpha < 1.0f / 255.0f);
+                    const bool  valid  = cand & !(alpha < 1.0f / 255.0f);
                     const float test_T = T * (1.0f - alpha);
-                    const bool  sat    = valid && (test_T < 0.0001f);
-                    const bool  upd    = valid && !sat;
+                    const bool  sat    = valid & (test_T < 0.0001f);
+                    const bool  upd    = valid & !sat;
                     const float wgt    = upd ? T * alpha : 0.0f;
                     Cr                 = Cr + wgt * eb.z;
                     Cg                 = Cg + wgt * eb.w;
                     Cb                 = Cb + wgt * ec.x;
                     T                  = upd ? test_T : (sat ? -T : T);
                     last_contrib       = upd ? contributor : last_contrib;
-                    const unsigned long long sm = __ballot(sat);
-                    if (sm) live -= __popcll(sm);
+                    const unsigned long long sm = __builtin_amdgcn_ballot_w64(sat);
+                    // keep the live-pixel count provably wave-uniform (scalar loop control)
+                    if (sm) live = (uint32_t)__builtin_amdgcn_readfirstlane((int)(live - (uint32_t)__popcll(sm)));
                 }
             }
             if (live == 0u && lane == 0) atomicSub(&s_live_waves, 1u);
