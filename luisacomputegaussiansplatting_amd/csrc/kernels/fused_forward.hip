@@ -128,10 +128,12 @@ __device__ __forceinline__ Projected project_splat(const CamParams& cp, float sc
 // predecessor a workgroup waits on is already running, whatever the dispatch order or XCD placement; one
 // returning atomic per 2048 splats keeps the single ticket word far below its ~88 ops/us saturation.
 // scan_state: [0] ticket counter (u32 in the low half), [1] error flag, [2..] per-chunk status words
-constexpr int kCullItems = 8;
-constexpr int kCullChunk = kThreads * kCullItems;
+constexpr int kCullThreads = 512; // 8 waves: the per-lane chain of dependent loads is 4 splats long, not 8
+constexpr int kCullWaves   = kCullThreads / 64;
+constexpr int kCullItems   = 4;
+constexpr int kCullChunk   = kCullThreads * kCullItems; // 2048 splats per ticket
 
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kCullThreads)
 k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __restrict__ fpp,
                const float* __restrict__ pos,
                const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ opacity,
@@ -140,8 +142,8 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
                uint32_t* __restrict__ d_counts)
 {
     __shared__ uint32_t s_ticket;
-    __shared__ uint32_t s_wave_vis[kCullItems][4];
-    __shared__ uint32_t s_wave_tiles[4];
+    __shared__ uint32_t s_wave_vis[kCullItems][kCullWaves];
+    __shared__ uint32_t s_wave_tiles[kCullWaves];
     __shared__ uint32_t s_prefix_vis;
 
     if (fpp) { // graph replay: per-call parameters come from device memory
@@ -163,7 +165,7 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
     uint32_t tiles_sum = 0;       // reference tiles_touched (for num_rendered)
 #pragma unroll
     for (int k = 0; k < kCullItems; ++k) {
-        const int64_t idx = base + (int64_t)k * kThreads + tid;
+        const int64_t idx = base + (int64_t)k * kCullThreads + tid;
         bool          visible = false;
         depth[k]              = 0.0f;
         rect[k]               = make_uint2(0u, 0u);
@@ -190,13 +192,13 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
 #pragma unroll
     for (int k = 0; k < kCullItems; ++k) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < kCullWaves; ++w) {
             if (w == wave) my_base[k] = bv;
             bv += s_wave_vis[k][w];
         }
     }
 #pragma unroll
-    for (int w = 0; w < 4; ++w) bt += s_wave_tiles[w];
+    for (int w = 0; w < kCullWaves; ++w) bt += s_wave_tiles[w];
 
     // ---- chained scan across workgroups (decoupled look-back), done by wave 0
     if (wave == 0) {
@@ -256,7 +258,7 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
         const uint32_t vid = prefix + my_base[k] + lv[k];
         sort_keys[vid]     = __float_as_uint(depth[k]);
         sort_vals[vid]     = vid;
-        vis_index[vid]     = (uint32_t)(base + (int64_t)k * kThreads + tid);
+        vis_index[vid]     = (uint32_t)(base + (int64_t)k * kCullThreads + tid);
         rects[vid]         = rect[k];
     }
 }
@@ -571,7 +573,7 @@ void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const
                          uint32_t* sort_vals, uint32_t* vis_index, uint2* rects, uint64_t* scan_state,
                          uint32_t* d_counts, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_cull_compact, dim3(chunks_for(P)), dim3(kThreads), 0, stream, P, cp, scale_modifier, d_fp, pos,
+    hipLaunchKernelGGL(k_cull_compact, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, P, cp, scale_modifier, d_fp, pos,
                        scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index, rects, scan_state, d_counts);
 }
 
