@@ -288,8 +288,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                                                             const uint32_t* __restrict__ tile_order)
 {
     __shared__ float4             s_a[256]; // mean.x, mean.y, conic.x, conic.y
-    __shared__ float4             s_b[256]; // conic.z, opacity, r, g
-    __shared__ float2             s_c[256]; // b, power floor (-t/2)
+    __shared__ float2             s_b[256]; // conic.z, power floor (-t/2): with s_a, all the cull test needs
+    __shared__ float4             s_c[256]; // opacity, r, g, b: read only by entries that pass it
     __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
     __shared__ uint32_t           s_live_waves;
 
@@ -357,8 +357,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         }
         if (kmask) {
             s_a[tid] = a;
-            s_b[tid] = b;
-            s_c[tid] = make_float2(c, -0.5f * t);
+            s_b[tid] = make_float2(b.x, -0.5f * t);
+            s_c[tid] = make_float4(b.y, b.z, b.w, c);
         }
         const uint32_t en = e + 256u;
         if (en < range_end) fetch(point_list[en], na, nb, nc);
@@ -374,24 +374,25 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     const uint32_t l   = (uint32_t)__ffsll((long long)m) - 1u;
                     m &= m - 1ull;
                     const uint32_t idx = w * 64u + l;
-                    const float4   ea = s_a[idx], eb = s_b[idx];
-                    const float2   ec = s_c[idx]; // loaded with the rest: no conditional LDS read in the hot loop
+                    const float4   ea = s_a[idx];
+                    const float2   eb = s_b[idx];
                     const uint32_t contributor = base - range_start + idx + 1u;
                     const float dx    = ea.x - pxf;
                     const float dy    = ea.y - pyf;
                     const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy; // shader.cpp:256
-                    const float floor_p = ec.y;
+                    const float floor_p = eb.y;
                     const bool  cand  = (T > 0.0f) & !(power > 0.0f) & (power >= floor_p);
                     if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue; // scalar test of the lane mask
-                    const float alpha  = fmin_(0.99f, eb.y * __expf(power));
+                    const float4 ec    = s_c[idx]; // one 16-byte read for the survivors of the test
+                    const float alpha  = fmin_(0.99f, ec.x * __expf(power));
                     const bool  valid  = cand & !(alpha < 1.0f / 255.0f);
                     const float test_T = T * (1.0f - alpha);
                     const bool  sat    = valid & (test_T < 0.0001f);
                     const bool  upd    = valid & !sat;
                     const float wgt    = upd ? T * alpha : 0.0f;
-                    Cr                 = Cr + wgt * eb.z;
-                    Cg                 = Cg + wgt * eb.w;
-                    Cb                 = Cb + wgt * ec.x;
+                    Cr                 = Cr + wgt * ec.y;
+                    Cg                 = Cg + wgt * ec.z;
+                    Cb                 = Cb + wgt * ec.w;
                     T                  = upd ? test_T : (sat ? -T : T);
                     last_contrib       = upd ? contributor : last_contrib;
                     const unsigned long long sm = __builtin_amdgcn_ballot_w64(sat);

@@ -159,3 +159,23 @@ def test_synth_stand_in_scenes(lcgs, oracle):
     scene = lcgs.synth_scene(0, 1002, 300000)
     _, orc, stats = _render_both(lcgs, oracle, scene, 800, 800, bg=(0, 0, 0), check_lists=True)
     assert orc["num_rendered"] > 1_000_000
+
+
+@pytest.mark.parametrize("P,spread", [(5000, 0.05), (30000, 0.04), (70000, 0.03)])
+def test_fused_long_tile_lists(lcgs, oracle, P, spread):
+    """Per-tile lists far beyond the staging depth of the renderer and of any per-tile scratch (4096+ entries per tile),
+    up to tens of thousands of entries on one tile."""
+    rng = np.random.default_rng(P)
+    scene = make_scene(rng, P, spread=spread, log_scale=(-3.6, 0.5))
+    scene["opacity"] *= 0.05  # keep transmittance alive deep into the lists
+    _, orc, _ = _render_both(lcgs, oracle, scene, 96, 64)
+    assert orc["num_rendered"] > 3 * P
+
+
+def test_fused_tile_list_of_one_depth(lcgs, oracle):
+    """Every splat at the same position: all depth keys equal, index order must survive untouched."""
+    rng = np.random.default_rng(77)
+    scene = make_scene(rng, 700, log_scale=(-3.0, 0.5))
+    scene["pos"][:] = scene["pos"][0]
+    scene["opacity"] *= 0.02
+    _render_both(lcgs, oracle, scene, 128, 96)
