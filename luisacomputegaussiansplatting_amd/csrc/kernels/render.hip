@@ -320,10 +320,10 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
     float    T = inside ? 1.0f : -1.0f; // T < 0: finished, |T| is the transmittance
     float    Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
     uint32_t last_contrib = 0u;
-    uint32_t live = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(inside))); // wave-uniform
+    bool     alive = __builtin_amdgcn_ballot_w64(inside) != 0ull; // wave-uniform: the strip has unfinished pixels
     if (tid == 0) s_live_waves = 0u;
     __syncthreads();
-    if (lane == 0 && live != 0u) atomicAdd(&s_live_waves, 1u);
+    if (lane == 0 && alive) atomicAdd(&s_live_waves, 1u);
 
     const uint32_t range_start = ranges[2 * (size_t)tile + 0];
     const uint32_t range_end   = ranges[2 * (size_t)tile + 1];
@@ -364,13 +364,13 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         if (en < range_end) fetch(point_list[en], na, nb, nc);
         __syncthreads();
 
-        if (live != 0u) {
-            for (uint32_t w = 0; w < 4u && __builtin_amdgcn_readfirstlane((int)live) != 0; ++w) {
+        if (alive) {
+            for (uint32_t w = 0; w < 4u && alive; ++w) {
                 unsigned long long m = s_mask[w][wave];
                 // readfirstlane returns int: cast through uint32_t so the low half is not sign-extended
                 m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) |
                     (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
-                while (m != 0ull && __builtin_amdgcn_readfirstlane((int)live) != 0) { // scalar loop control
+                while (m != 0ull) { // scalar loop control
                     const uint32_t l   = (uint32_t)__ffsll((long long)m) - 1u;
                     m &= m - 1ull;
                     const uint32_t idx = w * 64u + l;
@@ -384,7 +384,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     const bool  cand  = (T > 0.0f) & !(power > 0.0f) & (power >= floor_p);
                     if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue; // scalar test of the lane mask
                     const float4 ec    = s_c[idx]; // one 16-byte read for the survivors of the test
-                    const float alpha  = fmin_(0.99f, ec.x * __expf(power));
+                    // (alpha is never NaN where cand holds, so the hardware minimum equals min(0.99, x))
+                    const float alpha  = __builtin_fminf(0.99f, ec.x * __expf(power));
                     const bool  valid  = cand & !(alpha < 1.0f / 255.0f);
                     const float test_T = T * (1.0f - alpha);
                     const bool  sat    = valid & (test_T < 0.0001f);
@@ -395,12 +396,15 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     Cb                 = Cb + wgt * ec.w;
                     T                  = upd ? test_T : (sat ? -T : T);
                     last_contrib       = upd ? contributor : last_contrib;
-                    const unsigned long long sm = __builtin_amdgcn_ballot_w64(sat);
-                    // keep the live-pixel count provably wave-uniform (scalar loop control)
-                    if (sm) live = (uint32_t)__builtin_amdgcn_readfirstlane((int)(live - (uint32_t)__popcll(sm)));
+                    if (__builtin_amdgcn_ballot_w64(sat) != 0ull) { // rare: some pixel of the strip just saturated
+                        if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) {
+                            alive = false; // the whole strip is finished
+                            m     = 0ull;
+                        }
+                    }
                 }
             }
-            if (live == 0u && lane == 0) atomicSub(&s_live_waves, 1u);
+            if (!alive && lane == 0) atomicSub(&s_live_waves, 1u);
         }
         __syncthreads();
     }
