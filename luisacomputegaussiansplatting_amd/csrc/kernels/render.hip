@@ -277,7 +277,9 @@ __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, 
 // 64-bit mask per staging wave and strip) go to LDS; wave k then walks the set bits of "its" four masks with
 // scalar bit-scan instructions -- entries irrelevant to a strip cost that strip nothing, order is preserved.
 // ---------------------------------------------------------------------------------------------
-template <typename Fetch>
+typedef float v2f __attribute__((ext_vector_type(2))); // arithmetic on it lowers to v_pk_{add,mul}_f32 (IEEE per lane)
+
+template <typename Fetch, bool KEEP>
 __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg0, float bg1, float bg2,
                                                             const FrameParams* __restrict__ fpp,
                                                             const uint32_t* __restrict__ ranges,
@@ -287,8 +289,9 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                                                             const uint32_t* __restrict__ d_counts,
                                                             const uint32_t* __restrict__ tile_order)
 {
-    __shared__ float4             s_a[256]; // mean.x, mean.y, conic.x, conic.y
-    __shared__ float2             s_b[256]; // conic.z, power floor (-t/2): with s_a, all the cull test needs
+    // one 16-byte row per entry in each of three slabs: a single address register serves all three reads
+    __shared__ float4             s_a[256]; // mean.x, mean.y, conic.x, conic.z
+    __shared__ float4             s_b[256]; // conic.y, power floor (-t/2), -, -: with s_a, all the cull test needs
     __shared__ float4             s_c[256]; // opacity, r, g, b: read only by entries that pass it
     __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
     __shared__ uint32_t           s_live_waves;
@@ -312,13 +315,17 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t px = tx * kBlockX + (lane & 15u);
     const uint32_t py = ty * kBlockY + 4u * wave + (lane >> 4);
-    float          pxf = (float)px, pyf = (float)py;
-    asm volatile("" : "+v"(pxf), "+v"(pyf));
     const float rx0 = (float)(tx * kBlockX), ry0 = (float)(ty * kBlockY), rx1 = rx0 + (float)(kBlockX - 1);
     const bool  inside = (px < cp.width) && (py < cp.height);
+    // A finished pixel (saturated, or outside the image) gets a NaN y coordinate: its power is NaN, fails
+    // "power >= floor", and the pixel drops out of every later test without a compare of its own.
+    v2f pxy = {(float)px, inside ? (float)py : __builtin_nanf("")};
+    asm volatile("" : "+v"(pxy));
 
-    float    T = inside ? 1.0f : -1.0f; // T < 0: finished, |T| is the transmittance
-    float    Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
+    const unsigned long long lane_bit = 1ull << lane;
+    float    T = 1.0f;
+    float    Cr = 0.0f;
+    v2f      Cgb = {0.0f, 0.0f};
     uint32_t last_contrib = 0u;
     bool     alive = __builtin_amdgcn_ballot_w64(inside) != 0ull; // wave-uniform: the strip has unfinished pixels
     if (tid == 0) s_live_waves = 0u;
@@ -356,8 +363,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
             if (lane == 0) s_mask[wave][k] = m;
         }
         if (kmask) {
-            s_a[tid] = a;
-            s_b[tid] = make_float2(b.x, -0.5f * t);
+            s_a[tid] = make_float4(a.x, a.y, a.z, b.x);
+            *reinterpret_cast<float2*>(&s_b[tid]) = make_float2(a.w, -0.5f * t);
             s_c[tid] = make_float4(b.y, b.z, b.w, c);
         }
         const uint32_t en = e + 256u;
@@ -375,33 +382,46 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     m &= m - 1ull;
                     const uint32_t idx = w * 64u + l;
                     const float4   ea = s_a[idx];
-                    const float2   eb = s_b[idx];
-                    const uint32_t contributor = base - range_start + idx + 1u;
-                    const float dx    = ea.x - pxf;
-                    const float dy    = ea.y - pyf;
-                    const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy; // shader.cpp:256
-                    const float floor_p = eb.y;
-                    const bool  cand  = (T > 0.0f) & !(power > 0.0f) & (power >= floor_p);
-                    if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue; // scalar test of the lane mask
+                    const float2   eb = *reinterpret_cast<const float2*>(&s_b[idx]);
+                    // power = -0.5 (ca dx dx + cc dy dy) - cb dx dy, products left to right (shader.cpp:256); the
+                    // x and y halves ride in one packed instruction each
+                    const v2f   d     = (v2f){ea.x, ea.y} - pxy;
+                    const v2f   q     = ((v2f){ea.z, ea.w} * d) * d;
+                    float       cross = eb.x * d.x;
+                    asm volatile("" : "+v"(cross)); // keeps the vectoriser from pairing the scalar tail (costs moves)
+                    const float power = -0.5f * (q.x + q.y) - cross * d.y;
+                    const bool  cand  = !(power > 0.0f) & (power >= eb.y);
+                    const unsigned long long candm = __builtin_amdgcn_ballot_w64(cand);
+                    if (candm == 0ull) continue; // scalar test of the lane mask
                     const float4 ec    = s_c[idx]; // one 16-byte read for the survivors of the test
                     // (alpha is never NaN where cand holds, so the hardware minimum equals min(0.99, x))
                     const float alpha  = __builtin_fminf(0.99f, ec.x * __expf(power));
-                    const bool  valid  = cand & !(alpha < 1.0f / 255.0f);
-                    const float test_T = T * (1.0f - alpha);
-                    const bool  sat    = valid & (test_T < 0.0001f);
-                    const bool  upd    = valid & !sat;
-                    const float wgt    = upd ? T * alpha : 0.0f;
-                    Cr                 = Cr + wgt * ec.y;
-                    Cg                 = Cg + wgt * ec.z;
-                    Cb                 = Cb + wgt * ec.w;
-                    T                  = upd ? test_T : (sat ? -T : T);
-                    last_contrib       = upd ? contributor : last_contrib;
-                    if (__builtin_amdgcn_ballot_w64(sat) != 0ull) { // rare: some pixel of the strip just saturated
-                        if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) {
+                    const bool  opaque = !(alpha < 1.0f / 255.0f);
+                    const bool  valid  = cand & opaque;
+                    // a lane that skips the entry blends with alpha 0: T * 1 and C + 0 leave it bit-identical
+                    const float a      = valid ? alpha : 0.0f;
+                    float       test_T = T * (1.0f - a);
+                    float       wgt    = T * a;
+                    // scalar lane masks: ballot(valid & x) would be materialised through a VGPR
+                    const unsigned long long satm =
+                        __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & __builtin_amdgcn_ballot_w64(opaque) & candm;
+                    if (KEEP) {
+                        const bool upd = valid & !(test_T < 0.0001f);
+                        last_contrib   = upd ? base - range_start + idx + 1u : last_contrib;
+                    }
+                    if (satm != 0ull) { // rare: some pixel of the strip just saturated
+                        const bool sat = (satm & lane_bit) != 0ull;
+                        wgt    = sat ? 0.0f : wgt; // shader.cpp:268-272: the saturating entry is not blended
+                        test_T = sat ? T : test_T;
+                        pxy.y  = sat ? __builtin_nanf("") : pxy.y;
+                        if (__builtin_amdgcn_ballot_w64(pxy.y == pxy.y) == 0ull) {
                             alive = false; // the whole strip is finished
                             m     = 0ull;
                         }
                     }
+                    Cr  = Cr + wgt * ec.y;
+                    Cgb = Cgb + (v2f){wgt, wgt} * (v2f){ec.z, ec.w};
+                    T   = test_T;
                 }
             }
             if (!alive && lane == 0) atomicSub(&s_live_waves, 1u);
@@ -411,13 +431,15 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
 
     if (inside) {
         const size_t hw  = (size_t)cp.width * cp.height;
-        const float  Tk  = fabsf(T);
+        const float  Tk  = T;
         const size_t pix = (size_t)px + (size_t)cp.width * py;
         img[pix]          = bg0 * Tk + Cr;
-        img[pix + hw]     = bg1 * Tk + Cg;
-        img[pix + 2 * hw] = bg2 * Tk + Cb;
-        if (final_T) final_T[pix] = Tk;
-        if (n_contrib) n_contrib[pix] = last_contrib;
+        img[pix + hw]     = bg1 * Tk + Cgb.x;
+        img[pix + 2 * hw] = bg2 * Tk + Cgb.y;
+        if (KEEP) {
+            if (final_T) final_T[pix] = Tk;
+            if (n_contrib) n_contrib[pix] = last_contrib;
+        }
     }
 }
 
@@ -476,9 +498,13 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
         return (v && v[0] == 'a') ? 0 : 1;
     }();
     if (variant == 1) {
-        hipLaunchKernelGGL(k_render_forward_b<Fetch>, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(256), 0, stream,
-                           cp, bg[0], bg[1], bg[2], d_fp, ranges, point_list, fetch, img, final_T, n_contrib, d_counts,
-                           tile_order);
+        const dim3 grid(render_grid_size(cp.grid_x, cp.grid_y));
+        if (final_T || n_contrib)
+            hipLaunchKernelGGL((k_render_forward_b<Fetch, true>), grid, dim3(256), 0, stream, cp, bg[0], bg[1], bg[2], d_fp,
+                               ranges, point_list, fetch, img, final_T, n_contrib, d_counts, tile_order);
+        else // forward only: the last-contributor bookkeeping is compiled out
+            hipLaunchKernelGGL((k_render_forward_b<Fetch, false>), grid, dim3(256), 0, stream, cp, bg[0], bg[1], bg[2], d_fp,
+                               ranges, point_list, fetch, img, final_T, n_contrib, d_counts, tile_order);
         return;
     }
     hipLaunchKernelGGL(k_render_forward<Fetch>, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(64), 0, stream, cp, bg[0], bg[1], bg[2], d_fp, ranges,
