@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
                 while (m != 0ull) { // scalar loop control
                     const uint32_t l   = (uint32_t)__ffsll((long long)m) - 1u;
-                    m &= m - 1ull;
+                    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(l)); // one scalar op instead of add/addc/and
                     const uint32_t idx = w * 64u + l;
                     const float4   ea = s_a[idx];
                     const float2   eb = *reinterpret_cast<const float2*>(&s_b[idx]);
@@ -387,24 +387,27 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     // x and y halves ride in one packed instruction each
                     const v2f   d     = (v2f){ea.x, ea.y} - pxy;
                     const v2f   q     = ((v2f){ea.z, ea.w} * d) * d;
-                    float       cross = eb.x * d.x;
-                    asm volatile("" : "+v"(cross)); // keeps the vectoriser from pairing the scalar tail (costs moves)
-                    const float power = -0.5f * (q.x + q.y) - cross * d.y;
+                    // (on gfx950 a packed op costs two plain ones and v_add/v_mul issue at twice the rate of
+                    // everything else -- tools/microbench/issue_rates.hip -- so the scalar tail must stay scalar:
+                    // the empty asms stop the vectoriser from pairing it up behind extra moves)
+                    float qx = q.x, cross = eb.x * d.x;
+                    asm volatile("" : "+v"(qx), "+v"(cross));
+                    float half = -0.5f * (qx + q.y);
+                    asm volatile("" : "+v"(half));
+                    const float power = half - cross * d.y;
                     const bool  cand  = !(power > 0.0f) & (power >= eb.y);
-                    const unsigned long long candm = __builtin_amdgcn_ballot_w64(cand);
-                    if (candm == 0ull) continue; // scalar test of the lane mask
+                    if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue; // scalar test of the lane mask
                     const float4 ec    = s_c[idx]; // one 16-byte read for the survivors of the test
                     // (alpha is never NaN where cand holds, so the hardware minimum equals min(0.99, x))
                     const float alpha  = __builtin_fminf(0.99f, ec.x * __expf(power));
-                    const bool  opaque = !(alpha < 1.0f / 255.0f);
-                    const bool  valid  = cand & opaque;
+                    const bool  valid  = cand & !(alpha < 1.0f / 255.0f);
                     // a lane that skips the entry blends with alpha 0: T * 1 and C + 0 leave it bit-identical
                     const float a      = valid ? alpha : 0.0f;
                     float       test_T = T * (1.0f - a);
                     float       wgt    = T * a;
-                    // scalar lane masks: ballot(valid & x) would be materialised through a VGPR
-                    const unsigned long long satm =
-                        __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & __builtin_amdgcn_ballot_w64(opaque) & candm;
+                    // T >= 1e-4 holds for every lane (a saturating update is never applied), so a lane with
+                    // alpha 0 cannot pass this test: no "& valid" needed, the ballot stays a plain compare
+                    const unsigned long long satm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
                     if (KEEP) {
                         const bool upd = valid & !(test_T < 0.0001f);
                         last_contrib   = upd ? base - range_start + idx + 1u : last_contrib;

@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Per-kernel mean of rocprofv3 --pmc counters (counter_collection.csv), one line per kernel."""
+import csv, glob, re, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(set)
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+        n = re.sub(r"^void ", "", n).split("(")[0].split("<")[0].split("::")[-1]
+        acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[n].add(r["Dispatch_Id"])
+for n in acc:
+    k = max(1, len(cnt[n]))
+    print("%-24s launches=%d %s" % (n, k, {c: round(v / k) for c, v in sorted(acc[n].items())}))
