@@ -86,12 +86,40 @@ __device__ __forceinline__ bool splat_may_touch_rect(float mx, float my, float c
     return best - 1e-5f * slack <= t;
 }
 
-// Sums of nine values over the 64 lanes of a wave, results valid in lane 63.  DPP row shifts + row broadcasts (no
-// LDS).  The nine chains advance in lockstep, one DPP step each per round, so the 2-wait-state VALU-write -> DPP-read
-// hazard of a chain is covered by the eight other chains' instructions (hipcc pads nothing inside asm; the leading
-// s_nop covers the producers of v[]).  Lanes a step does not address (bank/row masks, shifted-in positions) keep
-// their value because the destination is the accumulator itself.
-__device__ __forceinline__ void wave_sum9_to_lane63(float v[9])
+// ---------------------------------------------------------------------------------------------------------------
+// Wave reduction of the per-pixel gradient terms, four list entries at a time.
+// Every entry yields nine per-lane values that must be summed over the 64 pixels of the strip.  Reducing each entry
+// on its own costs 9 x 6 cross-lane adds; instead the sums of FOUR entries (A, B, C, D) are folded together so that
+// each cross-lane step works on registers that are full of useful data (costs from tools/microbench/issue_rates):
+//   1. v_permlane32_swap + add on (A, B): lanes 0-31 now hold A summed over lane pairs (l, l+32), lanes 32-63 hold B;
+//      the same on (C, D)                                                   2 x 9 x (8.1 + 2.3) cycles
+//   2. v_permlane16_swap + add on (AB, CD): the four 16-lane rows hold A, C, B, D, each summed over rows   9 x 10.4
+//   3. four DPP row-shift adds: lane 15 of every row holds that entry's total                               36 x 4.2
+// = 112 issue cycles per entry instead of 224, and one LDS add instruction per value and FOUR entries (lanes 15, 31,
+// 47 and 63, each to its own entry's accumulator row) instead of one per value and entry.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void swap32_add9(const float x[9], const float y[9], float out[9])
+{
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+        // lanes 0-31: r[0] = own x, r[1] = partner's x;  lanes 32-63: r[0] = partner's y, r[1] = own y
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[g]), __float_as_uint(y[g]), false, false);
+        out[g]       = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+}
+__device__ __forceinline__ void swap16_add9(const float x[9], const float y[9], float out[9])
+{
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+        // rows 1 and 3 of x trade places with rows 0 and 2 of y: after the add the rows hold x.lo, y.lo, x.hi, y.hi
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[g]), __float_as_uint(y[g]), false, false);
+        out[g]       = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+}
+// sums over each 16-lane row, result in lane 15 of the row.  The nine chains advance in lockstep, one DPP step each
+// per round, so the 2-wait-state VALU-write -> DPP-read hazard of a chain is covered by the eight other chains'
+// instructions (hipcc pads nothing inside asm; the leading s_nop covers the producers of v[]).
+__device__ __forceinline__ void row_sum9_to_lane15(float v[9])
 {
     asm volatile("s_nop 1" ::: "memory");
 #define LCGS_DPP_STEP(ctrl)                                                                                         \
@@ -110,11 +138,63 @@ __device__ __forceinline__ void wave_sum9_to_lane63(float v[9])
     LCGS_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf");
     LCGS_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xe");
     LCGS_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xc"); // lane 15 of each row holds the row sum
-    LCGS_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
-    LCGS_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf"); // lane 63 holds the wave sum
 #undef LCGS_DPP_STEP
     asm volatile("s_nop 1" ::: "memory");
 }
+
+// Collects the value sets of up to four entries and adds their wave sums to the round's LDS accumulators.
+struct QuadReducer {
+    float    hold[9]; // entry A (then C) of the pair being formed
+    float    pair[9]; // (A, B) after step 1
+    uint32_t addr;    // lanes 15 / 31 / 47 / 63: LDS byte address of the accumulator row of entry A / C / B / D
+    uint32_t slot;    // wave-uniform: entries collected so far (0..3)
+
+    __device__ __forceinline__ void begin(uint32_t any_valid_row_address)
+    {
+        addr = any_valid_row_address; // rows of unused slots receive +0.0f
+        slot = 0u;
+    }
+    // row_address: LDS byte address of &s_grad[0][idx]; the nine sums go to row_address + g * 1024
+    __device__ __forceinline__ void push(const float v[9], uint32_t row_address_, bool is_row_end)
+    {
+        const uint32_t row_address = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_address_); // provably scalar
+        if (slot == 0u) {
+#pragma unroll
+            for (int g = 0; g < 9; ++g) hold[g] = v[g];
+            asm volatile("v_writelane_b32 %0, %1, 15" : "+v"(addr) : "s"(row_address));
+            slot = 1u;
+        } else if (slot == 1u) {
+            swap32_add9(hold, v, pair);
+            asm volatile("v_writelane_b32 %0, %1, 47" : "+v"(addr) : "s"(row_address));
+            slot = 2u;
+        } else if (slot == 2u) {
+#pragma unroll
+            for (int g = 0; g < 9; ++g) hold[g] = v[g];
+            asm volatile("v_writelane_b32 %0, %1, 31" : "+v"(addr) : "s"(row_address));
+            slot = 3u;
+        } else {
+            float quad[9], r[9];
+            swap32_add9(hold, v, quad);
+            asm volatile("v_writelane_b32 %0, %1, 63" : "+v"(addr) : "s"(row_address));
+            swap16_add9(pair, quad, r);
+            row_sum9_to_lane15(r);
+            if (is_row_end) {
+                // a raw ds_add_f32: hipcc's atomic optimiser would wrap a C++ atomicAdd in a per-lane scan loop
+#pragma unroll
+                for (int g = 0; g < 9; ++g)
+                    asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(addr), "v"(r[g]), "n"(g * 256 * 4) : "memory");
+            }
+            slot = 0u;
+        }
+    }
+    // pads the open group with zero value sets (their rows receive +0.0f)
+    __device__ __forceinline__ void finish(bool is_row_end)
+    {
+        const float zero[9] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)addr, 15);
+        while (slot != 0u) push(zero, a, is_row_end);
+    }
+};
 
 constexpr int kG2D = 12; // floats per splat in the 2-D gradient buffer: mean(2) conic(3) opacity(1) rgb(3) pad(3)
 
@@ -176,7 +256,12 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
     for (int w = 1; w < 4; ++w) hi = s_max[w] > hi ? s_max[w] : hi;
     const uint32_t range_start = ranges[2 * (size_t)tile + 0];
 
-    float T = T_final, acr = 0.0f, acg = 0.0f, acb = 0.0f, lcr = 0.0f, lcg = 0.0f, lcb = 0.0f, last_alpha = 0.0f;
+    // per-pixel recurrences, walked back to front: T = transmittance in front of the current splat,
+    // B = colour composited behind it
+    float             T = T_final, Br = 0.0f, Bg = 0.0f, Bb = 0.0f;
+    const float       nTf_bg     = -T_final * bg_dot;
+    const bool        is_row_end = (lane & 15u) == 15u;
+    QuadReducer       red;
 
     while (hi > 0u) {
         const uint32_t lo   = hi > 256u ? hi - 256u : 0u;
@@ -214,66 +299,61 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
         __syncthreads();
 
         // ---- walk "my" strip's entries back to front
+        red.begin((uint32_t)(uintptr_t)&s_grad[0][0]);
         for (int w = 3; w >= 0; --w) {
             unsigned long long m = s_mask[w][wave];
             m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) |
                 (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
             while (m != 0ull) {
                 const uint32_t l = 63u - (uint32_t)__clzll((long long)m);
-                m &= ~(1ull << l);
+                asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(l));
                 const uint32_t idx = (uint32_t)w * 64u + l;
                 const uint32_t pos = lo + idx; // 0-based list position
                 const float4   ea = s_a[idx], eb = s_b[idx];
                 const float2   ec = s_c[idx];
+                // the forward's own expression and evaluation order: the same splats pass the same thresholds
                 const float dx    = ea.x - pxf;
                 const float dy    = ea.y - pyf;
                 const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
-                const bool  cand  = (pos < last) && !(power > 0.0f) && (power >= ec.y);
-                if (!__any(cand)) continue;
+                const bool  cand  = (pos < last) & !(power > 0.0f) & (power >= ec.y);
+                if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
                 const float G      = __expf(power);
                 const float oG     = eb.y * G;
-                const float alpha  = fmin_(0.99f, oG);
-                const bool  valid  = cand && !(alpha < 1.0f / 255.0f);
-                if (!__any(valid)) continue;
-                const float one_m  = 1.0f - alpha;
-                const float Tn     = valid ? T / one_m : T; // the forward's T before this splat
-                const float wgt    = valid ? alpha * Tn : 0.0f;
-                // running "colour behind this splat"
-                const float nar = last_alpha * lcr + (1.0f - last_alpha) * acr;
-                const float nag = last_alpha * lcg + (1.0f - last_alpha) * acg;
-                const float nab = last_alpha * lcb + (1.0f - last_alpha) * acb;
-                float dL_dalpha = ((eb.z - nar) * dpr + (eb.w - nag) * dpg + (ec.x - nab) * dpb) * Tn;
-                dL_dalpha += (-T_final / one_m) * bg_dot;
-                if (valid) {
-                    acr = nar; acg = nag; acb = nab;
-                    lcr = eb.z; lcg = eb.w; lcb = ec.x;
-                    last_alpha = alpha;
-                    T          = Tn;
-                }
-                const bool  live_g = valid && (oG < 0.99f); // the 0.99 cap passes no gradient
-                const float dL_dG  = live_g ? eb.y * dL_dalpha : 0.0f;
-                const float gdx = G * dx, gdy = G * dy;
+                const float alpha  = __builtin_fminf(0.99f, oG);
+                const bool  valid  = cand & !(alpha < 1.0f / 255.0f);
+                if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
+                // A lane that does not blend this entry carries alpha 0 through the recurrences: 1 / (1 - 0) == 1
+                // leaves T alone, B + 0 * (c - B) leaves the colour behind alone, and all nine terms come out 0.
+                const float a    = valid ? alpha : 0.0f;
+                const float inv  = __builtin_amdgcn_rcpf(1.0f - a); // gradients carry a 1e-3 tolerance: 1-ulp rcp
+                const float Tn   = T * inv;                          // the forward's T in front of this splat
+                const float wgt  = a * Tn;
+                // colour behind this splat (B) enters dL/dalpha, then absorbs the splat
+                const float dr = eb.z - Br, dg = eb.w - Bg, db = ec.x - Bb;
+                const float dL_dalpha =
+                    __builtin_fmaf(__builtin_fmaf(dr, dpr, __builtin_fmaf(dg, dpg, db * dpb)), Tn, nTf_bg * inv);
+                Br = __builtin_fmaf(a, dr, Br);
+                Bg = __builtin_fmaf(a, dg, Bg);
+                Bb = __builtin_fmaf(a, db, Bb);
+                T  = Tn;
+                // the 0.99 cap passes no gradient to G / opacity
+                const float gfac = (valid & (oG < 0.99f)) ? dL_dalpha : 0.0f;
                 float v[9];
-                v[0] = dL_dG * (-(gdx * ea.z + gdy * ea.w));
-                v[1] = dL_dG * (-(gdy * eb.x + gdx * ea.w));
-                v[2] = -0.5f * gdx * dx * dL_dG;
-                v[3] = -gdx * dy * dL_dG;
-                v[4] = -0.5f * gdy * dy * dL_dG;
-                v[5] = live_g ? G * dL_dalpha : 0.0f;
+                v[5]           = G * gfac;      // dL/dopacity
+                const float h  = eb.y * v[5];   // G * dL/dG
+                const float hx = h * dx, hy = h * dy;
+                v[0] = hx;                      // the entry-uniform factors (conic, -1, -0.5) are applied once per
+                v[1] = hy;                      // entry when the round is flushed
+                v[2] = hx * dx;
+                v[3] = hx * dy;
+                v[4] = hy * dy;
                 v[6] = wgt * dpr;
                 v[7] = wgt * dpg;
                 v[8] = wgt * dpb;
-                // lane 63 holds each wave sum; a raw ds_add_f32 (hipcc's atomic optimiser would wrap a C++ atomicAdd
-                // in a per-active-lane scan loop, ~15 extra instructions per value)
-                const uint32_t lds_addr = (uint32_t)(uintptr_t)&s_grad[0][idx];
-                wave_sum9_to_lane63(v);
-                if (lane == 63u) {
-#pragma unroll
-                    for (int g = 0; g < 9; ++g)
-                        asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(lds_addr), "v"(v[g]), "n"(g * 256 * 4) : "memory");
-                }
+                red.push(v, (uint32_t)(uintptr_t)&s_grad[0][idx], is_row_end);
             }
         }
+        red.finish(is_row_end);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the raw LDS adds above have landed
         __syncthreads();
         // ---- flush the round.  Global float atomics run at full rate only when a wave instruction covers
@@ -285,7 +365,15 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
             const uint32_t idx = cidx / (uint32_t)kG2D, g = cidx - idx * (uint32_t)kG2D;
             const uint32_t v   = s_vid[idx];
             if (g < 9u && v != 0xFFFFFFFFu) {
-                const float s = s_grad[g][idx];
+                // sums -> gradients: d/dmean = -(conic . (S hx, S hy)), d/dconic = (-1/2, -1, -1/2) (S hx dx, ...)
+                float s = s_grad[g][idx];
+                if (g < 2u) {
+                    const float4 ea = s_a[idx];
+                    const float  cc = s_b[idx].x, s0 = s_grad[0][idx], s1 = s_grad[1][idx];
+                    s = (g == 0u) ? -(ea.z * s0 + ea.w * s1) : -(cc * s1 + ea.w * s0);
+                } else if (g < 5u) {
+                    s *= (g == 3u) ? -1.0f : -0.5f;
+                }
                 if (s != 0.0f) atomicAdd(&grads2d[(size_t)v * kG2D + g], s);
             }
         }

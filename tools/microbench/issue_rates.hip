@@ -12,7 +12,7 @@ constexpr int kIters = 2048;
 
 #define REP8(x) x x x x x x x x
 
-enum Op { CND64, CNDNEW, CNDZERO, ADD, SUB, ANDB, CMP64, RFL, MED3, MAX, BRANCH, LDSTP, CMPX, MUL,  PKMUL, FMA, EXP, CNDMASK, CMP, MULDEP, SALU, SALUDEP, LDSDEP, MIX_VS, PKADD, MOV, MIN, RCP, FFS_CHAIN };
+enum Op { DPPADD, DPPBC, SWAP32, SWAP16, DSADD1, DSADD64, WRLANE, BPERM, DIVF, CND64, CNDNEW, CNDZERO, ADD, SUB, ANDB, CMP64, RFL, MED3, MAX, BRANCH, LDSTP, CMPX, MUL,  PKMUL, FMA, EXP, CNDMASK, CMP, MULDEP, SALU, SALUDEP, LDSDEP, MIX_VS, PKADD, MOV, MIN, RCP, FFS_CHAIN };
 
 template <int OP>
 __global__ void __launch_bounds__(256) k(float* out, float seed)
@@ -122,6 +122,46 @@ __global__ void __launch_bounds__(256) k(float* out, float seed)
             asm volatile(REP8("v_cmp_lt_f32 vcc, %0, %8\n v_cmp_gt_f32 s[20:21], %1, %8\n s_and_b64 vcc, vcc, s[20:21]\n v_cndmask_b32 %2, %2, %8, vcc\n"
                               "v_cmp_lt_f32 vcc, %4, %8\n v_cmp_gt_f32 s[20:21], %5, %8\n s_and_b64 vcc, vcc, s[20:21]\n v_cndmask_b32 %6, %6, %8, vcc\n")
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc", "s20", "s21", "scc");
+        } else if (OP == DPPADD) {
+            asm volatile(REP8("v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (OP == DPPBC) {
+            asm volatile(REP8("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+                              "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n v_add_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n v_add_f32_dpp %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n v_add_f32_dpp %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (OP == SWAP32) {
+            asm volatile(REP8("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                              "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (OP == SWAP16) {
+            asm volatile(REP8("v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n"
+                              "v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (OP == DSADD1) {
+            // LDS float add from one active lane (the rest masked off by exec), as the gradient flush does
+            asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, 1\n"
+                         REP8("ds_add_f32 %0, %1\n ds_add_f32 %0, %2 offset:1024\n ds_add_f32 %0, %3 offset:2048\n ds_add_f32 %0, %4 offset:3072\n")
+                         "s_waitcnt lgkmcnt(0)\n s_mov_b64 exec, s[20:21]\n"
+                         : : "v"(addr), "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s20", "s21", "memory");
+        } else if (OP == DSADD64) {
+            // all 64 lanes, distinct consecutive addresses
+            asm volatile(REP8("ds_add_f32 %0, %1\n ds_add_f32 %0, %2 offset:1024\n ds_add_f32 %0, %3 offset:2048\n ds_add_f32 %0, %4 offset:3072\n")
+                         "s_waitcnt lgkmcnt(0)\n"
+                         : : "v"((threadIdx.x & 63u) * 4u), "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+        } else if (OP == WRLANE) {
+            asm volatile(REP8("v_writelane_b32 %0, s20, 15\n v_writelane_b32 %1, s20, 31\n v_writelane_b32 %2, s20, 47\n v_writelane_b32 %3, s20, 63\n"
+                              "v_writelane_b32 %4, s20, 15\n v_writelane_b32 %5, s20, 31\n v_writelane_b32 %6, s20, 47\n v_writelane_b32 %7, s20, 63\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "s20");
+        } else if (OP == BPERM) {
+            asm volatile(REP8("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n"
+                              "ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n")
+                         "s_waitcnt lgkmcnt(0)\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"((threadIdx.x & 63u) * 4u ^ 128u) : "memory");
+        } else if (OP == DIVF) {
+            // IEEE-correct float division as hipcc emits it for a / b (8 per iteration)
+            a0 = a0 / m; a1 = a1 / m; a2 = a2 / m; a3 = a3 / m; a4 = a4 / m; a5 = a5 / m; a6 = a6 / m; a7 = a7 / m;
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(m));
         } else if (OP == MULDEP) {
             asm volatile(REP8("v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n"
                               "v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n")
@@ -185,6 +225,15 @@ int main()
     float* d_out;
     CHECK(hipMalloc(&d_out, 4));
     for (int w : {1, 4, 8}) {
+        run<DPPADD>("add_dpp shr", 64, d_out, w, ghz, cus);
+        run<DPPBC>("add_dpp bcast", 64, d_out, w, ghz, cus);
+        run<SWAP32>("permlane32sw", 64, d_out, w, ghz, cus);
+        run<SWAP16>("permlane16sw", 64, d_out, w, ghz, cus);
+        run<DSADD1>("ds_add 1lane", 32, d_out, w, ghz, cus);
+        run<DSADD64>("ds_add 64ln", 32, d_out, w, ghz, cus);
+        run<WRLANE>("v_writelane", 64, d_out, w, ghz, cus);
+        run<BPERM>("ds_bpermute", 64, d_out, w, ghz, cus);
+        run<DIVF>("ieee div", 8, d_out, w, ghz, cus);
         run<ADD>("v_add", 64, d_out, w, ghz, cus);
         run<SUB>("v_sub", 64, d_out, w, ghz, cus);
         run<ANDB>("v_and", 64, d_out, w, ghz, cus);
