@@ -142,59 +142,21 @@ __device__ __forceinline__ void row_sum9_to_lane15(float v[9])
     asm volatile("s_nop 1" ::: "memory");
 }
 
-// Collects the value sets of up to four entries and adds their wave sums to the round's LDS accumulators.
-struct QuadReducer {
-    float    hold[9]; // entry A (then C) of the pair being formed
-    float    pair[9]; // (A, B) after step 1
-    uint32_t addr;    // lanes 15 / 31 / 47 / 63: LDS byte address of the accumulator row of entry A / C / B / D
-    uint32_t slot;    // wave-uniform: entries collected so far (0..3)
-
-    __device__ __forceinline__ void begin(uint32_t any_valid_row_address)
-    {
-        addr = any_valid_row_address; // rows of unused slots receive +0.0f
-        slot = 0u;
-    }
-    // row_address: LDS byte address of &s_grad[0][idx]; the nine sums go to row_address + g * 1024
-    __device__ __forceinline__ void push(const float v[9], uint32_t row_address_, bool is_row_end)
-    {
-        const uint32_t row_address = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_address_); // provably scalar
-        if (slot == 0u) {
+// Steps 2 and 3 on (AB, CD) and the LDS adds.  rows: lanes 15 / 31 / 47 / 63 hold the LDS byte address of the
+// accumulator row (&s_grad[0][idx]) of entry A / C / B / D; value g goes to row + g * 1024.
+__device__ __forceinline__ void reduce_quad_and_add(const float pair[9], const float quad[9], uint32_t rows,
+                                                    bool is_row_end)
+{
+    float r[9];
+    swap16_add9(pair, quad, r);
+    row_sum9_to_lane15(r);
+    if (is_row_end) {
+        // a raw ds_add_f32: hipcc's atomic optimiser would wrap a C++ atomicAdd in a per-lane scan loop
 #pragma unroll
-            for (int g = 0; g < 9; ++g) hold[g] = v[g];
-            asm volatile("v_writelane_b32 %0, %1, 15" : "+v"(addr) : "s"(row_address));
-            slot = 1u;
-        } else if (slot == 1u) {
-            swap32_add9(hold, v, pair);
-            asm volatile("v_writelane_b32 %0, %1, 47" : "+v"(addr) : "s"(row_address));
-            slot = 2u;
-        } else if (slot == 2u) {
-#pragma unroll
-            for (int g = 0; g < 9; ++g) hold[g] = v[g];
-            asm volatile("v_writelane_b32 %0, %1, 31" : "+v"(addr) : "s"(row_address));
-            slot = 3u;
-        } else {
-            float quad[9], r[9];
-            swap32_add9(hold, v, quad);
-            asm volatile("v_writelane_b32 %0, %1, 63" : "+v"(addr) : "s"(row_address));
-            swap16_add9(pair, quad, r);
-            row_sum9_to_lane15(r);
-            if (is_row_end) {
-                // a raw ds_add_f32: hipcc's atomic optimiser would wrap a C++ atomicAdd in a per-lane scan loop
-#pragma unroll
-                for (int g = 0; g < 9; ++g)
-                    asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(addr), "v"(r[g]), "n"(g * 256 * 4) : "memory");
-            }
-            slot = 0u;
-        }
+        for (int g = 0; g < 9; ++g)
+            asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(rows), "v"(r[g]), "n"(g * 256 * 4) : "memory");
     }
-    // pads the open group with zero value sets (their rows receive +0.0f)
-    __device__ __forceinline__ void finish(bool is_row_end)
-    {
-        const float zero[9] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)addr, 15);
-        while (slot != 0u) push(zero, a, is_row_end);
-    }
-};
+}
 
 constexpr int kG2D = 12; // floats per splat in the 2-D gradient buffer: mean(2) conic(3) opacity(1) rgb(3) pad(3)
 
@@ -261,7 +223,7 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
     float             T = T_final, Br = 0.0f, Bg = 0.0f, Bb = 0.0f;
     const float       nTf_bg     = -T_final * bg_dot;
     const bool        is_row_end = (lane & 15u) == 15u;
-    QuadReducer       red;
+    const uint32_t    grad_base  = (uint32_t)(uintptr_t)&s_grad[0][0]; // low half of a flat LDS address = LDS offset
 
     while (hi > 0u) {
         const uint32_t lo   = hi > 256u ? hi - 256u : 0u;
@@ -298,62 +260,99 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
         for (int g = 0; g < 9; ++g) s_grad[g][tid] = 0.0f;
         __syncthreads();
 
-        // ---- walk "my" strip's entries back to front
-        red.begin((uint32_t)(uintptr_t)&s_grad[0][0]);
-        for (int w = 3; w >= 0; --w) {
-            unsigned long long m = s_mask[w][wave];
-            m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) |
-                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
-            while (m != 0ull) {
-                const uint32_t l = 63u - (uint32_t)__clzll((long long)m);
-                asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(l));
-                const uint32_t idx = (uint32_t)w * 64u + l;
-                const uint32_t pos = lo + idx; // 0-based list position
-                const float4   ea = s_a[idx], eb = s_b[idx];
-                const float2   ec = s_c[idx];
-                // the forward's own expression and evaluation order: the same splats pass the same thresholds
-                const float dx    = ea.x - pxf;
-                const float dy    = ea.y - pyf;
-                const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
-                const bool  cand  = (pos < last) & !(power > 0.0f) & (power >= ec.y);
-                if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
-                const float G      = __expf(power);
-                const float oG     = eb.y * G;
-                const float alpha  = __builtin_fminf(0.99f, oG);
-                const bool  valid  = cand & !(alpha < 1.0f / 255.0f);
-                if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
-                // A lane that does not blend this entry carries alpha 0 through the recurrences: 1 / (1 - 0) == 1
-                // leaves T alone, B + 0 * (c - B) leaves the colour behind alone, and all nine terms come out 0.
-                const float a    = valid ? alpha : 0.0f;
-                const float inv  = __builtin_amdgcn_rcpf(1.0f - a); // gradients carry a 1e-3 tolerance: 1-ulp rcp
-                const float Tn   = T * inv;                          // the forward's T in front of this splat
-                const float wgt  = a * Tn;
-                // colour behind this splat (B) enters dL/dalpha, then absorbs the splat
-                const float dr = eb.z - Br, dg = eb.w - Bg, db = ec.x - Bb;
-                const float dL_dalpha =
-                    __builtin_fmaf(__builtin_fmaf(dr, dpr, __builtin_fmaf(dg, dpg, db * dpb)), Tn, nTf_bg * inv);
-                Br = __builtin_fmaf(a, dr, Br);
-                Bg = __builtin_fmaf(a, dg, Bg);
-                Bb = __builtin_fmaf(a, db, Bb);
-                T  = Tn;
-                // the 0.99 cap passes no gradient to G / opacity
-                const float gfac = (valid & (oG < 0.99f)) ? dL_dalpha : 0.0f;
-                float v[9];
-                v[5]           = G * gfac;      // dL/dopacity
-                const float h  = eb.y * v[5];   // G * dL/dG
-                const float hx = h * dx, hy = h * dy;
-                v[0] = hx;                      // the entry-uniform factors (conic, -1, -0.5) are applied once per
-                v[1] = hy;                      // entry when the round is flushed
-                v[2] = hx * dx;
-                v[3] = hx * dy;
-                v[4] = hy * dy;
-                v[6] = wgt * dpr;
-                v[7] = wgt * dpg;
-                v[8] = wgt * dpb;
-                red.push(v, (uint32_t)(uintptr_t)&s_grad[0][idx], is_row_end);
+        // ---- walk "my" strip's entries back to front, four at a time (see the reduction notes above)
+        {
+            int                w = 4;   // staging wave whose mask is being walked (scalar)
+            unsigned long long m = 0ull; // its remaining entries for this strip (scalar)
+            // Finds the next entry (back to front) that blends into at least one pixel of the strip and evaluates
+            // its nine per-pixel terms; false when the round's entries are exhausted.  Instantiated once per slot
+            // of the four-entry group so that every slot's values live in fixed registers (no copies).
+            auto next_entry = [&](float v[9], uint32_t& row) -> bool {
+                for (;;) {
+                    while (m == 0ull) {
+                        if (w == 0) return false;
+                        w = __builtin_amdgcn_readfirstlane(w - 1);
+                        const unsigned long long mm = s_mask[w][wave];
+                        m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mm >> 32)) << 32) |
+                            (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mm);
+                    }
+                    const uint32_t l = 63u - (uint32_t)__clzll((long long)m);
+                    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(l));
+                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)w * 64u + l));
+                    const uint32_t pos = lo + idx; // 0-based list position
+                    const float4   ea = s_a[idx], eb = s_b[idx];
+                    const float2   ec = s_c[idx];
+                    // the forward's own expression and evaluation order: the same splats pass the same thresholds
+                    const float dx    = ea.x - pxf;
+                    const float dy    = ea.y - pyf;
+                    const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
+                    const bool  cand  = (pos < last) & !(power > 0.0f) & (power >= ec.y);
+                    if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
+                    const float G     = __expf(power);
+                    const float oG    = eb.y * G;
+                    const float alpha = __builtin_fminf(0.99f, oG);
+                    const bool  valid = cand & !(alpha < 1.0f / 255.0f);
+                    // A lane that does not blend this entry carries alpha 0 through the recurrences: 1 / (1 - 0) == 1
+                    // leaves T alone, B + 0 * (c - B) leaves the colour behind alone, all nine terms come out 0.
+                    // (No second wave-level skip: the staging floor already implies alpha >= 1/255 somewhere.)
+                    const float a   = valid ? alpha : 0.0f;
+                    const float inv = __builtin_amdgcn_rcpf(1.0f - a); // gradients carry a 1e-3 tolerance
+                    const float Tn  = T * inv;                          // the forward's T in front of this splat
+                    const float wgt = a * Tn;
+                    // colour behind this splat (B) enters dL/dalpha, then absorbs the splat
+                    const float dr = eb.z - Br, dg = eb.w - Bg, db = ec.x - Bb;
+                    const float dL_dalpha =
+                        __builtin_fmaf(__builtin_fmaf(dr, dpr, __builtin_fmaf(dg, dpg, db * dpb)), Tn, nTf_bg * inv);
+                    Br = __builtin_fmaf(a, dr, Br);
+                    Bg = __builtin_fmaf(a, dg, Bg);
+                    Bb = __builtin_fmaf(a, db, Bb);
+                    T  = Tn;
+                    // the 0.99 cap passes no gradient to G / opacity
+                    const float gfac = (valid & (oG < 0.99f)) ? dL_dalpha : 0.0f;
+                    v[5]           = G * gfac;    // dL/dopacity
+                    const float h  = eb.y * v[5]; // G * dL/dG
+                    const float hx = h * dx, hy = h * dy;
+                    v[0] = hx;                    // the entry-uniform factors (conic, -1, -0.5) are applied once
+                    v[1] = hy;                    // per entry when the round is flushed
+                    v[2] = hx * dx;
+                    v[3] = hx * dy;
+                    v[4] = hy * dy;
+                    v[6] = wgt * dpr;
+                    v[7] = wgt * dpg;
+                    v[8] = wgt * dpb;
+                    row  = grad_base + idx * 4u;
+                    return true;
+                }
+            };
+            const float zero9[9] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+            uint32_t    rows     = grad_base; // rows of unused slots receive +0.0f
+            for (;;) {
+                float    A[9], B[9], pair[9], quad[9];
+                uint32_t row;
+                if (!next_entry(A, row)) break;
+                asm volatile("v_writelane_b32 %0, %1, 15" : "+v"(rows) : "s"(row));
+                if (!next_entry(B, row)) {
+                    swap32_add9(A, zero9, pair);
+                    reduce_quad_and_add(pair, zero9, rows, is_row_end);
+                    break;
+                }
+                asm volatile("v_writelane_b32 %0, %1, 47" : "+v"(rows) : "s"(row));
+                swap32_add9(A, B, pair);
+                if (!next_entry(A, row)) {
+                    reduce_quad_and_add(pair, zero9, rows, is_row_end);
+                    break;
+                }
+                asm volatile("v_writelane_b32 %0, %1, 31" : "+v"(rows) : "s"(row));
+                if (!next_entry(B, row)) {
+                    swap32_add9(A, zero9, quad);
+                    reduce_quad_and_add(pair, quad, rows, is_row_end);
+                    break;
+                }
+                asm volatile("v_writelane_b32 %0, %1, 63" : "+v"(rows) : "s"(row));
+                swap32_add9(A, B, quad);
+                reduce_quad_and_add(pair, quad, rows, is_row_end);
             }
         }
-        red.finish(is_row_end);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the raw LDS adds above have landed
         __syncthreads();
         // ---- flush the round.  Global float atomics run at full rate only when a wave instruction covers
