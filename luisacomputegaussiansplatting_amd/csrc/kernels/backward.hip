@@ -430,6 +430,14 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
         const uint32_t wave_first = blk * 256u + wave * 64u;
         const uint32_t nvalid     = wave_first < V ? ((V - wave_first) < 64u ? (V - wave_first) : 64u) : 0u;
         float*         row = reinterpret_cast<float*>(&s_sh[wave][lane * 13]); // this lane's 48 floats (+4 pad)
+        // Every global operand of this splat is requested here, together with the SH rows below: one memory round
+        // trip per block instead of one per use (lanes past V read the last survivor's rows and discard them).
+        const float* g2 = grads2d + (size_t)(valid ? vid : V - 1) * kG2D;
+        const float4 q0 = reinterpret_cast<const float4*>(g2)[0], q1 = reinterpret_cast<const float4*>(g2)[1];
+        const float  gcol2 = g2[8];
+        const float  px = pos[3 * (size_t)idx + 0], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
+        const float  sc0 = scale[3 * (size_t)idx + 0], sc1 = scale[3 * (size_t)idx + 1], sc2 = scale[3 * (size_t)idx + 2];
+        const float4 q = *reinterpret_cast<const float4*>(rotq + 4 * (size_t)idx); // (r,x,y,z)
 
         // ---- stage the SH rows (coalesced), or fetch them lane-wise for other degrees
         __syncthreads();
@@ -448,11 +456,8 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
         __syncthreads();
 
         if (valid) {
-            const float* g2 = grads2d + (size_t)vid * kG2D;
-            const float4 q0 = reinterpret_cast<const float4*>(g2)[0], q1 = reinterpret_cast<const float4*>(g2)[1];
             const float  gmx = q0.x, gmy = q0.y, gA = q0.z, gB = q0.w, gC = q1.x, gop = q1.y;
-            const float  gcol[3] = { q1.z, q1.w, g2[8] };
-            const float  px = pos[3 * (size_t)idx + 0], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
+            const float  gcol[3] = { q1.z, q1.w, gcol2 };
             float        gp[3] = { 0.0f, 0.0f, 0.0f };
 
             // ---- colour -> SH coefficients and position (through the view direction)
@@ -505,9 +510,7 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
             const float tx = (clx ? (float)clx * limx : rx) * v[2];
             const float ty = (cly ? (float)cly * limy : ry) * v[2];
             const float tz = v[2];
-            const float sc[3] = { scale_modifier * scale[3 * (size_t)idx + 0], scale_modifier * scale[3 * (size_t)idx + 1],
-                                  scale_modifier * scale[3 * (size_t)idx + 2] };
-            const float4 q = *reinterpret_cast<const float4*>(rotq + 4 * (size_t)idx); // (r,x,y,z)
+            const float sc[3] = { scale_modifier * sc0, scale_modifier * sc1, scale_modifier * sc2 };
             const float  x = q.y, y = q.z, z = q.w, w = q.x;
             float R[3][3];
             R[0][0] = 1.0f - 2.0f * y * y - 2.0f * z * z; R[0][1] = 2.0f * x * y - 2.0f * z * w; R[0][2] = 2.0f * x * z + 2.0f * y * w;
