@@ -522,10 +522,13 @@ __global__ void __launch_bounds__(kThreads) k_expand_emit(const uint32_t* __rest
 }
 
 // shad_get_ranges (gs_tile_splatter/shader.cpp:71-100) on 32-bit tile keys; ranges zero-filled by the caller
-__global__ void __launch_bounds__(kThreads) k_get_ranges_u32(const uint32_t* __restrict__ d_counts,
+__global__ void __launch_bounds__(kThreads) k_get_ranges_u32(uint32_t* __restrict__ d_counts,
                                                                const uint32_t* __restrict__ keys,
-                                                               uint32_t* __restrict__ ranges)
+                                                               uint32_t* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ scan_error_flag)
 {
+    // (also forwards the chained scan's time-out flag into the counter block the host reads back)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && scan_error_flag) d_counts[5] = *scan_error_flag;
     const uint32_t L = d_counts[2];
     for (uint32_t idx = blockIdx.x * kThreads + threadIdx.x; idx < L; idx += gridDim.x * kThreads) {
         const uint32_t curr_tile = keys[idx];
@@ -611,12 +614,13 @@ void launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts
                        rects_sorted, ws, pair_keys, pair_vals);
 }
 
-void launch_get_ranges_u32(int64_t L_cap, const uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
-                           hipStream_t stream)
+void launch_get_ranges_u32(int64_t L_cap, uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
+                           const uint32_t* scan_error_flag, hipStream_t stream)
 {
     unsigned blocks = blocks_for(L_cap);
     if (blocks > 4096u) blocks = 4096u;
-    hipLaunchKernelGGL(k_get_ranges_u32, dim3(blocks), dim3(kThreads), 0, stream, d_counts, keys, ranges);
+    hipLaunchKernelGGL(k_get_ranges_u32, dim3(blocks), dim3(kThreads), 0, stream, d_counts, keys, ranges,
+                       scan_error_flag);
 }
 
 void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t* list_vid, const uint32_t* vis_index,

@@ -100,14 +100,13 @@ void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scal
                           const float* pos,
                           const float* scale, const float* rotq, const float* sh, const float* opacity,
                           const uint32_t* vis_index, const uint32_t* d_counts, SplatRecord* recs, hipStream_t stream);
-void launch_get_ranges_u32(int64_t L_cap, const uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
-                           hipStream_t stream);
+void launch_get_ranges_u32(int64_t L_cap, uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
+                           const uint32_t* scan_error_flag, hipStream_t stream);
 void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t* list_vid, const uint32_t* vis_index,
                          uint32_t* list_idx, hipStream_t stream);
 
 // longest-list-first tile schedule for the renderers (order[G], a scheduling hint only)
-void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, const uint32_t* scan_error_flag,
-                       uint32_t* d_counts, hipStream_t stream);
+void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream);
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,

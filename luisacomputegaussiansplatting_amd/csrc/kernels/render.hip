@@ -452,12 +452,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
 // One workgroup: counting sort of the tiles into 1024 length buckets (descending); order inside a bucket is
 // whatever the LDS atomics produce.
 __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ ranges, uint32_t G,
-                                                       uint32_t* __restrict__ order,
-                                                       const uint32_t* __restrict__ scan_error_flag,
-                                                       uint32_t* __restrict__ d_counts)
+                                                       uint32_t* __restrict__ order)
 {
-    // (also forwards the chained scan's time-out flag into the counter block the host reads back)
-    if (threadIdx.x == 0 && scan_error_flag && d_counts) d_counts[5] = *scan_error_flag;
     __shared__ uint32_t s_bucket[1024];
     __shared__ uint32_t s_wave[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -516,11 +512,10 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
 
 } // namespace
 
-void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, const uint32_t* scan_error_flag,
-                       uint32_t* d_counts, hipStream_t stream)
+void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream)
 {
     if (G == 0) return;
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, ranges, G, order, scan_error_flag, d_counts);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, ranges, G, order);
 }
 
 void launch_render_forward_aos(const CamParams& cp, const float bg[3], const uint32_t* ranges,

@@ -79,12 +79,15 @@ struct lcgs_context {
     DeviceBuffer owned[5];
 
     // workspace of the fused frame
-    DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws, counts, sort_ws, expand_ws,
-        final_T, n_contrib, list_idx, grads2d;
-    // sub-allocations of zero_ws (one memset per frame): chained-scan states of the cull pass and the tile ranges
-    uint64_t* scan_state = nullptr;
-    uint32_t* ranges     = nullptr;
-    size_t    zero_bytes = 0;
+    DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws[2], counts, sort_ws,
+        expand_ws, final_T, n_contrib, list_idx, grads2d;
+    // zero_ws holds what a frame needs zeroed: the chained-scan states of the cull pass and the tile ranges.  Two
+    // copies alternate between frames so that the next frame's copy is cleared on the auxiliary stream while the
+    // current frame renders (zero_ready) instead of at the head of the next frame.
+    size_t    zero_scan_bytes = 0, zero_bytes = 0;
+    int       zero_cur        = 0;
+    bool      zero_ready[2]   = { false, false };
+    uint32_t* ranges          = nullptr; // tile ranges of the last frame (inside zero_ws[...])
     // device-resident per-call parameters + the captured frame graph (replayed while its key is unchanged)
     DeviceBuffer   frame_params;
     hipGraphExec_t graph_exec = nullptr;
@@ -101,11 +104,19 @@ struct lcgs_context {
                    capacity == o.capacity && stream == o.stream;
         }
     } graph_key;
-    DeviceBuffer tile_order; // longest-list-first schedule of the last frame's tiles
+    // Longest-list-first tile schedule: a scheduling hint, so a frame uses the order derived from the PREVIOUS
+    // frame's list lengths (computed on the auxiliary stream while that frame rendered); only the first frame of a
+    // resolution computes its own order in line.
+    DeviceBuffer tile_order[2];
+    int          order_cur = 0;  // tile_order[order_cur] is the newest complete order ...
+    uint32_t     order_G   = 0;  // ... valid for this many tiles (0: none yet)
+    uint32_t*    last_tile_order = nullptr; // the order the last frame rendered with (reused by the backward)
     bool use_graph = false; // opt-in (LCGS_GRAPH=1): measured no gain on MI355X, the short kernels are GPU-latency-bound
     // second stream: work that is independent of the sort chain (record building; gradient zero-fill) overlaps it
     hipStream_t aux_stream = nullptr;
-    hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_ranges = nullptr, ev_aux_done = nullptr, ev_render = nullptr,
+                ev_counts = nullptr;
+    bool        aux_pending = false, counts_pending = false;
     // launch-size hints from the last synchronised frame (live counts stay on the device; larger counts are
     // still handled correctly by chunk striding)
     int64_t hint_V = 0, hint_L = 0;
@@ -171,6 +182,18 @@ lcgs_status collect_marks(lcgs_context* ctx)
     return LCGS_OK;
 }
 
+// waits for the context's stream and for the counter read-back of the last frame (which travels on the auxiliary
+// stream, see enqueue_forward)
+lcgs_status sync_frame(lcgs_context* ctx)
+{
+    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->counts_pending) {
+        LCGS_HIP_CHECK(hipEventSynchronize(ctx->ev_counts));
+        ctx->counts_pending = false;
+    }
+    return LCGS_OK;
+}
+
 // after a stream synchronisation: problems the last (possibly asynchronous) frame reported through its counters
 lcgs_status check_frame_flags(lcgs_context* ctx)
 {
@@ -231,12 +254,17 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
     const size_t G = (size_t)cp.grid_x * cp.grid_y;
     auto         al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t b0 = al(fused_scan_state_bytes((int)P)), b1 = al(G * 2 * 4);
-    LCGS_TRY(ctx->zero_ws.ensure(b0 + b1));
-    ctx->scan_state = ctx->zero_ws.as<uint64_t>();
-    ctx->ranges     = reinterpret_cast<uint32_t*>(ctx->zero_ws.as<char>() + b0);
-    ctx->zero_bytes = b0 + b1;
+    for (int i = 0; i < 2; ++i) {
+        const void* before = ctx->zero_ws[i].ptr;
+        LCGS_TRY(ctx->zero_ws[i].ensure(b0 + b1));
+        if (ctx->zero_ws[i].ptr != before || ctx->zero_bytes != b0 + b1) ctx->zero_ready[i] = false;
+        before = ctx->tile_order[i].ptr;
+        LCGS_TRY(ctx->tile_order[i].ensure(G * 4));
+        if (ctx->tile_order[i].ptr != before) ctx->order_G = 0;
+    }
+    ctx->zero_scan_bytes = b0;
+    ctx->zero_bytes      = b0 + b1;
     LCGS_TRY(ctx->counts.ensure(64));
-    LCGS_TRY(ctx->tile_order.ensure(G * 4));
     LCGS_TRY(ctx->sort_ws.ensure(pair_sort_ws_bytes(std::max<int64_t>((int64_t)P, (int64_t)ctx->pair_capacity))));
     LCGS_TRY(ctx->expand_ws.ensure(expand_ws_bytes((int)P)));
     if (keep_state) {
@@ -249,30 +277,41 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
 
 // enqueue one fused forward frame (no synchronisation)
 // d_fp: when non-NULL, camera / bg / scale_modifier are read from device memory by the kernels (graph replay)
+// in_capture: the frame is being recorded into a hipGraph (fixed pointers): no per-frame buffer alternation
 lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float bg[3], float scale_modifier,
-                            float* d_img, int32_t* d_radii, bool keep_state, const FrameParams* d_fp)
+                            float* d_img, int32_t* d_radii, bool keep_state, const FrameParams* d_fp,
+                            bool in_capture = false)
 {
     hipStream_t  st       = ctx->stream;
     uint32_t*    d_counts = ctx->counts.as<uint32_t>();
     const int    P        = ctx->P;
     SplatRecord* recs     = ctx->recs.as<SplatRecord>();
+    const uint32_t G      = cp.grid_x * cp.grid_y;
     ctx->n_marks          = 0;
     LCGS_TRY(mark(ctx, "begin"));
 
-    // one memset per frame: scan states of the cull pass + tile ranges (the reference zero-fills ranges too,
-    // gs_tile_splatter/impl.cpp:147)
-    LCGS_HIP_CHECK(hipMemsetAsync(ctx->zero_ws.ptr, 0, ctx->zero_bytes, st));
+    // With per-stage profiling on, everything runs in order on the main stream so that stage times stay
+    // attributable; otherwise independent work moves to the auxiliary stream (see below).
+    const bool overlap  = !ctx->profiling;
+    const bool deferred = overlap && !in_capture;
+    // Zeroed per frame: scan states of the cull pass + tile ranges (the reference zero-fills ranges too,
+    // gs_tile_splatter/impl.cpp:147).  Normally the auxiliary stream cleared this frame's copy during the last frame.
+    const int zb = deferred ? ctx->zero_cur : 0;
+    if (ctx->aux_pending && !in_capture) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_aux_done, 0)); // zero copy + tile order
+    if (!(deferred && ctx->zero_ready[zb])) LCGS_HIP_CHECK(hipMemsetAsync(ctx->zero_ws[zb].ptr, 0, ctx->zero_bytes, st));
+    ctx->zero_ready[zb]  = false;
+    uint64_t* scan_state = ctx->zero_ws[zb].as<uint64_t>();
+    ctx->ranges          = reinterpret_cast<uint32_t*>(ctx->zero_ws[zb].as<char>() + ctx->zero_scan_bytes);
     launch_cull_compact(P, cp, scale_modifier, d_fp, ctx->pos, ctx->scale, ctx->rotq, ctx->opacity, d_radii,
                         ctx->sortk[0].as<uint32_t>(), ctx->sortv[0].as<uint32_t>(), ctx->vis_index.as<uint32_t>(),
-                        ctx->rects.as<uint2>(), ctx->scan_state, d_counts, st);
+                        ctx->rects.as<uint2>(), scan_state, d_counts, st);
     LCGS_TRY(mark(ctx, "cull_compact"));
     const int64_t hint_V = ctx->hint_V > 0 ? ctx->hint_V : P;
     const int64_t hint_L = ctx->hint_L > 0 ? ctx->hint_L : ctx->pair_capacity;
     // Record building (SH fetch + colour: bandwidth-bound) is independent of the sort chain (latency-bound short
-    // kernels): fork it onto the auxiliary stream so the two overlap; the renderer joins.  With per-stage
-    // profiling on, everything runs in order on the main stream so that stage times stay attributable.
-    const bool overlap = !ctx->profiling;
+    // kernels): fork it onto the auxiliary stream so the two overlap; the renderer joins.
     hipStream_t rec_stream = overlap ? ctx->aux_stream : st;
+    // (forking later -- after the depth sort or after the duplication -- was measured slower: 1073 / 1048 vs 1094 fps)
     if (overlap) {
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
@@ -301,19 +340,54 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
                                             ctx->pair_capacity, hint_L, 0, tile_bits, ctx->sort_ws.ptr, st);
     LCGS_TRY(mark(ctx, "tile_sort"));
 
-    launch_get_ranges_u32(hint_L, d_counts, ctx->pairk[where2].as<uint32_t>(), ctx->ranges, st);
-    launch_tile_order(ctx->ranges, cp.grid_x * cp.grid_y, ctx->tile_order.as<uint32_t>(),
-                      reinterpret_cast<const uint32_t*>(ctx->scan_state + 1), d_counts, st);
+    launch_get_ranges_u32(hint_L, d_counts, ctx->pairk[where2].as<uint32_t>(), ctx->ranges,
+                          reinterpret_cast<const uint32_t*>(scan_state + 1), st);
+    // tile schedule: the newest complete order if it matches this grid, else computed here
+    uint32_t* order_now = nullptr;
+    if (deferred && ctx->order_G == G) {
+        order_now = ctx->tile_order[ctx->order_cur].as<uint32_t>();
+    } else {
+        const int ob = deferred ? (ctx->order_cur ^ 1) : 0;
+        order_now    = ctx->tile_order[ob].as<uint32_t>();
+        launch_tile_order(ctx->ranges, G, order_now, st);
+        if (deferred) {
+            ctx->order_cur = ob;
+            ctx->order_G   = G;
+        }
+    }
     LCGS_TRY(mark(ctx, "ranges"));
+    if (deferred) {
+        // behind the records on the auxiliary stream, beside the renderer: this frame's list lengths -> next
+        // frame's schedule, and the next frame's zeroed copy
+        const int ob = ctx->order_cur ^ 1, znext = zb ^ 1;
+        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_ranges, st));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_ranges, 0));
+        launch_tile_order(ctx->ranges, G, ctx->tile_order[ob].as<uint32_t>(), ctx->aux_stream);
+        LCGS_HIP_CHECK(hipMemsetAsync(ctx->zero_ws[znext].ptr, 0, ctx->zero_bytes, ctx->aux_stream));
+        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_aux_done, ctx->aux_stream));
+        ctx->aux_pending       = true;
+        ctx->zero_ready[znext] = true;
+        ctx->zero_cur          = znext;
+        ctx->order_cur         = ob; // complete once ev_aux_done has fired (the next frame waits for it)
+    }
 
     if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0)); // records are ready
     launch_render_forward_rec(cp, bg, ctx->ranges, ctx->pairv[where2].as<uint32_t>(), recs, d_img,
                               keep_state ? ctx->final_T.as<float>() : nullptr,
-                              keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, d_fp,
-                              ctx->tile_order.as<uint32_t>(), st);
+                              keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, d_fp, order_now, st);
+    ctx->last_tile_order = order_now;
     LCGS_TRY(mark(ctx, "render"));
 
-    LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, d_counts, 32, hipMemcpyDeviceToHost, st));
+    if (deferred) {
+        // the counter read-back leaves through the auxiliary stream: the next frame does not queue behind it
+        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_render, st));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_render, 0));
+        LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, d_counts, 32, hipMemcpyDeviceToHost, ctx->aux_stream));
+        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_counts, ctx->aux_stream));
+        ctx->counts_pending = true;
+    } else {
+        LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, d_counts, 32, hipMemcpyDeviceToHost, st));
+    }
     ctx->last.valid          = true;
     ctx->last.has_state      = keep_state;
     ctx->last.cp             = cp;
@@ -364,8 +438,8 @@ lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx)
         se             = hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, prio);
         if (se != hipSuccess) se = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     }
-    if (se == hipSuccess) se = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
-    if (se == hipSuccess) se = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+    for (hipEvent_t* ev : { &ctx->ev_fork, &ctx->ev_join, &ctx->ev_ranges, &ctx->ev_aux_done, &ctx->ev_render, &ctx->ev_counts })
+        if (se == hipSuccess) se = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     if (se != hipSuccess) {
         lcgs_status s = hip_fail(se, "aux stream / events", __FILE__, __LINE__);
         delete ctx;
@@ -380,10 +454,11 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
     if (!ctx) return LCGS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     DeviceBuffer* bufs[] = { &ctx->recs, &ctx->sortk[0], &ctx->sortk[1], &ctx->sortv[0], &ctx->sortv[1], &ctx->vis_index,
                              &ctx->rects, &ctx->rects_sorted, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
-                             &ctx->pairv[1], &ctx->zero_ws, &ctx->counts, &ctx->sort_ws,
-                             &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order, &ctx->st_keys_tmp,
+                             &ctx->pairv[1], &ctx->zero_ws[0], &ctx->zero_ws[1], &ctx->counts, &ctx->sort_ws,
+                             &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order[0], &ctx->tile_order[1], &ctx->st_keys_tmp,
                              &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& b : ctx->owned) b.release();
@@ -392,8 +467,8 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
         (void)hipStreamSynchronize(ctx->aux_stream);
         (void)hipStreamDestroy(ctx->aux_stream);
     }
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (hipEvent_t ev : { ctx->ev_fork, ctx->ev_join, ctx->ev_ranges, ctx->ev_aux_done, ctx->ev_render, ctx->ev_counts })
+        if (ev) (void)hipEventDestroy(ev);
     ctx->frame_params.release();
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->events_created)
@@ -412,7 +487,7 @@ lcgs_status lcgs_set_stream(lcgs_context* ctx, void* stream)
 lcgs_status lcgs_synchronize(lcgs_context* ctx)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
-    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    LCGS_TRY(sync_frame(ctx));
     return check_frame_flags(ctx);
 }
 
@@ -622,7 +697,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
                 hipGraph_t graph = nullptr;
                 LCGS_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
                 lcgs_status cs = enqueue_forward(ctx, cp, bg_color, scale_modifier, d_img, d_radii, keep_state != 0,
-                                                 ctx->frame_params.as<FrameParams>());
+                                                 ctx->frame_params.as<FrameParams>(), /*in_capture=*/true);
                 hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
                 if (cs != LCGS_OK) {
                     if (graph) (void)hipGraphDestroy(graph);
@@ -643,7 +718,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
             LCGS_TRY(enqueue_forward(ctx, cp, bg_color, scale_modifier, d_img, d_radii, keep_state != 0, nullptr));
         }
         if (!num_rendered && !ctx->profiling) return LCGS_OK; // fully asynchronous frame
-        LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        LCGS_TRY(sync_frame(ctx));
         LCGS_TRY(collect_marks(ctx));
         ctx->stats.num_gaussians = ctx->P;
         ctx->stats.num_visible   = ctx->h_counts[0];
@@ -689,7 +764,7 @@ lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* out)
 {
     LCGS_REQUIRE(ctx && out, "NULL argument");
     LCGS_REQUIRE(ctx->last.valid, "no frame rendered yet");
-    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    LCGS_TRY(sync_frame(ctx));
     ctx->stats.num_gaussians = ctx->P;
     ctx->stats.num_visible   = ctx->h_counts[0];
     ctx->stats.num_rendered  = ctx->h_counts[1];
@@ -704,7 +779,7 @@ lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* out)
 lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t* d_ranges)
 {
     LCGS_REQUIRE(ctx && ctx->last.valid, "no frame rendered yet");
-    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    LCGS_TRY(sync_frame(ctx));
     const uint32_t L = ctx->h_counts[2];
     if (d_list && L)
         launch_map_to_index(L, ctx->counts.as<uint32_t>(), ctx->pairv[ctx->last.list_buf].as<uint32_t>(),
@@ -751,7 +826,7 @@ lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, cons
     LCGS_TRY(mark(ctx, "zero_grads"));
     launch_render_backward(ctx->last.cp, ctx->last.bg, ctx->ranges, ctx->pairv[ctx->last.list_buf].as<uint32_t>(),
                            ctx->recs.as<SplatRecord>(), ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(),
-                           d_dL_dimg, ctx->grads2d.as<float>(), ctx->tile_order.as<uint32_t>(), st);
+                           d_dL_dimg, ctx->grads2d.as<float>(), ctx->last_tile_order, st);
     LCGS_TRY(mark(ctx, "render_backward"));
     if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     launch_preprocess_backward(ctx->hint_V > 0 ? ctx->hint_V : (int64_t)P, ctx->sh_deg, ctx->last.cp,
