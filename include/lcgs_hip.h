@@ -176,6 +176,21 @@ LCGS_API lcgs_status lcgs_scene_upload(lcgs_context* ctx, int num_gaussians, int
                                        const float* h_scale, const float* h_rotq, const float* h_sh,
                                        const float* h_opacity);
 
+/* read_gs_ply (app/gaussians.cpp:75-171) + the upload of app/main.cpp:180-186,216-223 in one call, with the
+ * de-interleave and the activations done on the device: the binary vertex records are copied to
+ * the GPU as they lie in the file and become the five activated arrays there.  Equal to lcgs_ply_read +
+ * lcgs_scene_upload except for exp() (device libm vs host libm, <= 2 ulp in scale and opacity).  ascii files and
+ * files with non-float columns take the host path.  Synchronises the context's stream. */
+LCGS_API lcgs_status lcgs_scene_load_ply(lcgs_context* ctx, const char* path, int* num_gaussians);
+/* Device pointers of the bound scene (any of the outputs may be NULL). */
+LCGS_API lcgs_status lcgs_scene_pointers(lcgs_context* ctx, int* num_gaussians, int* sh_degree, const float** d_pos,
+                                         const float** d_scale, const float** d_rotq, const float** d_sh,
+                                         const float** d_opacity);
+
+/* Copies the bound scene to host arrays sized like lcgs_scene_upload's inputs (NULL outputs are skipped). */
+LCGS_API lcgs_status lcgs_scene_download(lcgs_context* ctx, float* h_pos, float* h_scale, float* h_rotq, float* h_sh,
+                                         float* h_opacity);
+
 /* One frame.  d_img: 3*H*W floats, CHW.  d_radii: P ints or NULL.  If num_rendered is non-NULL the call
  * synchronises the stream and stores the reference's num_rendered (sum of tiles touched); if NULL the
  * call only enqueues work.  keep_state != 0 keeps what lcgs_render_backward needs. */

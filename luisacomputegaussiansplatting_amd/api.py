@@ -130,6 +130,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists",
     "lcgs_render_backward", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png",
+    "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download",
 ]
 
 
@@ -138,6 +139,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: torch ships its own libamdhip64, and a process that initialises two copies loses
+    # the device in the second.  When torch is installed it is imported first, so that liblcgs_hip.so (linked against
+    # the same soname) binds to the copy torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise LcgsError(-1, f"{path} is missing: run luisacomputegaussiansplatting_amd.build_library() "
@@ -420,6 +428,23 @@ class Renderer:
         P = int(arrs[0].reshape(-1, 3).shape[0])
         self.P, self.sh_degree = P, sh_degree
         _check(load_library().lcgs_scene_upload(self.ctx._h, C.c_int(P), C.c_int(sh_degree), *[_ptr(a) for a in arrs]))
+
+    def load_ply(self, path: str) -> int:
+        """read_gs_ply + upload with the de-interleave / activations on the device (lcgs_scene_load_ply)."""
+        n = C.c_int(0)
+        _check(load_library().lcgs_scene_load_ply(self.ctx._h, path.encode(), C.byref(n)))
+        self.P, self.sh_degree, self._keep = n.value, 3, []
+        return n.value
+
+    def download_scene(self) -> dict:
+        """Host copies of the bound scene (same keys and shapes as read_gs_ply)."""
+        P, feat = self.P, (self.sh_degree + 1) ** 2 * 3
+        out = {"pos": np.zeros((P, 3), np.float32), "scale": np.zeros((P, 3), np.float32),
+               "rotq": np.zeros((P, 4), np.float32), "sh": np.zeros((P, feat), np.float32),
+               "opacity": np.zeros((P,), np.float32)}
+        _check(load_library().lcgs_scene_download(self.ctx._h, *[_ptr(out[k]) for k in
+                                                                  ("pos", "scale", "rotq", "sh", "opacity")]))
+        return out
 
     def forward(self, cam: Camera, img, bg=(0.0, 0.0, 0.0), scale_modifier: float = 1.0, radii=None,
                 keep_state: bool = False, sync: bool = True) -> Optional[int]:

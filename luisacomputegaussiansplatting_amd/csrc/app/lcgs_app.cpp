@@ -1,10 +1,14 @@
 // lcgs-app -- CLI work-alike of the reference's app/main.cpp on the MI355X library.
 //   lcgs-app --ply <path> [--res WxH] [--out dir] [--world colmap|blender] [--exp_N N] [--backend hip]
-//            [--path fused|stage] [--synth kind:count:seed]
+//            [--path fused|stage] [--synth kind:count:seed] [--ingest device|host] [--cameras file]
 // Same flags (app/main.cpp:52-124; `--key=value` and `--key value`, app/command_parser.hpp:5-79), the same
 // hard-coded look-at camera (app/main.cpp:191-207), the same frame loop (:266-308), the same output:
 // <out>/<ply stem>_<backend>.png, CHW float -> vertically flipped RGB8 with a truncating *255 (:323-339).
 // --display (ImGui window) is not available on a headless GPU box and is rejected.
+// Beyond the reference: the PLY is de-interleaved and activated on the device
+// (--ingest device, default; `host` = the reference's read_gs_ply order of work), and --cameras <file> renders a
+// batch of views of the resident scene (one `px py pz  tx ty tz  ux uy uz [fov]` line per camera, `#` comments),
+// writing <stem>_<backend>_<k>.png per view.
 #include <sys/stat.h>
 
 #include <chrono>
@@ -37,6 +41,8 @@ void usage(const char* argv0)
     printf("  --exp_N <N>              Number of frames to render (default: 1)\n");
     printf("  --path <fused|stage>     One-submission fused frame (default) or the three stage-level operators\n");
     printf("  --synth <kind:count:seed> Render a synthetic stand-in scene instead of --ply (kind 0 object, 1 unbounded)\n");
+    printf("  --ingest <device|host>   De-interleave/activate the PLY on the GPU (default) or on the host\n");
+    printf("  --cameras <file>         Render every camera of the file: `px py pz tx ty tz ux uy uz [fov]` per line\n");
     printf("  --display                Not supported (headless)\n");
 }
 
@@ -53,6 +59,7 @@ int main(int argc, char** argv)
 {
     unsigned    W = 1600, H = 1063; // app/main.cpp:38
     std::string ply_path = "gsplat.ply", backend = "hip", out_dir = "out", world = "colmap", path = "fused", synth;
+    std::string ingest = "device", cameras_file;
     int         exp_N = 1;
     // parse_command (app/command_parser.hpp:5-79): strip leading dashes, `key=value` or `key value`
     for (int i = 1; i < argc; ++i) {
@@ -92,6 +99,10 @@ int main(int argc, char** argv)
             exp_N = std::stoi(value);
         } else if (key == "path") path = value;
         else if (key == "synth") synth = value;
+        else if (key == "ingest") {
+            if (value != "device" && value != "host") die("Invalid ingest mode: " + value);
+            ingest = value;
+        } else if (key == "cameras") cameras_file = value;
         else if (key == "display") die("--display needs a GUI; this build is headless");
         else die("unknown option --" + key);
     }
@@ -109,6 +120,8 @@ int main(int argc, char** argv)
         lcgs_scene_host sc{};
         std::vector<float> spos, sfeat, sop, sscale, srot;
         int                P = 0;
+        bool               on_device = false;
+        auto               t_load = std::chrono::steady_clock::now();
         if (!synth.empty()) {
             int kind = 0; long long count = 0; unsigned long long seed = 0;
             if (sscanf(synth.c_str(), "%d:%lld:%llu", &kind, &count, &seed) != 3) die("--synth expects kind:count:seed");
@@ -117,61 +130,114 @@ int main(int argc, char** argv)
             lcgs::check(lcgs_synth_scene(kind, seed, 0, count, spos.data(), sfeat.data(), sop.data(), sscale.data(), srot.data()));
             sc = { P, 3, spos.data(), sfeat.data(), sop.data(), sscale.data(), srot.data() };
             ply_name = "synth" + std::to_string(kind) + "_" + std::to_string(count);
+        } else if (ingest == "device") {
+            lcgs::check(lcgs_scene_load_ply(device.ctx(), ply_path.c_str(), &P)); // records -> GPU -> activated arrays
+            on_device = true;
         } else {
             lcgs::check(lcgs_ply_read(ply_path.c_str(), &sc));
             P = sc.num_gaussians;
         }
         printf("num_gaussians: %d\n", P);
-        auto d_pos = upload(sc.pos, (size_t)P * 3), d_scale = upload(sc.scale, (size_t)P * 3),
-             d_rotq = upload(sc.rotq, (size_t)P * 4), d_sh = upload(sc.feature, (size_t)P * 48),
-             d_opacity = upload(sc.opacity, (size_t)P); // app/main.cpp:180-186, 216-223
+        // the five device arrays of app/main.cpp:180-186, 216-223 (owned here, or by the context after a device ingest)
+        lcgs::Buffer<float>     o_pos, o_scale, o_rotq, o_sh, o_opacity;
+        lcgs::BufferView<float> d_pos, d_scale, d_rotq, d_sh, d_opacity;
+        if (on_device) {
+            const float *pp, *ps, *pr, *pf, *po;
+            lcgs::check(lcgs_scene_pointers(device.ctx(), nullptr, nullptr, &pp, &ps, &pr, &pf, &po));
+            d_pos     = { const_cast<float*>(pp), (size_t)P * 3 };
+            d_scale   = { const_cast<float*>(ps), (size_t)P * 3 };
+            d_rotq    = { const_cast<float*>(pr), (size_t)P * 4 };
+            d_sh      = { const_cast<float*>(pf), (size_t)P * 48 };
+            d_opacity = { const_cast<float*>(po), (size_t)P };
+        } else {
+            o_pos = upload(sc.pos, (size_t)P * 3); o_scale = upload(sc.scale, (size_t)P * 3);
+            o_rotq = upload(sc.rotq, (size_t)P * 4); o_sh = upload(sc.feature, (size_t)P * 48);
+            o_opacity = upload(sc.opacity, (size_t)P);
+            d_pos = o_pos; d_scale = o_scale; d_rotq = o_rotq; d_sh = o_sh; d_opacity = o_opacity;
+            lcgs::check(lcgs_scene_bind(device.ctx(), P, 3, d_pos.ptr, d_scale.ptr, d_rotq.ptr, d_sh.ptr, d_opacity.ptr));
+        }
+        printf("scene resident in %.1f ms (%s ingest)\n",
+               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_load).count(),
+               !synth.empty() ? "synthetic" : ingest.c_str());
 
-        // ---- camera (app/main.cpp:191-207)
-        float pos[3] = { -3.0f, -0.5f, 3.3f }, target[3] = { 0.0f, 3.0f, 0.5f }, up[3] = { 0.0f, -1.0f, -1.0f };
-        if (world == "blender") { up[0] = 0.0f; up[1] = 0.0f; up[2] = 1.0f; }
-        lcgs::Camera cam   = lcgs::get_lookat_cam(pos, target, up);
-        cam.aspect_ratio   = (float)W / (float)H;
-        cam.width          = (int)W;
-        cam.height         = (int)H;
+        // ---- cameras: the hard-coded look-at of app/main.cpp:191-207, or one per line of --cameras
+        struct View { float pos[3], target[3], up[3], fov; };
+        std::vector<View> views;
+        if (cameras_file.empty()) {
+            View v = { { -3.0f, -0.5f, 3.3f }, { 0.0f, 3.0f, 0.5f }, { 0.0f, -1.0f, -1.0f }, 0.0f };
+            if (world == "blender") { v.up[0] = 0.0f; v.up[1] = 0.0f; v.up[2] = 1.0f; }
+            views.push_back(v);
+        } else {
+            FILE* cf = fopen(cameras_file.c_str(), "r");
+            if (!cf) die("cannot open " + cameras_file);
+            char line[1024];
+            while (fgets(line, sizeof(line), cf)) {
+                const char* q = line;
+                while (*q == ' ' || *q == '\t') ++q;
+                if (*q == '#' || *q == '\n' || *q == '\r' || *q == 0) continue;
+                View v{};
+                int  n = sscanf(q, "%f %f %f %f %f %f %f %f %f %f", &v.pos[0], &v.pos[1], &v.pos[2], &v.target[0], &v.target[1],
+                                &v.target[2], &v.up[0], &v.up[1], &v.up[2], &v.fov);
+                if (n < 9) die("bad camera line in " + cameras_file + ": " + line);
+                if (n < 10) v.fov = 0.0f;
+                views.push_back(v);
+            }
+            fclose(cf);
+            if (views.empty()) die("no cameras in " + cameras_file);
+        }
         const float bg[3]  = { 0.0f, 0.0f, 0.0f };
         lcgs::Buffer<float> d_img((size_t)W * H * 3);
         lcgs::Buffer<int>   d_radii((size_t)P);
-        int                 num_rendered = 0;
-        auto                t0 = std::chrono::steady_clock::now();
+        // stage-level operators and their buffers (the reference's own call sequence, app/main.cpp:227-308)
+        lcgs::SHProcessor sh_processor; lcgs::GSProjector projector; lcgs::GSTileSplatter tile_splatter;
+        lcgs::Buffer<float> d_color, d_means_2d, d_depth, d_covs_2d;
+        lcgs::Buffer<uint32_t> d_tiles, d_offsets, d_lu, d_ls, d_ranges;
+        lcgs::Buffer<uint64_t> d_ku, d_ks;
         if (path == "stage") {
-            // the reference's own call sequence (app/main.cpp:227-308) on the stage-level operators
-            lcgs::SHProcessor sh_processor; lcgs::GSProjector projector; lcgs::GSTileSplatter tile_splatter;
             sh_processor.create(device); projector.create(device); tile_splatter.create(device);
-            lcgs::Buffer<float> d_color((size_t)P * 3), d_means_2d((size_t)P * 2), d_depth((size_t)P), d_covs_2d((size_t)P * 3);
+            d_color = lcgs::Buffer<float>((size_t)P * 3); d_means_2d = lcgs::Buffer<float>((size_t)P * 2);
+            d_depth = lcgs::Buffer<float>((size_t)P); d_covs_2d = lcgs::Buffer<float>((size_t)P * 3);
             (void)hipMemset(d_means_2d.data(), 0, (size_t)P * 8); (void)hipMemset(d_depth.data(), 0, (size_t)P * 4); (void)hipMemset(d_covs_2d.data(), 0, (size_t)P * 12);
-            lcgs::Buffer<uint32_t> d_tiles((size_t)P), d_offsets((size_t)P);
+            d_tiles = lcgs::Buffer<uint32_t>((size_t)P); d_offsets = lcgs::Buffer<uint32_t>((size_t)P);
             const size_t L = 20000000; // app/main.cpp:245
-            lcgs::Buffer<uint64_t> d_ku(L), d_ks(L);
-            lcgs::Buffer<uint32_t> d_lu(L), d_ls(L), d_ranges((size_t)((W + 15) / 16) * ((H + 15) / 16) * 2);
-            for (int it = 0; it < exp_N; ++it) {
-                sh_processor.process({ P, 3, d_pos }, cam, d_sh, d_color, 3, 3);
-                projector.forward({ P, d_pos, d_scale, d_rotq, 1.0f }, { d_means_2d, d_covs_2d, d_depth }, cam);
-                num_rendered = tile_splatter.forward({ d_tiles, d_offsets, d_ku, d_lu, d_ks, d_ls, d_ranges },
-                                                     { P, { 0, 0, 0 }, d_means_2d, d_depth, d_covs_2d, d_color, d_opacity },
-                                                     { (int)H, (int)W, d_img, d_radii });
-            }
-        } else {
-            lcgs::check(lcgs_scene_bind(device.ctx(), P, 3, d_pos.data(), d_scale.data(), d_rotq.data(), d_sh.data(), d_opacity.data()));
-            for (int it = 0; it < exp_N; ++it)
-                lcgs::check(lcgs_render_forward(device.ctx(), &cam, bg, 1.0f, d_img.data(), d_radii.data(), 0,
-                                                it + 1 == exp_N ? &num_rendered : nullptr));
+            d_ku = lcgs::Buffer<uint64_t>(L); d_ks = lcgs::Buffer<uint64_t>(L);
+            d_lu = lcgs::Buffer<uint32_t>(L); d_ls = lcgs::Buffer<uint32_t>(L);
+            d_ranges = lcgs::Buffer<uint32_t>((size_t)((W + 15) / 16) * ((H + 15) / 16) * 2);
         }
-        std::vector<float> h_img((size_t)W * H * 3);
-        device.synchronize();
-        if (hipMemcpy(h_img.data(), d_img.data(), h_img.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) die("D2H copy failed");
-        double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        printf("num_rendered: %d\nexp time: %.3f ms\nfps: %.2f with test N %d\n", num_rendered, ms, 1000.0 / (ms / exp_N), exp_N);
+        std::vector<float>   h_img((size_t)W * H * 3);
         std::vector<uint8_t> rgb((size_t)W * H * 3);
-        lcgs_image_to_rgb8((int)W, (int)H, h_img.data(), rgb.data());
-        std::string img_name = out_dir + "/" + ply_name + "_" + backend + ".png";
-        lcgs::check(lcgs_write_png(img_name.c_str(), (int)W, (int)H, rgb.data()));
-        printf("result saved in %s\n", img_name.c_str());
-        if (synth.empty()) lcgs_scene_host_free(&sc);
+        for (size_t vi = 0; vi < views.size(); ++vi) {
+            lcgs::Camera cam = lcgs::get_lookat_cam(views[vi].pos, views[vi].target, views[vi].up);
+            if (views[vi].fov > 0.0f) cam.fov = views[vi].fov;
+            cam.aspect_ratio = (float)W / (float)H;
+            cam.width        = (int)W;
+            cam.height       = (int)H;
+            int  num_rendered = 0;
+            auto t0           = std::chrono::steady_clock::now();
+            if (path == "stage") {
+                for (int it = 0; it < exp_N; ++it) {
+                    sh_processor.process({ P, 3, d_pos }, cam, d_sh, d_color, 3, 3);
+                    projector.forward({ P, d_pos, d_scale, d_rotq, 1.0f }, { d_means_2d, d_covs_2d, d_depth }, cam);
+                    num_rendered = tile_splatter.forward({ d_tiles, d_offsets, d_ku, d_lu, d_ks, d_ls, d_ranges },
+                                                         { P, { 0, 0, 0 }, d_means_2d, d_depth, d_covs_2d, d_color, d_opacity },
+                                                         { (int)H, (int)W, d_img, d_radii });
+                }
+            } else {
+                for (int it = 0; it < exp_N; ++it)
+                    lcgs::check(lcgs_render_forward(device.ctx(), &cam, bg, 1.0f, d_img.data(), d_radii.data(), 0,
+                                                    it + 1 == exp_N ? &num_rendered : nullptr));
+            }
+            device.synchronize();
+            if (hipMemcpy(h_img.data(), d_img.data(), h_img.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) die("D2H copy failed");
+            double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            printf("num_rendered: %d\nexp time: %.3f ms\nfps: %.2f with test N %d\n", num_rendered, ms, 1000.0 / (ms / exp_N), exp_N);
+            lcgs_image_to_rgb8((int)W, (int)H, h_img.data(), rgb.data());
+            std::string img_name = out_dir + "/" + ply_name + "_" + backend +
+                                   (cameras_file.empty() ? std::string() : "_" + std::to_string(vi)) + ".png";
+            lcgs::check(lcgs_write_png(img_name.c_str(), (int)W, (int)H, rgb.data()));
+            printf("result saved in %s\n", img_name.c_str());
+        }
+        if (synth.empty() && !on_device) lcgs_scene_host_free(&sc);
     } catch (const lcgs::Error& e) {
         die(e.what());
     }

@@ -47,6 +47,15 @@ CamParams make_cam_params(const lcgs_camera& cam);
 // stream of an (opaque) context, for translation units that only see the forward declaration
 hipStream_t context_stream(lcgs_context* ctx);
 
+// what the device ingest path needs to know about a PLY file (host/ply.cpp)
+struct PlyProbe {
+    int64_t  num_vertices = 0;
+    size_t   stride = 0, payload_offset = 0;
+    uint32_t column_offset[59] = {};
+    bool     device_ok = false;
+};
+lcgs_status ply_probe(const char* path, PlyProbe* out);
+
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 inline int64_t  div_up64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -80,6 +80,106 @@ lcgs_status fail(lcgs_status s, const std::string& msg)
     return s;
 }
 
+// Parses the header (fp is left at the first payload byte) and looks the 59 wanted columns up by name.
+lcgs_status parse_header(FILE* fp, std::vector<Prop>& props, int64_t& N, size_t& stride, bool& binary,
+                         std::vector<int>& want)
+{
+    props.clear();
+    want.clear();
+    stride = 0;
+    N      = -1;
+    binary = false;
+    std::string line;
+    bool        ascii = false, in_vertex = false, seen_vertex = false, header_ok = false;
+    bool        first = true;
+    for (;;) {
+        char buf[1024];
+        if (!fgets(buf, sizeof(buf), fp)) break;
+        line = buf;
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        if (first) {
+            first = false;
+            if (line != "ply") {
+                return fail(LCGS_ERR_FORMAT, "not a PLY file (missing magic)");
+            }
+            continue;
+        }
+        std::istringstream ss(line);
+        std::string        tok;
+        ss >> tok;
+        if (tok == "format") {
+            std::string f;
+            ss >> f;
+            if (f == "binary_little_endian") binary = true;
+            else if (f == "ascii") ascii = true;
+            else {
+                return fail(LCGS_ERR_FORMAT, "unsupported PLY format: " + f);
+            }
+        } else if (tok == "element") {
+            std::string name;
+            int64_t     cnt;
+            ss >> name >> cnt;
+            if (name == "vertex") {
+                if (seen_vertex) {
+                        return fail(LCGS_ERR_FORMAT, "duplicate vertex element");
+                }
+                in_vertex = seen_vertex = true;
+                N                       = cnt;
+            } else {
+                if (!seen_vertex && cnt > 0) {
+                        return fail(LCGS_ERR_FORMAT, "elements before `vertex` are not supported");
+                }
+                in_vertex = false;
+            }
+        } else if (tok == "property") {
+            if (!in_vertex) continue;
+            std::string t, name;
+            ss >> t;
+            if (t == "list") {
+                return fail(LCGS_ERR_FORMAT, "list property in vertex element");
+            }
+            ss >> name;
+            int ty = type_from_name(t);
+            if (ty < 0) {
+                return fail(LCGS_ERR_FORMAT, "unknown property type: " + t);
+            }
+            props.push_back({ name, ty, stride });
+            stride += kTypeSize[ty];
+        } else if (tok == "end_header") {
+            header_ok = true;
+            break;
+        }
+    }
+    if (!header_ok || !seen_vertex || N < 0 || (!binary && !ascii)) {
+        return fail(LCGS_ERR_FORMAT, "No vertex element in the ply file"); // gaussians.cpp:80-82
+    }
+    if (N >= (1 << 30)) {
+        return fail(LCGS_ERR_FORMAT, "too many vertices");
+    }
+
+    // ---- property lookup by name (happly throws on a missing one, app/happly.h:974)
+    auto find = [&](const std::string& name) -> int {
+        for (size_t i = 0; i < props.size(); ++i)
+            if (props[i].name == name) return (int)i;
+        return -1;
+    };
+    // 59 columns in the order pos(3) dc(3) rest(45) opacity scale(3) rot(4)
+    std::vector<std::string> names = { "x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2" };
+    for (int i = 0; i < 45; ++i) names.push_back("f_rest_" + std::to_string(i));
+    names.push_back("opacity");
+    for (int i = 0; i < 3; ++i) names.push_back("scale_" + std::to_string(i));
+    for (int i = 0; i < 4; ++i) names.push_back("rot_" + std::to_string(i));
+    for (auto& n : names) {
+        int k = find(n);
+        if (k < 0) {
+            return fail(LCGS_ERR_FORMAT, "PLY vertex element has no property `" + n + "`");
+        }
+        want.push_back(k);
+    }
+
+    return LCGS_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -102,105 +202,17 @@ lcgs_status lcgs_ply_read(const char* path, lcgs_scene_host* out)
     FILE* fp = fopen(path, "rb");
     if (!fp) return fail(LCGS_ERR_IO, std::string("cannot open ") + path);
 
-    // ---- header
     std::vector<Prop> props;
-    std::string       line;
-    bool              binary = false, ascii = false, in_vertex = false, seen_vertex = false, header_ok = false;
+    std::vector<int>  want;
     int64_t           N = -1;
     size_t            stride = 0;
-    bool              first  = true;
-    for (;;) {
-        char buf[1024];
-        if (!fgets(buf, sizeof(buf), fp)) break;
-        line = buf;
-        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
-        if (first) {
-            first = false;
-            if (line != "ply") {
-                fclose(fp);
-                return fail(LCGS_ERR_FORMAT, "not a PLY file (missing magic)");
-            }
-            continue;
-        }
-        std::istringstream ss(line);
-        std::string        tok;
-        ss >> tok;
-        if (tok == "format") {
-            std::string f;
-            ss >> f;
-            if (f == "binary_little_endian") binary = true;
-            else if (f == "ascii") ascii = true;
-            else {
-                fclose(fp);
-                return fail(LCGS_ERR_FORMAT, "unsupported PLY format: " + f);
-            }
-        } else if (tok == "element") {
-            std::string name;
-            int64_t     cnt;
-            ss >> name >> cnt;
-            if (name == "vertex") {
-                if (seen_vertex) {
-                    fclose(fp);
-                    return fail(LCGS_ERR_FORMAT, "duplicate vertex element");
-                }
-                in_vertex = seen_vertex = true;
-                N                       = cnt;
-            } else {
-                if (!seen_vertex && cnt > 0) {
-                    fclose(fp);
-                    return fail(LCGS_ERR_FORMAT, "elements before `vertex` are not supported");
-                }
-                in_vertex = false;
-            }
-        } else if (tok == "property") {
-            if (!in_vertex) continue;
-            std::string t, name;
-            ss >> t;
-            if (t == "list") {
-                fclose(fp);
-                return fail(LCGS_ERR_FORMAT, "list property in vertex element");
-            }
-            ss >> name;
-            int ty = type_from_name(t);
-            if (ty < 0) {
-                fclose(fp);
-                return fail(LCGS_ERR_FORMAT, "unknown property type: " + t);
-            }
-            props.push_back({ name, ty, stride });
-            stride += kTypeSize[ty];
-        } else if (tok == "end_header") {
-            header_ok = true;
-            break;
-        }
-    }
-    if (!header_ok || !seen_vertex || N < 0 || (!binary && !ascii)) {
-        fclose(fp);
-        return fail(LCGS_ERR_FORMAT, "No vertex element in the ply file"); // gaussians.cpp:80-82
-    }
-    if (N >= (1 << 30)) {
-        fclose(fp);
-        return fail(LCGS_ERR_FORMAT, "too many vertices");
-    }
-
-    // ---- property lookup by name (happly throws on a missing one, app/happly.h:974)
-    auto find = [&](const std::string& name) -> int {
-        for (size_t i = 0; i < props.size(); ++i)
-            if (props[i].name == name) return (int)i;
-        return -1;
-    };
-    std::vector<int> want; // 59 columns in the order pos(3) dc(3) rest(45) opacity scale(3) rot(4)
-    std::vector<std::string> names = { "x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2" };
-    for (int i = 0; i < 45; ++i) names.push_back("f_rest_" + std::to_string(i));
-    names.push_back("opacity");
-    for (int i = 0; i < 3; ++i) names.push_back("scale_" + std::to_string(i));
-    for (int i = 0; i < 4; ++i) names.push_back("rot_" + std::to_string(i));
-    for (auto& n : names) {
-        int k = find(n);
-        if (k < 0) {
+    bool              binary = false;
+    {
+        lcgs_status hs = parse_header(fp, props, N, stride, binary, want);
+        if (hs != LCGS_OK) {
             fclose(fp);
-            return fail(LCGS_ERR_FORMAT, "PLY vertex element has no property `" + n + "`");
+            return hs;
         }
-        want.push_back(k);
     }
 
     // ---- payload
@@ -302,3 +314,40 @@ lcgs_status lcgs_ply_write_raw(const char* path, int num_gaussians, const float*
 }
 
 } // extern "C"
+
+namespace lcgs
+{
+
+// Header of a binary-little-endian 3DGS PLY for the device ingest path (lcgs_scene_load_ply): record count, stride,
+// payload offset and the byte offsets of the 59 wanted columns.  device_ok is false when the file needs the host
+// path (ascii, or a wanted column that is not float32).
+lcgs_status ply_probe(const char* path, PlyProbe* out)
+{
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return fail(LCGS_ERR_IO, std::string("cannot open ") + path);
+    std::vector<Prop> props;
+    std::vector<int>  want;
+    bool              binary = false;
+    size_t            stride = 0;
+    lcgs_status       hs     = parse_header(fp, props, out->num_vertices, stride, binary, want);
+    if (hs != LCGS_OK) {
+        fclose(fp);
+        return hs;
+    }
+    out->stride         = stride;
+    out->payload_offset = (size_t)ftell(fp);
+    out->device_ok      = binary && stride % 4 == 0;
+    for (int w = 0; w < 59; ++w) {
+        out->column_offset[w] = (uint32_t)props[want[w]].offset;
+        if (props[want[w]].type != 6 || props[want[w]].offset % 4 != 0) out->device_ok = false;
+    }
+    fseek(fp, 0, SEEK_END);
+    const size_t file_size = (size_t)ftell(fp);
+    fclose(fp);
+    if (binary && file_size < out->payload_offset + (size_t)out->num_vertices * stride)
+        return fail(LCGS_ERR_FORMAT, "PLY payload is truncated");
+    return LCGS_OK;
+}
+
+} // namespace lcgs
+

@@ -106,6 +106,13 @@ void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t
                          uint32_t* list_idx, hipStream_t stream);
 
 // longest-list-first tile schedule for the renderers (order[G], a scheduling hint only)
+// byte offsets, inside one vertex record, of the 59 wanted float columns (pos3 dc3 rest45 opacity scale3 rot4)
+struct PlyColumns {
+    uint32_t offset[59];
+};
+// records [first, first + count) of a PLY payload chunk already in device memory -> activated scene arrays
+void launch_ply_activate(const unsigned char* raw, int64_t first, int64_t count, uint32_t stride, const PlyColumns& cols,
+                         float* pos, float* scale, float* rotq, float* sh, float* opacity, hipStream_t stream);
 void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream);
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,

@@ -52,6 +52,17 @@ public:
     Buffer(const Buffer&)            = delete;
     Buffer& operator=(const Buffer&) = delete;
     Buffer(Buffer&& o) noexcept : m_ptr(o.m_ptr), m_size(o.m_size) { o.m_ptr = nullptr; }
+    Buffer& operator=(Buffer&& o) noexcept
+    {
+        if (this != &o) {
+            if (m_ptr) (void)hipFree(m_ptr);
+            m_ptr    = o.m_ptr;
+            m_size   = o.m_size;
+            o.m_ptr  = nullptr;
+            o.m_size = 0;
+        }
+        return *this;
+    }
     ~Buffer()
     {
         if (m_ptr) (void)hipFree(m_ptr);

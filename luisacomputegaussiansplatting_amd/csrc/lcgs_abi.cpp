@@ -1,6 +1,11 @@
 // lcgs_abi.cpp -- the C ABI of liblcgs_hip.so (include/lcgs_hip.h): context, workspace management and
 // the host-side orchestration of the HIP kernels.  No compute happens on the host; if there is no GPU
 // lcgs_create fails with LCGS_ERR_NO_DEVICE -- there is no CPU fallback.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <thread>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -411,7 +416,8 @@ lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx)
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
-        set_last_error("no HIP device available: liblcgs_hip has no CPU path");
+        set_last_error(std::string("no HIP device available (hipGetDeviceCount: ") + hipGetErrorString(e) + ", count " +
+                       std::to_string(count) + "): liblcgs_hip has no CPU path");
         return LCGS_ERR_NO_DEVICE;
     }
     LCGS_REQUIRE(device_id >= 0 && device_id < count, "device_id out of range");
@@ -660,6 +666,130 @@ lcgs_status lcgs_scene_upload(lcgs_context* ctx, int num_gaussians, int sh_degre
     LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // app/main.cpp:223
     return lcgs_scene_bind(ctx, num_gaussians, sh_degree, ctx->owned[0].as<float>(), ctx->owned[1].as<float>(),
                            ctx->owned[2].as<float>(), ctx->owned[3].as<float>(), ctx->owned[4].as<float>());
+}
+
+lcgs_status lcgs_scene_pointers(lcgs_context* ctx, int* num_gaussians, int* sh_degree, const float** d_pos,
+                                const float** d_scale, const float** d_rotq, const float** d_sh, const float** d_opacity)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (num_gaussians) *num_gaussians = ctx->P;
+    if (sh_degree) *sh_degree = ctx->sh_deg;
+    if (d_pos) *d_pos = ctx->pos;
+    if (d_scale) *d_scale = ctx->scale;
+    if (d_rotq) *d_rotq = ctx->rotq;
+    if (d_sh) *d_sh = ctx->sh;
+    if (d_opacity) *d_opacity = ctx->opacity;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_scene_download(lcgs_context* ctx, float* h_pos, float* h_scale, float* h_rotq, float* h_sh,
+                                float* h_opacity)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    const size_t P    = (size_t)ctx->P;
+    const size_t feat = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3;
+    const size_t sizes[5] = { P * 3 * 4, P * 3 * 4, P * 4 * 4, P * feat * 4, P * 4 };
+    const float* src[5]   = { ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity };
+    float*       dst[5]   = { h_pos, h_scale, h_rotq, h_sh, h_opacity };
+    for (int i = 0; i < 5; ++i)
+        if (dst[i] && sizes[i]) LCGS_HIP_CHECK(hipMemcpyAsync(dst[i], src[i], sizes[i], hipMemcpyDeviceToHost, ctx->stream));
+    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return LCGS_OK;
+}
+
+// Scene ingest with the de-interleave and the activations on the device.  The vertex records go
+// to the GPU exactly as they lie in the file -- mmap -> two pinned staging buffers filled by host threads ->
+// async copies -- and k_ply_activate turns each chunk into the five activated arrays while the next chunk is in
+// flight.  The host never touches a float: no 62 column vectors, no scalar activation loops
+// (app/gaussians.cpp:93-168), no second 1.45 GB host copy.
+lcgs_status lcgs_scene_load_ply(lcgs_context* ctx, const char* path, int* num_gaussians)
+{
+    LCGS_REQUIRE(ctx != nullptr && path != nullptr, "NULL argument");
+    if (num_gaussians) *num_gaussians = 0;
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    PlyProbe probe;
+    LCGS_TRY(ply_probe(path, &probe));
+    if (!probe.device_ok) { // ascii, or non-float columns: the general host parser
+        lcgs_scene_host h;
+        LCGS_TRY(lcgs_ply_read(path, &h));
+        lcgs_status s = lcgs_scene_upload(ctx, h.num_gaussians, h.sh_degree, h.pos, h.scale, h.rotq, h.feature, h.opacity);
+        if (num_gaussians) *num_gaussians = h.num_gaussians;
+        lcgs_scene_host_free(&h);
+        return s;
+    }
+    const int64_t N = probe.num_vertices;
+    LCGS_REQUIRE(N < (1 << 30), "too many vertices");
+    const size_t sizes[5] = { (size_t)N * 3 * 4, (size_t)N * 3 * 4, (size_t)N * 4 * 4, (size_t)N * 48 * 4, (size_t)N * 4 };
+    for (int i = 0; i < 5; ++i) LCGS_TRY(ctx->owned[i].ensure(std::max<size_t>(sizes[i], 16)));
+    if (N > 0) {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) {
+            set_last_error(std::string("cannot open ") + path);
+            return LCGS_ERR_IO;
+        }
+        const size_t map_bytes = probe.payload_offset + (size_t)N * probe.stride;
+        void*        map       = mmap(nullptr, map_bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (map == MAP_FAILED) {
+            set_last_error(std::string("cannot map ") + path);
+            return LCGS_ERR_IO;
+        }
+        (void)madvise(map, map_bytes, MADV_SEQUENTIAL);
+        const unsigned char* payload = static_cast<const unsigned char*>(map) + probe.payload_offset;
+        const int64_t        chunk   = std::max<int64_t>(1, ((int64_t)64 << 20) / (int64_t)probe.stride); // records
+        const size_t         cbytes  = (size_t)chunk * probe.stride;
+        unsigned char*       pinned[2] = { nullptr, nullptr };
+        hipEvent_t           done[2]   = { nullptr, nullptr };
+        DeviceBuffer         d_raw[2];
+        lcgs_status          st = LCGS_OK;
+        auto                 cleanup = [&]() {
+            for (int i = 0; i < 2; ++i) {
+                if (pinned[i]) (void)hipHostFree(pinned[i]);
+                if (done[i]) (void)hipEventDestroy(done[i]);
+                d_raw[i].release();
+            }
+            munmap(map, map_bytes);
+        };
+        for (int i = 0; i < 2 && st == LCGS_OK; ++i) {
+            if (hipHostMalloc(reinterpret_cast<void**>(&pinned[i]), cbytes, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess)
+                st = LCGS_ERR_OUT_OF_MEMORY;
+            else
+                st = d_raw[i].ensure(cbytes);
+        }
+        PlyColumns cols;
+        for (int w = 0; w < 59; ++w) cols.offset[w] = probe.column_offset[w];
+        int b = 0;
+        for (int64_t first = 0; first < N && st == LCGS_OK; first += chunk, b ^= 1) {
+            const int64_t count = std::min<int64_t>(chunk, N - first);
+            const size_t  bytes = (size_t)count * probe.stride;
+            if (first >= 2 * chunk && hipEventSynchronize(done[b]) != hipSuccess) st = LCGS_ERR_HIP; // buffer b is free again
+            if (st != LCGS_OK) break;
+            // page cache -> pinned memory with a few threads (one memcpy stream tops out well below PCIe rate)
+            const unsigned char* src = payload + (size_t)first * probe.stride;
+            const int            nt  = 8;
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) {
+                const size_t a = bytes * t / nt, e = bytes * (t + 1) / nt;
+                th.emplace_back([=] { memcpy(pinned[b] + a, src + a, e - a); });
+            }
+            for (auto& x : th) x.join();
+            if (hipMemcpyAsync(d_raw[b].ptr, pinned[b], bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = LCGS_ERR_HIP;
+            launch_ply_activate(d_raw[b].as<unsigned char>(), first, count, (uint32_t)probe.stride, cols,
+                                ctx->owned[0].as<float>(), ctx->owned[1].as<float>(), ctx->owned[2].as<float>(),
+                                ctx->owned[3].as<float>(), ctx->owned[4].as<float>(), ctx->stream);
+            if (hipEventRecord(done[b], ctx->stream) != hipSuccess) st = LCGS_ERR_HIP;
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == LCGS_OK) st = LCGS_ERR_HIP;
+        cleanup();
+        if (st != LCGS_OK) {
+            if (st == LCGS_ERR_HIP) set_last_error("device ingest of the PLY payload failed");
+            return st;
+        }
+    }
+    if (num_gaussians) *num_gaussians = (int)N;
+    return lcgs_scene_bind(ctx, (int)N, 3, ctx->owned[0].as<float>(), ctx->owned[1].as<float>(), ctx->owned[2].as<float>(),
+                           ctx->owned[3].as<float>(), ctx->owned[4].as<float>());
 }
 
 lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, const float bg_color[3],

@@ -1,0 +1,88 @@
+"""`-m gpu`: scene ingest with the de-interleave and the activations on the device against the
+host restatement of read_gs_ply (app/gaussians.cpp:75-171), itself pinned against the reference's happly reader in
+test_oracle_golden.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp_diff(a, b):
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    return np.abs(ai - bi)
+
+
+def _compare(dev_scene, host_scene):
+    # pure copies and the IEEE divide / square root: bit-identical
+    for k in ("pos", "sh", "rotq"):
+        assert np.array_equal(dev_scene[k].view(np.uint32), host_scene[k].reshape(dev_scene[k].shape).view(np.uint32)), k
+    # exp(): device libm vs host libm
+    assert _ulp_diff(dev_scene["scale"], host_scene["scale"].reshape(-1, 3)).max() <= 2
+    assert _ulp_diff(dev_scene["opacity"], host_scene["opacity"].reshape(-1)).max() <= 2
+
+
+def test_device_ingest_matches_host_reader_on_golden_ply(lcgs, golden_dir):
+    path = os.path.join(golden_dir, "tiny_scene.ply")
+    host = lcgs.read_gs_ply(path)
+    r = lcgs.Renderer(lcgs.Context(0))
+    assert r.load_ply(path) == host["pos"].shape[0]
+    _compare(r.download_scene(), host)
+
+
+@pytest.mark.parametrize("P", [0, 1, 63, 64, 65, 100003])
+def test_device_ingest_sizes_and_render(lcgs, tmp_path, P):
+    rng = np.random.default_rng(P + 5)
+    path = str(tmp_path / "s.ply")
+    rot = rng.normal(size=(P, 4)).astype(np.float32)
+    lcgs.write_ply_raw(path, rng.normal(0, 0.6, (P, 3)) + [0, 0, 0.5], rng.normal(0.3, 0.8, (P, 3)),
+                       rng.normal(0, 0.1, (P, 45)), rng.normal(0, 2.5, P), rng.normal(-4.0, 0.8, (P, 3)), rot)
+    host = lcgs.read_gs_ply(path)
+    r = lcgs.Renderer(lcgs.Context(0))
+    assert r.load_ply(path) == P
+    if P == 0:
+        return
+    _compare(r.download_scene(), host)
+    # the loaded scene renders; against the host-loaded scene the image differs only through the <= 2 ulp of exp()
+    cam = lcgs.get_lookat_cam([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1], width=160, height=120)
+    img = torch.zeros(3, 120, 160, device=DEV)
+    n = r.forward(cam, img)
+    r2 = lcgs.Renderer(lcgs.Context(0))
+    r2.upload_scene(host)
+    img2 = torch.zeros(3, 120, 160, device=DEV)
+    n2 = r2.forward(cam, img2)
+    assert abs(n - n2) <= max(2, n2 // 1000)
+    assert (img - img2).abs().max().item() < 5e-3 and (img - img2).abs().mean().item() < 1e-5
+
+
+def test_device_ingest_falls_back_for_ascii(lcgs, tmp_path):
+    path = str(tmp_path / "a.ply")
+    names = (["x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(45)] + ["opacity"] +
+             [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)])
+    rng = np.random.default_rng(2)
+    rows = rng.normal(0, 0.5, (7, len(names))).astype(np.float32)
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 7\n" + "".join(f"property float {n}\n" for n in names) + "end_header\n")
+        for row in rows:
+            f.write(" ".join(repr(float(v)) for v in row) + "\n")
+    host = lcgs.read_gs_ply(path)
+    r = lcgs.Renderer(lcgs.Context(0))
+    assert r.load_ply(path) == 7
+    dev = r.download_scene()
+    for k in ("pos", "sh", "rotq", "scale", "opacity"):
+        assert np.array_equal(dev[k], host[k].reshape(dev[k].shape))  # same host code path
+
+
+def test_device_ingest_errors(lcgs, tmp_path):
+    r = lcgs.Renderer(lcgs.Context(0))
+    with pytest.raises(lcgs.LcgsError):
+        r.load_ply(str(tmp_path / "missing.ply"))
+    bad = str(tmp_path / "bad.ply")
+    open(bad, "w").write("ply\nformat binary_little_endian 1.0\nelement vertex 5\nproperty float x\nend_header\n")
+    with pytest.raises(lcgs.LcgsError):
+        r.load_ply(bad)
