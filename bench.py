@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--ply", type=str, default=os.environ.get("LCGS_BICYCLE_PLY", ""))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-backward", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -226,6 +227,34 @@ def main():
                           "unit": "Msplats/s", "ms_per_step": round(el * 1e3 / args.steps, 4),
                           "grad_allreduce_bytes_per_gpu": 59 * 4 * P if world > 1 else 0,
                           "backward_stages_ms": {k: round(v, 4) for k, v in bwd_stages.items()}}
+
+        # ---- full training-style step: + the optimiser (gradients -> Adam on the raw parameters -> refreshed
+        # activated arrays, lcgs_adam_step), dense and restricted to the splats on screen
+        if not args.no_train_step:
+            raw = {"pos": d["pos"], "scale": torch.log(d["scale"]), "rotq": d["rotq"].clone(), "sh": d["sh"],
+                   "opacity": torch.log(d["opacity"] / (1 - d["opacity"]))}
+            act = {"pos": d["pos"], "scale": d["scale"], "rotq": d["rotq"], "sh": d["sh"], "opacity": d["opacity"]}
+            mom = [{k: torch.zeros_like(t) for k, t in raw.items()} for _ in range(2)]
+            lr = {"pos": 0.0, "sh_dc": 0.0, "sh_rest": 0.0, "opacity": 0.0, "scale": 0.0, "rot": 0.0}  # scene stays put
+            out["train_step"] = {}
+            for mode in ("dense", "visible_only"):
+                def full_step(i):
+                    train_step()
+                    r.adam_step(views, raw, mom[0], mom[1], act, i + 1, lr, visible_only=(mode == "visible_only"))
+                for i in range(2):
+                    full_step(i)
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    full_step(i)
+                barrier()
+                el2 = time.perf_counter() - t0
+                if dist is not None:
+                    tt = torch.tensor([el2], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    el2 = float(tt.item())
+                out["train_step"][mode] = {"value": round(world * P * args.steps / el2 / 1e6, 1), "unit": "Msplats/s",
+                                           "ms_per_step": round(el2 * 1e3 / args.steps, 4)}
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference) on this box's host cores, rank 0, N = 1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -238,6 +238,32 @@ typedef struct lcgs_grads {
 } lcgs_grads;
 LCGS_API lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads);
 
+/* Optimiser step (the reference only names training on its roadmap, doc/roadmap.md:4).
+ * The scene is parameterised as in 3DGS training: raw.pos / raw.sh are the values themselves,
+ * scale = exp(raw.scale), opacity = sigmoid(raw.opacity), rotq = raw.rotq / |raw.rotq|.  One call maps the
+ * gradients w.r.t. the ACTIVATED values (lcgs_render_backward's outputs, possibly summed over views) to the raw
+ * parameters, applies Adam (torch.optim.Adam semantics, per-attribute learning rates, `step` counts from 1) to
+ * raw / m / v in place and rewrites the activated arrays (`activated`; pos and sh may alias raw.pos / raw.sh).
+ * All pointers are device arrays laid out like the scene (3P, 3P, 4P, P*(deg+1)^2*3, P).
+ * visible_only != 0: only the splats that reached the screen in the last lcgs_render_forward of this context are
+ * touched ("sparse Adam").  Enqueues on the context's stream. */
+typedef struct lcgs_params {
+    float* pos;
+    float* scale;
+    float* rotq;
+    float* sh;
+    float* opacity;
+} lcgs_params;
+typedef struct lcgs_adam_config {
+    float lr_pos, lr_sh_dc, lr_sh_rest, lr_opacity, lr_scale, lr_rot;
+    float beta1, beta2, eps;
+    int   step;         /* 1, 2, ... (bias correction) */
+    int   visible_only; /* 0: every splat (dense Adam) */
+} lcgs_adam_config;
+LCGS_API lcgs_status lcgs_adam_step(lcgs_context* ctx, int num_gaussians, int sh_degree, const lcgs_adam_config* cfg,
+                                    const lcgs_grads* grads, const lcgs_params* raw, const lcgs_params* m,
+                                    const lcgs_params* v, const lcgs_params* activated);
+
 /* ------------------------------------------------------------------------------------------
  * Scene ingest / image egress (host side of `render(ply, camera) -> image`)
  * ------------------------------------------------------------------------------------------ */

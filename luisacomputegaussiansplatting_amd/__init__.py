@@ -30,6 +30,7 @@ from .api import (  # noqa: F401
     local_to_world_matrix,
     projection_matrix,
     read_gs_ply,
+    render_autograd,
     synth_scene,
     world_to_local_matrix,
     write_png,

@@ -115,6 +115,17 @@ class _Grads(C.Structure):
                 ("d_dL_dsh", C.c_void_p), ("d_dL_dopacity", C.c_void_p)]
 
 
+class _Params(C.Structure):
+    _fields_ = [("pos", C.c_void_p), ("scale", C.c_void_p), ("rotq", C.c_void_p), ("sh", C.c_void_p),
+                ("opacity", C.c_void_p)]
+
+
+class _AdamConfig(C.Structure):
+    _fields_ = [("lr_pos", C.c_float), ("lr_sh_dc", C.c_float), ("lr_sh_rest", C.c_float), ("lr_opacity", C.c_float),
+                ("lr_scale", C.c_float), ("lr_rot", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("step", C.c_int), ("visible_only", C.c_int)]
+
+
 class _SceneHost(C.Structure):
     _fields_ = [("num_gaussians", C.c_int), ("sh_degree", C.c_int), ("pos", C.POINTER(C.c_float)),
                 ("feature", C.POINTER(C.c_float)), ("opacity", C.POINTER(C.c_float)),
@@ -130,7 +141,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists",
     "lcgs_render_backward", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png",
-    "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download",
+    "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_adam_step",
 ]
 
 
@@ -473,6 +484,52 @@ class Renderer:
 
     def last_lists(self, d_list, d_ranges):
         _check(load_library().lcgs_debug_last_lists(self.ctx._h, _ptr(d_list), _ptr(d_ranges)))
+
+    def adam_step(self, grads: dict, raw: dict, m: dict, v: dict, activated: dict, step: int, lr: dict,
+                  betas=(0.9, 0.999), eps: float = 1e-15, visible_only: bool = False, sh_degree: int = 3):
+        """lcgs_adam_step: gradients w.r.t. the activated values -> Adam on the raw parameters -> refreshed activated
+        arrays.  Every dict has the keys pos / scale / rotq / sh / opacity (device tensors); lr has pos, sh_dc,
+        sh_rest, opacity, scale, rot."""
+        keys = ("pos", "scale", "rotq", "sh", "opacity")
+        P = int(raw["pos"].shape[0])
+        cfg = _AdamConfig(lr["pos"], lr["sh_dc"], lr["sh_rest"], lr["opacity"], lr["scale"], lr["rot"], betas[0], betas[1],
+                          eps, int(step), 1 if visible_only else 0)
+        g = _Grads(*[_ptr(grads[k]) for k in keys])
+        packs = [_Params(*[_ptr(d[k]) for k in keys]) for d in (raw, m, v, activated)]
+        _check(load_library().lcgs_adam_step(self.ctx._h, C.c_int(P), C.c_int(sh_degree), C.byref(cfg), C.byref(g),
+                                             *[C.byref(p) for p in packs]))
+
+
+def render_autograd(renderer: "Renderer", cam: Camera, pos, scale, rotq, sh, opacity, bg=(0.0, 0.0, 0.0),
+                    scale_modifier: float = 1.0):
+    """Differentiable frame for torch: `img = render_autograd(r, cam, pos, scale, rotq, sh, opacity)` (activated
+    parameters, CHW float image); `img.backward(...)` / `torch.autograd.grad` run lcgs_render_backward.  torch is the
+    owner of the tensors and of the autograd graph only; both directions are the HIP kernels."""
+    import torch
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, pos, scale, rotq, sh, opacity):
+            args = [t.detach().contiguous() for t in (pos, scale, rotq, sh, opacity)]
+            renderer.bind_scene(*args)
+            img = torch.empty(3, cam.height, cam.width, device=args[0].device, dtype=torch.float32)
+            n = renderer.forward(cam, img, bg=bg, scale_modifier=scale_modifier, keep_state=True, sync=True)
+            if n == 0:
+                img[:] = torch.tensor(bg, device=img.device).view(3, 1, 1)  # nothing drawn: the image is the background
+            ctx.shapes = [t.shape for t in (pos, scale, rotq, sh, opacity)]
+            ctx.empty = n == 0
+            ctx.save_for_backward(*args)
+            return img
+
+        @staticmethod
+        def backward(ctx, dL_dimg):
+            args = ctx.saved_tensors
+            grads = [torch.zeros_like(t) for t in args]
+            if not ctx.empty:  # uses the state kept by this renderer's last forward: backward follows its forward
+                renderer.backward(dL_dimg.contiguous(), *grads)
+            return tuple(g.view(s) for g, s in zip(grads, ctx.shapes))
+
+    return _Fn.apply(pos, scale, rotq, sh, opacity)
 
 
 # ---------------------------------------------------------------------------------------------- host io

@@ -106,6 +106,18 @@ void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t
                          uint32_t* list_idx, hipStream_t stream);
 
 // longest-list-first tile schedule for the renderers (order[G], a scheduling hint only)
+// optimiser step (train.hip): five attribute arrays each for gradients, raw parameters, Adam moments, activated values
+struct AdamArrays {
+    float *pos, *scale, *rotq, *sh, *opacity;
+};
+struct AdamRates {
+    float pos, sh_dc, sh_rest, opacity, scale, rot;
+};
+// row_list != NULL: only rows row_list[0 .. *d_row_count) are updated (launch sized for row_hint rows)
+void launch_adam_step(int64_t P, int sh_floats, const uint32_t* row_list, const uint32_t* d_row_count, int64_t row_hint,
+                      const AdamArrays& grad, const AdamArrays& raw, const AdamArrays& m, const AdamArrays& v,
+                      const AdamArrays& act, const AdamRates& lr, float beta1, float beta2, float eps, int step,
+                      hipStream_t stream);
 // byte offsets, inside one vertex record, of the 59 wanted float columns (pos3 dc3 rest45 opacity scale3 rot4)
 struct PlyColumns {
     uint32_t offset[59];

@@ -668,6 +668,41 @@ lcgs_status lcgs_scene_upload(lcgs_context* ctx, int num_gaussians, int sh_degre
                            ctx->owned[2].as<float>(), ctx->owned[3].as<float>(), ctx->owned[4].as<float>());
 }
 
+lcgs_status lcgs_adam_step(lcgs_context* ctx, int num_gaussians, int sh_degree, const lcgs_adam_config* cfg,
+                           const lcgs_grads* grads, const lcgs_params* raw, const lcgs_params* m, const lcgs_params* v,
+                           const lcgs_params* activated)
+{
+    LCGS_REQUIRE(ctx && cfg && grads && raw && m && v && activated, "NULL argument");
+    LCGS_REQUIRE(num_gaussians >= 0, "num_gaussians is negative");
+    LCGS_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "sh_degree must be in [0,3]");
+    LCGS_REQUIRE(cfg->step >= 1, "step counts from 1");
+    LCGS_REQUIRE(cfg->beta1 >= 0.0f && cfg->beta1 < 1.0f && cfg->beta2 >= 0.0f && cfg->beta2 < 1.0f, "betas must be in [0,1)");
+    if (num_gaussians == 0) return LCGS_OK;
+    const lcgs_params* packs[4] = { raw, m, v, activated };
+    for (const lcgs_params* p : packs)
+        LCGS_REQUIRE(p->pos && p->scale && p->rotq && p->sh && p->opacity, "NULL device pointer in a parameter pack");
+    LCGS_REQUIRE(grads->d_dL_dpos && grads->d_dL_dscale && grads->d_dL_drotq && grads->d_dL_dsh && grads->d_dL_dopacity,
+                 "NULL gradient pointer");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    const uint32_t* row_list = nullptr;
+    const uint32_t* d_rows   = nullptr;
+    int64_t         hint     = num_gaussians;
+    if (cfg->visible_only) {
+        LCGS_REQUIRE(ctx->last.valid && ctx->P == num_gaussians,
+                     "visible_only needs a forward frame of this scene in this context");
+        row_list = ctx->vis_index.as<uint32_t>();
+        d_rows   = ctx->counts.as<uint32_t>(); // [0] = survivors of the last frame
+        hint     = ctx->hint_V > 0 ? std::min<int64_t>(ctx->hint_V, num_gaussians) : num_gaussians;
+    }
+    auto pack = [](const lcgs_params* p) { return AdamArrays{ p->pos, p->scale, p->rotq, p->sh, p->opacity }; };
+    const AdamArrays g = { grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh, grads->d_dL_dopacity };
+    const AdamRates  lr = { cfg->lr_pos, cfg->lr_sh_dc, cfg->lr_sh_rest, cfg->lr_opacity, cfg->lr_scale, cfg->lr_rot };
+    launch_adam_step(num_gaussians, (sh_degree + 1) * (sh_degree + 1) * 3, row_list, d_rows, hint, g, pack(raw), pack(m),
+                     pack(v), pack(activated), lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->step, ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    return LCGS_OK;
+}
+
 lcgs_status lcgs_scene_pointers(lcgs_context* ctx, int* num_gaussians, int* sh_degree, const float** d_pos,
                                 const float** d_scale, const float** d_rotq, const float** d_sh, const float** d_opacity)
 {

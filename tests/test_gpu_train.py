@@ -1,0 +1,140 @@
+"""`-m gpu`: the optimiser step behind the backward against torch's own autograd + Adam on the CPU,
+and the torch autograd binding of the frame against the oracle backward."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_scene
+from gpu_util import DEV
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("pos", "scale", "rotq", "sh", "opacity")
+LR = {"pos": 1.6e-4, "sh_dc": 2.5e-3, "sh_rest": 1.25e-4, "opacity": 5e-2, "scale": 5e-3, "rot": 1e-3}
+
+
+def _activate(raw):
+    return {"pos": raw["pos"], "scale": torch.exp(raw["scale"]),
+            "rotq": raw["rotq"] / raw["rotq"].norm(dim=1, keepdim=True), "sh": raw["sh"],
+            "opacity": torch.sigmoid(raw["opacity"])}
+
+
+def _torch_reference(raw0, grads_seq, eps):
+    """torch.optim.Adam on the raw parameters, gradients w.r.t. the activated values pushed through autograd."""
+    raw = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in raw0.items()}
+    dc_mask = torch.zeros(48, dtype=torch.float64)
+    dc_mask[:3] = 1.0
+    # SH has two learning rates (dc, rest): two parameter tensors behind one activated array
+    sh_dc = (raw["sh"].detach()[:, :3]).clone().requires_grad_(True)
+    sh_rest = (raw["sh"].detach()[:, 3:]).clone().requires_grad_(True)
+    groups = [{"params": [raw["pos"]], "lr": LR["pos"]}, {"params": [sh_dc], "lr": LR["sh_dc"]},
+              {"params": [sh_rest], "lr": LR["sh_rest"]}, {"params": [raw["opacity"]], "lr": LR["opacity"]},
+              {"params": [raw["scale"]], "lr": LR["scale"]}, {"params": [raw["rotq"]], "lr": LR["rot"]}]
+    opt = torch.optim.Adam(groups, lr=0.0, eps=eps, betas=(0.9, 0.999))
+    for g in grads_seq:
+        opt.zero_grad()
+        act = _activate({**raw, "sh": torch.cat([sh_dc, sh_rest], dim=1)})
+        loss = sum((act[k] * torch.tensor(g[k], dtype=torch.float64)).sum() for k in KEYS)
+        loss.backward()
+        opt.step()
+    out = {**{k: raw[k].detach() for k in KEYS if k != "sh"}, "sh": torch.cat([sh_dc, sh_rest], dim=1).detach()}
+    return {k: v.numpy() for k, v in out.items()}, {k: v.detach().numpy() for k, v in _activate(out).items()}
+
+
+def _raw_scene(rng, P):
+    return {"pos": rng.normal(0, 1, (P, 3)).astype(np.float32), "scale": rng.normal(-4, 1, (P, 3)).astype(np.float32),
+            "rotq": rng.normal(0, 1, (P, 4)).astype(np.float32), "sh": rng.normal(0, 0.3, (P, 48)).astype(np.float32),
+            "opacity": rng.normal(0, 2, P).astype(np.float32)}
+
+
+@pytest.mark.parametrize("P", [1, 257, 20011])
+def test_adam_step_matches_torch(lcgs, P):
+    rng = np.random.default_rng(P)
+    raw0 = _raw_scene(rng, P)
+    grads_seq = [{k: (rng.normal(0, 1, raw0[k].shape) * 10.0 ** rng.uniform(-4, 0)).astype(np.float32) for k in KEYS}
+                 for _ in range(3)]
+    eps = 1e-8
+    ref_raw, ref_act = _torch_reference(raw0, grads_seq, eps)
+    r = lcgs.Renderer(lcgs.Context(0))
+    raw = {k: torch.from_numpy(raw0[k]).to(DEV) for k in KEYS}
+    m = {k: torch.zeros_like(raw[k]) for k in KEYS}
+    v = {k: torch.zeros_like(raw[k]) for k in KEYS}
+    act = {k: t.clone() for k, t in _activate(raw).items()}
+    act["pos"], act["sh"] = raw["pos"], raw["sh"]  # raw == activated: one array
+    for step, g in enumerate(grads_seq, 1):
+        r.adam_step({k: torch.from_numpy(g[k]).to(DEV) for k in KEYS}, raw, m, v, act, step, LR, eps=eps)
+    r.ctx.synchronize()
+    for k in KEYS:
+        a, b = raw[k].cpu().numpy().astype(np.float64), ref_raw[k]
+        assert np.allclose(a, b, rtol=2e-5, atol=2e-6), (k, np.abs(a - b).max())
+        a, b = act[k].cpu().numpy().astype(np.float64), ref_act[k]
+        assert np.allclose(a, b, rtol=2e-5, atol=2e-6), ("activated " + k, np.abs(a - b).max())
+
+
+def test_adam_visible_only_touches_survivors_only(lcgs):
+    rng = np.random.default_rng(3)
+    P = 4000
+    scene = make_scene(rng, P)
+    scene["pos"][:1500] += 100.0  # far outside the frustum: culled
+    raw = {"pos": scene["pos"], "scale": np.log(scene["scale"]), "rotq": scene["rotq"] * 1.7, "sh": scene["sh"],
+           "opacity": np.log(scene["opacity"] / (1 - scene["opacity"]))}
+    raw = {k: torch.from_numpy(np.ascontiguousarray(val, dtype=np.float32)).to(DEV) for k, val in raw.items()}
+    act = {k: t.clone() for k, t in _activate(raw).items()}
+    act["pos"], act["sh"] = raw["pos"], raw["sh"]
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.bind_scene(*[act[k] for k in KEYS])
+    cam = lcgs.get_lookat_cam([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1], width=128, height=96)
+    img = torch.zeros(3, 96, 128, device=DEV)
+    radii = torch.zeros(P, dtype=torch.int32, device=DEV)
+    r.forward(cam, img, radii=radii, keep_state=True)
+    g = {k: torch.zeros_like(raw[k]) for k in KEYS}
+    r.backward(torch.randn(3, 96, 128, device=DEV), *[g[k] for k in KEYS])
+    before = {k: t.clone() for k, t in raw.items()}
+    m = {k: torch.zeros_like(raw[k]) for k in KEYS}
+    v = {k: torch.zeros_like(raw[k]) for k in KEYS}
+    r.adam_step(g, raw, m, v, act, 1, LR, visible_only=True)
+    r.ctx.synchronize()
+    st = r.frame_stats()
+    touched = torch.zeros(P, dtype=torch.bool, device=DEV)
+    for k in KEYS:
+        touched |= (raw[k] != before[k]).reshape(P, -1).any(dim=1)
+    assert not touched[:1500].any()  # culled splats: parameters and moments untouched
+    assert all((m[k][:1500] == 0).all() and (v[k][:1500] == 0).all() for k in KEYS)
+    assert 0 < int(touched.sum()) <= st["num_visible"]
+    # survivors with a non-zero gradient moved, exactly as in the dense step
+    raw_d = {k: before[k].clone() for k in KEYS}
+    act_d = {k: t.clone() for k, t in _activate(raw_d).items()}
+    act_d["pos"], act_d["sh"] = raw_d["pos"], raw_d["sh"]
+    md = {k: torch.zeros_like(raw[k]) for k in KEYS}
+    vd = {k: torch.zeros_like(raw[k]) for k in KEYS}
+    r.adam_step(g, raw_d, md, vd, act_d, 1, LR, visible_only=False)
+    r.ctx.synchronize()
+    vis = (radii > 0)
+    for k in KEYS:
+        assert torch.equal(raw[k][vis], raw_d[k][vis]), k
+
+
+def test_autograd_binding_matches_oracle_backward(lcgs, oracle):
+    rng = np.random.default_rng(8)
+    scene = make_scene(rng, 3000, log_scale=(-3.6, 0.7))
+    W, H = 128, 96
+    pose = ([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1])
+    cam = lcgs.get_lookat_cam(*pose, width=W, height=H)
+    t = {k: torch.from_numpy(scene[k]).to(DEV).requires_grad_(True) for k in KEYS}
+    r = lcgs.Renderer(lcgs.Context(0))
+    img = lcgs.render_autograd(r, cam, *[t[k] for k in KEYS], bg=(0.1, 0.2, 0.3))
+    dL = torch.from_numpy(np.random.default_rng(0).normal(size=(3, H, W)).astype(np.float32)).to(DEV)
+    (img * dL).sum().backward()
+    ref = oracle.render_backward_full(scene, oracle.lookat(*pose, width=W, height=H), dL.cpu().numpy(), bg=(0.1, 0.2, 0.3))
+    for k in KEYS:
+        a, b = t[k].grad.cpu().numpy().astype(np.float64), ref[k].astype(np.float64).reshape(t[k].shape)
+        assert np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30) <= 1e-3, k
+
+
+def test_adam_step_argument_checks(lcgs):
+    r = lcgs.Renderer(lcgs.Context(0))
+    z = {k: torch.zeros(s, device=DEV) for k, s in zip(KEYS, ((4, 3), (4, 3), (4, 4), (4, 48), (4,)))}
+    with pytest.raises(lcgs.LcgsError):
+        r.adam_step(z, z, z, z, z, 0, LR)  # step counts from 1
+    with pytest.raises(lcgs.LcgsError):
+        r.adam_step(z, z, z, z, z, 1, LR, visible_only=True)  # no forward frame in this context
