@@ -198,6 +198,14 @@ LCGS_API lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* c
                                          float scale_modifier, float* d_img, int32_t* d_radii,
                                          int keep_state, int* num_rendered);
 
+/* A batch of views of the bound scene (no counterpart in the reference, whose app renders one
+ * hard-coded camera, app/main.cpp:191-207).  d_imgs[i]: 3*H_i*W_i floats, CHW, for cameras[i].  Enqueues only: the
+ * work is ordered after what is already on the context's stream, and the stream waits for the whole batch; views
+ * alternate between two internal workspaces so that two frames are in flight.  Per-view counters are not returned
+ * (lcgs_get_frame_stats describes the last view rendered by the context itself). */
+LCGS_API lcgs_status lcgs_render_forward_batch(lcgs_context* ctx, int num_views, const lcgs_camera* cameras,
+                                               const float bg_color[3], float scale_modifier, float* const* d_imgs);
+
 /* Per-stage device time of the last lcgs_render_forward / lcgs_render_backward in milliseconds
  * (hipEvent pairs on the context's stream).  Enable with lcgs_set_profiling(ctx, 1). */
 #define LCGS_MAX_STAGES 16

@@ -142,6 +142,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_render_backward", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_adam_step",
+    "lcgs_render_forward_batch",
 ]
 
 
@@ -464,6 +465,15 @@ class Renderer:
                                                   _ptr(img), _ptr(radii), C.c_int(1 if keep_state else 0),
                                                   C.byref(n) if sync else None))
         return n.value if sync else None
+
+    def forward_batch(self, cams, imgs, bg=(0.0, 0.0, 0.0), scale_modifier: float = 1.0):
+        """lcgs_render_forward_batch: one image per camera, two frames in flight; enqueues only."""
+        n = len(cams)
+        assert n == len(imgs)
+        cam_arr = (Camera * n)(*cams)
+        ptrs = (C.c_void_p * n)(*[_ptr(t).value for t in imgs])
+        _check(load_library().lcgs_render_forward_batch(self.ctx._h, C.c_int(n), cam_arr, _f3(bg),
+                                                        C.c_float(scale_modifier), ptrs))
 
     def backward(self, dL_dimg, dpos, dscale, drotq, dsh, dopacity):
         g = _Grads(_ptr(dpos), _ptr(dscale), _ptr(drotq), _ptr(dsh), _ptr(dopacity))

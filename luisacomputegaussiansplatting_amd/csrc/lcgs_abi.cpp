@@ -122,6 +122,11 @@ struct lcgs_context {
     hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_ranges = nullptr, ev_aux_done = nullptr, ev_render = nullptr,
                 ev_counts = nullptr;
     bool        aux_pending = false, counts_pending = false;
+    // lcgs_render_forward_batch: a sibling context (own workspace, own streams) that renders every other view, so
+    // that one view's latency-bound sort chain overlaps the other's bandwidth- and VALU-bound kernels
+    lcgs_context* twin         = nullptr;
+    hipStream_t   twin_stream  = nullptr; // owned
+    hipEvent_t    ev_batch_fork = nullptr, ev_batch_join = nullptr;
     // launch-size hints from the last synchronised frame (live counts stay on the device; larger counts are
     // still handled correctly by chunk striding)
     int64_t hint_V = 0, hint_L = 0;
@@ -459,6 +464,16 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
 {
     if (!ctx) return LCGS_OK;
     (void)hipSetDevice(ctx->device);
+    if (ctx->twin) {
+        (void)lcgs_destroy(ctx->twin);
+        ctx->twin = nullptr;
+    }
+    if (ctx->twin_stream) {
+        (void)hipStreamSynchronize(ctx->twin_stream);
+        (void)hipStreamDestroy(ctx->twin_stream);
+    }
+    for (hipEvent_t ev : { ctx->ev_batch_fork, ctx->ev_batch_join })
+        if (ev) (void)hipEventDestroy(ev);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     DeviceBuffer* bufs[] = { &ctx->recs, &ctx->sortk[0], &ctx->sortk[1], &ctx->sortv[0], &ctx->sortv[1], &ctx->vis_index,
@@ -494,6 +509,10 @@ lcgs_status lcgs_synchronize(lcgs_context* ctx)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
     LCGS_TRY(sync_frame(ctx));
+    if (ctx->twin) {
+        LCGS_TRY(sync_frame(ctx->twin));
+        LCGS_TRY(check_frame_flags(ctx->twin));
+    }
     return check_frame_flags(ctx);
 }
 
@@ -909,6 +928,49 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
     }
     set_last_error("pair buffer growth did not converge");
     return LCGS_ERR_CAPACITY;
+}
+
+// Camera batches.  Views are independent, and a single frame leaves the GPU half idle while its
+// sort chain waits on memory round trips, so the batch alternates between this context and a sibling context with
+// its own workspace and streams: two frames are in flight at any time (measured on the bicycle stand-in: 1250 vs
+// 1110 frames/s; three or four in flight were slower).  Everything is ordered after prior work on the context's
+// stream and the stream waits for the whole batch, so callers see ordinary stream semantics.
+lcgs_status lcgs_render_forward_batch(lcgs_context* ctx, int num_views, const lcgs_camera* cameras,
+                                      const float bg_color[3], float scale_modifier, float* const* d_imgs)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(num_views >= 0, "num_views is negative");
+    if (num_views == 0) return LCGS_OK;
+    LCGS_REQUIRE(cameras != nullptr && d_imgs != nullptr && bg_color != nullptr, "NULL argument");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    const bool two = num_views > 1 && !ctx->profiling && !ctx->use_graph && ctx->P > 0;
+    if (two && !ctx->twin) {
+        LCGS_HIP_CHECK(hipStreamCreateWithFlags(&ctx->twin_stream, hipStreamNonBlocking));
+        LCGS_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_batch_fork, hipEventDisableTiming));
+        LCGS_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_batch_join, hipEventDisableTiming));
+        LCGS_TRY(lcgs_create(ctx->device, ctx->twin_stream, &ctx->twin));
+    }
+    if (two) {
+        lcgs_context* t = ctx->twin;
+        if (t->pos != ctx->pos || t->P != ctx->P || t->sh != ctx->sh || t->sh_deg != ctx->sh_deg)
+            LCGS_TRY(lcgs_scene_bind(t, ctx->P, ctx->sh_deg, ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity));
+        // launch sizes and pair capacity learnt by the synchronised frames of this context serve the sibling too
+        t->hint_V        = std::max(t->hint_V, ctx->hint_V);
+        t->hint_L        = std::max(t->hint_L, ctx->hint_L);
+        t->pair_capacity = std::max(t->pair_capacity, ctx->pair_capacity);
+        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_batch_fork, ctx->stream));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->twin_stream, ctx->ev_batch_fork, 0));
+    }
+    for (int i = 0; i < num_views; ++i) {
+        lcgs_context* target = (two && (i & 1)) ? ctx->twin : ctx;
+        LCGS_REQUIRE(d_imgs[i] != nullptr, "NULL image pointer in the batch");
+        LCGS_TRY(lcgs_render_forward(target, &cameras[i], bg_color, scale_modifier, d_imgs[i], nullptr, 0, nullptr));
+    }
+    if (two) {
+        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_batch_join, ctx->twin_stream));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_batch_join, 0));
+    }
+    return LCGS_OK;
 }
 
 lcgs_status lcgs_set_profiling(lcgs_context* ctx, int enabled)

@@ -179,3 +179,33 @@ def test_fused_tile_list_of_one_depth(lcgs, oracle):
     scene["pos"][:] = scene["pos"][0]
     scene["opacity"] *= 0.02
     _render_both(lcgs, oracle, scene, 128, 96)
+
+
+def test_forward_batch_equals_single_frames(lcgs, oracle):
+    """lcgs_render_forward_batch (two frames in flight on sibling workspaces) == the same views rendered one by one."""
+    rng = np.random.default_rng(31)
+    scene = make_scene(rng, 60000, log_scale=(-4.2, 0.8))
+    r = lcgs.Renderer(lcgs.Context(0))
+    d = upload_scene(scene)
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    cams, sizes = [], [(640, 480), (320, 240), (640, 480), (801, 333), (640, 480)]
+    for k, (w, h) in enumerate(sizes):
+        ang = 0.5 * k
+        cams.append(lcgs.get_lookat_cam([-3 * np.cos(ang), -0.5 + 3 * np.sin(ang), 2.3], [0, 0, 0.5], [0, 0, 1], width=w, height=h))
+    singles = []
+    for cam, (w, h) in zip(cams, sizes):
+        img = torch.zeros(3, h, w, device=DEV)
+        r.forward(cam, img, bg=(0.2, 0.1, 0.0), sync=True)
+        singles.append(img)
+    for rep in range(2):  # second round: the sibling context is warm
+        imgs = [torch.full((3, h, w), -1.0, device=DEV) for (w, h) in sizes]
+        r.forward_batch(cams, imgs, bg=(0.2, 0.1, 0.0))
+        r.ctx.synchronize()
+        for a, b in zip(imgs, singles):
+            assert torch.equal(a, b)
+    # a batch of one, and an empty batch
+    one = [torch.zeros(3, 480, 640, device=DEV)]
+    r.forward_batch(cams[:1], one, bg=(0.2, 0.1, 0.0))
+    r.forward_batch([], [])
+    r.ctx.synchronize()
+    assert torch.equal(one[0], singles[0])
