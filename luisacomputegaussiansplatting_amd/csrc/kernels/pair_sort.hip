@@ -225,7 +225,9 @@ int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
     uint32_t* vb[2] = { vals_a, vals_b };
     int       src = 0, shift = begin_bit;
     for (int p = 0; p < n_pass; ++p) {
-        const int      bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+        // the live bits are split evenly over the passes (13 tile bits: 7 + 6, not 8 + 5): fewer buckets per pass
+        // means longer contiguous runs per bucket in the scatter's stores
+        const int      bits = (end_bit - shift + (n_pass - p) - 1) / (n_pass - p);
         const uint32_t mask = (1u << bits) - 1u;
         hipLaunchKernelGGL(k_hist, dim3((unsigned)blocks), dim3(kThreads), 0, stream, kb[src], d_n, shift, mask, counts);
         hipLaunchKernelGGL(k_rowscan, dim3(kRadix), dim3(kThreads), 0, stream, counts, d_n, totals);
