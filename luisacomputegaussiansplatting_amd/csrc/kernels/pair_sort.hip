@@ -19,13 +19,13 @@ namespace
 
 constexpr int kThreads = 256;
 constexpr int kWaves   = kThreads / 64;
-constexpr int kItems   = 16;
-constexpr int kKPB     = kThreads * kItems; // 4096 keys per chunk
 constexpr int kRadix   = 256;
 
+template <int kItems>
 __global__ void __launch_bounds__(kThreads) k_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
                                                      int shift, uint32_t mask, uint32_t* __restrict__ counts)
 {
+    constexpr int kKPB = kThreads * kItems;
     __shared__ uint32_t s_hist[kRadix];
     const uint32_t n  = *d_n;
     const uint32_t nb = (n + kKPB - 1) / kKPB;
@@ -45,9 +45,11 @@ __global__ void __launch_bounds__(kThreads) k_hist(const uint32_t* __restrict__ 
 }
 
 // one workgroup per digit: counts[d][0..nb) -> exclusive prefix in place; totals[d] = row sum
+template <int kItems>
 __global__ void __launch_bounds__(kThreads) k_rowscan(uint32_t* __restrict__ counts, const uint32_t* __restrict__ d_n,
                                                         uint32_t* __restrict__ totals)
 {
+    constexpr int kKPB = kThreads * kItems;
     __shared__ uint32_t s_wave[kWaves];
     __shared__ uint32_t s_carry;
     const uint32_t n    = *d_n;
@@ -77,6 +79,7 @@ __global__ void __launch_bounds__(kThreads) k_rowscan(uint32_t* __restrict__ cou
     if (threadIdx.x == 0) totals[blockIdx.x] = s_carry;
 }
 
+template <int kItems>
 __global__ void __launch_bounds__(kThreads) k_scatter(const uint32_t* __restrict__ keys_in,
                                                         const uint32_t* __restrict__ vals_in,
                                                         uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
@@ -84,6 +87,7 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const uint32_t* __restrict
                                                         int bits, const uint32_t* __restrict__ row_excl,
                                                         const uint32_t* __restrict__ totals)
 {
+    constexpr int kKPB = kThreads * kItems;
     __shared__ uint32_t s_wave_hist[kWaves][kRadix];
     __shared__ uint32_t s_global_delta[kRadix];
     __shared__ uint32_t s_digit_base[kRadix];
@@ -200,18 +204,25 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const uint32_t* __restrict
 
 } // namespace
 
+// Keys per chunk.  Small inputs (the survivors' depth sort, V ~ 2.4 M) are latency-bound: more, smaller chunks keep
+// more workgroups in flight (2048: 0.149 ms vs 0.158 ms at 4096, 0.189 ms at 1024); the pair partition (L ~ 7.5 M) prefers the longer
+// per-bucket runs of 4096-key chunks (0.141 vs 0.150 ms).
+constexpr int64_t kSmallInput = 4 << 20;
+inline int items_for(int64_t expected) { return expected <= kSmallInput ? 8 : 16; }
+
 size_t pair_sort_ws_bytes(int64_t n_cap)
 {
-    const int64_t nb = (n_cap + kKPB - 1) / kKPB;
+    const int64_t nb = (n_cap + kThreads * 8 - 1) / (kThreads * 8); // the smaller chunk size bounds the table
     return (size_t)(nb * kRadix + kRadix + 64) * sizeof(uint32_t);
 }
 
-// Ping-pongs a -> b -> a ...; returns 0 if the result ended in (keys_a, vals_a), 1 if in (keys_b, vals_b).
-// grid_hint: expected element count (bounds the launch; larger live counts are handled by chunk striding).
-int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, const uint32_t* d_n,
-                         int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws_, hipStream_t stream)
+namespace
 {
-    if (n_cap <= 0) return 0;
+template <int kItems>
+int run_pair_sort(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, const uint32_t* d_n,
+                  int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws_, hipStream_t stream)
+{
+    constexpr int kKPB = kThreads * kItems;
     const int n_pass = (end_bit - begin_bit + 7) / 8;
     if (n_pass <= 0) return 0;
     const int64_t nb_cap = (n_cap + kKPB - 1) / kKPB;
@@ -229,14 +240,26 @@ int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
         // means longer contiguous runs per bucket in the scatter's stores
         const int      bits = (end_bit - shift + (n_pass - p) - 1) / (n_pass - p);
         const uint32_t mask = (1u << bits) - 1u;
-        hipLaunchKernelGGL(k_hist, dim3((unsigned)blocks), dim3(kThreads), 0, stream, kb[src], d_n, shift, mask, counts);
-        hipLaunchKernelGGL(k_rowscan, dim3(kRadix), dim3(kThreads), 0, stream, counts, d_n, totals);
-        hipLaunchKernelGGL(k_scatter, dim3((unsigned)blocks), dim3(kThreads), 0, stream, kb[src], vb[src], kb[src ^ 1],
-                           vb[src ^ 1], d_n, shift, mask, bits, counts, totals);
+        hipLaunchKernelGGL(k_hist<kItems>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, kb[src], d_n, shift, mask, counts);
+        hipLaunchKernelGGL(k_rowscan<kItems>, dim3(kRadix), dim3(kThreads), 0, stream, counts, d_n, totals);
+        hipLaunchKernelGGL(k_scatter<kItems>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, kb[src], vb[src],
+                           kb[src ^ 1], vb[src ^ 1], d_n, shift, mask, bits, counts, totals);
         src ^= 1;
         shift += bits;
     }
     return src;
+}
+} // namespace
+
+// Ping-pongs a -> b -> a ...; returns 0 if the result ended in (keys_a, vals_a), 1 if in (keys_b, vals_b).
+// grid_hint: expected element count (bounds the launch; larger live counts are handled by chunk striding).
+int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, const uint32_t* d_n,
+                         int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws_, hipStream_t stream)
+{
+    if (n_cap <= 0) return 0;
+    if (items_for(grid_hint > 0 ? grid_hint : n_cap) == 8)
+        return run_pair_sort<8>(keys_a, keys_b, vals_a, vals_b, d_n, n_cap, grid_hint, begin_bit, end_bit, ws_, stream);
+    return run_pair_sort<16>(keys_a, keys_b, vals_a, vals_b, d_n, n_cap, grid_hint, begin_bit, end_bit, ws_, stream);
 }
 
 } // namespace lcgs
