@@ -256,9 +256,12 @@ def main():
         # ---- full training-style step: + the optimiser (gradients -> Adam on the raw parameters -> refreshed
         # activated arrays, lcgs_adam_step), dense and restricted to the splats on screen
         if not args.no_train_step:
-            raw = {"pos": d["pos"], "scale": torch.log(d["scale"]), "rotq": d["rotq"].clone(), "sh": d["sh"],
-                   "opacity": torch.log(d["opacity"] / (1 - d["opacity"]))}
-            act = {"pos": d["pos"], "scale": d["scale"], "rotq": d["rotq"], "sh": d["sh"], "opacity": d["opacity"]}
+            # (on a copy of the scene: exp(log(s)) is not s to the last bit, and the parity block below compares the
+            # frame of the pristine scene)
+            act = {k: d[k].clone() for k in ("pos", "scale", "rotq", "sh", "opacity")}
+            raw = {"pos": act["pos"], "scale": torch.log(act["scale"]), "rotq": act["rotq"].clone(), "sh": act["sh"],
+                   "opacity": torch.log(act["opacity"] / (1 - act["opacity"]))}
+            r.bind_scene(act["pos"], act["scale"], act["rotq"], act["sh"], act["opacity"])
             mom = [{k: torch.zeros_like(t) for k, t in raw.items()} for _ in range(2)]
             lr = {"pos": 0.0, "sh_dc": 0.0, "sh_rest": 0.0, "opacity": 0.0, "scale": 0.0, "rot": 0.0}  # scene stays put
             out["train_step"] = {}
@@ -280,6 +283,8 @@ def main():
                     el2 = float(tt.item())
                 out["train_step"][mode] = {"value": round(world * P * args.steps / el2 / 1e6, 1), "unit": "Msplats/s",
                                            "ms_per_step": round(el2 * 1e3 / args.steps, 4)}
+            r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+            del act, raw, mom
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference) on this box's host cores, rank 0, N = 1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -298,6 +303,7 @@ def main():
                 break
         out["cpu_baseline"] = {"value": round(frames / el, 4), "unit": "frames/s", "cores": o.get_threads(), "kind": "port",
                                "sample": f"{frames} full frame(s) of the same workload ({P} splats, {W}x{H}) in {el:.1f} s"}
+        n_rendered = r.forward(cam, img, sync=True)  # the frame the oracle is compared with
         gi = img.cpu().numpy()
         diff = np.abs(gi - ref["img"]).max(axis=0)
         out["parity"] = {"num_rendered_equal": bool(ref["num_rendered"] == n_rendered),
