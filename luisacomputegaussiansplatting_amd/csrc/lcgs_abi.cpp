@@ -522,6 +522,7 @@ lcgs_status lcgs_sh_process(lcgs_context* ctx, int num_points, const float* d_po
                             const float* d_sh, float* d_color, int level, int channel)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
     LCGS_REQUIRE(num_points >= 0, "num_points < 0");
     LCGS_REQUIRE(camera != nullptr, "camera is NULL");
     LCGS_REQUIRE(level >= -1 && level <= 3, "SH level must be in [-1,3]");
@@ -540,6 +541,7 @@ lcgs_status lcgs_project_forward(lcgs_context* ctx, int num_gaussians, const flo
                                  float* d_depth, const lcgs_camera* camera, int use_focal)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
     LCGS_REQUIRE(num_gaussians >= 0, "num_gaussians < 0");
     LCGS_TRY(check_camera(camera));
     if (num_gaussians == 0) return LCGS_OK;
@@ -554,6 +556,7 @@ lcgs_status lcgs_project_forward(lcgs_context* ctx, int num_gaussians, const flo
 lcgs_status lcgs_inclusive_sum_u32(lcgs_context* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
     LCGS_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "n out of range");
     if (n == 0) return LCGS_OK;
     LCGS_REQUIRE(d_in && d_out, "NULL device pointer");
@@ -568,6 +571,7 @@ lcgs_status lcgs_sort_pairs_u64_u32(lcgs_context* ctx, const uint64_t* d_keys_in
                                     int end_bit)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
     LCGS_REQUIRE(n >= 0 && n < ((int64_t)1 << 30), "n out of range");
     LCGS_REQUIRE(begin_bit >= 0 && end_bit <= 64 && begin_bit <= end_bit, "bad bit range");
     if (n == 0) return LCGS_OK;
@@ -589,6 +593,7 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
                                     const lcgs_tile_output* output, int use_focal, int* num_rendered)
 {
     LCGS_REQUIRE(ctx && accel && input && output, "NULL argument");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
     if (num_rendered) *num_rendered = 0;
     const int P = input->num_gaussians;
     LCGS_REQUIRE(P >= 0, "num_gaussians < 0");
@@ -670,6 +675,7 @@ lcgs_status lcgs_scene_upload(lcgs_context* ctx, int num_gaussians, int sh_degre
                               const float* h_scale, const float* h_rotq, const float* h_sh, const float* h_opacity)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
     LCGS_REQUIRE(num_gaussians >= 0 && num_gaussians < (1 << 30), "num_gaussians out of range");
     LCGS_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "sh_degree must be in [0,3]");
     if (num_gaussians > 0) LCGS_REQUIRE(h_pos && h_scale && h_rotq && h_sh && h_opacity, "NULL host pointer");
@@ -740,6 +746,7 @@ lcgs_status lcgs_scene_download(lcgs_context* ctx, float* h_pos, float* h_scale,
                                 float* h_opacity)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
     const size_t P    = (size_t)ctx->P;
     const size_t feat = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3;
     const size_t sizes[5] = { P * 3 * 4, P * 3 * 4, P * 4 * 4, P * feat * 4, P * 4 };
@@ -851,6 +858,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
                                 int* num_rendered)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
     LCGS_TRY(check_camera(camera));
     LCGS_REQUIRE(bg_color != nullptr, "bg_color is NULL");
     LCGS_REQUIRE(d_img != nullptr, "d_img is NULL");
@@ -1006,6 +1014,7 @@ lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* out)
 lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t* d_ranges)
 {
     LCGS_REQUIRE(ctx && ctx->last.valid, "no frame rendered yet");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
     LCGS_TRY(sync_frame(ctx));
     const uint32_t L = ctx->h_counts[2];
     if (d_list && L)
@@ -1022,6 +1031,7 @@ lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t*
 lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads)
 {
     LCGS_REQUIRE(ctx && d_dL_dimg && grads, "NULL argument");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
     LCGS_REQUIRE(grads->d_dL_dpos && grads->d_dL_dscale && grads->d_dL_drotq && grads->d_dL_dsh && grads->d_dL_dopacity,
                  "NULL gradient buffer");
     if (!ctx->last.valid || !ctx->last.has_state) {
