@@ -192,10 +192,27 @@ def main():
                        "write_bytes": k["write_bytes"], "source": "profiles/r01_pmc_traffic.json"}
     except Exception:
         traffic = None
+    # The dominant kernel is VALU-issue-bound, not HBM-bound: beside the mandatory HBM figures, its VALU issue
+    # utilisation = wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/r01_pmc_sq.txt) x the average issue
+    # cost of the compositing loop's instruction mix on this part (3.27 cycles: tools/microbench/issue_rates.hip,
+    # profiles/r01_issue_rates.txt) / (1024 SIMDs x launch duration x 2.4 GHz).
+    valu = None
+    try:
+        import ast
+        for line in open(os.path.join(ROOT, "profiles", "r01_pmc_sq.txt")):
+            if line.startswith(stage_kernel.get(dominant, "?") + " "):
+                insts = ast.literal_eval(line[line.index("{"):])["SQ_INSTS_VALU"]
+                if data == "synthetic" and P == P_BICYCLE and (W, H) == (1920, 1080) and dominant == "render":
+                    valu = {"wave_instructions_per_launch": insts, "avg_issue_cycles_per_instruction": 3.27,
+                            "simd_cycles_available": round(1024 * dom_ms * 1e-3 * 2.4e9),
+                            "frac": round(insts * 3.27 / (1024 * dom_ms * 1e-3 * 2.4e9), 4)}
+    except Exception:
+        valu = None
     roofline = {"kernel": stage_kernel.get(dominant, dominant), "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": stage_bytes.get(dominant, 0), "avg_launch_ms": round(dom_ms, 4),
-                "note": "the dominant kernel (per-tile compositing) is VALU/SALU-issue bound, not HBM bound; see DESIGN.md 4"}
+                "valu_issue": valu,
+                "note": "the dominant kernel (per-tile compositing) is VALU-issue bound, not HBM bound; see DESIGN.md 4"}
     frame_bytes = algorithmic_bytes(P, V, Lref, G, W, H)
     frame_gbs = frame_bytes / (ms_per_step * 1e-3) / 1e9
 
