@@ -206,12 +206,43 @@ int main(int argc, char** argv)
         }
         std::vector<float>   h_img((size_t)W * H * 3);
         std::vector<uint8_t> rgb((size_t)W * H * 3);
-        for (size_t vi = 0; vi < views.size(); ++vi) {
-            lcgs::Camera cam = lcgs::get_lookat_cam(views[vi].pos, views[vi].target, views[vi].up);
-            if (views[vi].fov > 0.0f) cam.fov = views[vi].fov;
+        auto make_camera = [&](const View& v) {
+            lcgs::Camera cam = lcgs::get_lookat_cam(v.pos, v.target, v.up);
+            if (v.fov > 0.0f) cam.fov = v.fov;
             cam.aspect_ratio = (float)W / (float)H;
             cam.width        = (int)W;
             cam.height       = (int)H;
+            return cam;
+        };
+        auto save_view = [&](const float* d_view, size_t vi) {
+            if (hipMemcpy(h_img.data(), d_view, h_img.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) die("D2H copy failed");
+            lcgs_image_to_rgb8((int)W, (int)H, h_img.data(), rgb.data());
+            std::string img_name = out_dir + "/" + ply_name + "_" + backend +
+                                   (cameras_file.empty() ? std::string() : "_" + std::to_string(vi)) + ".png";
+            lcgs::check(lcgs_write_png(img_name.c_str(), (int)W, (int)H, rgb.data()));
+            printf("result saved in %s\n", img_name.c_str());
+        };
+        if (!cameras_file.empty() && path == "fused" && exp_N == 1) {
+            // the whole camera file as one batch: two frames in flight (lcgs_render_forward_batch)
+            lcgs::Scene               scene(device);
+            std::vector<lcgs::Camera> cams;
+            std::vector<lcgs::Buffer<float>> imgs;
+            std::vector<float*>       img_ptrs;
+            for (const View& v : views) {
+                cams.push_back(make_camera(v));
+                imgs.emplace_back((size_t)W * H * 3);
+                img_ptrs.push_back(imgs.back().data());
+            }
+            auto t0 = std::chrono::steady_clock::now();
+            scene.render_batch(cams, img_ptrs, bg);
+            device.synchronize();
+            double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            printf("exp time: %.3f ms\nfps: %.2f with %zu views in one batch\n", ms, 1000.0 * views.size() / ms, views.size());
+            for (size_t vi = 0; vi < views.size(); ++vi) save_view(img_ptrs[vi], vi);
+            views.clear(); // done
+        }
+        for (size_t vi = 0; vi < views.size(); ++vi) {
+            lcgs::Camera cam = make_camera(views[vi]);
             int  num_rendered = 0;
             auto t0           = std::chrono::steady_clock::now();
             if (path == "stage") {
@@ -228,14 +259,9 @@ int main(int argc, char** argv)
                                                     it + 1 == exp_N ? &num_rendered : nullptr));
             }
             device.synchronize();
-            if (hipMemcpy(h_img.data(), d_img.data(), h_img.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) die("D2H copy failed");
             double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             printf("num_rendered: %d\nexp time: %.3f ms\nfps: %.2f with test N %d\n", num_rendered, ms, 1000.0 / (ms / exp_N), exp_N);
-            lcgs_image_to_rgb8((int)W, (int)H, h_img.data(), rgb.data());
-            std::string img_name = out_dir + "/" + ply_name + "_" + backend +
-                                   (cameras_file.empty() ? std::string() : "_" + std::to_string(vi)) + ".png";
-            lcgs::check(lcgs_write_png(img_name.c_str(), (int)W, (int)H, rgb.data()));
-            printf("result saved in %s\n", img_name.c_str());
+            save_view(d_img.data(), vi);
         }
         if (synth.empty() && !on_device) lcgs_scene_host_free(&sc);
     } catch (const lcgs::Error& e) {

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "lcgs_hip.h"
 
@@ -185,6 +186,49 @@ public:
         lcgs_tile_output o{ output.height, output.width, output.target_img.ptr, output.radii.ptr, nullptr, nullptr };
         check(lcgs_tile_splat_forward(m_dev->ctx(), &a, &i, &o, use_focal ? 1 : 0, &num_rendered));
         return num_rendered;
+    }
+
+private:
+    Device* m_dev = nullptr;
+};
+
+// ---- beyond the reference's three operators: the fused frame and what surrounds it (no counterpart classes in the
+// reference; thin wrappers over the C ABI so that C++ callers do not have to drop to it) ----
+class Scene
+{
+public:
+    explicit Scene(Device& device) : m_dev(&device) {}
+    // read_gs_ply + upload with the de-interleave / activations on the device (app/gaussians.cpp:75-171,
+    // app/main.cpp:180-186,216-223)
+    int load_ply(const std::string& path)
+    {
+        int n = 0;
+        check(lcgs_scene_load_ply(m_dev->ctx(), path.c_str(), &n));
+        return n;
+    }
+    void bind(int num_gaussians, BufferView<float> pos, BufferView<float> scale, BufferView<float> rotq,
+              BufferView<float> sh, BufferView<float> opacity, int sh_degree = 3)
+    {
+        check(lcgs_scene_bind(m_dev->ctx(), num_gaussians, sh_degree, pos.ptr, scale.ptr, rotq.ptr, sh.ptr, opacity.ptr));
+    }
+    // one frame (app/main.cpp:266-308 in one submission); returns the reference's num_rendered
+    int render(const Camera& cam, BufferView<float> img, const float bg[3], float scale_modifier = 1.0f,
+               bool keep_state = false)
+    {
+        int n = 0;
+        check(lcgs_render_forward(m_dev->ctx(), &cam, bg, scale_modifier, img.ptr, nullptr, keep_state ? 1 : 0, &n));
+        return n;
+    }
+    // a batch of views, two frames in flight; enqueues only
+    void render_batch(const std::vector<Camera>& cams, const std::vector<float*>& imgs, const float bg[3],
+                      float scale_modifier = 1.0f)
+    {
+        if (cams.size() != imgs.size()) throw Error(LCGS_ERR_INVALID_ARG, "render_batch: cams/imgs size mismatch");
+        check(lcgs_render_forward_batch(m_dev->ctx(), (int)cams.size(), cams.data(), bg, scale_modifier, imgs.data()));
+    }
+    void backward(BufferView<float> dL_dimg, const lcgs_grads& grads)
+    {
+        check(lcgs_render_backward(m_dev->ctx(), dL_dimg.ptr, &grads));
     }
 
 private:
