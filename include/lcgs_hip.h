@@ -187,6 +187,13 @@ LCGS_API lcgs_status lcgs_scene_pointers(lcgs_context* ctx, int* num_gaussians, 
                                          const float** d_scale, const float** d_rotq, const float** d_sh,
                                          const float** d_opacity);
 
+/* Opt-in reduced-precision SH for the fused forward.  enable != 0 converts the bound degree-3
+ * coefficients to an f16 copy owned by the context (on the device; call again after the coefficients change, and
+ * after every lcgs_scene_bind); the per-frame colour pass then reads 96 instead of 192 bytes per on-screen splat.
+ * f16 keeps 11 significant bits, so this path is outside the 1e-4 image bar by construction (observed: ~1e-3);
+ * the backward and the stage-level operators keep reading the f32 coefficients.  enable == 0 returns to f32. */
+LCGS_API lcgs_status lcgs_scene_use_half_sh(lcgs_context* ctx, int enable);
+
 /* Copies the bound scene to host arrays sized like lcgs_scene_upload's inputs (NULL outputs are skipped). */
 LCGS_API lcgs_status lcgs_scene_download(lcgs_context* ctx, float* h_pos, float* h_scale, float* h_rotq, float* h_sh,
                                          float* h_opacity);

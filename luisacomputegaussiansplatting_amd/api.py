@@ -142,7 +142,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_render_backward", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_adam_step",
-    "lcgs_render_forward_batch",
+    "lcgs_render_forward_batch", "lcgs_scene_use_half_sh",
 ]
 
 
@@ -447,6 +447,10 @@ class Renderer:
         _check(load_library().lcgs_scene_load_ply(self.ctx._h, path.encode(), C.byref(n)))
         self.P, self.sh_degree, self._keep = n.value, 3, []
         return n.value
+
+    def use_half_sh(self, enable: bool = True):
+        """lcgs_scene_use_half_sh: opt-in f16 copy of the SH coefficients for the fused forward (outside the 1e-4 bar)."""
+        _check(load_library().lcgs_scene_use_half_sh(self.ctx._h, C.c_int(1 if enable else 0)))
 
     def download_scene(self) -> dict:
         """Host copies of the bound scene (same keys and shapes as read_gs_ply)."""

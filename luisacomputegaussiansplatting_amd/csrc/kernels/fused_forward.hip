@@ -23,6 +23,8 @@
 //   k_get_ranges_u32     per-tile [start,end) (gs_tile_splatter/shader.cpp:71-100).
 //
 // Element counts (V, L) never leave the device: kernels read them from d_counts.
+#include <hip/hip_fp16.h>
+
 #include "launch.hpp"
 
 namespace lcgs
@@ -271,6 +273,9 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
 // 12 consecutive lanes cover one splat's 192 B, so an instruction touches ~8 lines -- parks them in LDS with a
 // 13-float4 row pitch (208 B: conflict-free for the per-lane ds_read_b128 that follows) and each lane then
 // reads its own 48 coefficients back.
+// HALF: the coefficients come from the opt-in f16 copy (lcgs_scene_use_half_sh; 96-byte rows, six 16-byte chunks per
+// splat, 7-chunk LDS pitch) and are widened to f32 before the same evaluation.
+template <bool HALF>
 __global__ void __launch_bounds__(kThreads)
 k_build_records(int sh_deg, CamParams cp, float scale_modifier, const FrameParams* __restrict__ fpp,
                 const float* __restrict__ pos,
@@ -278,7 +283,7 @@ k_build_records(int sh_deg, CamParams cp, float scale_modifier, const FrameParam
                 const float* __restrict__ opacity, const uint32_t* __restrict__ vis_index,
                 const uint32_t* __restrict__ d_counts, SplatRecord* __restrict__ recs)
 {
-    __shared__ float4 s_sh[kThreads / 64][64 * 13];
+    __shared__ float4 s_sh[kThreads / 64][64 * (HALF ? 7 : 13)];
 
     if (fpp) {
         cp             = fpp->cp;
@@ -292,7 +297,25 @@ k_build_records(int sh_deg, CamParams cp, float scale_modifier, const FrameParam
     const int      idx   = (int)vis_index[valid ? vid : V - 1];
     const bool     staged = sh_deg == 3 && ((reinterpret_cast<uintptr_t>(sh) & 15) == 0);
 
-    if (staged) {
+    if (HALF) {
+        const uint32_t wave_first = blk * kThreads + wave * 64;
+        const uint32_t nvalid     = wave_first < V ? ((V - wave_first) < 64u ? (V - wave_first) : 64u) : 0u;
+        float4         q[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const uint32_t c    = (uint32_t)i * 64u + lane;
+            const uint32_t slot = c / 6u, part = c - slot * 6u;
+            const int      sidx = __shfl(idx, (int)slot, 64);
+            q[i]                = make_float4(0, 0, 0, 0);
+            if (slot < nvalid) q[i] = reinterpret_cast<const float4*>(reinterpret_cast<const __half*>(sh) + (size_t)sidx * 48)[part];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const uint32_t c    = (uint32_t)i * 64u + lane;
+            const uint32_t slot = c / 6u, part = c - slot * 6u;
+            s_sh[wave][slot * 7u + part] = q[i];
+        }
+    } else if (staged) {
         const uint32_t wave_first = blk * kThreads + wave * 64;
         const uint32_t nvalid     = wave_first < V ? ((V - wave_first) < 64u ? (V - wave_first) : 64u) : 0u;
         float4         q[12];
@@ -319,7 +342,13 @@ k_build_records(int sh_deg, CamParams cp, float scale_modifier, const FrameParam
 
     // colour (sh_preprocessor.cpp:27-157)
     float raw[3];
-    if (staged) {
+    if (HALF) {
+        float4 q[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) q[k] = s_sh[wave][lane * 7 + k];
+        const __half* h = reinterpret_cast<const __half*>(q);
+        sh_to_color(3, cp.campos, px, py, pz, [&](int k, int c) { return __half2float(h[k * 3 + c]); }, raw);
+    } else if (staged) {
         float4 q[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) q[k] = s_sh[wave][lane * 13 + k];
@@ -583,10 +612,30 @@ void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const
 void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const FrameParams* d_fp,
                           const float* pos,
                           const float* scale, const float* rotq, const float* sh, const float* opacity,
-                          const uint32_t* vis_index, const uint32_t* d_counts, SplatRecord* recs, hipStream_t stream)
+                          const uint32_t* vis_index, const uint32_t* d_counts, SplatRecord* recs, hipStream_t stream,
+                          const uint16_t* sh_half)
 {
-    hipLaunchKernelGGL(k_build_records, dim3(blocks_for(P_cap)), dim3(kThreads), 0, stream, sh_deg, cp,
-                       scale_modifier, d_fp, pos, scale, rotq, sh, opacity, vis_index, d_counts, recs);
+    if (sh_half)
+        hipLaunchKernelGGL(k_build_records<true>, dim3(blocks_for(P_cap)), dim3(kThreads), 0, stream, sh_deg, cp,
+                           scale_modifier, d_fp, pos, scale, rotq, reinterpret_cast<const float*>(sh_half), opacity,
+                           vis_index, d_counts, recs);
+    else
+        hipLaunchKernelGGL(k_build_records<false>, dim3(blocks_for(P_cap)), dim3(kThreads), 0, stream, sh_deg, cp,
+                           scale_modifier, d_fp, pos, scale, rotq, sh, opacity, vis_index, d_counts, recs);
+}
+
+__global__ void __launch_bounds__(256) k_sh_to_half(int64_t n, const float* __restrict__ src, __half* __restrict__ dst)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dst[i] = __float2half_rn(src[i]);
+}
+
+void launch_sh_to_half(int64_t n, const float* src, uint16_t* dst, hipStream_t stream)
+{
+    if (n <= 0) return;
+    int64_t b = (n + 255) / 256;
+    if (b > 65536) b = 65536;
+    hipLaunchKernelGGL(k_sh_to_half, dim3((unsigned)b), dim3(256), 0, stream, n, src, reinterpret_cast<__half*>(dst));
 }
 
 

@@ -99,7 +99,9 @@ int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
 void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const FrameParams* d_fp,
                           const float* pos,
                           const float* scale, const float* rotq, const float* sh, const float* opacity,
-                          const uint32_t* vis_index, const uint32_t* d_counts, SplatRecord* recs, hipStream_t stream);
+                          const uint32_t* vis_index, const uint32_t* d_counts, SplatRecord* recs, hipStream_t stream,
+                          const uint16_t* sh_half = nullptr); // non-NULL: f16 coefficient rows (degree 3 only)
+void launch_sh_to_half(int64_t n, const float* src, uint16_t* dst, hipStream_t stream);
 void launch_get_ranges_u32(int64_t L_cap, uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
                            const uint32_t* scan_error_flag, hipStream_t stream);
 void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t* list_vid, const uint32_t* vis_index,

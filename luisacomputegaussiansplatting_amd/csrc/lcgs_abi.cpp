@@ -82,6 +82,8 @@ struct lcgs_context {
     int          P = 0, sh_deg = 3;
     const float *pos = nullptr, *scale = nullptr, *rotq = nullptr, *sh = nullptr, *opacity = nullptr;
     DeviceBuffer owned[5];
+    DeviceBuffer sh_half;            // opt-in f16 copy of sh for the fused forward's colour pass (lcgs_scene_use_half_sh)
+    bool         use_half_sh = false;
 
     // workspace of the fused frame
     DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws[2], counts, sort_ws,
@@ -327,7 +329,8 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
     }
     launch_build_records((int)std::min<int64_t>(P, hint_V), ctx->sh_deg, cp, scale_modifier, d_fp, ctx->pos, ctx->scale,
-                         ctx->rotq, ctx->sh, ctx->opacity, ctx->vis_index.as<uint32_t>(), d_counts, recs, rec_stream);
+                         ctx->rotq, ctx->sh, ctx->opacity, ctx->vis_index.as<uint32_t>(), d_counts, recs, rec_stream,
+                         ctx->use_half_sh ? ctx->sh_half.as<uint16_t>() : nullptr);
     if (overlap) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
     LCGS_TRY(mark(ctx, "build_records"));
 
@@ -465,6 +468,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
     if (!ctx) return LCGS_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->twin) {
+        ctx->twin->sh_half.ptr = nullptr; // borrowed from this context
         (void)lcgs_destroy(ctx->twin);
         ctx->twin = nullptr;
     }
@@ -480,7 +484,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
                              &ctx->rects, &ctx->rects_sorted, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
                              &ctx->pairv[1], &ctx->zero_ws[0], &ctx->zero_ws[1], &ctx->counts, &ctx->sort_ws,
                              &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order[0], &ctx->tile_order[1], &ctx->st_keys_tmp,
-                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar };
+                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& b : ctx->owned) b.release();
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
@@ -668,6 +672,7 @@ lcgs_status lcgs_scene_bind(lcgs_context* ctx, int num_gaussians, int sh_degree,
     ctx->sh      = d_sh;
     ctx->opacity = d_opacity;
     ctx->last.valid = false;
+    ctx->use_half_sh = false; // a new scene: the f16 copy (if any) is stale
     return LCGS_OK;
 }
 
@@ -739,6 +744,25 @@ lcgs_status lcgs_scene_pointers(lcgs_context* ctx, int* num_gaussians, int* sh_d
     if (d_rotq) *d_rotq = ctx->rotq;
     if (d_sh) *d_sh = ctx->sh;
     if (d_opacity) *d_opacity = ctx->opacity;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_scene_use_half_sh(lcgs_context* ctx, int enable)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!enable) {
+        ctx->use_half_sh = false;
+        return LCGS_OK;
+    }
+    LCGS_REQUIRE(ctx->pos != nullptr || ctx->P == 0, "no scene bound");
+    LCGS_REQUIRE(ctx->sh_deg == 3, "the f16 coefficient path exists for sh_degree 3 only");
+    const int64_t n = (int64_t)ctx->P * 48;
+    LCGS_TRY(ctx->sh_half.ensure(std::max<size_t>((size_t)n * 2, 16)));
+    launch_sh_to_half(n, ctx->sh, ctx->sh_half.as<uint16_t>(), ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    ctx->use_half_sh = true;
+    if (ctx->twin) ctx->twin->use_half_sh = false; // the sibling of a camera batch re-binds; see below
     return LCGS_OK;
 }
 
@@ -962,6 +986,12 @@ lcgs_status lcgs_render_forward_batch(lcgs_context* ctx, int num_views, const lc
         lcgs_context* t = ctx->twin;
         if (t->pos != ctx->pos || t->P != ctx->P || t->sh != ctx->sh || t->sh_deg != ctx->sh_deg)
             LCGS_TRY(lcgs_scene_bind(t, ctx->P, ctx->sh_deg, ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity));
+        t->use_half_sh = false;
+        if (ctx->use_half_sh) { // the sibling reads the same f16 copy (not owned: never grown or freed through it)
+            t->sh_half.ptr   = ctx->sh_half.ptr;
+            t->sh_half.bytes = 0;
+            t->use_half_sh   = true;
+        }
         // launch sizes and pair capacity learnt by the synchronised frames of this context serve the sibling too
         t->hint_V        = std::max(t->hint_V, ctx->hint_V);
         t->hint_L        = std::max(t->hint_L, ctx->hint_L);

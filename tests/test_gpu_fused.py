@@ -209,3 +209,36 @@ def test_forward_batch_equals_single_frames(lcgs, oracle):
     r.forward_batch([], [])
     r.ctx.synchronize()
     assert torch.equal(one[0], singles[0])
+
+
+def test_half_precision_sh_is_opt_in_and_close(lcgs, oracle):
+    """lcgs_scene_use_half_sh: f16 coefficient rows for the colour pass -- close to, but by
+    construction not within 1e-4 of, the f32 frame; switching it off restores the f32 frame bit for bit."""
+    rng = np.random.default_rng(41)
+    scene = make_scene(rng, 50000, log_scale=(-4.2, 0.8))
+    r = lcgs.Renderer(lcgs.Context(0))
+    d = upload_scene(scene)
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    cam = lcgs.get_lookat_cam(*POSE, width=640, height=480)
+    ref = torch.zeros(3, 480, 640, device=DEV)
+    n_ref = r.forward(cam, ref)
+    r.use_half_sh(True)
+    half = torch.zeros(3, 480, 640, device=DEV)
+    n_half = r.forward(cam, half)
+    assert n_half == n_ref  # geometry is untouched
+    err = (half - ref).abs()
+    assert 0.0 < err.max().item() < 5e-3 and err.mean().item() < 2e-4
+    # camera batches read the same f16 copy
+    imgs = [torch.zeros(3, 480, 640, device=DEV) for _ in range(3)]
+    r.forward_batch([cam] * 3, imgs)
+    r.ctx.synchronize()
+    assert all(torch.equal(i, half) for i in imgs)
+    r.use_half_sh(False)
+    again = torch.zeros(3, 480, 640, device=DEV)
+    r.forward(cam, again)
+    assert torch.equal(again, ref)
+    # a re-bind drops the copy
+    r.use_half_sh(True)
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    r.forward(cam, again)
+    assert torch.equal(again, ref)
