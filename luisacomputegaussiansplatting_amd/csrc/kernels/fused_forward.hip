@@ -12,7 +12,7 @@
 //                        (decoupled look-back across workgroups, 8-byte self-validating status words).
 //   k_build_records      one DENSE pass over the V survivors: 192-byte SH fetch + colour (the dominant
 //                        stream, paid only for splats that reach the screen) -> packed 48-byte records.
-//   depth sort           32-bit radix sort of the V survivors by depth bits (radix_sort.hip) -- the low
+//   depth sort           32-bit radix sort of the V survivors by depth bits (pair_sort.hip) -- the low
 //                        32 bits of the reference's 64-bit key, sorted BEFORE duplication, on V ~ L/5 items.
 //   k_expand_*           pruned tile counts in depth order -> pair offsets -> wave-cooperative, load-balanced
 //                        duplication: every 64 consecutive output pairs are written by 64 consecutive lanes

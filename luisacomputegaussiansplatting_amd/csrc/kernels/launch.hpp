@@ -30,30 +30,6 @@ void   launch_inclusive_sum_u32(const uint32_t* in, uint32_t* out, int64_t n, vo
 void   launch_inclusive_sum_u32_dyn(const uint32_t* in, uint32_t* out, int64_t n_cap, const uint32_t* d_n, void* temp,
                                     hipStream_t stream);
 
-// ---- radix_sort.hip : stable LSD radix sort of (key, u32 value) pairs over key bits [begin, end) ----
-// Result always lands in keys_out/vals_out.  keys_in/vals_in are clobbered when more than one pass runs
-// (they serve as the ping-pong partner); pass tmp buffers of n elements to keep the inputs intact.
-size_t sort_temp_bytes(int64_t n);
-void   launch_sort_pairs_u64(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, int64_t n,
-                             int begin_bit, int end_bit, void* temp, hipStream_t stream);
-void   launch_sort_pairs_u32(uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, int64_t n,
-                             int begin_bit, int end_bit, void* temp, hipStream_t stream);
-// Variants whose element count lives in device memory (*d_n <= n_cap): the whole frame can be
-// enqueued without a host round trip.
-void launch_sort_pairs_u32_dyn(uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
-                               const uint32_t* d_n, int64_t n_cap, int begin_bit, int end_bit, void* temp,
-                               hipStream_t stream);
-
-// Input-preserving form (inputs must not alias out/tmp); the last pass lands in (keys_out, vals_out).
-void launch_sort_pairs_u64_preserve(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
-                                    uint32_t* vals_out, uint64_t* keys_tmp, uint32_t* vals_tmp, int64_t n, int begin_bit,
-                                    int end_bit, void* temp, hipStream_t stream);
-
-// Ping-pong form: passes alternate a -> b -> a ...; returns 0 if the result ended in (keys_a, vals_a), 1 if in b.
-int launch_sort_pairs_u32_pingpong(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                                   const uint32_t* d_n, int64_t n_cap, int begin_bit, int end_bit, void* temp,
-                                   hipStream_t stream);
-
 // ---- render.hip : per-tile front-to-back compositing (gs_tile_splatter/shader.cpp:171-288) ----
 // Reference-layout inputs (means_2d[2P] pixel, conic[3P], opacity[P], color[3P]).
 void launch_render_forward_aos(const CamParams& cp, const float bg[3], const uint32_t* ranges,
@@ -96,6 +72,11 @@ size_t pair_sort_ws_bytes(int64_t n_cap);
 // ping-pongs a -> b -> a ...; returns 0 if the result ended in (keys_a, vals_a), 1 if in (keys_b, vals_b)
 int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, const uint32_t* d_n,
                          int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws, hipStream_t stream);
+// stage-level 64-bit sort on the same kernels: n host-known, inputs intact, (keys_tmp, vals_tmp) = scratch of n elements,
+// ws = pair_sort_ws_bytes(n)
+void launch_pair_sort_u64_preserve(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
+                                   uint32_t* vals_out, uint64_t* keys_tmp, uint32_t* vals_tmp, int64_t n, int begin_bit,
+                                   int end_bit, void* ws, hipStream_t stream);
 void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const FrameParams* d_fp,
                           const float* pos,
                           const float* scale, const float* rotq, const float* sh, const float* opacity,

@@ -1,7 +1,7 @@
-// pair_sort.hip -- the stable LSD radix sort of (u32 key, u32 value) pairs used twice per fused frame
-// (survivors by depth bits; pairs by tile id).  Same role as radix_sort.hip (lcpp DeviceRadixSort, call site
-// lcgs/src/gs_tile_splatter/impl.cpp:135-143) but with the element count read from device memory and three
-// launches per digit instead of five:
+// pair_sort.hip -- the stable LSD radix sort of (key, u32 value) pairs: u32 keys twice per fused frame (survivors by
+// depth bits; pairs by tile id, element count read from device memory), u64 keys for the stage-level operator and
+// the exported primitive (lcpp DeviceRadixSort::SortPairs<ulong, uint>, call site
+// lcgs/src/gs_tile_splatter/impl.cpp:135-143).  Three launches per digit:
 //   k_hist     per-chunk digit counts -> counts[digit][chunk]            (reads the keys)
 //   k_rowscan  one workgroup per digit: exclusive scan of its row + the row total
 //   k_scatter  wave64-ballot stable ranking, LDS staging into chunk-sorted order, coalesced runs out;
@@ -21,13 +21,15 @@ constexpr int kThreads = 256;
 constexpr int kWaves   = kThreads / 64;
 constexpr int kRadix   = 256;
 
-template <int kItems>
-__global__ void __launch_bounds__(kThreads) k_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
-                                                     int shift, uint32_t mask, uint32_t* __restrict__ counts)
+// d_n == NULL: the element count is the host-known n_host (stage-level callers)
+template <int kItems, typename K>
+__global__ void __launch_bounds__(kThreads) k_hist(const K* __restrict__ keys, const uint32_t* __restrict__ d_n,
+                                                     uint32_t n_host, int shift, uint32_t mask,
+                                                     uint32_t* __restrict__ counts)
 {
     constexpr int kKPB = kThreads * kItems;
     __shared__ uint32_t s_hist[kRadix];
-    const uint32_t n  = *d_n;
+    const uint32_t n  = d_n ? *d_n : n_host;
     const uint32_t nb = (n + kKPB - 1) / kKPB;
     for (uint32_t chunk = blockIdx.x; chunk < nb; chunk += gridDim.x) {
         s_hist[threadIdx.x] = 0;
@@ -36,7 +38,7 @@ __global__ void __launch_bounds__(kThreads) k_hist(const uint32_t* __restrict__ 
 #pragma unroll 4
         for (int r = 0; r < kItems; ++r) {
             const uint32_t i = base + r * kThreads + threadIdx.x;
-            if (i < n) atomicAdd(&s_hist[(keys[i] >> shift) & mask], 1u);
+            if (i < n) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & mask], 1u);
         }
         __syncthreads();
         counts[(size_t)threadIdx.x * nb + chunk] = s_hist[threadIdx.x];
@@ -47,12 +49,12 @@ __global__ void __launch_bounds__(kThreads) k_hist(const uint32_t* __restrict__ 
 // one workgroup per digit: counts[d][0..nb) -> exclusive prefix in place; totals[d] = row sum
 template <int kItems>
 __global__ void __launch_bounds__(kThreads) k_rowscan(uint32_t* __restrict__ counts, const uint32_t* __restrict__ d_n,
-                                                        uint32_t* __restrict__ totals)
+                                                        uint32_t n_host, uint32_t* __restrict__ totals)
 {
     constexpr int kKPB = kThreads * kItems;
     __shared__ uint32_t s_wave[kWaves];
     __shared__ uint32_t s_carry;
-    const uint32_t n    = *d_n;
+    const uint32_t n    = d_n ? *d_n : n_host;
     const uint32_t nb   = (n + kKPB - 1) / kKPB;
     uint32_t*      row  = counts + (size_t)blockIdx.x * nb;
     const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -79,11 +81,12 @@ __global__ void __launch_bounds__(kThreads) k_rowscan(uint32_t* __restrict__ cou
     if (threadIdx.x == 0) totals[blockIdx.x] = s_carry;
 }
 
-template <int kItems>
-__global__ void __launch_bounds__(kThreads) k_scatter(const uint32_t* __restrict__ keys_in,
+template <int kItems, typename K>
+__global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys_in,
                                                         const uint32_t* __restrict__ vals_in,
-                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                        const uint32_t* __restrict__ d_n, int shift, uint32_t mask,
+                                                        K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                        const uint32_t* __restrict__ d_n, uint32_t n_host, int shift,
+                                                        uint32_t mask,
                                                         int bits, const uint32_t* __restrict__ row_excl,
                                                         const uint32_t* __restrict__ totals)
 {
@@ -92,10 +95,10 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const uint32_t* __restrict
     __shared__ uint32_t s_global_delta[kRadix];
     __shared__ uint32_t s_digit_base[kRadix];
     __shared__ uint32_t s_scan[kWaves];
-    __shared__ uint32_t s_keys[kKPB];
+    __shared__ K        s_keys[kKPB];
     __shared__ uint32_t s_vals[kKPB];
 
-    const uint32_t n  = *d_n;
+    const uint32_t n  = d_n ? *d_n : n_host;
     const uint32_t nb = (n + kKPB - 1) / kKPB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (blockIdx.x >= nb) return;
@@ -127,15 +130,16 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const uint32_t* __restrict
         for (int w = 0; w < kWaves; ++w) s_wave_hist[w][tid] = 0;
         __syncthreads();
 
-        uint32_t key[kItems], rank[kItems];
+        K        key[kItems];
+        uint32_t rank[kItems];
         volatile uint32_t* my_hist = s_wave_hist[wave];
         // ---- per-wave stable ranking, 64 keys per round in memory order
 #pragma unroll
         for (int r = 0; r < kItems; ++r) {
             const uint32_t i     = wave_base + r * 64 + lane;
             const bool     valid = i < n;
-            key[r]               = valid ? keys_in[i] : 0u;
-            const uint32_t d     = (key[r] >> shift) & mask;
+            key[r]               = valid ? keys_in[i] : (K)0;
+            const uint32_t d     = (uint32_t)(key[r] >> shift) & mask;
             unsigned long long peers = __ballot(valid);
             for (int b = 0; b < bits; ++b) {
                 const bool               bit = (d >> b) & 1u;
@@ -184,7 +188,7 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const uint32_t* __restrict
         for (int r = 0; r < kItems; ++r) {
             const uint32_t i = wave_base + r * 64 + lane;
             if (i < n) {
-                const uint32_t d   = (key[r] >> shift) & mask;
+                const uint32_t d   = (uint32_t)(key[r] >> shift) & mask;
                 const uint32_t pos = s_wave_hist[wave][d] + rank[r];
                 s_keys[pos]        = key[r];
                 s_vals[pos]        = vals_in[i];
@@ -193,8 +197,8 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const uint32_t* __restrict
         __syncthreads();
 #pragma unroll 4
         for (uint32_t i = tid; i < in_block; i += kThreads) {
-            const uint32_t k   = s_keys[i];
-            const uint32_t dst = s_global_delta[(k >> shift) & mask] + i;
+            const K        k   = s_keys[i];
+            const uint32_t dst = s_global_delta[(uint32_t)(k >> shift) & mask] + i;
             keys_out[dst]      = k;
             vals_out[dst]      = s_vals[i];
         }
@@ -218,13 +222,13 @@ size_t pair_sort_ws_bytes(int64_t n_cap)
 
 namespace
 {
-template <int kItems>
-int run_pair_sort(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, const uint32_t* d_n,
-                  int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws_, hipStream_t stream)
+// pass p reads (src_k[p], src_v[p]) and writes (dst_k[p], dst_v[p])
+template <int kItems, typename K>
+void run_passes(const K* const* src_k, const uint32_t* const* src_v, K* const* dst_k, uint32_t* const* dst_v, int n_pass,
+                const uint32_t* d_n, int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws_,
+                hipStream_t stream)
 {
-    constexpr int kKPB = kThreads * kItems;
-    const int n_pass = (end_bit - begin_bit + 7) / 8;
-    if (n_pass <= 0) return 0;
+    constexpr int kKPB   = kThreads * kItems;
     const int64_t nb_cap = (n_cap + kKPB - 1) / kKPB;
     uint32_t*     counts = reinterpret_cast<uint32_t*>(ws_);
     uint32_t*     totals = counts + nb_cap * kRadix;
@@ -232,22 +236,20 @@ int run_pair_sort(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t
     int64_t       blocks = (hint + kKPB - 1) / kKPB;
     if (blocks > nb_cap) blocks = nb_cap;
     if (blocks < 1) blocks = 1;
-    uint32_t* kb[2] = { keys_a, keys_b };
-    uint32_t* vb[2] = { vals_a, vals_b };
-    int       src = 0, shift = begin_bit;
+    const uint32_t n_host = (uint32_t)n_cap;
+    int            shift  = begin_bit;
     for (int p = 0; p < n_pass; ++p) {
         // the live bits are split evenly over the passes (13 tile bits: 7 + 6, not 8 + 5): fewer buckets per pass
         // means longer contiguous runs per bucket in the scatter's stores
         const int      bits = (end_bit - shift + (n_pass - p) - 1) / (n_pass - p);
         const uint32_t mask = (1u << bits) - 1u;
-        hipLaunchKernelGGL(k_hist<kItems>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, kb[src], d_n, shift, mask, counts);
-        hipLaunchKernelGGL(k_rowscan<kItems>, dim3(kRadix), dim3(kThreads), 0, stream, counts, d_n, totals);
-        hipLaunchKernelGGL(k_scatter<kItems>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, kb[src], vb[src],
-                           kb[src ^ 1], vb[src ^ 1], d_n, shift, mask, bits, counts, totals);
-        src ^= 1;
+        hipLaunchKernelGGL((k_hist<kItems, K>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, src_k[p], d_n, n_host,
+                           shift, mask, counts);
+        hipLaunchKernelGGL(k_rowscan<kItems>, dim3(kRadix), dim3(kThreads), 0, stream, counts, d_n, n_host, totals);
+        hipLaunchKernelGGL((k_scatter<kItems, K>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, src_k[p], src_v[p],
+                           dst_k[p], dst_v[p], d_n, n_host, shift, mask, bits, counts, totals);
         shift += bits;
     }
-    return src;
 }
 } // namespace
 
@@ -257,9 +259,53 @@ int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
                          int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws_, hipStream_t stream)
 {
     if (n_cap <= 0) return 0;
+    const int n_pass = (end_bit - begin_bit + 7) / 8;
+    if (n_pass <= 0) return 0;
+    const uint32_t* sk[8];
+    const uint32_t* sv[8];
+    uint32_t*       dk[8];
+    uint32_t*       dv[8];
+    uint32_t*       kb[2] = { keys_a, keys_b };
+    uint32_t*       vb[2] = { vals_a, vals_b };
+    for (int p = 0; p < n_pass; ++p) {
+        sk[p] = kb[p & 1];
+        sv[p] = vb[p & 1];
+        dk[p] = kb[(p & 1) ^ 1];
+        dv[p] = vb[(p & 1) ^ 1];
+    }
     if (items_for(grid_hint > 0 ? grid_hint : n_cap) == 8)
-        return run_pair_sort<8>(keys_a, keys_b, vals_a, vals_b, d_n, n_cap, grid_hint, begin_bit, end_bit, ws_, stream);
-    return run_pair_sort<16>(keys_a, keys_b, vals_a, vals_b, d_n, n_cap, grid_hint, begin_bit, end_bit, ws_, stream);
+        run_passes<8, uint32_t>(sk, sv, dk, dv, n_pass, d_n, n_cap, grid_hint, begin_bit, end_bit, ws_, stream);
+    else
+        run_passes<16, uint32_t>(sk, sv, dk, dv, n_pass, d_n, n_cap, grid_hint, begin_bit, end_bit, ws_, stream);
+    return n_pass & 1;
+}
+
+// The stage-level sort (lcpp DeviceRadixSort::SortPairs<ulong, uint>, call site gs_tile_splatter/impl.cpp:135-143):
+// n host-known pairs, inputs left intact, result in (keys_out, vals_out); (keys_tmp, vals_tmp) is scratch of n elements.
+void launch_pair_sort_u64_preserve(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
+                                   uint32_t* vals_out, uint64_t* keys_tmp, uint32_t* vals_tmp, int64_t n, int begin_bit,
+                                   int end_bit, void* ws_, hipStream_t stream)
+{
+    if (n <= 0) return;
+    const int n_pass = (end_bit - begin_bit + 7) / 8;
+    if (n_pass <= 0) { // nothing to sort on: the result is a copy
+        (void)hipMemcpyAsync(keys_out, keys_in, (size_t)n * 8, hipMemcpyDeviceToDevice, stream);
+        (void)hipMemcpyAsync(vals_out, vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, stream);
+        return;
+    }
+    const uint64_t* sk[8];
+    const uint32_t* sv[8];
+    uint64_t*       dk[8];
+    uint32_t*       dv[8];
+    // the last pass must land in `out`: destinations alternate backwards from it
+    for (int p = 0; p < n_pass; ++p) {
+        const bool to_out = ((n_pass - 1 - p) & 1) == 0;
+        dk[p]             = to_out ? keys_out : keys_tmp;
+        dv[p]             = to_out ? vals_out : vals_tmp;
+        sk[p]             = p == 0 ? keys_in : dk[p - 1];
+        sv[p]             = p == 0 ? vals_in : dv[p - 1];
+    }
+    run_passes<8, uint64_t>(sk, sv, dk, dv, n_pass, nullptr, n, n, begin_bit, end_bit, ws_, stream);
 }
 
 } // namespace lcgs

@@ -584,10 +584,10 @@ lcgs_status lcgs_sort_pairs_u64_u32(lcgs_context* ctx, const uint64_t* d_keys_in
                  "in-place sort is not supported");
     LCGS_TRY(ctx->st_keys_tmp.ensure((size_t)n * 8));
     LCGS_TRY(ctx->st_vals_tmp.ensure((size_t)n * 4));
-    LCGS_TRY(ctx->st_sort_temp.ensure(sort_temp_bytes(n)));
-    launch_sort_pairs_u64_preserve(d_keys_in, d_vals_in, d_keys_out, d_vals_out, ctx->st_keys_tmp.as<uint64_t>(),
-                                   ctx->st_vals_tmp.as<uint32_t>(), n, begin_bit, end_bit, ctx->st_sort_temp.ptr,
-                                   ctx->stream);
+    LCGS_TRY(ctx->st_sort_temp.ensure(pair_sort_ws_bytes(n)));
+    launch_pair_sort_u64_preserve(d_keys_in, d_vals_in, d_keys_out, d_vals_out, ctx->st_keys_tmp.as<uint64_t>(),
+                                  ctx->st_vals_tmp.as<uint32_t>(), n, begin_bit, end_bit, ctx->st_sort_temp.ptr,
+                                  ctx->stream);
     LCGS_HIP_CHECK(hipGetLastError());
     return LCGS_OK;
 }
@@ -640,10 +640,10 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
     const int tile_bits = std::max(1, ceil_log2_u32(cp.grid_x * cp.grid_y));
     LCGS_TRY(ctx->st_keys_tmp.ensure((size_t)L * 8));
     LCGS_TRY(ctx->st_vals_tmp.ensure((size_t)L * 4));
-    LCGS_TRY(ctx->st_sort_temp.ensure(sort_temp_bytes(L)));
-    launch_sort_pairs_u64_preserve(accel->point_list_keys_unsorted, accel->point_list_unsorted, accel->point_list_keys,
-                                   accel->point_list, ctx->st_keys_tmp.as<uint64_t>(), ctx->st_vals_tmp.as<uint32_t>(),
-                                   L, 0, 32 + tile_bits, ctx->st_sort_temp.ptr, st);
+    LCGS_TRY(ctx->st_sort_temp.ensure(pair_sort_ws_bytes(L)));
+    launch_pair_sort_u64_preserve(accel->point_list_keys_unsorted, accel->point_list_unsorted, accel->point_list_keys,
+                                  accel->point_list, ctx->st_keys_tmp.as<uint64_t>(), ctx->st_vals_tmp.as<uint32_t>(),
+                                  L, 0, 32 + tile_bits, ctx->st_sort_temp.ptr, st);
     const size_t G = (size_t)cp.grid_x * cp.grid_y;
     LCGS_HIP_CHECK(hipMemsetAsync(accel->ranges, 0, G * 2 * 4, st)); // impl.cpp:147
     launch_get_ranges_u64(L, accel->point_list_keys, accel->ranges, st); // impl.cpp:150-156
