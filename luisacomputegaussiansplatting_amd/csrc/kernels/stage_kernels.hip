@@ -15,16 +15,47 @@ namespace
 constexpr int kThreads = 256;
 
 // shad_sh_process (lcgs/src/sh_preprocessor.cpp:159-166) + mp_compute_color_from_sh (:27-157)
+// Degree 3 (the only degree the reference's app uses): a wave's 64 consecutive splats own 12 KiB of contiguous
+// coefficients, fetched as 12 fully coalesced 16-byte loads per lane into an LDS slab with a 13-chunk row pitch
+// (conflict-free for the per-lane 16-byte reads that follow); other degrees / unaligned buffers read lane-wise.
 __global__ void __launch_bounds__(kThreads) k_sh_process(int P, int deg, CamParams cp, const float* __restrict__ pos,
                                                            const float* __restrict__ sh, float* __restrict__ color)
 {
-    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    __shared__ float4 s_sh[kThreads / 64][64 * 13];
+    const int  idx    = blockIdx.x * kThreads + threadIdx.x;
+    const int  lane   = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool staged = deg == 3 && ((reinterpret_cast<uintptr_t>(sh) & 15) == 0);
+    if (staged) {
+        const int64_t first = (int64_t)blockIdx.x * kThreads + wave * 64; // first splat of this wave
+        const int64_t rows  = first < P ? (P - first < 64 ? P - first : 64) : 0;
+        const float4* src   = reinterpret_cast<const float4*>(sh + (size_t)first * 48);
+        float4        q[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int c = i * 64 + lane; // chunk c of the wave's slab = row c / 12, part c % 12
+            q[i]        = c < rows * 12 ? src[c] : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int c = i * 64 + lane;
+            s_sh[wave][(c / 12) * 13 + (c % 12)] = q[i];
+        }
+        __builtin_amdgcn_wave_barrier(); // a wave reads only what it wrote
+    }
     if (idx >= P) return;
-    const int    feat_dim = (deg + 1) * (deg + 1);
-    const float* s        = sh + (size_t)idx * feat_dim * 3;
-    const float  px = pos[3 * (size_t)idx + 0], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
-    float        raw[3];
-    sh_to_color(deg, cp.campos, px, py, pz, [&](int k, int c) { return s[k * 3 + c]; }, raw);
+    const float px = pos[3 * (size_t)idx + 0], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
+    float       raw[3];
+    if (staged) {
+        float4 q[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) q[k] = s_sh[wave][lane * 13 + k];
+        const float* f = reinterpret_cast<const float*>(q);
+        sh_to_color(3, cp.campos, px, py, pz, [&](int k, int c) { return f[k * 3 + c]; }, raw);
+    } else {
+        const int    feat_dim = (deg + 1) * (deg + 1);
+        const float* s        = sh + (size_t)idx * feat_dim * 3;
+        sh_to_color(deg, cp.campos, px, py, pz, [&](int k, int c) { return s[k * 3 + c]; }, raw);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) color[3 * (size_t)idx + c] = clamp_(raw[c], 0.0f, 1.0f); // :153
 }
