@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--no-backward", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--no-batch", action="store_true")
+    ap.add_argument("--no-stage-path", action="store_true")
     ap.add_argument("--half-sh", action="store_true", help="also time the opt-in f16 SH colour pass")
     args = ap.parse_args()
 
@@ -160,6 +161,43 @@ def main():
                      "unit": "frames/s", "ms_per_step": round(el_p * 1e3 / args.steps, 4),
                      "images_equal": bool(torch.equal(imgs[0], imgs[1]))}
 
+    # ---- the drop-in boundary itself: the reference's three operators in its own call order (app/main.cpp:266-308)
+    # on the same frame -- SHProcessor.process, GSProjector.forward, GSTileSplatter.forward (which synchronises once
+    # per frame for num_rendered, like impl.cpp:106-107).  Informational: `value` is the fused frame.
+    stage_path = None
+    if not args.no_stage_path:
+        shp, prj, spl = L.SHProcessor(), L.GSProjector(), L.GSTileSplatter()
+        for op in (shp, prj, spl):
+            op.create(ctx)
+        z = lambda *sh_, dt=torch.float32: torch.zeros(*sh_, dtype=dt, device=dev)
+        Lcap = 20_000_000  # app/main.cpp:245
+        G_ = ((W + 15) // 16) * ((H + 15) // 16)
+        color, means, covs, depth = z(P, 3), z(P, 2), z(P, 3), z(P)
+        accel = L.GSTileSplatterAccelProxy(z(P, dt=torch.int32), z(P, dt=torch.int32), z(Lcap, dt=torch.int64),
+                                           z(Lcap, dt=torch.int32), z(Lcap, dt=torch.int64), z(Lcap, dt=torch.int32),
+                                           z(2 * G_, dt=torch.int32))
+        radii_s, img_s = z(P, dt=torch.int32), z(3, H, W)
+
+        def stage_frame():
+            shp.process(L.GPUPointsProxy(P, 3, d["pos"]), cam, d["sh"], color, 3, 3)
+            prj.forward(L.GSProjectorInputProxy(P, d["pos"], d["scale"], d["rotq"], 1.0),
+                        L.GSProjectorOutputProxy(means, covs, depth), cam)
+            return spl.forward(accel, L.GSTileSplatterInputProxy(P, (0.0, 0.0, 0.0), means, depth, covs, color, d["opacity"]),
+                               L.GSSplatForwardOutputProxy(H, W, img_s, radii_s))
+        n_stage = 0
+        for _ in range(max(1, args.warmup)):
+            n_stage = stage_frame()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            stage_frame()
+        barrier()
+        el_s = time.perf_counter() - t0
+        stage_path = {"value": round(world * args.steps / el_s, 2), "unit": "frames/s",
+                      "ms_per_step": round(el_s * 1e3 / args.steps, 4), "num_rendered": int(n_stage),
+                      "max_abs_diff_vs_fused": float((img_s - img).abs().max().item())}
+        del accel, color, means, covs, depth, radii_s, img_s
+
     # ---- opt-in f16 SH coefficients for the colour pass (outside the 1e-4 bar, never `value`)
     half_sh = None
     if args.half_sh:
@@ -247,6 +285,8 @@ def main():
                            "unit": "GB/s", "frac": round(frame_gbs / HBM_PEAK_GBS, 4)},
         "stages_ms": {k: round(v, 4) for k, v in acc.items()},
     }
+    if stage_path is not None:
+        out["stage_path"] = stage_path
     if half_sh is not None:
         out["half_sh"] = half_sh
     if pipelined is not None:
