@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
                                                            const uint32_t* __restrict__ n_contrib,
                                                            const float* __restrict__ dL_dimg,
                                                            float* __restrict__ grads2d,
-                                                           const uint32_t* __restrict__ tile_order)
+                                                           const uint32_t* __restrict__ tile_order,
+                                                           const uint8_t* __restrict__ strip_masks)
 {
     __shared__ float4             s_a[256]; // mean.x, mean.y, conic.x, conic.y
     __shared__ float4             s_b[256]; // conic.z, opacity, r, g
@@ -234,16 +235,23 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
         float    c = 0.0f, t = -1.0f;
         uint32_t vid = 0, kmask = 0;
         if (have) {
-            vid             = point_list[range_start + e];
-            const float4* p = reinterpret_cast<const float4*>(recs + vid);
-            a = p[0];                                           // mx, my, ca, cb
-            b = p[1];                                           // cc, opacity, r, g
-            c = reinterpret_cast<const float*>(recs + vid)[8];  // b
-            t = (2.0f * __logf(255.0f * b.y)) * 1.0001f + 2e-4f;
+            vid = point_list[range_start + e];
+            // the forward kept every entry's strip bits: entries that reach no strip are not even fetched
+            const bool known = strip_masks != nullptr;
+            if (known) kmask = strip_masks[range_start + e];
+            if (!known || kmask != 0u) {
+                const float4* p = reinterpret_cast<const float4*>(recs + vid);
+                a = p[0];                                           // mx, my, ca, cb
+                b = p[1];                                           // cc, opacity, r, g
+                c = reinterpret_cast<const float*>(recs + vid)[8];  // b
+                t = (2.0f * __logf(255.0f * b.y)) * 1.0001f + 2e-4f;
+            }
+            if (!known) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float y0 = ry0 + 4.0f * k;
-                if (splat_may_touch_rect(a.x, a.y, a.z, a.w, b.x, t, rx0, y0, rx1, y0 + 3.0f)) kmask |= 1u << k;
+                for (int k = 0; k < 4; ++k) {
+                    const float y0 = ry0 + 4.0f * k;
+                    if (splat_may_touch_rect(a.x, a.y, a.z, a.w, b.x, t, rx0, y0, rx1, y0 + 3.0f)) kmask |= 1u << k;
+                }
             }
         }
         __syncthreads(); // previous round fully flushed
@@ -640,11 +648,12 @@ void launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t s
 
 void launch_render_backward(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                             const SplatRecord* recs, const float* final_T, const uint32_t* n_contrib,
-                            const float* dL_dimg, float* grads2d, const uint32_t* tile_order, hipStream_t stream)
+                            const float* dL_dimg, float* grads2d, const uint32_t* tile_order, hipStream_t stream,
+                            const uint8_t* strip_masks)
 {
     if (cp.grid_x * cp.grid_y == 0) return;
     hipLaunchKernelGGL(k_render_backward, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(256), 0, stream, cp, bg[0],
-                       bg[1], bg[2], ranges, point_list, recs, final_T, n_contrib, dL_dimg, grads2d, tile_order);
+                       bg[1], bg[2], ranges, point_list, recs, final_T, n_contrib, dL_dimg, grads2d, tile_order, strip_masks);
 }
 
 void launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,

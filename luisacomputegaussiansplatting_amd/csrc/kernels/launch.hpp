@@ -112,14 +112,18 @@ void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipS
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,
-                               const uint32_t* tile_order, hipStream_t stream);
+                               const uint32_t* tile_order, hipStream_t stream, uint8_t* strip_masks = nullptr);
+// strip_masks[list position] = the four per-strip reach bits of that entry (written when final_T / n_contrib are
+// kept); the backward takes them instead of repeating the tests
+bool render_forward_writes_strip_masks();
 
 // ---- backward.hip ----
 size_t grads2d_bytes(int64_t V_cap);
 void   launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t stream);
 void   launch_render_backward(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                               const SplatRecord* recs, const float* final_T, const uint32_t* n_contrib,
-                              const float* dL_dimg, float* grads2d, const uint32_t* tile_order, hipStream_t stream);
+                              const float* dL_dimg, float* grads2d, const uint32_t* tile_order, hipStream_t stream,
+                              const uint8_t* strip_masks = nullptr);
 void   launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
                                   const float* scale, const float* rotq, const float* sh, const uint32_t* vis_index,
                                   const uint32_t* d_counts, const float* grads2d, float* dL_dpos, float* dL_dscale,

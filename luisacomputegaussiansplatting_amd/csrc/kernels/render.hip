@@ -287,7 +287,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                                                             float* __restrict__ img, float* __restrict__ final_T,
                                                             uint32_t* __restrict__ n_contrib,
                                                             const uint32_t* __restrict__ d_counts,
-                                                            const uint32_t* __restrict__ tile_order)
+                                                            const uint32_t* __restrict__ tile_order,
+                                                            uint8_t* __restrict__ strip_masks)
 {
     // one 16-byte row per entry in each of three slabs: a single address register serves all three reads
     __shared__ float4             s_a[256]; // mean.x, mean.y, conic.x, conic.z
@@ -356,6 +357,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                 if (splat_may_touch_rect(a.x, a.y, a.z, a.w, b.x, t, rx0, y0, rx1, y0 + 3.0f)) kmask |= 1u << k;
             }
         }
+        // (kept for the backward, which walks the same list positions: it need not repeat the four strip tests)
+        if (KEEP && strip_masks && have) strip_masks[e] = (uint8_t)kmask;
         __syncthreads(); // previous round's readers are done with the slab and the masks
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -489,7 +492,8 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
 template <typename Fetch>
 void launch_render(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                    Fetch fetch, float* img, float* final_T, uint32_t* n_contrib, const uint32_t* d_counts,
-                   const FrameParams* d_fp, const uint32_t* tile_order, hipStream_t stream)
+                   const FrameParams* d_fp, const uint32_t* tile_order, hipStream_t stream,
+                   uint8_t* strip_masks = nullptr)
 {
     if (cp.grid_x * cp.grid_y == 0) return;
     static const int variant = [] {
@@ -500,10 +504,10 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
         const dim3 grid(render_grid_size(cp.grid_x, cp.grid_y));
         if (final_T || n_contrib)
             hipLaunchKernelGGL((k_render_forward_b<Fetch, true>), grid, dim3(256), 0, stream, cp, bg[0], bg[1], bg[2], d_fp,
-                               ranges, point_list, fetch, img, final_T, n_contrib, d_counts, tile_order);
+                               ranges, point_list, fetch, img, final_T, n_contrib, d_counts, tile_order, strip_masks);
         else // forward only: the last-contributor bookkeeping is compiled out
             hipLaunchKernelGGL((k_render_forward_b<Fetch, false>), grid, dim3(256), 0, stream, cp, bg[0], bg[1], bg[2], d_fp,
-                               ranges, point_list, fetch, img, final_T, n_contrib, d_counts, tile_order);
+                               ranges, point_list, fetch, img, final_T, n_contrib, d_counts, tile_order, nullptr);
         return;
     }
     hipLaunchKernelGGL(k_render_forward<Fetch>, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(64), 0, stream, cp, bg[0], bg[1], bg[2], d_fp, ranges,
@@ -530,10 +534,17 @@ void launch_render_forward_aos(const CamParams& cp, const float bg[3], const uin
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,
-                               const uint32_t* tile_order, hipStream_t stream)
+                               const uint32_t* tile_order, hipStream_t stream, uint8_t* strip_masks)
 {
     launch_render(cp, bg, ranges, point_list, FetchRec{ recs }, img, final_T, n_contrib, d_counts, d_fp, tile_order,
-                  stream);
+                  stream, strip_masks);
+}
+
+// true when the forward renderer in use fills strip_masks (the workgroup-per-tile variant does)
+bool render_forward_writes_strip_masks()
+{
+    const char* v = getenv("LCGS_RENDER_VARIANT");
+    return !(v && v[0] == 'a');
 }
 
 } // namespace lcgs

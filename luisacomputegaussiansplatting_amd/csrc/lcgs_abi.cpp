@@ -87,7 +87,7 @@ struct lcgs_context {
 
     // workspace of the fused frame
     DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws[2], counts, sort_ws,
-        expand_ws, final_T, n_contrib, list_idx, grads2d;
+        expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks;
     // zero_ws holds what a frame needs zeroed: the chained-scan states of the cull pass and the tile ranges.  Two
     // copies alternate between frames so that the next frame's copy is cleared on the auxiliary stream while the
     // current frame renders (zero_ready) instead of at the head of the next frame.
@@ -282,6 +282,7 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
     if (keep_state) {
         LCGS_TRY(ctx->final_T.ensure((size_t)cp.width * cp.height * 4));
         LCGS_TRY(ctx->n_contrib.ensure((size_t)cp.width * cp.height * 4));
+        LCGS_TRY(ctx->strip_masks.ensure((size_t)ctx->pair_capacity));
     }
     if (!ctx->h_counts) LCGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counts), 64, hipHostMallocDefault));
     return LCGS_OK;
@@ -387,7 +388,8 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0)); // records are ready
     launch_render_forward_rec(cp, bg, ctx->ranges, ctx->pairv[where2].as<uint32_t>(), recs, d_img,
                               keep_state ? ctx->final_T.as<float>() : nullptr,
-                              keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, d_fp, order_now, st);
+                              keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, d_fp, order_now, st,
+                              keep_state ? ctx->strip_masks.as<uint8_t>() : nullptr);
     ctx->last_tile_order = order_now;
     LCGS_TRY(mark(ctx, "render"));
 
@@ -484,7 +486,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
                              &ctx->rects, &ctx->rects_sorted, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
                              &ctx->pairv[1], &ctx->zero_ws[0], &ctx->zero_ws[1], &ctx->counts, &ctx->sort_ws,
                              &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order[0], &ctx->tile_order[1], &ctx->st_keys_tmp,
-                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half };
+                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& b : ctx->owned) b.release();
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
@@ -1093,7 +1095,8 @@ lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, cons
     LCGS_TRY(mark(ctx, "zero_grads"));
     launch_render_backward(ctx->last.cp, ctx->last.bg, ctx->ranges, ctx->pairv[ctx->last.list_buf].as<uint32_t>(),
                            ctx->recs.as<SplatRecord>(), ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(),
-                           d_dL_dimg, ctx->grads2d.as<float>(), ctx->last_tile_order, st);
+                           d_dL_dimg, ctx->grads2d.as<float>(), ctx->last_tile_order, st,
+                           render_forward_writes_strip_masks() ? ctx->strip_masks.as<uint8_t>() : nullptr);
     LCGS_TRY(mark(ctx, "render_backward"));
     if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     launch_preprocess_backward(ctx->hint_V > 0 ? ctx->hint_V : (int64_t)P, ctx->sh_deg, ctx->last.cp,
