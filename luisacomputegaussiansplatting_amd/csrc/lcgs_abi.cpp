@@ -124,6 +124,10 @@ struct lcgs_context {
     hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_ranges = nullptr, ev_aux_done = nullptr, ev_render = nullptr,
                 ev_counts = nullptr;
     bool        aux_pending = false, counts_pending = false;
+    // keep_state frames clear the 2-D gradient rows on the auxiliary stream (beside the renderer) so that the backward
+    // does not start with a 40 us zero-fill; consumed by the first backward of that frame
+    hipEvent_t  ev_g2d_zero = nullptr;
+    bool        g2d_zeroed  = false;
     // lcgs_render_forward_batch: a sibling context (own workspace, own streams) that renders every other view, so
     // that one view's latency-bound sort chain overlaps the other's bandwidth- and VALU-bound kernels
     lcgs_context* twin         = nullptr;
@@ -283,6 +287,7 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
         LCGS_TRY(ctx->final_T.ensure((size_t)cp.width * cp.height * 4));
         LCGS_TRY(ctx->n_contrib.ensure((size_t)cp.width * cp.height * 4));
         LCGS_TRY(ctx->strip_masks.ensure((size_t)ctx->pair_capacity));
+        LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)P)));
     }
     if (!ctx->h_counts) LCGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counts), 64, hipHostMallocDefault));
     return LCGS_OK;
@@ -333,6 +338,12 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
                          ctx->rotq, ctx->sh, ctx->opacity, ctx->vis_index.as<uint32_t>(), d_counts, recs, rec_stream,
                          ctx->use_half_sh ? ctx->sh_half.as<uint16_t>() : nullptr);
     if (overlap) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+    ctx->g2d_zeroed = false;
+    if (deferred && keep_state) { // behind the records, beside the sort chain and the renderer
+        launch_zero_grads2d(d_counts, ctx->grads2d.as<float>(), ctx->aux_stream);
+        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_g2d_zero, ctx->aux_stream));
+        ctx->g2d_zeroed = true;
+    }
     LCGS_TRY(mark(ctx, "build_records"));
 
     // survivors by depth bits: the low 32 bits of the reference key, sorted before duplication
@@ -454,7 +465,8 @@ lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx)
         se             = hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, prio);
         if (se != hipSuccess) se = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     }
-    for (hipEvent_t* ev : { &ctx->ev_fork, &ctx->ev_join, &ctx->ev_ranges, &ctx->ev_aux_done, &ctx->ev_render, &ctx->ev_counts })
+    for (hipEvent_t* ev : { &ctx->ev_fork, &ctx->ev_join, &ctx->ev_ranges, &ctx->ev_aux_done, &ctx->ev_render, &ctx->ev_counts,
+                            &ctx->ev_g2d_zero })
         if (se == hipSuccess) se = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     if (se != hipSuccess) {
         lcgs_status s = hip_fail(se, "aux stream / events", __FILE__, __LINE__);
@@ -494,7 +506,8 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
         (void)hipStreamSynchronize(ctx->aux_stream);
         (void)hipStreamDestroy(ctx->aux_stream);
     }
-    for (hipEvent_t ev : { ctx->ev_fork, ctx->ev_join, ctx->ev_ranges, ctx->ev_aux_done, ctx->ev_render, ctx->ev_counts })
+    for (hipEvent_t ev : { ctx->ev_fork, ctx->ev_join, ctx->ev_ranges, ctx->ev_aux_done, ctx->ev_render, ctx->ev_counts,
+                           ctx->ev_g2d_zero })
         if (ev) (void)hipEventDestroy(ev);
     ctx->frame_params.release();
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -1090,8 +1103,14 @@ lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, cons
     LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dsh, 0, P * feat * 4, zs));
     LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dopacity, 0, P * 4, zs));
     if (overlap) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
-    LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)P)));
-    launch_zero_grads2d(ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(), st);
+    if (ctx->g2d_zeroed && overlap) { // cleared during the forward (first backward of this frame only)
+        LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_g2d_zero, 0));
+        ctx->g2d_zeroed = false;
+    } else {
+        LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)P)));
+        launch_zero_grads2d(ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(), st);
+        ctx->g2d_zeroed = false;
+    }
     LCGS_TRY(mark(ctx, "zero_grads"));
     launch_render_backward(ctx->last.cp, ctx->last.bg, ctx->ranges, ctx->pairv[ctx->last.list_buf].as<uint32_t>(),
                            ctx->recs.as<SplatRecord>(), ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(),
