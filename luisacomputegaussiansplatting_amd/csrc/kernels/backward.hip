@@ -391,28 +391,107 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
 // ---------------------------------------------------------------------------------------------------------------
 // 2-D gradients -> parameter gradients, one lane per surviving splat.
 // ---------------------------------------------------------------------------------------------------------------
-// The 16 SH basis terms and their direction gradients, signs as composed by sh_preprocessor.cpp:49-147.
-// X(k, basis, d/dx, d/dy, d/dz) with x, y, z, xx, yy, zz in scope.
-#define LCGS_SH_TERMS(X)                                                                                              \
-    X(0, SH_C0, 0.0f, 0.0f, 0.0f)                                                                                     \
-    X(1, -SH_C1 * y, 0.0f, -SH_C1, 0.0f)                                                                              \
-    X(2, SH_C1 * z, 0.0f, 0.0f, SH_C1)                                                                                \
-    X(3, -SH_C1 * x, -SH_C1, 0.0f, 0.0f)                                                                              \
-    X(4, SH_C2_0 * x * y, SH_C2_0 * y, SH_C2_0 * x, 0.0f)                                                             \
-    X(5, SH_C2_1 * y * z, 0.0f, SH_C2_1 * z, SH_C2_1 * y)                                                             \
-    X(6, SH_C2_2 * (2.0f * zz - xx - yy), SH_C2_2 * (-2.0f * x), SH_C2_2 * (-2.0f * y), SH_C2_2 * (4.0f * z))         \
-    X(7, SH_C2_3 * z * x, SH_C2_3 * z, 0.0f, SH_C2_3 * x)                                                             \
-    X(8, SH_C2_4 * (xx - yy), SH_C2_4 * 2.0f * x, SH_C2_4 * -2.0f * y, 0.0f)                                          \
-    X(9, SH_C3_0 * y * (3.0f * xx - yy), SH_C3_0 * 6.0f * x * y, SH_C3_0 * (3.0f * xx - 3.0f * yy), 0.0f)             \
-    X(10, SH_C3_1 * x * y * z, SH_C3_1 * y * z, SH_C3_1 * x * z, SH_C3_1 * x * y)                                     \
-    X(11, SH_C3_2 * y * (4.0f * zz - xx - yy), SH_C3_2 * (-2.0f * x * y), SH_C3_2 * (4.0f * zz - xx - 3.0f * yy),     \
-      SH_C3_2 * 8.0f * y * z)                                                                                         \
-    X(12, SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), SH_C3_3 * (-6.0f * x * z), SH_C3_3 * (-6.0f * y * z),    \
-      SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy))                                                                  \
-    X(13, SH_C3_4 * x * (4.0f * zz - xx - yy), SH_C3_4 * (4.0f * zz - 3.0f * xx - yy), SH_C3_4 * (-2.0f * x * y),     \
-      SH_C3_4 * 8.0f * x * z)                                                                                         \
-    X(14, SH_C3_5 * z * (xx - yy), SH_C3_5 * 2.0f * x * z, SH_C3_5 * -2.0f * y * z, SH_C3_5 * (xx - yy))              \
-    X(15, SH_C3_6 * x * (xx - 3.0f * yy), SH_C3_6 * (3.0f * xx - 3.0f * yy), SH_C3_6 * (-6.0f * x * y), 0.0f)
+// dL/d{pixel mean (gmx, gmy), conic (gA, gB, gC)} -> dL/d{pos (added to gp), scale (gs), rotq (gq: r,x,y,z)} through the
+// EWA projection.  The forward quantities are recomputed (the order of gs_math.hpp is irrelevant for the derivative).
+__device__ __forceinline__ void geom_backward(const CamParams& cp, float scale_modifier, float px, float py, float pz,
+                                              float sc0, float sc1, float sc2, float4 q, float gmx, float gmy, float gA,
+                                              float gB, float gC, float gp[3], float gs[3], float4& gq)
+{
+    // ---- geometry: recompute the forward quantities (gs_math.hpp order is irrelevant for the derivative)
+    float v[3];
+    view_transform(cp, px, py, pz, v);
+    const float limx = 1.3f * cp.tanfovx, limy = 1.3f * cp.tanfovy;
+    const float rx = v[0] / v[2], ry = v[1] / v[2];
+    const int   clx = (rx < -limx) ? -1 : (rx > limx ? 1 : 0);
+    const int   cly = (ry < -limy) ? -1 : (ry > limy ? 1 : 0);
+    const float tx = (clx ? (float)clx * limx : rx) * v[2];
+    const float ty = (cly ? (float)cly * limy : ry) * v[2];
+    const float tz = v[2];
+    const float sc[3] = { scale_modifier * sc0, scale_modifier * sc1, scale_modifier * sc2 };
+    const float  x = q.y, y = q.z, z = q.w, w = q.x;
+    float R[3][3];
+    R[0][0] = 1.0f - 2.0f * y * y - 2.0f * z * z; R[0][1] = 2.0f * x * y - 2.0f * z * w; R[0][2] = 2.0f * x * z + 2.0f * y * w;
+    R[1][0] = 2.0f * x * y + 2.0f * z * w; R[1][1] = 1.0f - 2.0f * x * x - 2.0f * z * z; R[1][2] = 2.0f * y * z - 2.0f * x * w;
+    R[2][0] = 2.0f * x * z - 2.0f * y * w; R[2][1] = 2.0f * y * z + 2.0f * x * w; R[2][2] = 1.0f - 2.0f * x * x - 2.0f * y * y;
+    float M[3][3], Sig[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) M[r][k] = R[r][k] * sc[k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Sig[r][k] = M[r][0] * M[k][0] + M[r][1] * M[k][1] + M[r][2] * M[k][2];
+    const float j00 = cp.focalx / tz, j11 = cp.focaly / tz, j02 = -cp.focalx * tx / (tz * tz),
+                j12 = -cp.focaly * ty / (tz * tz);
+    float T0[3], T1[3], ST0[3], ST1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        T0[r] = cp.right[r] * j00 + cp.front[r] * j02;
+        T1[r] = cp.up[r] * j11 + cp.front[r] * j12;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        ST0[r] = Sig[r][0] * T0[0] + Sig[r][1] * T0[1] + Sig[r][2] * T0[2];
+        ST1[r] = Sig[r][0] * T1[0] + Sig[r][1] * T1[1] + Sig[r][2] * T1[2];
+    }
+    const float a = T0[0] * ST0[0] + T0[1] * ST0[1] + T0[2] * ST0[2] + 0.3f;
+    const float b = T1[0] * ST0[0] + T1[1] * ST0[1] + T1[2] * ST0[2];
+    const float c = T1[0] * ST1[0] + T1[1] * ST1[1] + T1[2] * ST1[2] + 0.3f;
+    const float D = a * c - b * b + 1e-6f;
+    const float iD2 = 1.0f / (D * D);
+    const float g00 = (-c * c * gA + b * c * gB + (D - a * c) * gC) * iD2;
+    const float g11 = ((D - a * c) * gA + a * b * gB - a * a * gC) * iD2;
+    const float g01 = (2.0f * b * c * gA - (D + 2.0f * b * b) * gB + 2.0f * a * b * gC) * iD2;
+    float Gm[3][3], dT0[3], dT1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Gm[r][k] = g00 * T0[r] * T0[k] + g01 * T1[r] * T0[k] + g11 * T1[r] * T1[k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        dT0[r] = 2.0f * g00 * ST0[r] + g01 * ST1[r];
+        dT1[r] = 2.0f * g11 * ST1[r] + g01 * ST0[r];
+    }
+    const float dj00 = cp.right[0] * dT0[0] + cp.right[1] * dT0[1] + cp.right[2] * dT0[2];
+    const float dj02 = cp.front[0] * dT0[0] + cp.front[1] * dT0[1] + cp.front[2] * dT0[2];
+    const float dj11 = cp.up[0] * dT1[0] + cp.up[1] * dT1[1] + cp.up[2] * dT1[2];
+    const float dj12 = cp.front[0] * dT1[0] + cp.front[1] * dT1[1] + cp.front[2] * dT1[2];
+    const float itz2 = 1.0f / (tz * tz), itz3 = itz2 / tz;
+    const float dtx = dj02 * (-cp.focalx * itz2);
+    const float dty = dj12 * (-cp.focaly * itz2);
+    const float dtz = dj00 * (-cp.focalx * itz2) + dj11 * (-cp.focaly * itz2) + dj02 * (2.0f * cp.focalx * tx * itz3) +
+                      dj12 * (2.0f * cp.focaly * ty * itz3);
+    float dv[3];
+    dv[0] = clx ? 0.0f : dtx;
+    dv[1] = cly ? 0.0f : dty;
+    dv[2] = dtz + (clx ? dtx * (float)clx * limx : 0.0f) + (cly ? dty * (float)cly * limy : 0.0f);
+    const float pw = 1.0f / (v[2] + 1e-6f);
+    dv[0] += gmx * cp.focalx * pw;
+    dv[1] += gmy * cp.focaly * pw;
+    dv[2] += -(gmx * cp.focalx * v[0] + gmy * cp.focaly * v[1]) * pw * pw;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gp[i] += cp.right[i] * dv[0] + cp.up[i] * dv[1] + cp.front[i] * dv[2];
+
+    float dM[3][3], dR[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            dM[r][k] = (Gm[r][0] + Gm[0][r]) * M[0][k] + (Gm[r][1] + Gm[1][r]) * M[1][k] + (Gm[r][2] + Gm[2][r]) * M[2][k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gs[k] = scale_modifier * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) dR[r][k] = dM[r][k] * sc[k];
+    }
+    const float gx_ = 2.0f * (y * (dR[0][1] + dR[1][0]) + z * (dR[0][2] + dR[2][0]) + w * (dR[2][1] - dR[1][2])) - 4.0f * x * (dR[1][1] + dR[2][2]);
+    const float gy_ = 2.0f * (x * (dR[0][1] + dR[1][0]) + z * (dR[1][2] + dR[2][1]) + w * (dR[0][2] - dR[2][0])) - 4.0f * y * (dR[0][0] + dR[2][2]);
+    const float gz_ = 2.0f * (x * (dR[0][2] + dR[2][0]) + y * (dR[1][2] + dR[2][1]) + w * (dR[1][0] - dR[0][1])) - 4.0f * z * (dR[0][0] + dR[1][1]);
+    const float gw_ = 2.0f * (z * (dR[1][0] - dR[0][1]) + y * (dR[0][2] - dR[2][0]) + x * (dR[2][1] - dR[1][2]));
+
+    gq = make_float4(gw_, gx_, gy_, gz_);
+}
 
 // One lane per surviving splat (dense ids).  The splat's 48 SH coefficients arrive through the wave's LDS slab
 // (cooperative 16-byte loads, 12 lanes per 192-byte row), the SH gradient row is written back IN PLACE into the
@@ -508,105 +587,16 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
                 gp[2] += (ddz - z * dd) * inv;
             }
 
-            // ---- geometry: recompute the forward quantities (gs_math.hpp order is irrelevant for the derivative)
-            float v[3];
-            view_transform(cp, px, py, pz, v);
-            const float limx = 1.3f * cp.tanfovx, limy = 1.3f * cp.tanfovy;
-            const float rx = v[0] / v[2], ry = v[1] / v[2];
-            const int   clx = (rx < -limx) ? -1 : (rx > limx ? 1 : 0);
-            const int   cly = (ry < -limy) ? -1 : (ry > limy ? 1 : 0);
-            const float tx = (clx ? (float)clx * limx : rx) * v[2];
-            const float ty = (cly ? (float)cly * limy : ry) * v[2];
-            const float tz = v[2];
-            const float sc[3] = { scale_modifier * sc0, scale_modifier * sc1, scale_modifier * sc2 };
-            const float  x = q.y, y = q.z, z = q.w, w = q.x;
-            float R[3][3];
-            R[0][0] = 1.0f - 2.0f * y * y - 2.0f * z * z; R[0][1] = 2.0f * x * y - 2.0f * z * w; R[0][2] = 2.0f * x * z + 2.0f * y * w;
-            R[1][0] = 2.0f * x * y + 2.0f * z * w; R[1][1] = 1.0f - 2.0f * x * x - 2.0f * z * z; R[1][2] = 2.0f * y * z - 2.0f * x * w;
-            R[2][0] = 2.0f * x * z - 2.0f * y * w; R[2][1] = 2.0f * y * z + 2.0f * x * w; R[2][2] = 1.0f - 2.0f * x * x - 2.0f * y * y;
-            float M[3][3], Sig[3][3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) M[r][k] = R[r][k] * sc[k];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) Sig[r][k] = M[r][0] * M[k][0] + M[r][1] * M[k][1] + M[r][2] * M[k][2];
-            const float j00 = cp.focalx / tz, j11 = cp.focaly / tz, j02 = -cp.focalx * tx / (tz * tz),
-                        j12 = -cp.focaly * ty / (tz * tz);
-            float T0[3], T1[3], ST0[3], ST1[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                T0[r] = cp.right[r] * j00 + cp.front[r] * j02;
-                T1[r] = cp.up[r] * j11 + cp.front[r] * j12;
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                ST0[r] = Sig[r][0] * T0[0] + Sig[r][1] * T0[1] + Sig[r][2] * T0[2];
-                ST1[r] = Sig[r][0] * T1[0] + Sig[r][1] * T1[1] + Sig[r][2] * T1[2];
-            }
-            const float a = T0[0] * ST0[0] + T0[1] * ST0[1] + T0[2] * ST0[2] + 0.3f;
-            const float b = T1[0] * ST0[0] + T1[1] * ST0[1] + T1[2] * ST0[2];
-            const float c = T1[0] * ST1[0] + T1[1] * ST1[1] + T1[2] * ST1[2] + 0.3f;
-            const float D = a * c - b * b + 1e-6f;
-            const float iD2 = 1.0f / (D * D);
-            const float g00 = (-c * c * gA + b * c * gB + (D - a * c) * gC) * iD2;
-            const float g11 = ((D - a * c) * gA + a * b * gB - a * a * gC) * iD2;
-            const float g01 = (2.0f * b * c * gA - (D + 2.0f * b * b) * gB + 2.0f * a * b * gC) * iD2;
-            float Gm[3][3], dT0[3], dT1[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) Gm[r][k] = g00 * T0[r] * T0[k] + g01 * T1[r] * T0[k] + g11 * T1[r] * T1[k];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                dT0[r] = 2.0f * g00 * ST0[r] + g01 * ST1[r];
-                dT1[r] = 2.0f * g11 * ST1[r] + g01 * ST0[r];
-            }
-            const float dj00 = cp.right[0] * dT0[0] + cp.right[1] * dT0[1] + cp.right[2] * dT0[2];
-            const float dj02 = cp.front[0] * dT0[0] + cp.front[1] * dT0[1] + cp.front[2] * dT0[2];
-            const float dj11 = cp.up[0] * dT1[0] + cp.up[1] * dT1[1] + cp.up[2] * dT1[2];
-            const float dj12 = cp.front[0] * dT1[0] + cp.front[1] * dT1[1] + cp.front[2] * dT1[2];
-            const float itz2 = 1.0f / (tz * tz), itz3 = itz2 / tz;
-            const float dtx = dj02 * (-cp.focalx * itz2);
-            const float dty = dj12 * (-cp.focaly * itz2);
-            const float dtz = dj00 * (-cp.focalx * itz2) + dj11 * (-cp.focaly * itz2) + dj02 * (2.0f * cp.focalx * tx * itz3) +
-                              dj12 * (2.0f * cp.focaly * ty * itz3);
-            float dv[3];
-            dv[0] = clx ? 0.0f : dtx;
-            dv[1] = cly ? 0.0f : dty;
-            dv[2] = dtz + (clx ? dtx * (float)clx * limx : 0.0f) + (cly ? dty * (float)cly * limy : 0.0f);
-            const float pw = 1.0f / (v[2] + 1e-6f);
-            dv[0] += gmx * cp.focalx * pw;
-            dv[1] += gmy * cp.focaly * pw;
-            dv[2] += -(gmx * cp.focalx * v[0] + gmy * cp.focaly * v[1]) * pw * pw;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) gp[i] += cp.right[i] * dv[0] + cp.up[i] * dv[1] + cp.front[i] * dv[2];
-
-            float dM[3][3], dR[3][3], gs[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    dM[r][k] = (Gm[r][0] + Gm[0][r]) * M[0][k] + (Gm[r][1] + Gm[1][r]) * M[1][k] + (Gm[r][2] + Gm[2][r]) * M[2][k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                gs[k] = scale_modifier * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
-#pragma unroll
-                for (int r = 0; r < 3; ++r) dR[r][k] = dM[r][k] * sc[k];
-            }
-            const float gx_ = 2.0f * (y * (dR[0][1] + dR[1][0]) + z * (dR[0][2] + dR[2][0]) + w * (dR[2][1] - dR[1][2])) - 4.0f * x * (dR[1][1] + dR[2][2]);
-            const float gy_ = 2.0f * (x * (dR[0][1] + dR[1][0]) + z * (dR[1][2] + dR[2][1]) + w * (dR[0][2] - dR[2][0])) - 4.0f * y * (dR[0][0] + dR[2][2]);
-            const float gz_ = 2.0f * (x * (dR[0][2] + dR[2][0]) + y * (dR[1][2] + dR[2][1]) + w * (dR[1][0] - dR[0][1])) - 4.0f * z * (dR[0][0] + dR[1][1]);
-            const float gw_ = 2.0f * (z * (dR[1][0] - dR[0][1]) + y * (dR[0][2] - dR[2][0]) + x * (dR[2][1] - dR[1][2]));
+            float  gs[3];
+            float4 gq;
+            geom_backward(cp, scale_modifier, px, py, pz, sc0, sc1, sc2, q, gmx, gmy, gA, gB, gC, gp, gs, gq);
 
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 dL_dpos[3 * (size_t)idx + i]   = gp[i];
                 dL_dscale[3 * (size_t)idx + i] = gs[i];
             }
-            *reinterpret_cast<float4*>(dL_drotq + 4 * (size_t)idx) = make_float4(gw_, gx_, gy_, gz_); // (r,x,y,z)
+            *reinterpret_cast<float4*>(dL_drotq + 4 * (size_t)idx) = gq; // (r,x,y,z)
             dL_dopacity[idx] = gop;
         }
 

@@ -79,6 +79,30 @@ LCGS_HD int32_t f2i_sat(float x)
     return (int32_t)x;
 }
 
+// The 16 SH basis terms and their direction gradients, signs as composed by sh_preprocessor.cpp:49-147.
+// X(k, basis, d/dx, d/dy, d/dz) with x, y, z, xx, yy, zz in scope.
+#define LCGS_SH_TERMS(X)                                                                                              \
+    X(0, SH_C0, 0.0f, 0.0f, 0.0f)                                                                                     \
+    X(1, -SH_C1 * y, 0.0f, -SH_C1, 0.0f)                                                                              \
+    X(2, SH_C1 * z, 0.0f, 0.0f, SH_C1)                                                                                \
+    X(3, -SH_C1 * x, -SH_C1, 0.0f, 0.0f)                                                                              \
+    X(4, SH_C2_0 * x * y, SH_C2_0 * y, SH_C2_0 * x, 0.0f)                                                             \
+    X(5, SH_C2_1 * y * z, 0.0f, SH_C2_1 * z, SH_C2_1 * y)                                                             \
+    X(6, SH_C2_2 * (2.0f * zz - xx - yy), SH_C2_2 * (-2.0f * x), SH_C2_2 * (-2.0f * y), SH_C2_2 * (4.0f * z))         \
+    X(7, SH_C2_3 * z * x, SH_C2_3 * z, 0.0f, SH_C2_3 * x)                                                             \
+    X(8, SH_C2_4 * (xx - yy), SH_C2_4 * 2.0f * x, SH_C2_4 * -2.0f * y, 0.0f)                                          \
+    X(9, SH_C3_0 * y * (3.0f * xx - yy), SH_C3_0 * 6.0f * x * y, SH_C3_0 * (3.0f * xx - 3.0f * yy), 0.0f)             \
+    X(10, SH_C3_1 * x * y * z, SH_C3_1 * y * z, SH_C3_1 * x * z, SH_C3_1 * x * y)                                     \
+    X(11, SH_C3_2 * y * (4.0f * zz - xx - yy), SH_C3_2 * (-2.0f * x * y), SH_C3_2 * (4.0f * zz - xx - 3.0f * yy),     \
+      SH_C3_2 * 8.0f * y * z)                                                                                         \
+    X(12, SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), SH_C3_3 * (-6.0f * x * z), SH_C3_3 * (-6.0f * y * z),    \
+      SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy))                                                                  \
+    X(13, SH_C3_4 * x * (4.0f * zz - xx - yy), SH_C3_4 * (4.0f * zz - 3.0f * xx - yy), SH_C3_4 * (-2.0f * x * y),     \
+      SH_C3_4 * 8.0f * x * z)                                                                                         \
+    X(14, SH_C3_5 * z * (xx - yy), SH_C3_5 * 2.0f * x * z, SH_C3_5 * -2.0f * y * z, SH_C3_5 * (xx - yy))              \
+    X(15, SH_C3_6 * x * (xx - 3.0f * yy), SH_C3_6 * (3.0f * xx - 3.0f * yy), SH_C3_6 * (-6.0f * x * y), 0.0f)
+
+
 // ---------------------------------------------------------------------------------------------
 // SH colour: lcgs/src/sh_preprocessor.cpp:27-157 with util/sh.hpp:31-34,43-50,68-84,120-138.
 // `sh` points at this splat's (deg+1)^2 x 3 coefficients; sh_at(k, c) abstracts the fetch so the
