@@ -617,6 +617,97 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
     }
 }
 
+// The same step for frames whose forward kept the colour Jacobian (build_records<.., JAC>; degree 3): nothing of the
+// 192-byte coefficient row is read again.  dL/dsh[k][c] = basis_k(direction) * dL/dcolour[c] (clamp-masked) is an
+// outer product of 16 + 3 numbers per splat: each lane parks those 19 floats in LDS and the wave writes the 192-byte
+// gradient rows cooperatively (12 lanes x 16 B per row), forming the products on the way out.  The direction part of
+// dL/dpos comes from the kept 3x3 Jacobian.  No 53 KB slab, a third of the registers: more workgroups in flight on
+// a kernel that is bound by bytes in flight.
+constexpr int kJacPitch = 19; // floats per splat in the LDS slab (odd: conflict-free per-lane writes)
+
+__global__ void __launch_bounds__(256)
+k_preprocess_backward_jac(CamParams cp, float scale_modifier, const float* __restrict__ pos,
+                          const float* __restrict__ scale, const float* __restrict__ rotq,
+                          const uint32_t* __restrict__ vis_index, const uint32_t* __restrict__ d_counts,
+                          const float* __restrict__ grads2d, const float4* __restrict__ shjac,
+                          float* __restrict__ dL_dpos, float* __restrict__ dL_dscale, float* __restrict__ dL_drotq,
+                          float* __restrict__ dL_dsh, float* __restrict__ dL_dopacity)
+{
+    __shared__ float s_outer[4][64 * kJacPitch];
+    const uint32_t V = d_counts[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t blk = blockIdx.x; blk * 256u < V; blk += gridDim.x) {
+        const uint32_t vid   = blk * 256u + threadIdx.x;
+        const bool     valid = vid < V;
+        const uint32_t vsafe = valid ? vid : V - 1;
+        const int      idx   = (int)vis_index[vsafe];
+        const uint32_t wave_first = blk * 256u + wave * 64u;
+        const uint32_t nvalid     = wave_first < V ? ((V - wave_first) < 64u ? (V - wave_first) : 64u) : 0u;
+        const float4* g2 = reinterpret_cast<const float4*>(grads2d + (size_t)vsafe * kG2D);
+        const float4  q0 = g2[0], q1 = g2[1];
+        const float   gcol2 = reinterpret_cast<const float*>(g2)[8];
+        const float4  j0 = shjac[(size_t)vsafe * 3 + 0], j1 = shjac[(size_t)vsafe * 3 + 1], j2 = shjac[(size_t)vsafe * 3 + 2];
+        const float   px = pos[3 * (size_t)idx + 0], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
+        const float   sc0 = scale[3 * (size_t)idx + 0], sc1 = scale[3 * (size_t)idx + 1], sc2 = scale[3 * (size_t)idx + 2];
+        const float4  q = *reinterpret_cast<const float4*>(rotq + 4 * (size_t)idx); // (r,x,y,z)
+        float*        mine = &s_outer[wave][lane * kJacPitch];
+        if (valid) {
+            const float    gmx = q0.x, gmy = q0.y, gA = q0.z, gB = q0.w, gC = q1.x, gop = q1.y;
+            const float    gcol[3] = { q1.z, q1.w, gcol2 };
+            const uint32_t mask    = __float_as_uint(j2.y);
+            float          gp[3];
+            {
+                const float dx = px - cp.campos[0], dy = py - cp.campos[1], dz = pz - cp.campos[2];
+                const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+                const float x = dx * inv, y = dy * inv, z = dz * inv;
+                const float xx = x * x, yy = y * y, zz = z * z;
+#define LCGS_BASIS(k, B, DX, DY, DZ) mine[k] = (B);
+                LCGS_SH_TERMS(LCGS_BASIS)
+#undef LCGS_BASIS
+#pragma unroll
+                for (int c = 0; c < 3; ++c) mine[16 + c] = ((mask >> c) & 1u) ? gcol[c] : 0.0f; // clamp mask
+                // J rows of clamped channels are already zero: no mask needed here
+                const float ddx = gcol[0] * j0.x + gcol[1] * j0.w + gcol[2] * j1.z;
+                const float ddy = gcol[0] * j0.y + gcol[1] * j1.x + gcol[2] * j1.w;
+                const float ddz = gcol[0] * j0.z + gcol[1] * j1.y + gcol[2] * j2.x;
+                const float dd  = x * ddx + y * ddy + z * ddz;
+                gp[0] = (ddx - x * dd) * inv;
+                gp[1] = (ddy - y * dd) * inv;
+                gp[2] = (ddz - z * dd) * inv;
+            }
+            float  gs[3];
+            float4 gq;
+            geom_backward(cp, scale_modifier, px, py, pz, sc0, sc1, sc2, q, gmx, gmy, gA, gB, gC, gp, gs, gq);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                dL_dpos[3 * (size_t)idx + i]   = gp[i];
+                dL_dscale[3 * (size_t)idx + i] = gs[i];
+            }
+            *reinterpret_cast<float4*>(dL_drotq + 4 * (size_t)idx) = gq; // (r,x,y,z)
+            dL_dopacity[idx] = gop;
+        }
+        __syncthreads();
+        // ---- SH gradient rows: 12 consecutive lanes write one splat's 192 contiguous bytes
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const uint32_t cidx = (uint32_t)i * 64u + lane;
+            const uint32_t slot = cidx / 12u, part = cidx - slot * 12u;
+            const int      sidx = __shfl(idx, (int)slot, 64);
+            if (slot < nvalid) {
+                const float* o = &s_outer[wave][slot * kJacPitch];
+                float        v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t f = part * 4u + (uint32_t)e, k = f / 3u, ch = f - 3u * k; // row[k * 3 + ch]
+                    v[e]             = o[k] * o[16u + ch];
+                }
+                reinterpret_cast<float4*>(dL_dsh + (size_t)sidx * 48)[part] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __syncthreads(); // the slab is reused by the next iteration
+    }
+}
+
 } // namespace
 
 size_t grads2d_bytes(int64_t V_cap) { return (size_t)V_cap * kG2D * sizeof(float); }
@@ -649,11 +740,18 @@ void launch_render_backward(const CamParams& cp, const float bg[3], const uint32
 void launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
                                 const float* scale, const float* rotq, const float* sh, const uint32_t* vis_index,
                                 const uint32_t* d_counts, const float* grads2d, float* dL_dpos, float* dL_dscale,
-                                float* dL_drotq, float* dL_dsh, float* dL_dopacity, hipStream_t stream)
+                                float* dL_drotq, float* dL_dsh, float* dL_dopacity, hipStream_t stream,
+                                const float4* shjac)
 {
     int64_t blocks = (v_hint + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 65536) blocks = 65536;
+    if (shjac && sh_deg == 3 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0) {
+        hipLaunchKernelGGL(k_preprocess_backward_jac, dim3((unsigned)blocks), dim3(256), 0, stream, cp, scale_modifier, pos,
+                           scale, rotq, vis_index, d_counts, grads2d, shjac, dL_dpos, dL_dscale, dL_drotq, dL_dsh,
+                           dL_dopacity);
+        return;
+    }
     hipLaunchKernelGGL(k_preprocess_backward, dim3((unsigned)blocks), dim3(256), 0, stream, sh_deg, cp, scale_modifier,
                        pos, scale, rotq, sh, vis_index, d_counts, grads2d, dL_dpos, dL_dscale, dL_drotq, dL_dsh,
                        dL_dopacity);

@@ -275,13 +275,17 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
 // reads its own 48 coefficients back.
 // HALF: the coefficients come from the opt-in f16 copy (lcgs_scene_use_half_sh; 96-byte rows, six 16-byte chunks per
 // splat, 7-chunk LDS pitch) and are widened to f32 before the same evaluation.
-template <bool HALF>
+// JAC (frames that keep backward state, degree 3): also stores, per survivor, the 3x3 Jacobian of the un-clamped
+// colour w.r.t. the unit view direction with the colour clamp folded in (rows of clamped channels are zero) and
+// the clamp mask -- 48 bytes that let the backward derive dL/dsh and the direction part of dL/dpos WITHOUT reading
+// the 192-byte coefficient row again.
+template <bool HALF, bool JAC>
 __global__ void __launch_bounds__(kThreads)
 k_build_records(int sh_deg, CamParams cp, float scale_modifier, const FrameParams* __restrict__ fpp,
                 const float* __restrict__ pos,
                 const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ sh,
                 const float* __restrict__ opacity, const uint32_t* __restrict__ vis_index,
-                const uint32_t* __restrict__ d_counts, SplatRecord* __restrict__ recs)
+                const uint32_t* __restrict__ d_counts, SplatRecord* __restrict__ recs, float4* __restrict__ shjac)
 {
     __shared__ float4 s_sh[kThreads / 64][64 * (HALF ? 7 : 13)];
 
@@ -338,28 +342,73 @@ k_build_records(int sh_deg, CamParams cp, float scale_modifier, const FrameParam
     if (valid) {
 
     const float px = pos[3 * (size_t)idx + 0], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
-    const Projected pr = project_splat(cp, scale_modifier, idx, px, py, pz, scale, rotq, opacity);
 
-    // colour (sh_preprocessor.cpp:27-157)
+    // colour (sh_preprocessor.cpp:27-157) first, projection after: the 48 coefficients and the projection's
+    // intermediates are never live together
     float raw[3];
+    // d raw[c] / d (unit direction)[j] from the same coefficients (only formed when JAC)
+    auto colour_jacobian = [&](auto coef) {
+        const float dx = px - cp.campos[0], dy = py - cp.campos[1], dz = pz - cp.campos[2];
+        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        const float x = dx * inv, y = dy * inv, z = dz * inv;
+        const float xx = x * x, yy = y * y, zz = z * z;
+        float       J[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+#define LCGS_JAC(k, B, DX, DY, DZ)                                                                                    \
+    {                                                                                                                 \
+        const float ddx = (DX), ddy = (DY), ddz = (DZ);                                                               \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                 \
+        {                                                                                                             \
+            const float ck = coef(k, c);                                                                              \
+            J[c][0] += ck * ddx;                                                                                      \
+            J[c][1] += ck * ddy;                                                                                      \
+            J[c][2] += ck * ddz;                                                                                      \
+        }                                                                                                             \
+        asm volatile("" ::: "memory"); /* one coefficient triple in registers at a time (they come from LDS) */        \
+    }
+        LCGS_SH_TERMS(LCGS_JAC)
+#undef LCGS_JAC
+        uint32_t mask = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bool open = raw[c] > 0.0f && raw[c] < 1.0f; // the clamp passes a gradient only inside (0, 1)
+            mask |= open ? (1u << c) : 0u;
+            if (!open) J[c][0] = J[c][1] = J[c][2] = 0.0f;
+        }
+        float4* o = shjac + (size_t)vid * 3;
+        o[0]      = make_float4(J[0][0], J[0][1], J[0][2], J[1][0]);
+        o[1]      = make_float4(J[1][1], J[1][2], J[2][0], J[2][1]);
+        o[2]      = make_float4(J[2][2], __uint_as_float(mask), 0.0f, 0.0f);
+    };
     if (HALF) {
         float4 q[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) q[k] = s_sh[wave][lane * 7 + k];
         const __half* h = reinterpret_cast<const __half*>(q);
         sh_to_color(3, cp.campos, px, py, pz, [&](int k, int c) { return __half2float(h[k * 3 + c]); }, raw);
+        if (JAC) {
+            asm volatile("" ::: "memory"); // re-read the row from LDS instead of carrying it through the colour pass
+            const __half* h2 = reinterpret_cast<const __half*>(&s_sh[wave][lane * 7]);
+            colour_jacobian([&](int k, int c) { return __half2float(h2[k * 3 + c]); });
+        }
     } else if (staged) {
         float4 q[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) q[k] = s_sh[wave][lane * 13 + k];
         const float* f = reinterpret_cast<const float*>(q);
         sh_to_color(3, cp.campos, px, py, pz, [&](int k, int c) { return f[k * 3 + c]; }, raw);
+        if (JAC) {
+            asm volatile("" ::: "memory"); // re-read the row from LDS instead of carrying it through the colour pass
+            const float* f2 = reinterpret_cast<const float*>(&s_sh[wave][lane * 13]);
+            colour_jacobian([&](int k, int c) { return f2[k * 3 + c]; });
+        }
     } else {
         const int    feat_dim = (sh_deg + 1) * (sh_deg + 1);
         const float* s        = sh + (size_t)idx * feat_dim * 3;
         sh_to_color(sh_deg, cp.campos, px, py, pz, [&](int k, int c) { return s[k * 3 + c]; }, raw);
     }
 
+    asm volatile("" ::: "memory");
+    const Projected pr = project_splat(cp, scale_modifier, idx, px, py, pz, scale, rotq, opacity);
     float4* out = reinterpret_cast<float4*>(recs + vid);
     out[0]      = make_float4(pr.pix_x, pr.pix_y, pr.conic[0], pr.conic[1]);
     out[1]      = make_float4(pr.conic[2], opacity[idx], clamp_(raw[0], 0.0f, 1.0f), clamp_(raw[1], 0.0f, 1.0f));
@@ -613,15 +662,27 @@ void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scal
                           const float* pos,
                           const float* scale, const float* rotq, const float* sh, const float* opacity,
                           const uint32_t* vis_index, const uint32_t* d_counts, SplatRecord* recs, hipStream_t stream,
-                          const uint16_t* sh_half)
+                          const uint16_t* sh_half, float4* shjac)
 {
-    if (sh_half)
-        hipLaunchKernelGGL(k_build_records<true>, dim3(blocks_for(P_cap)), dim3(kThreads), 0, stream, sh_deg, cp,
-                           scale_modifier, d_fp, pos, scale, rotq, reinterpret_cast<const float*>(sh_half), opacity,
-                           vis_index, d_counts, recs);
-    else
-        hipLaunchKernelGGL(k_build_records<false>, dim3(blocks_for(P_cap)), dim3(kThreads), 0, stream, sh_deg, cp,
-                           scale_modifier, d_fp, pos, scale, rotq, sh, opacity, vis_index, d_counts, recs);
+    // the Jacobian needs the staged (degree 3, 16-byte aligned) coefficient path
+    float4* jac = (shjac && sh_deg == 3 && (sh_half || (reinterpret_cast<uintptr_t>(sh) & 15) == 0)) ? shjac : nullptr;
+    const dim3 grid(blocks_for(P_cap)), block(kThreads);
+#define LCGS_BUILD(H, J, SRC)                                                                                         \
+    hipLaunchKernelGGL((k_build_records<H, J>), grid, block, 0, stream, sh_deg, cp, scale_modifier, d_fp, pos, scale,   \
+                       rotq, SRC, opacity, vis_index, d_counts, recs, jac)
+    if (sh_half) {
+        if (jac) LCGS_BUILD(true, true, reinterpret_cast<const float*>(sh_half));
+        else LCGS_BUILD(true, false, reinterpret_cast<const float*>(sh_half));
+    } else {
+        if (jac) LCGS_BUILD(false, true, sh);
+        else LCGS_BUILD(false, false, sh);
+    }
+#undef LCGS_BUILD
+}
+
+bool build_records_writes_jacobian(int sh_deg, const float* sh, bool half)
+{
+    return sh_deg == 3 && (half || (reinterpret_cast<uintptr_t>(sh) & 15) == 0);
 }
 
 __global__ void __launch_bounds__(256) k_sh_to_half(int64_t n, const float* __restrict__ src, __half* __restrict__ dst)

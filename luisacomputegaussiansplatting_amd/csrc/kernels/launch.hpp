@@ -81,7 +81,9 @@ void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scal
                           const float* pos,
                           const float* scale, const float* rotq, const float* sh, const float* opacity,
                           const uint32_t* vis_index, const uint32_t* d_counts, SplatRecord* recs, hipStream_t stream,
-                          const uint16_t* sh_half = nullptr); // non-NULL: f16 coefficient rows (degree 3 only)
+                          const uint16_t* sh_half = nullptr, // non-NULL: f16 coefficient rows (degree 3 only)
+                          float4* shjac = nullptr);          // non-NULL: 3 x float4 per survivor for the backward
+bool build_records_writes_jacobian(int sh_deg, const float* sh, bool half);
 void launch_sh_to_half(int64_t n, const float* src, uint16_t* dst, hipStream_t stream);
 void launch_get_ranges_u32(int64_t L_cap, uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
                            const uint32_t* scan_error_flag, hipStream_t stream);
@@ -127,6 +129,7 @@ void   launch_render_backward(const CamParams& cp, const float bg[3], const uint
 void   launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
                                   const float* scale, const float* rotq, const float* sh, const uint32_t* vis_index,
                                   const uint32_t* d_counts, const float* grads2d, float* dL_dpos, float* dL_dscale,
-                                  float* dL_drotq, float* dL_dsh, float* dL_dopacity, hipStream_t stream);
+                                  float* dL_drotq, float* dL_dsh, float* dL_dopacity, hipStream_t stream,
+                                  const float4* shjac = nullptr); // the forward's colour Jacobian rows, if kept
 
 } // namespace lcgs

@@ -87,7 +87,8 @@ struct lcgs_context {
 
     // workspace of the fused frame
     DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws[2], counts, sort_ws,
-        expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks;
+        expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks, shjac;
+    bool         last_has_jac = false; // the last keep_state frame stored the colour Jacobian (degree 3)
     // zero_ws holds what a frame needs zeroed: the chained-scan states of the cull pass and the tile ranges.  Two
     // copies alternate between frames so that the next frame's copy is cleared on the auxiliary stream while the
     // current frame renders (zero_ready) instead of at the head of the next frame.
@@ -288,6 +289,7 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
         LCGS_TRY(ctx->n_contrib.ensure((size_t)cp.width * cp.height * 4));
         LCGS_TRY(ctx->strip_masks.ensure((size_t)ctx->pair_capacity));
         LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)P)));
+        LCGS_TRY(ctx->shjac.ensure(P * 48));
     }
     if (!ctx->h_counts) LCGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counts), 64, hipHostMallocDefault));
     return LCGS_OK;
@@ -336,7 +338,9 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     }
     launch_build_records((int)std::min<int64_t>(P, hint_V), ctx->sh_deg, cp, scale_modifier, d_fp, ctx->pos, ctx->scale,
                          ctx->rotq, ctx->sh, ctx->opacity, ctx->vis_index.as<uint32_t>(), d_counts, recs, rec_stream,
-                         ctx->use_half_sh ? ctx->sh_half.as<uint16_t>() : nullptr);
+                         ctx->use_half_sh ? ctx->sh_half.as<uint16_t>() : nullptr,
+                         keep_state ? ctx->shjac.as<float4>() : nullptr);
+    ctx->last_has_jac = keep_state && build_records_writes_jacobian(ctx->sh_deg, ctx->sh, ctx->use_half_sh);
     if (overlap) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
     ctx->g2d_zeroed = false;
     if (deferred && keep_state) { // behind the records, beside the sort chain and the renderer
@@ -498,7 +502,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
                              &ctx->rects, &ctx->rects_sorted, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
                              &ctx->pairv[1], &ctx->zero_ws[0], &ctx->zero_ws[1], &ctx->counts, &ctx->sort_ws,
                              &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order[0], &ctx->tile_order[1], &ctx->st_keys_tmp,
-                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks };
+                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& b : ctx->owned) b.release();
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
@@ -1122,7 +1126,7 @@ lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, cons
                                ctx->last.scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->sh,
                                ctx->vis_index.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(),
                                grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh,
-                               grads->d_dL_dopacity, st);
+                               grads->d_dL_dopacity, st, ctx->last_has_jac ? ctx->shjac.as<float4>() : nullptr);
     LCGS_TRY(mark(ctx, "preprocess_backward"));
     LCGS_HIP_CHECK(hipGetLastError());
     if (ctx->profiling) {
