@@ -688,7 +688,7 @@ k_preprocess_backward_jac(CamParams cp, float scale_modifier, const float* __res
         }
         __syncthreads();
         // ---- SH gradient rows: 12 consecutive lanes write one splat's 192 contiguous bytes
-#pragma unroll
+#pragma unroll 1
         for (int i = 0; i < 12; ++i) {
             const uint32_t cidx = (uint32_t)i * 64u + lane;
             const uint32_t slot = cidx / 12u, part = cidx - slot * 12u;
