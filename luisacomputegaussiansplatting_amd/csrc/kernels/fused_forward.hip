@@ -385,22 +385,12 @@ k_build_records(int sh_deg, CamParams cp, float scale_modifier, const FrameParam
         for (int k = 0; k < 6; ++k) q[k] = s_sh[wave][lane * 7 + k];
         const __half* h = reinterpret_cast<const __half*>(q);
         sh_to_color(3, cp.campos, px, py, pz, [&](int k, int c) { return __half2float(h[k * 3 + c]); }, raw);
-        if (JAC) {
-            asm volatile("" ::: "memory"); // re-read the row from LDS instead of carrying it through the colour pass
-            const __half* h2 = reinterpret_cast<const __half*>(&s_sh[wave][lane * 7]);
-            colour_jacobian([&](int k, int c) { return __half2float(h2[k * 3 + c]); });
-        }
     } else if (staged) {
         float4 q[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) q[k] = s_sh[wave][lane * 13 + k];
         const float* f = reinterpret_cast<const float*>(q);
         sh_to_color(3, cp.campos, px, py, pz, [&](int k, int c) { return f[k * 3 + c]; }, raw);
-        if (JAC) {
-            asm volatile("" ::: "memory"); // re-read the row from LDS instead of carrying it through the colour pass
-            const float* f2 = reinterpret_cast<const float*>(&s_sh[wave][lane * 13]);
-            colour_jacobian([&](int k, int c) { return f2[k * 3 + c]; });
-        }
     } else {
         const int    feat_dim = (sh_deg + 1) * (sh_deg + 1);
         const float* s        = sh + (size_t)idx * feat_dim * 3;
@@ -414,6 +404,17 @@ k_build_records(int sh_deg, CamParams cp, float scale_modifier, const FrameParam
     out[1]      = make_float4(pr.conic[2], opacity[idx], clamp_(raw[0], 0.0f, 1.0f), clamp_(raw[1], 0.0f, 1.0f));
     out[2]      = make_float4(clamp_(raw[2], 0.0f, 1.0f), pr.depth, __uint_as_float(pr.rmin[0] | (pr.rmin[1] << 16)),
                               __uint_as_float(pr.rw | (pr.rh << 16)));
+    if (JAC) {
+        // last, with the record gone from the registers; the coefficients are read from the LDS row once more
+        asm volatile("" ::: "memory");
+        if (HALF) {
+            const __half* h2 = reinterpret_cast<const __half*>(&s_sh[wave][lane * 7]);
+            colour_jacobian([&](int k, int c) { return __half2float(h2[k * 3 + c]); });
+        } else {
+            const float* f2 = reinterpret_cast<const float*>(&s_sh[wave][lane * 13]);
+            colour_jacobian([&](int k, int c) { return f2[k * 3 + c]; });
+        }
+    }
     }
     __syncthreads(); // the LDS slab is reused by the next iteration
     }
