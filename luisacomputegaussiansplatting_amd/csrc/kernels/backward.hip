@@ -98,22 +98,25 @@ __device__ __forceinline__ bool splat_may_touch_rect(float mx, float my, float c
 // = 112 issue cycles per entry instead of 224, and one LDS add instruction per value and FOUR entries (lanes 15, 31,
 // 47 and 63, each to its own entry's accumulator row) instead of one per value and entry.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void swap32_add9(const float x[9], const float y[9], float out[9])
+// (inline asm rather than __builtin_amdgcn_permlane32_swap: the builtin returns fresh values, and the compiler copies
+// both operands first -- two extra moves per swap; x and y are dead after the call, the swap may clobber them.  The
+// s_nop covers the 2-wait-state VALU-write -> permlane-read hazard, which nothing pads inside asm.)
+__device__ __forceinline__ void swap32_add9(float x[9], float y[9], float out[9])
 {
 #pragma unroll
     for (int g = 0; g < 9; ++g) {
-        // lanes 0-31: r[0] = own x, r[1] = partner's x;  lanes 32-63: r[0] = partner's y, r[1] = own y
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[g]), __float_as_uint(y[g]), false, false);
-        out[g]       = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        // lanes 0-31: x = own x, y = partner's x;  lanes 32-63: x = partner's y, y = own y
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x[g]), "+v"(y[g]));
+        out[g] = x[g] + y[g];
     }
 }
-__device__ __forceinline__ void swap16_add9(const float x[9], const float y[9], float out[9])
+__device__ __forceinline__ void swap16_add9(float x[9], float y[9], float out[9])
 {
 #pragma unroll
     for (int g = 0; g < 9; ++g) {
         // rows 1 and 3 of x trade places with rows 0 and 2 of y: after the add the rows hold x.lo, y.lo, x.hi, y.hi
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[g]), __float_as_uint(y[g]), false, false);
-        out[g]       = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x[g]), "+v"(y[g]));
+        out[g] = x[g] + y[g];
     }
 }
 // sums over each 16-lane row, result in lane 15 of the row.  The nine chains advance in lockstep, one DPP step each
@@ -144,7 +147,7 @@ __device__ __forceinline__ void row_sum9_to_lane15(float v[9])
 
 // Steps 2 and 3 on (AB, CD) and the LDS adds.  rows: lanes 15 / 31 / 47 / 63 hold the LDS byte address of the
 // accumulator row (&s_grad[0][idx]) of entry A / C / B / D; value g goes to row + g * 1024.
-__device__ __forceinline__ void reduce_quad_and_add(const float pair[9], const float quad[9], uint32_t rows,
+__device__ __forceinline__ void reduce_quad_and_add(float pair[9], float quad[9], uint32_t rows,
                                                     bool is_row_end)
 {
     float r[9];
@@ -332,27 +335,29 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
                     return true;
                 }
             };
-            const float zero9[9] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
             uint32_t    rows     = grad_base; // rows of unused slots receive +0.0f
             for (;;) {
                 float    A[9], B[9], pair[9], quad[9];
                 uint32_t row;
                 if (!next_entry(A, row)) break;
                 asm volatile("v_writelane_b32 %0, %1, 15" : "+v"(rows) : "s"(row));
-                if (!next_entry(B, row)) {
-                    swap32_add9(A, zero9, pair);
-                    reduce_quad_and_add(pair, zero9, rows, is_row_end);
+                if (!next_entry(B, row)) { // pad the open group with zero value sets (their rows receive +0.0f)
+                    float z1[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, z2[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+                    swap32_add9(A, z1, pair);
+                    reduce_quad_and_add(pair, z2, rows, is_row_end);
                     break;
                 }
                 asm volatile("v_writelane_b32 %0, %1, 47" : "+v"(rows) : "s"(row));
                 swap32_add9(A, B, pair);
                 if (!next_entry(A, row)) {
-                    reduce_quad_and_add(pair, zero9, rows, is_row_end);
+                    float z1[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+                    reduce_quad_and_add(pair, z1, rows, is_row_end);
                     break;
                 }
                 asm volatile("v_writelane_b32 %0, %1, 31" : "+v"(rows) : "s"(row));
                 if (!next_entry(B, row)) {
-                    swap32_add9(A, zero9, quad);
+                    float z1[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+                    swap32_add9(A, z1, quad);
                     reduce_quad_and_add(pair, quad, rows, is_row_end);
                     break;
                 }
