@@ -172,7 +172,8 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
                                                            const float* __restrict__ dL_dimg,
                                                            float* __restrict__ grads2d,
                                                            const uint32_t* __restrict__ tile_order,
-                                                           const uint8_t* __restrict__ strip_masks)
+                                                           const uint8_t* __restrict__ strip_masks,
+                                                           const uint32_t* __restrict__ d_counts)
 {
     __shared__ float4             s_a[256]; // mean.x, mean.y, conic.x, conic.y
     __shared__ float4             s_b[256]; // conic.z, opacity, r, g
@@ -190,6 +191,9 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
         ty = t / cp.grid_x;
     } else if (!tile_of_workgroup(blockIdx.x, cp.grid_x, cp.grid_y, tx, ty)) return;
     const uint32_t tile = ty * cp.grid_x + tx;
+    // a frame that drew nothing left final_T / n_contrib untouched (the forward returns before writing them, like
+    // gs_tile_splatter/impl.cpp:109): there is nothing to differentiate, and nothing valid to read
+    if (d_counts && d_counts[1] == 0u) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t px = tx * kBlockX + (lane & 15u);
     const uint32_t py = ty * kBlockY + 4u * wave + (lane >> 4);
@@ -221,6 +225,10 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
 #pragma unroll
     for (int w = 1; w < 4; ++w) hi = s_max[w] > hi ? s_max[w] : hi;
     const uint32_t range_start = ranges[2 * (size_t)tile + 0];
+    {   // never walk past the tile's own list, whatever n_contrib holds
+        const uint32_t len = ranges[2 * (size_t)tile + 1] - range_start;
+        hi                 = hi < len ? hi : len;
+    }
 
     // per-pixel recurrences, walked back to front: T = transmittance in front of the current splat,
     // B = colour composited behind it
@@ -735,11 +743,11 @@ void launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t s
 void launch_render_backward(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                             const SplatRecord* recs, const float* final_T, const uint32_t* n_contrib,
                             const float* dL_dimg, float* grads2d, const uint32_t* tile_order, hipStream_t stream,
-                            const uint8_t* strip_masks)
+                            const uint8_t* strip_masks, const uint32_t* d_counts)
 {
     if (cp.grid_x * cp.grid_y == 0) return;
     hipLaunchKernelGGL(k_render_backward, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(256), 0, stream, cp, bg[0],
-                       bg[1], bg[2], ranges, point_list, recs, final_T, n_contrib, dL_dimg, grads2d, tile_order, strip_masks);
+                       bg[1], bg[2], ranges, point_list, recs, final_T, n_contrib, dL_dimg, grads2d, tile_order, strip_masks, d_counts);
 }
 
 void launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,

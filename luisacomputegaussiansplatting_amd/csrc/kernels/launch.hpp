@@ -125,7 +125,7 @@ void   launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t
 void   launch_render_backward(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                               const SplatRecord* recs, const float* final_T, const uint32_t* n_contrib,
                               const float* dL_dimg, float* grads2d, const uint32_t* tile_order, hipStream_t stream,
-                              const uint8_t* strip_masks = nullptr);
+                              const uint8_t* strip_masks = nullptr, const uint32_t* d_counts = nullptr);
 void   launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
                                   const float* scale, const float* rotq, const float* sh, const uint32_t* vis_index,
                                   const uint32_t* d_counts, const float* grads2d, float* dL_dpos, float* dL_dscale,

@@ -75,3 +75,24 @@ def test_backward_requires_forward_state(lcgs):
     with pytest.raises(lcgs.LcgsError) as e:
         r.backward(z(3, 32, 32), z(100, 3), z(100, 3), z(100, 4), z(100, 48), z(100))
     assert e.value.status == 8  # LCGS_ERR_STATE
+
+
+def test_backward_of_an_empty_frame_is_all_zeros(lcgs):
+    """Nothing reaches the screen (every splat behind the camera): forward leaves the image alone, backward zero-fills."""
+    rng = np.random.default_rng(9)
+    scene = make_scene(rng, 700)
+    scene["pos"][:] = np.array(POSE[0]) - 3.0 * (np.array(POSE[1]) - np.array(POSE[0]))
+    r = lcgs.Renderer(lcgs.Context(0))
+    d = upload_scene(scene)
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    img = torch.full((3, 48, 64), -1.0, device=DEV)
+    assert r.forward(lcgs.get_lookat_cam(*POSE, width=64, height=48), img, keep_state=True) == 0
+    assert (img == -1.0).all()
+    g = {k: torch.full_like(d[k], 9.0) for k in ("pos", "scale", "rotq", "sh", "opacity")}
+    r.backward(torch.randn(3, 48, 64, device=DEV), g["pos"], g["scale"], g["rotq"], g["sh"], g["opacity"])
+    r.ctx.synchronize()
+    assert all((t == 0).all() for t in g.values())
+    # and a second backward on the same frame state is allowed
+    r.backward(torch.randn(3, 48, 64, device=DEV), g["pos"], g["scale"], g["rotq"], g["sh"], g["opacity"])
+    r.ctx.synchronize()
+    assert all((t == 0).all() for t in g.values())
