@@ -48,6 +48,10 @@ lcgs_status DeviceBuffer::ensure(size_t need)
     }
     LCGS_HIP_CHECK(hipMalloc(&ptr, new_bytes));
     bytes = new_bytes;
+    // test hook: fresh workspace starts as garbage instead of whatever the allocator hands out (usually zeros), so
+    // that a kernel reading what no kernel wrote shows up in the parity tests
+    static const bool poison = getenv("LCGS_POISON") != nullptr;
+    if (poison) LCGS_HIP_CHECK(hipMemset(ptr, 0xA5, new_bytes));
     return LCGS_OK;
 }
 
