@@ -242,3 +242,36 @@ def test_half_precision_sh_is_opt_in_and_close(lcgs, oracle):
     r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
     r.forward(cam, again)
     assert torch.equal(again, ref)
+
+
+def test_resolution_and_view_changes_on_one_context(lcgs, oracle):
+    """One context through a sequence of frames that change resolution (tile count), view and keep_state, with a
+    backward in the middle: every frame must equal the same frame from a fresh context (workspace alternation,
+    previous-frame tile schedule, zeroed copies and counters all carry state from frame to frame)."""
+    rng = np.random.default_rng(77)
+    scene = make_scene(rng, 30000, log_scale=(-4.0, 0.8))
+    d = upload_scene(scene)
+    seq = [((640, 480), 0.0, False), ((320, 200), 0.4, False), ((640, 480), 0.4, True), ((1000, 700), 0.9, False),
+           ((320, 200), 0.0, True), ((320, 200), 0.0, False), ((1000, 700), 0.2, False)]
+
+    def cam_for(res, ang):
+        return lcgs.get_lookat_cam([-3 * np.cos(ang), -0.5 + 3 * np.sin(ang), 2.3], [0, 0, 0.5], [0, 0, 1], width=res[0],
+                                   height=res[1])
+
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    outs = []
+    for k, (res, ang, keep) in enumerate(seq):
+        img = torch.full((3, res[1], res[0]), -1.0, device=DEV)
+        r.forward(cam_for(res, ang), img, keep_state=keep, sync=(k % 2 == 0))
+        if keep:
+            g = [torch.zeros_like(d[key]) for key in ("pos", "scale", "rotq", "sh", "opacity")]
+            r.backward(torch.ones(3, res[1], res[0], device=DEV), *g)
+        outs.append(img)
+    r.ctx.synchronize()
+    for (res, ang, keep), img in zip(seq, outs):
+        fresh = lcgs.Renderer(lcgs.Context(0))
+        fresh.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+        ref = torch.zeros(3, res[1], res[0], device=DEV)
+        fresh.forward(cam_for(res, ang), ref, sync=True)
+        assert torch.equal(img, ref), (res, ang, keep)
