@@ -275,3 +275,24 @@ def test_resolution_and_view_changes_on_one_context(lcgs, oracle):
         ref = torch.zeros(3, res[1], res[0], device=DEV)
         fresh.forward(cam_for(res, ang), ref, sync=True)
         assert torch.equal(img, ref), (res, ang, keep)
+
+
+def test_asynchronous_overflow_is_reported_at_the_next_sync(lcgs, oracle):
+    """A frame enqueued without synchronisation that needs more pairs than the workspace holds: its lists are
+    truncated, the next synchronising call says so (LCGS_ERR_CAPACITY) and grows the workspace; rendering the frame
+    again gives the full image."""
+    rng = np.random.default_rng(13)
+    scene = make_scene(rng, 6000, log_scale=(-1.0, 0.2))  # big splats: L >> max(4 * P, 2^22)
+    r = lcgs.Renderer(lcgs.Context(0))
+    d = upload_scene(scene)
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    cam = lcgs.get_lookat_cam(*POSE, width=1920, height=1080)
+    img = torch.zeros(3, 1080, 1920, device=DEV)
+    r.forward(cam, img, sync=False)
+    with pytest.raises(lcgs.LcgsError) as e:
+        r.ctx.synchronize()
+    assert e.value.status == 5  # LCGS_ERR_CAPACITY
+    n = r.forward(cam, img, sync=True)
+    ref = oracle.render(scene, oracle.lookat(*POSE, width=1920, height=1080), ambig_eps=1e-5)
+    assert n == ref["num_rendered"] and n > (1 << 22)
+    assert_image_parity(img.cpu().numpy(), ref)
