@@ -296,3 +296,29 @@ def test_asynchronous_overflow_is_reported_at_the_next_sync(lcgs, oracle):
     ref = oracle.render(scene, oracle.lookat(*POSE, width=1920, height=1080), ambig_eps=1e-5)
     assert n == ref["num_rendered"] and n > (1 << 22)
     assert_image_parity(img.cpu().numpy(), ref)
+
+
+def test_asynchronous_overflow_inside_a_camera_batch(lcgs):
+    """Same through lcgs_render_forward_batch: both workspaces (the context's and its sibling's) report and grow."""
+    rng = np.random.default_rng(13)
+    scene = make_scene(rng, 6000, log_scale=(-1.0, 0.2))
+    d = upload_scene(scene)
+    cam = lcgs.get_lookat_cam(*POSE, width=1920, height=1080)
+    good = lcgs.Renderer(lcgs.Context(0))
+    good.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    ref = torch.zeros(3, 1080, 1920, device=DEV)
+    good.forward(cam, ref, sync=True)
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    imgs = [torch.zeros(3, 1080, 1920, device=DEV) for _ in range(4)]
+    errors = 0
+    for attempt in range(4):
+        r.forward_batch([cam] * 4, imgs)
+        try:
+            r.ctx.synchronize()
+            break
+        except lcgs.LcgsError as e:
+            assert e.status == 5
+            errors += 1
+    assert 1 <= errors <= 3
+    assert all(torch.equal(i, ref) for i in imgs)
