@@ -100,3 +100,23 @@ def test_c4_garden_forward_backward_gradients(lcgs, oracle):
         assert np.isfinite(a).all()
         rel = np.linalg.norm(a - b) / np.linalg.norm(b)
         assert rel <= 1e-3, f"{name}: relative L2 error {rel:.2e} (BASELINE tolerance 1e-3)"
+
+
+def test_very_large_frame_more_than_65536_tiles(lcgs, oracle):
+    """5008 x 4000 = 313 x 250 = 78 250 tiles: 17 live tile bits (three partition passes), tile ids beyond 16 bits, a
+    renderer grid of 78 K workgroups, a resolution that is not a multiple of 16."""
+    from conftest import make_scene
+    from gpu_util import DEV, assert_image_parity, upload_scene
+
+    rng = np.random.default_rng(99)
+    scene = make_scene(rng, 40000, spread=0.9, log_scale=(-3.6, 0.9))
+    W, H = 5008, 4000
+    pose = ([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1])
+    r = lcgs.Renderer(lcgs.Context(0))
+    d = upload_scene(scene)
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    img = torch.zeros(3, H, W, device=DEV)
+    n = r.forward(lcgs.get_lookat_cam(*pose, width=W, height=H), img, bg=(0.0, 0.1, 0.0), sync=True)
+    ref = oracle.render(scene, oracle.lookat(*pose, width=W, height=H), bg=(0.0, 0.1, 0.0), ambig_eps=1e-5)
+    assert n == ref["num_rendered"]
+    assert_image_parity(img.cpu().numpy(), ref)
