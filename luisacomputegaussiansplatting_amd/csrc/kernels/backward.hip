@@ -378,11 +378,13 @@ __global__ void __launch_bounds__(256) k_render_backward(CamParams cp, float bg0
         __syncthreads();
         // ---- flush the round.  Global float atomics run at full rate only when a wave instruction covers
         // contiguous bytes (MI355X_MICROARCH "Global float atomics": 64 lanes in 64 different rows are ~17x
-        // slower), so 12 consecutive lanes own one entry's 12-float gradient row instead of one lane per entry.
+        // slower), so consecutive lanes own one entry's gradient row instead of one lane per entry: 16 lanes per
+        // entry (9 of them active; shifts and masks instead of a division by 12 in a loop that runs every round).
         s_vid[tid] = (have && kmask != 0u) ? vid : 0xFFFFFFFFu;
         __syncthreads();
-        for (uint32_t cidx = tid; cidx < 256u * (uint32_t)kG2D; cidx += 256u) {
-            const uint32_t idx = cidx / (uint32_t)kG2D, g = cidx - idx * (uint32_t)kG2D;
+#pragma unroll 4
+        for (uint32_t cidx = tid; cidx < 256u * 16u; cidx += 256u) {
+            const uint32_t idx = cidx >> 4, g = cidx & 15u;
             const uint32_t v   = s_vid[idx];
             if (g < 9u && v != 0xFFFFFFFFu) {
                 // sums -> gradients: d/dmean = -(conic . (S hx, S hy)), d/dconic = (-1/2, -1, -1/2) (S hx dx, ...)
