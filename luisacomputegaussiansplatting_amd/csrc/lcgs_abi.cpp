@@ -51,7 +51,10 @@ lcgs_status DeviceBuffer::ensure(size_t need)
     // test hook: fresh workspace starts as garbage instead of whatever the allocator hands out (usually zeros), so
     // that a kernel reading what no kernel wrote shows up in the parity tests
     static const bool poison = getenv("LCGS_POISON") != nullptr;
-    if (poison) LCGS_HIP_CHECK(hipMemset(ptr, 0xA5, new_bytes));
+    if (poison) {
+        LCGS_HIP_CHECK(hipMemset(ptr, 0xA5, new_bytes)); // (legacy stream: not ordered against non-blocking streams,
+        LCGS_HIP_CHECK(hipDeviceSynchronize());          //  so finish it before anybody writes real data)
+    }
     return LCGS_OK;
 }
 
@@ -176,6 +179,14 @@ namespace
 
 lcgs_status mark(lcgs_context* ctx, const char* name)
 {
+    // debugging hook: LCGS_DEBUG_SYNC=1 waits for the device after every stage and names it (a faulting kernel
+    // then aborts right after its stage's line instead of at some later synchronisation)
+    static const bool debug_sync = getenv("LCGS_DEBUG_SYNC") != nullptr;
+    if (debug_sync) {
+        fprintf(stderr, "[lcgs %p] %s ...\n", (void*)ctx, name);
+        (void)hipDeviceSynchronize();
+        fprintf(stderr, "[lcgs %p] %s done\n", (void*)ctx, name);
+    }
     if (!ctx->profiling) return LCGS_OK;
     if (!ctx->events_created) {
         for (int i = 0; i < kMaxEvents; ++i) LCGS_HIP_CHECK(hipEventCreate(&ctx->events[i]));
