@@ -93,15 +93,17 @@ struct lcgs_context {
     bool         use_half_sh = false;
 
     // workspace of the fused frame
-    DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws[2], counts, sort_ws,
+    DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws[3], counts, sort_ws,
         expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks, shjac;
     bool         last_has_jac = false; // the last keep_state frame stored the colour Jacobian (degree 3)
-    // zero_ws holds what a frame needs zeroed: the chained-scan states of the cull pass and the tile ranges.  Two
-    // copies alternate between frames so that the next frame's copy is cleared on the auxiliary stream while the
-    // current frame renders (zero_ready) instead of at the head of the next frame.
+    // zero_ws holds what a frame needs zeroed: the chained-scan states of the cull pass and the tile ranges.  Three
+    // copies rotate: while frame N runs, the auxiliary stream clears the copy of frame N + 2.  Two frames ahead, not
+    // one, so that no wait is needed when a frame starts: the fill issued during frame N - 1 sits on the auxiliary
+    // stream in front of frame N's record builder, whose completion frame N's renderer waited for -- and frame N + 1
+    // starts behind that renderer.
     size_t    zero_scan_bytes = 0, zero_bytes = 0;
     int       zero_cur        = 0;
-    bool      zero_ready[2]   = { false, false };
+    bool      zero_ready[3]   = { false, false, false };
     uint32_t* ranges          = nullptr; // tile ranges of the last frame (inside zero_ws[...])
     // device-resident per-call parameters + the captured frame graph (replayed while its key is unchanged)
     DeviceBuffer   frame_params;
@@ -286,11 +288,13 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
     const size_t G = (size_t)cp.grid_x * cp.grid_y;
     auto         al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t b0 = al(fused_scan_state_bytes((int)P)), b1 = al(G * 2 * 4);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         const void* before = ctx->zero_ws[i].ptr;
         LCGS_TRY(ctx->zero_ws[i].ensure(b0 + b1));
         if (ctx->zero_ws[i].ptr != before || ctx->zero_bytes != b0 + b1) ctx->zero_ready[i] = false;
-        before = ctx->tile_order[i].ptr;
+    }
+    for (int i = 0; i < 2; ++i) {
+        const void* before = ctx->tile_order[i].ptr;
         LCGS_TRY(ctx->tile_order[i].ensure(G * 4));
         if (ctx->tile_order[i].ptr != before) ctx->order_G = 0;
     }
@@ -332,7 +336,13 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     // Zeroed per frame: scan states of the cull pass + tile ranges (the reference zero-fills ranges too,
     // gs_tile_splatter/impl.cpp:147).  Normally the auxiliary stream cleared this frame's copy during the last frame.
     const int zb = deferred ? ctx->zero_cur : 0;
-    if (ctx->aux_pending && !in_capture) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_aux_done, 0)); // zero copy + tile order
+    if (!deferred && ctx->aux_pending && !in_capture) {
+        // leaving the pipelined mode (profiling switched on): the auxiliary stream may still be filling a copy or
+        // writing a tile schedule this in-order frame is about to use
+        LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_aux_done, 0));
+        ctx->aux_pending = false;
+        for (bool& r : ctx->zero_ready) r = false;
+    }
     if (!(deferred && ctx->zero_ready[zb])) LCGS_HIP_CHECK(hipMemsetAsync(ctx->zero_ws[zb].ptr, 0, ctx->zero_bytes, st));
     ctx->zero_ready[zb]  = false;
     uint64_t* scan_state = ctx->zero_ws[zb].as<uint64_t>();
@@ -403,7 +413,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     if (deferred) {
         // behind the records on the auxiliary stream, beside the renderer: this frame's list lengths -> next
         // frame's schedule, and the next frame's zeroed copy
-        const int ob = ctx->order_cur ^ 1, znext = zb ^ 1;
+        const int ob = ctx->order_cur ^ 1, znext = (zb + 2) % 3; // the copy of the frame after the next
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_ranges, st));
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_ranges, 0));
         launch_tile_order(ctx->ranges, G, ctx->tile_order[ob].as<uint32_t>(), ctx->aux_stream);
@@ -411,8 +421,8 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_aux_done, ctx->aux_stream));
         ctx->aux_pending       = true;
         ctx->zero_ready[znext] = true;
-        ctx->zero_cur          = znext;
-        ctx->order_cur         = ob; // complete once ev_aux_done has fired (the next frame waits for it)
+        ctx->zero_cur          = (zb + 1) % 3;
+        ctx->order_cur         = ob; // written before the next frame's record builder runs: its renderer waits for that
     }
 
     if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0)); // records are ready
@@ -515,7 +525,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     DeviceBuffer* bufs[] = { &ctx->recs, &ctx->sortk[0], &ctx->sortk[1], &ctx->sortv[0], &ctx->sortv[1], &ctx->vis_index,
                              &ctx->rects, &ctx->rects_sorted, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
-                             &ctx->pairv[1], &ctx->zero_ws[0], &ctx->zero_ws[1], &ctx->counts, &ctx->sort_ws,
+                             &ctx->pairv[1], &ctx->zero_ws[0], &ctx->zero_ws[1], &ctx->zero_ws[2], &ctx->counts, &ctx->sort_ws,
                              &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order[0], &ctx->tile_order[1], &ctx->st_keys_tmp,
                              &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac };
     for (DeviceBuffer* b : bufs) b->release();
