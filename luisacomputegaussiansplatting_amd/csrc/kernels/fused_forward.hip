@@ -25,6 +25,8 @@
 // Element counts (V, L) never leave the device: kernels read them from d_counts.
 #include <hip/hip_fp16.h>
 
+#include <hip/hip_ext.h>
+
 #include "launch.hpp"
 
 namespace lcgs
@@ -653,10 +655,17 @@ void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const
                          const float* scale,
                          const float* rotq, const float* opacity, int32_t* radii, uint32_t* sort_keys,
                          uint32_t* sort_vals, uint32_t* vis_index, uint2* rects, uint64_t* scan_state,
-                         uint32_t* d_counts, hipStream_t stream)
+                         uint32_t* d_counts, hipStream_t stream, hipEvent_t done)
 {
-    hipLaunchKernelGGL(k_cull_compact, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, P, cp, scale_modifier, d_fp, pos,
-                       scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index, rects, scan_state, d_counts);
+    // `done` rides on the dispatch packet itself (completion signal): no separate event-record packet sits between
+    // this kernel and the next one on the stream
+    if (done)
+        hipExtLaunchKernelGGL(k_cull_compact, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, nullptr, done, 0, P, cp,
+                              scale_modifier, d_fp, pos, scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index, rects,
+                              scan_state, d_counts);
+    else
+        hipLaunchKernelGGL(k_cull_compact, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, P, cp, scale_modifier, d_fp,
+                           pos, scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index, rects, scan_state, d_counts);
 }
 
 void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const FrameParams* d_fp,
@@ -726,12 +735,16 @@ void launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts
 }
 
 void launch_get_ranges_u32(int64_t L_cap, uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
-                           const uint32_t* scan_error_flag, hipStream_t stream)
+                           const uint32_t* scan_error_flag, hipStream_t stream, hipEvent_t done)
 {
     unsigned blocks = blocks_for(L_cap);
     if (blocks > 4096u) blocks = 4096u;
-    hipLaunchKernelGGL(k_get_ranges_u32, dim3(blocks), dim3(kThreads), 0, stream, d_counts, keys, ranges,
-                       scan_error_flag);
+    if (done)
+        hipExtLaunchKernelGGL(k_get_ranges_u32, dim3(blocks), dim3(kThreads), 0, stream, nullptr, done, 0, d_counts, keys,
+                              ranges, scan_error_flag);
+    else
+        hipLaunchKernelGGL(k_get_ranges_u32, dim3(blocks), dim3(kThreads), 0, stream, d_counts, keys, ranges,
+                           scan_error_flag);
 }
 
 void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t* list_vid, const uint32_t* vis_index,

@@ -60,7 +60,8 @@ void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const
                          const float* scale,
                          const float* rotq, const float* opacity, int32_t* radii, uint32_t* sort_keys,
                          uint32_t* sort_vals, uint32_t* vis_index, uint2* rects, uint64_t* scan_state,
-                         uint32_t* d_counts, hipStream_t stream);
+                         uint32_t* d_counts, hipStream_t stream,
+                         hipEvent_t done = nullptr); // optional completion event carried by the dispatch itself
 size_t expand_ws_bytes(int P_cap);
 // v_hint: expected survivor count (bounds the launch; larger live counts are handled by chunk striding)
 void launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts, uint32_t grid_x,
@@ -86,7 +87,7 @@ void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scal
 bool build_records_writes_jacobian(int sh_deg, const float* sh, bool half);
 void launch_sh_to_half(int64_t n, const float* src, uint16_t* dst, hipStream_t stream);
 void launch_get_ranges_u32(int64_t L_cap, uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
-                           const uint32_t* scan_error_flag, hipStream_t stream);
+                           const uint32_t* scan_error_flag, hipStream_t stream, hipEvent_t done = nullptr);
 void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t* list_vid, const uint32_t* vis_index,
                          uint32_t* list_idx, hipStream_t stream);
 
@@ -114,7 +115,8 @@ void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipS
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,
-                               const uint32_t* tile_order, hipStream_t stream, uint8_t* strip_masks = nullptr);
+                               const uint32_t* tile_order, hipStream_t stream, uint8_t* strip_masks = nullptr,
+                               hipEvent_t done = nullptr);
 // strip_masks[list position] = the four per-strip reach bits of that entry (written when final_T / n_contrib are
 // kept); the backward takes them instead of repeating the tests
 bool render_forward_writes_strip_masks();

@@ -21,6 +21,8 @@
 // (-ffp-contract=off); exp() is the hardware v_exp_f32 path (__expf).
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
+
 #include "launch.hpp"
 
 namespace lcgs
@@ -493,7 +495,7 @@ template <typename Fetch>
 void launch_render(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                    Fetch fetch, float* img, float* final_T, uint32_t* n_contrib, const uint32_t* d_counts,
                    const FrameParams* d_fp, const uint32_t* tile_order, hipStream_t stream,
-                   uint8_t* strip_masks = nullptr)
+                   uint8_t* strip_masks = nullptr, hipEvent_t done = nullptr)
 {
     if (cp.grid_x * cp.grid_y == 0) return;
     static const int variant = [] {
@@ -502,12 +504,15 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
     }();
     if (variant == 1) {
         const dim3 grid(render_grid_size(cp.grid_x, cp.grid_y));
+        // (`done`, when given, is carried by the dispatch packet: no separate event-record packet behind the kernel)
         if (final_T || n_contrib)
-            hipLaunchKernelGGL((k_render_forward_b<Fetch, true>), grid, dim3(256), 0, stream, cp, bg[0], bg[1], bg[2], d_fp,
-                               ranges, point_list, fetch, img, final_T, n_contrib, d_counts, tile_order, strip_masks);
+            hipExtLaunchKernelGGL((k_render_forward_b<Fetch, true>), grid, dim3(256), 0, stream, nullptr, done, 0, cp, bg[0],
+                                  bg[1], bg[2], d_fp, ranges, point_list, fetch, img, final_T, n_contrib, d_counts,
+                                  tile_order, strip_masks);
         else // forward only: the last-contributor bookkeeping is compiled out
-            hipLaunchKernelGGL((k_render_forward_b<Fetch, false>), grid, dim3(256), 0, stream, cp, bg[0], bg[1], bg[2], d_fp,
-                               ranges, point_list, fetch, img, final_T, n_contrib, d_counts, tile_order, nullptr);
+            hipExtLaunchKernelGGL((k_render_forward_b<Fetch, false>), grid, dim3(256), 0, stream, nullptr, done, 0, cp, bg[0],
+                                  bg[1], bg[2], d_fp, ranges, point_list, fetch, img, final_T, n_contrib, d_counts,
+                                  tile_order, (uint8_t*)nullptr);
         return;
     }
     hipLaunchKernelGGL(k_render_forward<Fetch>, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(64), 0, stream, cp, bg[0], bg[1], bg[2], d_fp, ranges,
@@ -534,10 +539,10 @@ void launch_render_forward_aos(const CamParams& cp, const float bg[3], const uin
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,
-                               const uint32_t* tile_order, hipStream_t stream, uint8_t* strip_masks)
+                               const uint32_t* tile_order, hipStream_t stream, uint8_t* strip_masks, hipEvent_t done)
 {
     launch_render(cp, bg, ranges, point_list, FetchRec{ recs }, img, final_T, n_contrib, d_counts, d_fp, tile_order,
-                  stream, strip_masks);
+                  stream, strip_masks, done);
 }
 
 // true when the forward renderer in use fills strip_masks (the workgroup-per-tile variant does)

@@ -349,7 +349,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     ctx->ranges          = reinterpret_cast<uint32_t*>(ctx->zero_ws[zb].as<char>() + ctx->zero_scan_bytes);
     launch_cull_compact(P, cp, scale_modifier, d_fp, ctx->pos, ctx->scale, ctx->rotq, ctx->opacity, d_radii,
                         ctx->sortk[0].as<uint32_t>(), ctx->sortv[0].as<uint32_t>(), ctx->vis_index.as<uint32_t>(),
-                        ctx->rects.as<uint2>(), scan_state, d_counts, st);
+                        ctx->rects.as<uint2>(), scan_state, d_counts, st, (overlap && !in_capture) ? ctx->ev_fork : nullptr);
     LCGS_TRY(mark(ctx, "cull_compact"));
     const int64_t hint_V = ctx->hint_V > 0 ? ctx->hint_V : P;
     const int64_t hint_L = ctx->hint_L > 0 ? ctx->hint_L : ctx->pair_capacity;
@@ -358,7 +358,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     hipStream_t rec_stream = overlap ? ctx->aux_stream : st;
     // (forking later -- after the depth sort or after the duplication -- was measured slower: 1073 / 1048 vs 1094 fps)
     if (overlap) {
-        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));
+        if (in_capture) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st)); // (otherwise carried by the cull dispatch)
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
     }
     launch_build_records((int)std::min<int64_t>(P, hint_V), ctx->sh_deg, cp, scale_modifier, d_fp, ctx->pos, ctx->scale,
@@ -395,7 +395,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     LCGS_TRY(mark(ctx, "tile_sort"));
 
     launch_get_ranges_u32(hint_L, d_counts, ctx->pairk[where2].as<uint32_t>(), ctx->ranges,
-                          reinterpret_cast<const uint32_t*>(scan_state + 1), st);
+                          reinterpret_cast<const uint32_t*>(scan_state + 1), st, deferred ? ctx->ev_ranges : nullptr);
     // tile schedule: the newest complete order if it matches this grid, else computed here
     uint32_t* order_now = nullptr;
     if (deferred && ctx->order_G == G) {
@@ -414,8 +414,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
         // behind the records on the auxiliary stream, beside the renderer: this frame's list lengths -> next
         // frame's schedule, and the next frame's zeroed copy
         const int ob = ctx->order_cur ^ 1, znext = (zb + 2) % 3; // the copy of the frame after the next
-        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_ranges, st));
-        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_ranges, 0));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_ranges, 0)); // (carried by the ranges dispatch)
         launch_tile_order(ctx->ranges, G, ctx->tile_order[ob].as<uint32_t>(), ctx->aux_stream);
         LCGS_HIP_CHECK(hipMemsetAsync(ctx->zero_ws[znext].ptr, 0, ctx->zero_bytes, ctx->aux_stream));
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_aux_done, ctx->aux_stream));
@@ -429,14 +428,13 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     launch_render_forward_rec(cp, bg, ctx->ranges, ctx->pairv[where2].as<uint32_t>(), recs, d_img,
                               keep_state ? ctx->final_T.as<float>() : nullptr,
                               keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, d_fp, order_now, st,
-                              keep_state ? ctx->strip_masks.as<uint8_t>() : nullptr);
+                              keep_state ? ctx->strip_masks.as<uint8_t>() : nullptr, deferred ? ctx->ev_render : nullptr);
     ctx->last_tile_order = order_now;
     LCGS_TRY(mark(ctx, "render"));
 
     if (deferred) {
         // the counter read-back leaves through the auxiliary stream: the next frame does not queue behind it
-        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_render, st));
-        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_render, 0));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_render, 0)); // (carried by the render dispatch)
         LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, d_counts, 32, hipMemcpyDeviceToHost, ctx->aux_stream));
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_counts, ctx->aux_stream));
         ctx->counts_pending = true;
