@@ -82,6 +82,8 @@ def main():
         sys.exit(subprocess.call(cmd))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: liblcgs_hip has no CPU path")
+    # a launcher that narrows each rank's visibility to one GPU leaves fewer devices than local ranks
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
