@@ -497,7 +497,7 @@ lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx)
         if (se == hipSuccess) se = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     if (se != hipSuccess) {
         lcgs_status s = hip_fail(se, "aux stream / events", __FILE__, __LINE__);
-        delete ctx;
+        (void)lcgs_destroy(ctx); // releases whichever of the stream / events were created
         return s;
     }
     *out_ctx    = ctx;
@@ -547,6 +547,12 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
 lcgs_status lcgs_set_stream(lcgs_context* ctx, void* stream)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (ctx->stream != reinterpret_cast<hipStream_t>(stream)) {
+        // frames still in flight were ordered against the old stream: drain them before switching
+        LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+        LCGS_TRY(sync_frame(ctx));
+        if (ctx->twin) LCGS_TRY(sync_frame(ctx->twin));
+    }
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
     return LCGS_OK;
 }

@@ -277,6 +277,33 @@ def test_resolution_and_view_changes_on_one_context(lcgs, oracle):
         assert torch.equal(img, ref), (res, ang, keep)
 
 
+def test_stream_switch_with_frames_in_flight(lcgs, oracle):
+    """lcgs_set_stream while asynchronous frames are queued: the frames before and after the switch (NULL stream,
+    two user streams, back) all equal the frame of a fresh context."""
+    rng = np.random.default_rng(78)
+    scene = make_scene(rng, 40000, log_scale=(-4.0, 0.8))
+    d = upload_scene(scene)
+    cam = lcgs.get_lookat_cam([-3.0, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1], width=800, height=600)
+    s1, s2 = torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)
+    torch.cuda.synchronize()
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    order = (None, s1, s1, s2, None, s2)
+    outs = [torch.full((3, 600, 800), -1.0, device=DEV) for _ in order]
+    torch.cuda.synchronize()  # the fills ran on torch's stream, not on the ones used below
+    for st, img in zip(order, outs):
+        r.ctx.set_stream(0 if st is None else st.cuda_stream)
+        r.forward(cam, img, sync=False)
+    r.ctx.synchronize()
+    torch.cuda.synchronize()
+    fresh = lcgs.Renderer(lcgs.Context(0))
+    fresh.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    ref = torch.zeros(3, 600, 800, device=DEV)
+    fresh.forward(cam, ref, sync=True)
+    for k, img in enumerate(outs):
+        assert torch.equal(img, ref), k
+
+
 def test_asynchronous_overflow_is_reported_at_the_next_sync(lcgs, oracle):
     """A frame enqueued without synchronisation that needs more pairs than the workspace holds: its lists are
     truncated, the next synchronising call says so (LCGS_ERR_CAPACITY) and grows the workspace; rendering the frame
