@@ -84,10 +84,30 @@ struct Projected {
     uint32_t rmin[2], rw, rh; // pruned rect: origin + size in tiles
 };
 
-__device__ __forceinline__ Projected project_splat(const CamParams& cp, float scale_modifier, int idx,
-                                                   float px, float py, float pz, const float* __restrict__ scale,
-                                                   const float* __restrict__ rotq, const float* __restrict__ opacity)
+// One splat's inputs, loaded before any of the arithmetic so that all of a lane's loads are in flight together.
+struct SplatIn {
+    float  px, py, pz, sx, sy, sz;
+    float4 q; // stored (r,x,y,z)
+};
+
+__device__ __forceinline__ SplatIn load_splat(int64_t idx, const float* __restrict__ pos, const float* __restrict__ scale,
+                                              const float* __restrict__ rotq)
 {
+    SplatIn in;
+    in.px = pos[3 * (size_t)idx + 0];
+    in.py = pos[3 * (size_t)idx + 1];
+    in.pz = pos[3 * (size_t)idx + 2];
+    in.sx = scale[3 * (size_t)idx + 0];
+    in.sy = scale[3 * (size_t)idx + 1];
+    in.sz = scale[3 * (size_t)idx + 2];
+    in.q  = *reinterpret_cast<const float4*>(rotq + 4 * (size_t)idx);
+    return in;
+}
+
+__device__ __forceinline__ Projected project_splat(const CamParams& cp, float scale_modifier, const SplatIn& in,
+                                                   float opac)
+{
+    const float px = in.px, py = in.py, pz = in.pz;
     Projected r;
     r.visible   = false;
     r.radius    = 0;
@@ -100,9 +120,8 @@ __device__ __forceinline__ Projected project_splat(const CamParams& cp, float sc
     if (v[2] < 0.2f) return r; // gs_projector/shader.cpp:121
     ndc_from_view(cp, v, ndc);
     r.depth    = v[2];
-    float s[3] = { scale_modifier * scale[3 * (size_t)idx + 0], scale_modifier * scale[3 * (size_t)idx + 1],
-                   scale_modifier * scale[3 * (size_t)idx + 2] };
-    const float4 q = *reinterpret_cast<const float4*>(rotq + 4 * (size_t)idx); // stored (r,x,y,z)
+    float s[3] = { scale_modifier * in.sx, scale_modifier * in.sy, scale_modifier * in.sz };
+    const float4 q = in.q;
     float        Sig[3][3], t[3], cov2d[3], filt[3];
     cov3d_from_scale_rot(s, q.y, q.z, q.w, q.x, Sig);
     cam_clamp(cp, v, t);
@@ -115,7 +134,7 @@ __device__ __forceinline__ Projected project_splat(const CamParams& cp, float sc
     r.ref_tiles = (fmax[0] - fmin[0]) * (fmax[1] - fmin[1]);
     if (r.radius <= 0) r.ref_tiles = 0; // radius <= 0 never emits pairs (gs_tile_splatter/shader.cpp:41-42)
     if (r.ref_tiles == 0) return r;
-    tight_rect(r.pix_x, r.pix_y, filt[0], filt[1], filt[2], opacity[idx], fmin, fmax, tmin, tmax);
+    tight_rect(r.pix_x, r.pix_y, filt[0], filt[1], filt[2], opac, fmin, fmax, tmin, tmax);
     r.rmin[0] = tmin[0];
     r.rmin[1] = tmin[1];
     r.rw      = tmax[0] - tmin[0];
@@ -125,18 +144,77 @@ __device__ __forceinline__ Projected project_splat(const CamParams& cp, float sc
 }
 
 // Pass A over ALL splats: project, cull, and compact the survivors' indices IN INDEX ORDER through a
-// single-pass chained scan (decoupled look-back across workgroups).  Reads 12 B per splat, +32 B for the
-// ones in front of the near plane; writes radii (4 B/splat) and 12 B per survivor.
-// A workgroup owns a chunk of kCullItems x 256 consecutive splats (lane t takes splats t, t+256, ... of the
-// chunk: coalesced) and takes ONE ticket per chunk -- tickets are handed out in start order, so every
-// predecessor a workgroup waits on is already running, whatever the dispatch order or XCD placement; one
-// returning atomic per 2048 splats keeps the single ticket word far below its ~88 ops/us saturation.
+// single-pass chained scan (decoupled look-back across workgroups).  Writes 12 B per survivor (+ radii on request).
+// A workgroup owns a chunk of kCullItems x 512 consecutive splats and works on it in two phases:
+//   1. every splat: view transform, the reference's near test (exact), and a CONSERVATIVE screen test -- an upper
+//      bound of the reference radius from trace(cov2d) <= (|T0|^2 + |T1|^2) * lambda_max(Sigma), with explicit slack;
+//      a splat this rejects provably has an empty tile rect (tiles_touched == 0).  The candidates' chunk-local
+//      indices are compacted, in index order, into LDS.
+//   2. the candidates only (40 % of the bicycle stand-in's splats; dense lanes): the full projection, radius,
+//      rect and opacity-aware pruning, bit for bit the reference's expressions.
+// Results are identical to running phase 2 on everything (that is what RADII = true does, for callers who want
+// the reference's radii array, which is defined for off-screen splats too).
+// The chunk takes ONE ticket -- tickets are handed out in start order, so every predecessor a workgroup waits on
+// is already running, whatever the dispatch order or XCD placement; one returning atomic per 2048 splats keeps
+// the single ticket word far below its ~88 ops/us saturation.
 // scan_state: [0] ticket counter (u32 in the low half), [1] error flag, [2..] per-chunk status words
 constexpr int kCullThreads = 512; // 8 waves: the per-lane chain of dependent loads is 4 splats long, not 8
 constexpr int kCullWaves   = kCullThreads / 64;
 constexpr int kCullItems   = 4;
 constexpr int kCullChunk   = kCullThreads * kCullItems; // 2048 splats per ticket
 
+// Phase-1 test.  Returns false only if the splat certainly emits no pair: behind the near plane (the reference's
+// own test) or bound-of-radius disc entirely off the rasterised tiles.  Any NaN makes every comparison false, i.e.
+// the splat stays a candidate and phase 2 decides.
+struct ScreenBound {
+    float lr2, lu2, lf2, drf, duf; // |right|^2, |up|^2, |front|^2, |right.front|, |up.front| (1,1,1,0,0 if orthonormal)
+    float xhi, yhi;                // 16 * (grid - 1): first pixel column / row that is never rasterised
+};
+
+__device__ __forceinline__ ScreenBound make_screen_bound(const CamParams& cp)
+{
+    ScreenBound b;
+    b.lr2 = cp.right[0] * cp.right[0] + cp.right[1] * cp.right[1] + cp.right[2] * cp.right[2];
+    b.lu2 = cp.up[0] * cp.up[0] + cp.up[1] * cp.up[1] + cp.up[2] * cp.up[2];
+    b.lf2 = cp.front[0] * cp.front[0] + cp.front[1] * cp.front[1] + cp.front[2] * cp.front[2];
+    b.drf = fabsf(cp.right[0] * cp.front[0] + cp.right[1] * cp.front[1] + cp.right[2] * cp.front[2]);
+    b.duf = fabsf(cp.up[0] * cp.front[0] + cp.up[1] * cp.front[1] + cp.up[2] * cp.front[2]);
+    b.xhi = (float)(kBlockX * (cp.grid_x - 1u));
+    b.yhi = (float)(kBlockY * (cp.grid_y - 1u));
+    return b;
+}
+
+__device__ __forceinline__ bool may_reach_screen(const CamParams& cp, const ScreenBound& sb, float scale_modifier,
+                                                 const SplatIn& in)
+{
+    float v[3], ndc[2];
+    view_transform(cp, in.px, in.py, in.pz, v);
+    if (v[2] < 0.2f) return false; // gs_projector/shader.cpp:121 (same expression as project_splat)
+    ndc_from_view(cp, v, ndc);
+    const float px = ndc2pix(ndc[0], cp.width), py = ndc2pix(ndc[1], cp.height); // bit-identical to phase 2
+    const float iz = __builtin_amdgcn_rcpf(v[2]);
+    const float cx = fminf(fabsf(v[0] * iz), 1.3f * cp.tanfovx) * 1.001f; // |t.x / t.z| after cam_clamp
+    const float cy = fminf(fabsf(v[1] * iz), 1.3f * cp.tanfovy) * 1.001f;
+    const float a = cp.focalx * iz, b = cp.focaly * iz;                   // |j00|, |j11|; |j02| = a cx, |j12| = b cy
+    const float t0 = a * a * (sb.lr2 + cx * (cx * sb.lf2 + 2.0f * sb.drf)); // >= |T0|^2
+    const float t1 = b * b * (sb.lu2 + cy * (cy * sb.lf2 + 2.0f * sb.duf)); // >= |T1|^2
+    // lambda_max(Sigma) = |R diag(s)|^2 <= (|R| s_max)^2, and R(q) = I + |q|^2 (R(q/|q|) - I): |R| <= |1 - n| + n
+    const float4 q  = in.q;
+    const float  n  = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    const float  sm = fabsf(scale_modifier) * fmaxf(fmaxf(fabsf(in.sx), fabsf(in.sy)), fabsf(in.sz));
+    const float  g  = (fabsf(1.0f - n) + n) * sm;
+    const float  tr = (t0 + t1) * (g * g) * 1.01f; // >= cov2d.xx + cov2d.yy, 1 % slack for the rounding of either side
+    // filtered: mid = tr/2 + 0.3, det >= 0  =>  lambda1 = mid + sqrt(max(0.1, mid^2 - det)) <= 2 mid + 0.05
+    const float rb = 3.0f * __builtin_amdgcn_sqrtf(tr + 0.65f) * 1.001f + 2.0f; // >= ceil(3 sqrt(lambda1)), + 1 px slack
+    // get_rect: the rect is empty iff px + r < 1 or px - r >= 16 (grid_x - 1), likewise in y
+    if (px + rb < 1.0f) return false;
+    if (py + rb < 1.0f) return false;
+    if (px - rb >= sb.xhi) return false;
+    if (py - rb >= sb.yhi) return false;
+    return true;
+}
+
+template <bool RADII>
 __global__ void __launch_bounds__(kCullThreads)
 k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __restrict__ fpp,
                const float* __restrict__ pos,
@@ -149,6 +227,7 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
     __shared__ uint32_t s_wave_vis[kCullItems][kCullWaves];
     __shared__ uint32_t s_wave_tiles[kCullWaves];
     __shared__ uint32_t s_prefix_vis;
+    __shared__ uint16_t s_cand[kCullChunk]; // chunk-local indices of the phase-1 survivors, in index order
 
     if (fpp) { // graph replay: per-call parameters come from device memory
         cp             = fpp->cp;
@@ -162,30 +241,83 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
     uint64_t*      states  = scan_state + 2;
     const int64_t  base    = (int64_t)bid * kCullChunk;
 
-    uint32_t vis_mask = 0;        // bit k: splat k of this lane survives
+    // ---- phase 1: candidates of the chunk -> s_cand (lane t takes splats t, t + 512, ...: coalesced)
+    uint32_t ncand;
+    if (RADII) {
+        const int64_t left = (int64_t)P - base;
+        ncand              = left >= kCullChunk ? (uint32_t)kCullChunk : (uint32_t)(left > 0 ? left : 0);
+        for (int c = tid; c < kCullChunk; c += kCullThreads) s_cand[c] = (uint16_t)c;
+        __syncthreads();
+    } else {
+        const ScreenBound sb = make_screen_bound(cp);
+        uint32_t          rank[kCullItems], cmask = 0;
+        SplatIn           in[kCullItems]; // all 28 loads of the lane's four splats are issued before the first test
+#pragma unroll
+        for (int k = 0; k < kCullItems; ++k) {
+            const int64_t idx = base + (int64_t)k * kCullThreads + tid;
+            in[k]             = load_splat(idx < P ? idx : (int64_t)P - 1, pos, scale, rotq);
+        }
+#pragma unroll
+        for (int k = 0; k < kCullItems; ++k) {
+            const int64_t idx = base + (int64_t)k * kCullThreads + tid;
+            const bool    c   = idx < P && may_reach_screen(cp, sb, scale_modifier, in[k]);
+            const unsigned long long m = __ballot(c);
+            rank[k] = __popcll(m & ((1ull << lane) - 1ull));
+            if (c) cmask |= 1u << k;
+            if (lane == 0) s_wave_vis[k][wave] = __popcll(m);
+        }
+        __syncthreads();
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < kCullItems; ++k) {
+#pragma unroll
+            for (int w = 0; w < kCullWaves; ++w) {
+                if (w == wave && ((cmask >> k) & 1u)) s_cand[run + rank[k]] = (uint16_t)(k * kCullThreads + tid);
+                run += s_wave_vis[k][w];
+            }
+        }
+        ncand = run;
+        __syncthreads(); // s_cand complete; s_wave_vis free for phase 2
+    }
+
+    // ---- phase 2: the full projection of the candidates (dense lanes), survivors ranked in index order
+    uint32_t vis_mask = 0;        // bit k: candidate k of this lane survives
     uint32_t lv[kCullItems];      // exclusive rank of the survivor inside its wave, per round
+    uint32_t gidx[kCullItems];    // its splat index
     float    depth[kCullItems];
     uint2    rect[kCullItems];    // pruned rect: x | y << 16, w | h << 16
     uint32_t tiles_sum = 0;       // reference tiles_touched (for num_rendered)
 #pragma unroll
     for (int k = 0; k < kCullItems; ++k) {
-        const int64_t idx = base + (int64_t)k * kCullThreads + tid;
-        bool          visible = false;
-        depth[k]              = 0.0f;
-        rect[k]               = make_uint2(0u, 0u);
-        if (idx < P) {
-            const Projected pr = project_splat(cp, scale_modifier, (int)idx, pos[3 * (size_t)idx + 0],
-                                               pos[3 * (size_t)idx + 1], pos[3 * (size_t)idx + 2], scale, rotq, opacity);
-            visible  = pr.visible;
-            depth[k] = pr.depth;
-            rect[k]  = make_uint2(pr.rmin[0] | (pr.rmin[1] << 16), pr.rw | (pr.rh << 16));
-            tiles_sum += pr.ref_tiles;
-            if (radii) radii[idx] = pr.radius;
+        bool visible = false;
+        depth[k]     = 0.0f;
+        rect[k]      = make_uint2(0u, 0u);
+        gidx[k]      = 0u;
+        lv[k]        = 0u;
+        if ((uint32_t)(k * kCullThreads) < ncand) { // workgroup-uniform
+            const uint32_t c = (uint32_t)(k * kCullThreads + tid);
+            if (c < ncand) {
+                const int64_t idx = base + (int64_t)s_cand[c];
+                gidx[k]           = (uint32_t)idx;
+                const SplatIn   in = load_splat(idx, pos, scale, rotq);
+                const float     op = opacity[idx];
+                // keep the compiler from sinking the scale / rotation / opacity loads below the near test: a
+                // candidate always passes it, and one round trip is cheaper than two
+                asm volatile("" ::"v"(in.sx), "v"(in.sy), "v"(in.sz), "v"(in.q.x), "v"(in.q.y), "v"(in.q.z), "v"(in.q.w), "v"(op));
+                const Projected pr = project_splat(cp, scale_modifier, in, op);
+                visible  = pr.visible;
+                depth[k] = pr.depth;
+                rect[k]  = make_uint2(pr.rmin[0] | (pr.rmin[1] << 16), pr.rw | (pr.rh << 16));
+                tiles_sum += pr.ref_tiles;
+                if (RADII) radii[idx] = pr.radius;
+            }
+            const unsigned long long m = __ballot(visible);
+            lv[k] = __popcll(m & ((1ull << lane) - 1ull));
+            if (visible) vis_mask |= 1u << k;
+            if (lane == 0) s_wave_vis[k][wave] = __popcll(m);
+        } else if (lane == 0) {
+            s_wave_vis[k][wave] = 0u;
         }
-        const unsigned long long m = __ballot(visible);
-        lv[k] = __popcll(m & ((1ull << lane) - 1ull));
-        if (visible) vis_mask |= 1u << k;
-        if (lane == 0) s_wave_vis[k][wave] = __popcll(m);
     }
     uint32_t wt_total;
     (void)wave_excl_scan(tiles_sum, wt_total);
@@ -262,7 +394,7 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
         const uint32_t vid = prefix + my_base[k] + lv[k];
         sort_keys[vid]     = __float_as_uint(depth[k]);
         sort_vals[vid]     = vid;
-        vis_index[vid]     = (uint32_t)(base + (int64_t)k * kCullThreads + tid);
+        vis_index[vid]     = gidx[k];
         rects[vid]         = rect[k];
     }
 }
@@ -400,7 +532,9 @@ k_build_records(int sh_deg, CamParams cp, float scale_modifier, const FrameParam
     }
 
     asm volatile("" ::: "memory");
-    const Projected pr = project_splat(cp, scale_modifier, idx, px, py, pz, scale, rotq, opacity);
+    SplatIn in = load_splat(idx, pos, scale, rotq);
+    in.px = px; in.py = py; in.pz = pz; // already in registers
+    const Projected pr = project_splat(cp, scale_modifier, in, opacity[idx]);
     float4* out = reinterpret_cast<float4*>(recs + vid);
     out[0]      = make_float4(pr.pix_x, pr.pix_y, pr.conic[0], pr.conic[1]);
     out[1]      = make_float4(pr.conic[2], opacity[idx], clamp_(raw[0], 0.0f, 1.0f), clamp_(raw[1], 0.0f, 1.0f));
@@ -659,13 +793,15 @@ void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const
 {
     // `done` rides on the dispatch packet itself (completion signal): no separate event-record packet sits between
     // this kernel and the next one on the stream
-    if (done)
-        hipExtLaunchKernelGGL(k_cull_compact, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, nullptr, done, 0, P, cp,
-                              scale_modifier, d_fp, pos, scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index, rects,
-                              scan_state, d_counts);
+    // (hipExtLaunchKernelGGL with NULL events is an ordinary launch)
+    if (radii)
+        hipExtLaunchKernelGGL(k_cull_compact<true>, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, nullptr, done, 0, P,
+                              cp, scale_modifier, d_fp, pos, scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index,
+                              rects, scan_state, d_counts);
     else
-        hipLaunchKernelGGL(k_cull_compact, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, P, cp, scale_modifier, d_fp,
-                           pos, scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index, rects, scan_state, d_counts);
+        hipExtLaunchKernelGGL(k_cull_compact<false>, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, nullptr, done, 0, P,
+                              cp, scale_modifier, d_fp, pos, scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index,
+                              rects, scan_state, d_counts);
 }
 
 void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const FrameParams* d_fp,
