@@ -645,13 +645,19 @@ __global__ void __launch_bounds__(1024) k_expand_offsets(uint32_t* __restrict__ 
 // lane finds its source splat by a 10-step search.  Stores stay fully coalesced.
 constexpr int kEmitWindow = 4096;
 
+template <bool HIST>
 __global__ void __launch_bounds__(kThreads) k_expand_emit(const uint32_t* __restrict__ d_counts, uint32_t grid_x,
                                                             const uint32_t* __restrict__ order,
                                                             const uint2* __restrict__ rects_sorted,
                                                             const uint32_t* __restrict__ block_offsets,
                                                             uint32_t* __restrict__ pair_keys,
-                                                            uint32_t* __restrict__ pair_vals)
+                                                            uint32_t* __restrict__ pair_vals,
+                                                            // HIST: also the tile sort's first per-chunk digit counts
+                                                            int h_shift, uint32_t h_mask, uint32_t h_kpc,
+                                                            uint32_t* __restrict__ h_counts)
 {
+    static_assert(kThreads == 256, "thread t owns digit t of the 256-row count table");
+    __shared__ uint32_t s_hist[2][256]; // a 4096-pair window is one 4096-key sort chunk or two 2048-key ones
     __shared__ uint32_t s_off[kExpandChunk + 1];
     __shared__ uint32_t s_vid[kExpandChunk];
     __shared__ uint32_t s_xy[kExpandChunk];
@@ -667,6 +673,10 @@ __global__ void __launch_bounds__(kThreads) k_expand_emit(const uint32_t* __rest
     for (uint32_t win = blockIdx.x; win < nwin; win += gridDim.x) {
         const uint32_t p0 = win * kEmitWindow;
         const uint32_t p1 = (L - p0) < (uint32_t)kEmitWindow ? L : p0 + kEmitWindow;
+        if (HIST) {
+            s_hist[0][tid] = 0;
+            s_hist[1][tid] = 0;
+        }
         if (tid == 0) { // largest chunk c with block_offsets[c] <= p0
             uint32_t lo = 0, hi = nb;
             while (hi - lo > 1) {
@@ -728,10 +738,19 @@ __global__ void __launch_bounds__(kThreads) k_expand_emit(const uint32_t* __rest
                 const uint32_t xy0   = s_xy[l];
                 const uint32_t ty    = (xy0 >> 16) + local / ww;
                 const uint32_t tx    = (xy0 & 0xFFFFu) + local % ww;
-                pair_keys[p]         = ty * grid_x + tx;
+                const uint32_t key   = ty * grid_x + tx;
+                pair_keys[p]         = key;
                 pair_vals[p]         = s_vid[l];
+                if (HIST) atomicAdd(&s_hist[(p - p0) >= h_kpc ? 1 : 0][(key >> h_shift) & h_mask], 1u);
             }
             __syncthreads();
+        }
+        if (HIST) { // (the chunk loop ended on a barrier: the counts are complete)
+            const uint32_t nbs = (L + h_kpc - 1) / h_kpc; // the sort's chunk count for this L
+            const uint32_t c0  = p0 / h_kpc;
+            h_counts[(size_t)tid * nbs + c0] = s_hist[0][tid];
+            if (h_kpc < (uint32_t)kEmitWindow && c0 + 1 < nbs) h_counts[(size_t)tid * nbs + c0 + 1] = s_hist[1][tid];
+            __syncthreads(); // before the next window clears them
         }
     }
 }
@@ -850,9 +869,10 @@ void launch_sh_to_half(int64_t n, const float* src, uint16_t* dst, hipStream_t s
 
 size_t expand_ws_bytes(int P_cap) { return (size_t)((P_cap + kExpandChunk - 1) / kExpandChunk + 4) * sizeof(uint32_t); }
 
-void launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts, uint32_t grid_x,
+bool launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts, uint32_t grid_x,
                    const uint32_t* order, const uint2* rects, uint2* rects_sorted, uint32_t* pair_keys,
-                   uint32_t* pair_vals, uint32_t capacity, uint32_t* ws, hipStream_t stream)
+                   uint32_t* pair_vals, uint32_t capacity, uint32_t* ws, hipStream_t stream,
+                   const PairSortFirstPass* first_pass)
 {
     int64_t hint   = v_hint > 0 ? v_hint : P_cap;
     int64_t blocks = (hint + kExpandChunk - 1) / kExpandChunk;
@@ -866,8 +886,16 @@ void launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts
     int64_t eblocks = (lh + kEmitWindow - 1) / kEmitWindow;
     if (eblocks > 16384) eblocks = 16384;
     if (eblocks < 1) eblocks = 1;
-    hipLaunchKernelGGL(k_expand_emit, dim3((unsigned)eblocks), dim3(kThreads), 0, stream, d_counts, grid_x, order,
-                       rects_sorted, ws, pair_keys, pair_vals);
+    const bool hist = first_pass && first_pass->valid &&
+                      (first_pass->keys_per_chunk == kEmitWindow || first_pass->keys_per_chunk * 2 == kEmitWindow);
+    if (hist)
+        hipLaunchKernelGGL(k_expand_emit<true>, dim3((unsigned)eblocks), dim3(kThreads), 0, stream, d_counts, grid_x, order,
+                           rects_sorted, ws, pair_keys, pair_vals, first_pass->shift, first_pass->mask,
+                           (uint32_t)first_pass->keys_per_chunk, first_pass->counts);
+    else
+        hipLaunchKernelGGL(k_expand_emit<false>, dim3((unsigned)eblocks), dim3(kThreads), 0, stream, d_counts, grid_x, order,
+                           rects_sorted, ws, pair_keys, pair_vals, 0, 0u, (uint32_t)kEmitWindow, (uint32_t*)nullptr);
+    return hist;
 }
 
 void launch_get_ranges_u32(int64_t L_cap, uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,

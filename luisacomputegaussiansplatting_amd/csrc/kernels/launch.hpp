@@ -62,17 +62,33 @@ void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const
                          uint32_t* sort_vals, uint32_t* vis_index, uint2* rects, uint64_t* scan_state,
                          uint32_t* d_counts, hipStream_t stream,
                          hipEvent_t done = nullptr); // optional completion event carried by the dispatch itself
+struct PairSortFirstPass;
 size_t expand_ws_bytes(int P_cap);
 // v_hint: expected survivor count (bounds the launch; larger live counts are handled by chunk striding)
-void launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts, uint32_t grid_x,
+// returns true iff the first-pass counts were written
+bool launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts, uint32_t grid_x,
                    const uint32_t* order, const uint2* rects, uint2* rects_sorted, uint32_t* pair_keys,
-                   uint32_t* pair_vals, uint32_t capacity, uint32_t* ws, hipStream_t stream);
+                   uint32_t* pair_vals, uint32_t capacity, uint32_t* ws, hipStream_t stream,
+                   const PairSortFirstPass* first_pass = nullptr); // non-NULL: also leave the tile sort's first counts
 
 // ---- pair_sort.hip : stable radix sort of (u32 key, u32 value) pairs, count in device memory ----
 size_t pair_sort_ws_bytes(int64_t n_cap);
 // ping-pongs a -> b -> a ...; returns 0 if the result ended in (keys_a, vals_a), 1 if in (keys_b, vals_b)
+// first_hist_done: pass 0's chunk counts are already in ws (see pair_sort_first_pass)
 int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, const uint32_t* d_n,
-                         int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws, hipStream_t stream);
+                         int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws, hipStream_t stream,
+                         bool first_hist_done = false);
+// Lets the kernel that writes the keys also count them: counts[digit * nb + chunk] over all 256 digits,
+// nb = ceil(n / keys_per_chunk), digit = (key >> shift) & mask -- exactly what the sort's first k_hist would write
+// for the same (n_cap, grid_hint, begin_bit, end_bit, ws).
+struct PairSortFirstPass {
+    int       shift;
+    uint32_t  mask;
+    int       keys_per_chunk; // 2048 or 4096
+    uint32_t* counts;
+    bool      valid;
+};
+PairSortFirstPass pair_sort_first_pass(int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws);
 // stage-level 64-bit sort on the same kernels: n host-known, inputs intact, (keys_tmp, vals_tmp) = scratch of n elements,
 // ws = pair_sort_ws_bytes(n)
 void launch_pair_sort_u64_preserve(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,

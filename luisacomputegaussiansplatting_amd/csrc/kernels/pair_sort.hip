@@ -220,13 +220,28 @@ size_t pair_sort_ws_bytes(int64_t n_cap)
     return (size_t)(nb * kRadix + kRadix + 64) * sizeof(uint32_t);
 }
 
+// What a producer needs to leave pass 0's per-chunk digit counts behind (so that the sort skips its first k_hist):
+// counts[digit * nb + chunk] for all 256 digits, nb = ceil(n / keys_per_chunk), digit = (key >> shift) & mask.
+PairSortFirstPass pair_sort_first_pass(int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws)
+{
+    PairSortFirstPass fp;
+    const int n_pass  = (end_bit - begin_bit + 7) / 8;
+    const int bits    = n_pass > 0 ? (end_bit - begin_bit + n_pass - 1) / n_pass : 0;
+    fp.shift          = begin_bit;
+    fp.mask           = (1u << bits) - 1u;
+    fp.keys_per_chunk = kThreads * items_for(grid_hint > 0 ? grid_hint : n_cap);
+    fp.counts         = reinterpret_cast<uint32_t*>(ws);
+    fp.valid          = n_pass > 0 && n_cap > 0;
+    return fp;
+}
+
 namespace
 {
 // pass p reads (src_k[p], src_v[p]) and writes (dst_k[p], dst_v[p])
 template <int kItems, typename K>
 void run_passes(const K* const* src_k, const uint32_t* const* src_v, K* const* dst_k, uint32_t* const* dst_v, int n_pass,
                 const uint32_t* d_n, int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws_,
-                hipStream_t stream)
+                hipStream_t stream, bool first_hist_done = false)
 {
     constexpr int kKPB   = kThreads * kItems;
     const int64_t nb_cap = (n_cap + kKPB - 1) / kKPB;
@@ -243,8 +258,9 @@ void run_passes(const K* const* src_k, const uint32_t* const* src_v, K* const* d
         // means longer contiguous runs per bucket in the scatter's stores
         const int      bits = (end_bit - shift + (n_pass - p) - 1) / (n_pass - p);
         const uint32_t mask = (1u << bits) - 1u;
-        hipLaunchKernelGGL((k_hist<kItems, K>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, src_k[p], d_n, n_host,
-                           shift, mask, counts);
+        if (!(p == 0 && first_hist_done)) // the producer of the keys may have left pass 0's chunk counts in `counts`
+            hipLaunchKernelGGL((k_hist<kItems, K>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, src_k[p], d_n,
+                               n_host, shift, mask, counts);
         hipLaunchKernelGGL(k_rowscan<kItems>, dim3(kRadix), dim3(kThreads), 0, stream, counts, d_n, n_host, totals);
         hipLaunchKernelGGL((k_scatter<kItems, K>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, src_k[p], src_v[p],
                            dst_k[p], dst_v[p], d_n, n_host, shift, mask, bits, counts, totals);
@@ -256,7 +272,8 @@ void run_passes(const K* const* src_k, const uint32_t* const* src_v, K* const* d
 // Ping-pongs a -> b -> a ...; returns 0 if the result ended in (keys_a, vals_a), 1 if in (keys_b, vals_b).
 // grid_hint: expected element count (bounds the launch; larger live counts are handled by chunk striding).
 int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, const uint32_t* d_n,
-                         int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws_, hipStream_t stream)
+                         int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws_, hipStream_t stream,
+                         bool first_hist_done)
 {
     if (n_cap <= 0) return 0;
     const int n_pass = (end_bit - begin_bit + 7) / 8;
@@ -274,9 +291,11 @@ int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
         dv[p] = vb[(p & 1) ^ 1];
     }
     if (items_for(grid_hint > 0 ? grid_hint : n_cap) == 8)
-        run_passes<8, uint32_t>(sk, sv, dk, dv, n_pass, d_n, n_cap, grid_hint, begin_bit, end_bit, ws_, stream);
+        run_passes<8, uint32_t>(sk, sv, dk, dv, n_pass, d_n, n_cap, grid_hint, begin_bit, end_bit, ws_, stream,
+                                first_hist_done);
     else
-        run_passes<16, uint32_t>(sk, sv, dk, dv, n_pass, d_n, n_cap, grid_hint, begin_bit, end_bit, ws_, stream);
+        run_passes<16, uint32_t>(sk, sv, dk, dv, n_pass, d_n, n_cap, grid_hint, begin_bit, end_bit, ws_, stream,
+                                 first_hist_done);
     return n_pass & 1;
 }
 

@@ -382,16 +382,20 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     const uint32_t* order = ctx->sortv[where].as<uint32_t>();
     LCGS_TRY(mark(ctx, "depth_sort"));
 
-    launch_expand(P, hint_V, hint_L, d_counts, cp.grid_x, order, ctx->rects.as<uint2>(), ctx->rects_sorted.as<uint2>(),
-                  ctx->pairk[0].as<uint32_t>(), ctx->pairv[0].as<uint32_t>(), ctx->pair_capacity,
-                  ctx->expand_ws.as<uint32_t>(), st);
+    // stable partition by tile id: only ceil(log2 G) key bits are live.  The kernel that writes the pairs also leaves
+    // the partition's first per-chunk digit counts in the sort workspace (the depth sort is done with it by then).
+    const int tile_bits = std::max(1, ceil_log2_u32(cp.grid_x * cp.grid_y));
+    const PairSortFirstPass first = pair_sort_first_pass(ctx->pair_capacity, hint_L, 0, tile_bits, ctx->sort_ws.ptr);
+    const bool counted =
+        launch_expand(P, hint_V, hint_L, d_counts, cp.grid_x, order, ctx->rects.as<uint2>(), ctx->rects_sorted.as<uint2>(),
+                      ctx->pairk[0].as<uint32_t>(), ctx->pairv[0].as<uint32_t>(), ctx->pair_capacity,
+                      ctx->expand_ws.as<uint32_t>(), st, &first);
     LCGS_TRY(mark(ctx, "expand"));
 
-    // stable partition by tile id: only ceil(log2 G) key bits are live
-    const int tile_bits = std::max(1, ceil_log2_u32(cp.grid_x * cp.grid_y));
     const int where2 = launch_pair_sort_u32(ctx->pairk[0].as<uint32_t>(), ctx->pairk[1].as<uint32_t>(),
                                             ctx->pairv[0].as<uint32_t>(), ctx->pairv[1].as<uint32_t>(), d_counts + 2,
-                                            ctx->pair_capacity, hint_L, 0, tile_bits, ctx->sort_ws.ptr, st);
+                                            ctx->pair_capacity, hint_L, 0, tile_bits, ctx->sort_ws.ptr, st,
+                                            /*first_hist_done=*/counted);
     LCGS_TRY(mark(ctx, "tile_sort"));
 
     launch_get_ranges_u32(hint_L, d_counts, ctx->pairk[where2].as<uint32_t>(), ctx->ranges,
