@@ -654,7 +654,7 @@ __global__ void __launch_bounds__(kThreads) k_expand_emit(const uint32_t* __rest
                                                             uint32_t* __restrict__ pair_vals,
                                                             // HIST: also the tile sort's first per-chunk digit counts
                                                             int h_shift, uint32_t h_mask, uint32_t h_kpc,
-                                                            uint32_t* __restrict__ h_counts)
+                                                            uint32_t* __restrict__ h_counts, uint32_t h_stride)
 {
     static_assert(kThreads == 256, "thread t owns digit t of the 256-row count table");
     __shared__ uint32_t s_hist[2][256]; // a 4096-pair window is one 4096-key sort chunk or two 2048-key ones
@@ -748,8 +748,8 @@ __global__ void __launch_bounds__(kThreads) k_expand_emit(const uint32_t* __rest
         if (HIST) { // (the chunk loop ended on a barrier: the counts are complete)
             const uint32_t nbs = (L + h_kpc - 1) / h_kpc; // the sort's chunk count for this L
             const uint32_t c0  = p0 / h_kpc;
-            h_counts[(size_t)tid * nbs + c0] = s_hist[0][tid];
-            if (h_kpc < (uint32_t)kEmitWindow && c0 + 1 < nbs) h_counts[(size_t)tid * nbs + c0 + 1] = s_hist[1][tid];
+            h_counts[(size_t)tid * h_stride + c0] = s_hist[0][tid];
+            if (h_kpc < (uint32_t)kEmitWindow && c0 + 1 < nbs) h_counts[(size_t)tid * h_stride + c0 + 1] = s_hist[1][tid];
             __syncthreads(); // before the next window clears them
         }
     }
@@ -891,10 +891,10 @@ bool launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts
     if (hist)
         hipLaunchKernelGGL(k_expand_emit<true>, dim3((unsigned)eblocks), dim3(kThreads), 0, stream, d_counts, grid_x, order,
                            rects_sorted, ws, pair_keys, pair_vals, first_pass->shift, first_pass->mask,
-                           (uint32_t)first_pass->keys_per_chunk, first_pass->counts);
+                           (uint32_t)first_pass->keys_per_chunk, first_pass->counts, first_pass->row_stride);
     else
         hipLaunchKernelGGL(k_expand_emit<false>, dim3((unsigned)eblocks), dim3(kThreads), 0, stream, d_counts, grid_x, order,
-                           rects_sorted, ws, pair_keys, pair_vals, 0, 0u, (uint32_t)kEmitWindow, (uint32_t*)nullptr);
+                           rects_sorted, ws, pair_keys, pair_vals, 0, 0u, (uint32_t)kEmitWindow, (uint32_t*)nullptr, 0u);
     return hist;
 }
 

@@ -78,14 +78,15 @@ size_t pair_sort_ws_bytes(int64_t n_cap);
 int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, const uint32_t* d_n,
                          int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws, hipStream_t stream,
                          bool first_hist_done = false);
-// Lets the kernel that writes the keys also count them: counts[digit * nb + chunk] over all 256 digits,
-// nb = ceil(n / keys_per_chunk), digit = (key >> shift) & mask -- exactly what the sort's first k_hist would write
+// Lets the kernel that writes the keys also count them: counts[digit * row_stride + chunk] over all 256 digits,
+// chunk = position / keys_per_chunk, digit = (key >> shift) & mask -- exactly what the sort's first k_hist would write
 // for the same (n_cap, grid_hint, begin_bit, end_bit, ws).
 struct PairSortFirstPass {
     int       shift;
     uint32_t  mask;
     int       keys_per_chunk; // 2048 or 4096
     uint32_t* counts;
+    uint32_t  row_stride;
     bool      valid;
 };
 PairSortFirstPass pair_sort_first_pass(int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws);

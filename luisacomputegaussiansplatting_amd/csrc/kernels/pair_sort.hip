@@ -3,6 +3,7 @@
 // the exported primitive (lcpp DeviceRadixSort::SortPairs<ulong, uint>, call site
 // lcgs/src/gs_tile_splatter/impl.cpp:135-143).  Three launches per digit:
 //   k_hist     per-chunk digit counts -> counts[digit][chunk]            (reads the keys)
+//              (each kernel requests everything its first chunk needs before it reads the live element count)
 //   k_rowscan  one workgroup per digit: exclusive scan of its row + the row total
 //   k_scatter  wave64-ballot stable ranking, LDS staging into chunk-sorted order, coalesced runs out;
 //              the global digit bases are re-derived per workgroup from the 256 row totals
@@ -21,49 +22,89 @@ constexpr int kThreads = 256;
 constexpr int kWaves   = kThreads / 64;
 constexpr int kRadix   = 256;
 
-// d_n == NULL: the element count is the host-known n_host (stage-level callers)
+// Layout of the count table: counts[digit * row_stride + chunk], row_stride = the chunk CAPACITY rounded up to 8 --
+// host-known, so every address is known before the live element count (*d_n) has been read, and each kernel issues
+// all the loads of its first chunk at once, ahead of that read: these launches are short and latency-bound, one
+// round trip each instead of three or four is most of their running time.
+// d_n == NULL: the element count is the host-known n_cap (stage-level callers).  Buffers hold n_cap elements.
 template <int kItems, typename K>
 __global__ void __launch_bounds__(kThreads) k_hist(const K* __restrict__ keys, const uint32_t* __restrict__ d_n,
-                                                     uint32_t n_host, int shift, uint32_t mask,
-                                                     uint32_t* __restrict__ counts)
+                                                     uint32_t n_cap, int shift, uint32_t mask,
+                                                     uint32_t* __restrict__ counts, uint32_t row_stride)
 {
     constexpr int kKPB = kThreads * kItems;
     __shared__ uint32_t s_hist[kRadix];
-    const uint32_t n  = d_n ? *d_n : n_host;
+    uint32_t chunk = blockIdx.x;
+    K        key[kItems];
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+        const uint32_t i = chunk * kKPB + r * kThreads + threadIdx.x;
+        key[r]           = i < n_cap ? keys[i] : (K)0;
+    }
+    s_hist[threadIdx.x] = 0;
+    const uint32_t n  = d_n ? *d_n : n_cap;
     const uint32_t nb = (n + kKPB - 1) / kKPB;
-    for (uint32_t chunk = blockIdx.x; chunk < nb; chunk += gridDim.x) {
-        s_hist[threadIdx.x] = 0;
-        __syncthreads();
-        const uint32_t base = chunk * kKPB;
-#pragma unroll 4
+    __syncthreads();
+    while (chunk < nb) {
+#pragma unroll
         for (int r = 0; r < kItems; ++r) {
-            const uint32_t i = base + r * kThreads + threadIdx.x;
-            if (i < n) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & mask], 1u);
+            const uint32_t i = chunk * kKPB + r * kThreads + threadIdx.x;
+            if (i < n) atomicAdd(&s_hist[(uint32_t)(key[r] >> shift) & mask], 1u);
         }
         __syncthreads();
-        counts[(size_t)threadIdx.x * nb + chunk] = s_hist[threadIdx.x];
+        counts[(size_t)threadIdx.x * row_stride + chunk] = s_hist[threadIdx.x];
+        chunk += gridDim.x;
+        if (chunk >= nb) break;
+        __syncthreads();
+        s_hist[threadIdx.x] = 0;
+#pragma unroll
+        for (int r = 0; r < kItems; ++r) {
+            const uint32_t i = chunk * kKPB + r * kThreads + threadIdx.x;
+            key[r]           = i < n ? keys[i] : (K)0;
+        }
         __syncthreads();
     }
 }
 
-// one workgroup per digit: counts[d][0..nb) -> exclusive prefix in place; totals[d] = row sum
+// one workgroup per digit: counts[d][0..nb) -> exclusive prefix in place; totals[d] = row sum.
+// Thread t owns 8 consecutive chunks (two 16-byte loads); rows longer than 2048 chunks take further rounds.
 template <int kItems>
 __global__ void __launch_bounds__(kThreads) k_rowscan(uint32_t* __restrict__ counts, const uint32_t* __restrict__ d_n,
-                                                        uint32_t n_host, uint32_t* __restrict__ totals)
+                                                        uint32_t n_cap, uint32_t* __restrict__ totals,
+                                                        uint32_t row_stride)
 {
     constexpr int kKPB = kThreads * kItems;
+    constexpr int kPer = 8;
     __shared__ uint32_t s_wave[kWaves];
-    __shared__ uint32_t s_carry;
-    const uint32_t n    = d_n ? *d_n : n_host;
-    const uint32_t nb   = (n + kKPB - 1) / kKPB;
-    uint32_t*      row  = counts + (size_t)blockIdx.x * nb;
+    uint32_t*      row  = counts + (size_t)blockIdx.x * row_stride;
     const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < nb; base += kThreads) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < nb ? row[i] : 0u;
-        uint32_t       inc = v;
+    uint4          a = make_uint4(0, 0, 0, 0), b = a;
+    uint32_t       i0 = threadIdx.x * kPer;
+    if (i0 < row_stride) { // row_stride is a multiple of 8: the whole group is inside the row
+        a = *reinterpret_cast<const uint4*>(row + i0);
+        b = *reinterpret_cast<const uint4*>(row + i0 + 4);
+    }
+    const uint32_t n  = d_n ? *d_n : n_cap;
+    const uint32_t nb = (n + kKPB - 1) / kKPB;
+    uint32_t       carry_in = 0;
+    for (uint32_t base = 0; base < nb; base += kThreads * kPer) {
+        if (base > 0) {
+            i0 = base + threadIdx.x * kPer;
+            a = b = make_uint4(0, 0, 0, 0);
+            if (i0 < row_stride) {
+                a = *reinterpret_cast<const uint4*>(row + i0);
+                b = *reinterpret_cast<const uint4*>(row + i0 + 4);
+            }
+        }
+        uint32_t v[kPer] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+        uint32_t e[kPer], tot = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            if (i0 + j >= nb) v[j] = 0; // stale words beyond the live chunks
+            e[j] = tot;
+            tot += v[j];
+        }
+        uint32_t inc = tot;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(inc, off, 64);
@@ -71,24 +112,31 @@ __global__ void __launch_bounds__(kThreads) k_rowscan(uint32_t* __restrict__ cou
         }
         if (lane == 63) s_wave[wave] = inc;
         __syncthreads();
-        uint32_t carry = s_carry;
-        for (int w = 0; w < wave; ++w) carry += s_wave[w];
-        if (i < nb) row[i] = carry + inc - v;
-        __syncthreads();
-        if (threadIdx.x == kThreads - 1) s_carry = carry + inc;
-        __syncthreads();
+        uint32_t carry = carry_in, block_total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            if (w < wave) carry += s_wave[w];
+            block_total += s_wave[w];
+        }
+        const uint32_t ex = carry + inc - tot;
+        if (i0 < row_stride) {
+            *reinterpret_cast<uint4*>(row + i0)     = make_uint4(ex + e[0], ex + e[1], ex + e[2], ex + e[3]);
+            *reinterpret_cast<uint4*>(row + i0 + 4) = make_uint4(ex + e[4], ex + e[5], ex + e[6], ex + e[7]);
+        }
+        carry_in += block_total;
+        __syncthreads(); // s_wave is reused by the next round
     }
-    if (threadIdx.x == 0) totals[blockIdx.x] = s_carry;
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry_in;
 }
 
 template <int kItems, typename K>
 __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys_in,
                                                         const uint32_t* __restrict__ vals_in,
                                                         K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                        const uint32_t* __restrict__ d_n, uint32_t n_host, int shift,
+                                                        const uint32_t* __restrict__ d_n, uint32_t n_cap, int shift,
                                                         uint32_t mask,
                                                         int bits, const uint32_t* __restrict__ row_excl,
-                                                        const uint32_t* __restrict__ totals)
+                                                        const uint32_t* __restrict__ totals, uint32_t row_stride)
 {
     constexpr int kKPB = kThreads * kItems;
     __shared__ uint32_t s_wave_hist[kWaves][kRadix];
@@ -98,15 +146,26 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys
     __shared__ K        s_keys[kKPB];
     __shared__ uint32_t s_vals[kKPB];
 
-    const uint32_t n  = d_n ? *d_n : n_host;
-    const uint32_t nb = (n + kKPB - 1) / kKPB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // everything the first chunk needs is requested before the element count arrives (capacity-guarded)
+    uint32_t       chunk = blockIdx.x;
+    const uint32_t own   = totals[tid];
+    uint32_t       rex   = chunk < row_stride ? row_excl[(size_t)tid * row_stride + chunk] : 0u;
+    K              key[kItems];
+    uint32_t       val[kItems];
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+        const uint32_t i = chunk * kKPB + wave * 64 * kItems + r * 64 + lane;
+        key[r]           = i < n_cap ? keys_in[i] : (K)0;
+        val[r]           = i < n_cap ? vals_in[i] : 0u;
+    }
+    const uint32_t n  = d_n ? *d_n : n_cap;
+    const uint32_t nb = (n + kKPB - 1) / kKPB;
     if (blockIdx.x >= nb) return;
 
     // global exclusive base of each digit from the 256 row totals
     {
-        const uint32_t own = totals[tid];
-        uint32_t       inc = own;
+        uint32_t inc = own;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(inc, off, 64);
@@ -122,7 +181,7 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys
         __syncthreads();
     }
 
-    for (uint32_t chunk = blockIdx.x; chunk < nb; chunk += gridDim.x) {
+    for (;;) {
         const uint32_t block_base = chunk * kKPB;
         const uint32_t wave_base  = block_base + wave * 64 * kItems;
         const uint32_t in_block   = (n - block_base) < (uint32_t)kKPB ? (n - block_base) : (uint32_t)kKPB;
@@ -130,7 +189,6 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys
         for (int w = 0; w < kWaves; ++w) s_wave_hist[w][tid] = 0;
         __syncthreads();
 
-        K        key[kItems];
         uint32_t rank[kItems];
         volatile uint32_t* my_hist = s_wave_hist[wave];
         // ---- per-wave stable ranking, 64 keys per round in memory order
@@ -138,7 +196,7 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys
         for (int r = 0; r < kItems; ++r) {
             const uint32_t i     = wave_base + r * 64 + lane;
             const bool     valid = i < n;
-            key[r]               = valid ? keys_in[i] : (K)0;
+            if (!valid) key[r] = (K)0;
             const uint32_t d     = (uint32_t)(key[r] >> shift) & mask;
             unsigned long long peers = __ballot(valid);
             for (int b = 0; b < bits; ++b) {
@@ -178,7 +236,7 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys
         for (int w = 0; w < kWaves; ++w)
             if (w < wave) carry += s_scan[w];
         const uint32_t start = carry + inc - total;
-        s_global_delta[tid]  = s_digit_base[tid] + row_excl[(size_t)tid * nb + chunk] - start;
+        s_global_delta[tid]  = s_digit_base[tid] + rex - start;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) s_wave_hist[w][tid] = start + wave_off[w];
         __syncthreads();
@@ -191,18 +249,26 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys
                 const uint32_t d   = (uint32_t)(key[r] >> shift) & mask;
                 const uint32_t pos = s_wave_hist[wave][d] + rank[r];
                 s_keys[pos]        = key[r];
-                s_vals[pos]        = vals_in[i];
+                s_vals[pos]        = val[r];
             }
         }
         __syncthreads();
-#pragma unroll 4
         for (uint32_t i = tid; i < in_block; i += kThreads) {
             const K        k   = s_keys[i];
             const uint32_t dst = s_global_delta[(uint32_t)(k >> shift) & mask] + i;
             keys_out[dst]      = k;
             vals_out[dst]      = s_vals[i];
         }
+        chunk += gridDim.x;
+        if (chunk >= nb) break;
         __syncthreads();
+        rex = row_excl[(size_t)tid * row_stride + chunk];
+#pragma unroll
+        for (int r = 0; r < kItems; ++r) {
+            const uint32_t i = chunk * kKPB + wave * 64 * kItems + r * 64 + lane;
+            key[r]           = i < n ? keys_in[i] : (K)0;
+            val[r]           = i < n ? vals_in[i] : 0u;
+        }
     }
 }
 
@@ -214,10 +280,16 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys
 constexpr int64_t kSmallInput = 4 << 20;
 inline int items_for(int64_t expected) { return expected <= kSmallInput ? 8 : 16; }
 
+inline int64_t row_stride_for(int64_t n_cap, int items)
+{
+    const int64_t nb = (n_cap + kThreads * items - 1) / (kThreads * items);
+    return (nb + 7) & ~(int64_t)7; // rows start 32-byte aligned (k_rowscan's 16-byte accesses)
+}
+
 size_t pair_sort_ws_bytes(int64_t n_cap)
 {
-    const int64_t nb = (n_cap + kThreads * 8 - 1) / (kThreads * 8); // the smaller chunk size bounds the table
-    return (size_t)(nb * kRadix + kRadix + 64) * sizeof(uint32_t);
+    const int64_t stride = row_stride_for(n_cap, 8); // the smaller chunk size bounds the table
+    return (size_t)(stride * kRadix + kRadix + 64) * sizeof(uint32_t);
 }
 
 // What a producer needs to leave pass 0's per-chunk digit counts behind (so that the sort skips its first k_hist):
@@ -231,6 +303,7 @@ PairSortFirstPass pair_sort_first_pass(int64_t n_cap, int64_t grid_hint, int beg
     fp.mask           = (1u << bits) - 1u;
     fp.keys_per_chunk = kThreads * items_for(grid_hint > 0 ? grid_hint : n_cap);
     fp.counts         = reinterpret_cast<uint32_t*>(ws);
+    fp.row_stride     = (uint32_t)row_stride_for(n_cap, fp.keys_per_chunk / kThreads);
     fp.valid          = n_pass > 0 && n_cap > 0;
     return fp;
 }
@@ -245,8 +318,9 @@ void run_passes(const K* const* src_k, const uint32_t* const* src_v, K* const* d
 {
     constexpr int kKPB   = kThreads * kItems;
     const int64_t nb_cap = (n_cap + kKPB - 1) / kKPB;
+    const uint32_t stride = (uint32_t)row_stride_for(n_cap, kItems);
     uint32_t*     counts = reinterpret_cast<uint32_t*>(ws_);
-    uint32_t*     totals = counts + nb_cap * kRadix;
+    uint32_t*     totals = counts + (size_t)stride * kRadix;
     int64_t       hint   = grid_hint > 0 ? grid_hint : n_cap;
     int64_t       blocks = (hint + kKPB - 1) / kKPB;
     if (blocks > nb_cap) blocks = nb_cap;
@@ -260,10 +334,10 @@ void run_passes(const K* const* src_k, const uint32_t* const* src_v, K* const* d
         const uint32_t mask = (1u << bits) - 1u;
         if (!(p == 0 && first_hist_done)) // the producer of the keys may have left pass 0's chunk counts in `counts`
             hipLaunchKernelGGL((k_hist<kItems, K>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, src_k[p], d_n,
-                               n_host, shift, mask, counts);
-        hipLaunchKernelGGL(k_rowscan<kItems>, dim3(kRadix), dim3(kThreads), 0, stream, counts, d_n, n_host, totals);
+                               n_host, shift, mask, counts, stride);
+        hipLaunchKernelGGL(k_rowscan<kItems>, dim3(kRadix), dim3(kThreads), 0, stream, counts, d_n, n_host, totals, stride);
         hipLaunchKernelGGL((k_scatter<kItems, K>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, src_k[p], src_v[p],
-                           dst_k[p], dst_v[p], d_n, n_host, shift, mask, bits, counts, totals);
+                           dst_k[p], dst_v[p], d_n, n_host, shift, mask, bits, counts, totals, stride);
         shift += bits;
     }
 }
