@@ -570,25 +570,38 @@ constexpr int kExpandChunk = kThreads * kExpandSub;  // 1024 survivors
 
 __device__ __forceinline__ uint32_t rect_tiles(uint2 rc) { return (rc.y & 0xFFFFu) * (rc.y >> 16); }
 
-__global__ void __launch_bounds__(kThreads) k_expand_reduce(const uint32_t* __restrict__ d_counts,
+__global__ void __launch_bounds__(kThreads) k_expand_reduce(const uint32_t* __restrict__ d_counts, uint32_t v_cap,
                                                               const uint32_t* __restrict__ order,
                                                               const uint2* __restrict__ rects,
                                                               uint2* __restrict__ rects_sorted,
                                                               uint32_t* __restrict__ block_sums)
 {
     __shared__ uint32_t s_wave[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the first chunk's `order` entries are requested before the survivor count arrives (the buffer holds v_cap)
+    uint32_t chunk = blockIdx.x;
+    uint32_t src[kExpandSub];
+#pragma unroll
+    for (int s = 0; s < kExpandSub; ++s) {
+        const uint32_t k = chunk * kExpandChunk + s * kThreads + threadIdx.x;
+        src[s]           = k < v_cap ? order[k] : 0u;
+    }
     const uint32_t V  = d_counts[0];
     const uint32_t nb = (V + kExpandChunk - 1) / kExpandChunk;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t chunk = blockIdx.x; chunk < nb; chunk += gridDim.x) {
+    while (chunk < nb) {
+        uint2 rc[kExpandSub];
+#pragma unroll
+        for (int s = 0; s < kExpandSub; ++s) { // the one random gather (four in flight); emit reads the sorted copy
+            const uint32_t k = chunk * kExpandChunk + s * kThreads + threadIdx.x;
+            rc[s]            = k < V ? rects[src[s]] : make_uint2(0u, 0u);
+        }
         uint32_t sum = 0;
 #pragma unroll
         for (int s = 0; s < kExpandSub; ++s) {
             const uint32_t k = chunk * kExpandChunk + s * kThreads + threadIdx.x;
             if (k < V) {
-                const uint2 rc  = rects[order[k]]; // the one random gather; emit reads the sorted copy
-                rects_sorted[k] = rc;
-                sum += rect_tiles(rc);
+                rects_sorted[k] = rc[s];
+                sum += rect_tiles(rc[s]);
             }
         }
 #pragma unroll
@@ -596,26 +609,44 @@ __global__ void __launch_bounds__(kThreads) k_expand_reduce(const uint32_t* __re
         if (lane == 0) s_wave[wave] = sum;
         __syncthreads();
         if (threadIdx.x == 0) block_sums[chunk] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        chunk += gridDim.x;
+        if (chunk >= nb) break;
         __syncthreads();
+        for (int s = 0; s < kExpandSub; ++s) {
+            const uint32_t k = chunk * kExpandChunk + s * kThreads + threadIdx.x;
+            src[s]           = k < V ? order[k] : 0u;
+        }
     }
 }
 
 // exclusive scan of the block sums in place by one workgroup; d_counts[4] = pairs wanted,
 // [2] = pairs emitted (clamped to the workspace capacity), [3] = overflow flag
 __global__ void __launch_bounds__(1024) k_expand_offsets(uint32_t* __restrict__ d_counts,
-                                                           uint32_t* __restrict__ block_sums, uint32_t capacity)
+                                                           uint32_t* __restrict__ block_sums, uint32_t nb_cap,
+                                                           uint32_t capacity)
 {
     __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // thread t owns sums 4t .. 4t+3 (one 16-byte load, requested before the survivor count arrives; the buffer
+    // holds nb_cap rounded up to 4 words); more than 4096 chunks take further rounds
+    uint32_t i0 = threadIdx.x * 4;
+    uint4    a  = i0 < nb_cap ? *reinterpret_cast<const uint4*>(block_sums + i0) : make_uint4(0, 0, 0, 0);
     const uint32_t V  = d_counts[0];
     const uint32_t nb = (V + kExpandChunk - 1) / kExpandChunk;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < nb; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < nb ? block_sums[i] : 0u;
-        uint32_t       inc = v;
+    uint32_t       carry_in = 0;
+    for (uint32_t base = 0; base < nb; base += 4096) {
+        if (base > 0) {
+            i0 = base + threadIdx.x * 4;
+            a  = i0 < nb_cap ? *reinterpret_cast<const uint4*>(block_sums + i0) : make_uint4(0, 0, 0, 0);
+        }
+        uint32_t v[4] = { a.x, a.y, a.z, a.w }, e[4], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i0 + j >= nb) v[j] = 0;
+            e[j] = tot;
+            tot += v[j];
+        }
+        uint32_t inc = tot;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(inc, off, 64);
@@ -623,15 +654,19 @@ __global__ void __launch_bounds__(1024) k_expand_offsets(uint32_t* __restrict__ 
         }
         if (lane == 63) s_wave[wave] = inc;
         __syncthreads();
-        uint32_t carry = s_carry;
-        for (int w = 0; w < wave; ++w) carry += s_wave[w];
-        if (i < nb) block_sums[i] = carry + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + inc;
+        uint32_t carry = carry_in, round_total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) carry += s_wave[w];
+            round_total += s_wave[w];
+        }
+        const uint32_t ex = carry + inc - tot;
+        if (i0 < nb_cap) *reinterpret_cast<uint4*>(block_sums + i0) = make_uint4(ex + e[0], ex + e[1], ex + e[2], ex + e[3]);
+        carry_in += round_total;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const uint32_t L = s_carry;
+        const uint32_t L = carry_in;
         d_counts[4]      = L;
         d_counts[2]      = L < capacity ? L : capacity;
         d_counts[3]      = L > capacity ? 1u : 0u;
@@ -677,16 +712,21 @@ __global__ void __launch_bounds__(kThreads) k_expand_emit(const uint32_t* __rest
             s_hist[0][tid] = 0;
             s_hist[1][tid] = 0;
         }
-        if (tid == 0) { // largest chunk c with block_offsets[c] <= p0
-            uint32_t lo = 0, hi = nb;
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (block_offsets[mid] <= p0) lo = mid;
-                else hi = mid;
-            }
-            s_c0 = lo;
-        }
+        // largest chunk c with block_offsets[c] <= p0 (offsets are non-decreasing, [0] = 0): every thread probes one
+        // of 256 evenly spaced entries, then the gap after the best one is probed the same way -- two rounds of
+        // independent loads (more only beyond 65 K chunks) instead of a 12-step dependent search by one thread
+        if (tid == 0) s_c0 = 0;
         __syncthreads();
+        for (uint32_t span = nb; span > 1;) {
+            const uint32_t step = (span + kThreads - 1) / kThreads;
+            const uint32_t lo   = s_c0;
+            const uint32_t idx  = lo + tid * step;
+            const bool     hit  = idx < lo + span && idx < nb && block_offsets[idx] <= p0;
+            __syncthreads(); // everyone has read s_c0
+            if (hit) atomicMax(&s_c0, idx);
+            __syncthreads();
+            span = step; // the answer lies in [s_c0, s_c0 + step)
+        }
         for (uint32_t c = s_c0; c < nb; ++c) {
             const uint32_t base = block_offsets[c];
             if (base >= p1) break;
@@ -755,27 +795,55 @@ __global__ void __launch_bounds__(kThreads) k_expand_emit(const uint32_t* __rest
     }
 }
 
-// shad_get_ranges (gs_tile_splatter/shader.cpp:71-100) on 32-bit tile keys; ranges zero-filled by the caller
-__global__ void __launch_bounds__(kThreads) k_get_ranges_u32(uint32_t* __restrict__ d_counts,
+// shad_get_ranges (gs_tile_splatter/shader.cpp:71-100) on 32-bit tile keys; ranges zero-filled by the caller.
+// A thread takes four consecutive keys (one 16-byte load) and the key before them, requested before the pair
+// count arrives (the key buffer holds l_cap entries, l_cap a multiple of 4 or the tail is read key by key).
+__global__ void __launch_bounds__(kThreads) k_get_ranges_u32(uint32_t* __restrict__ d_counts, uint32_t l_cap,
                                                                const uint32_t* __restrict__ keys,
                                                                uint32_t* __restrict__ ranges,
                                                                const uint32_t* __restrict__ scan_error_flag)
 {
     // (also forwards the chained scan's time-out flag into the counter block the host reads back)
     if (blockIdx.x == 0 && threadIdx.x == 0 && scan_error_flag) d_counts[5] = *scan_error_flag;
+    uint32_t g  = blockIdx.x * kThreads + threadIdx.x; // group of four keys
+    uint32_t i0 = g * 4u;
+    uint4    k4 = make_uint4(0, 0, 0, 0);
+    uint32_t kp = 0;
+    if (i0 + 4u <= l_cap) k4 = *reinterpret_cast<const uint4*>(keys + i0);
+    else if (i0 < l_cap) {
+        k4.x = keys[i0];
+        if (i0 + 1 < l_cap) k4.y = keys[i0 + 1];
+        if (i0 + 2 < l_cap) k4.z = keys[i0 + 2];
+    }
+    if (i0 > 0 && i0 - 1 < l_cap) kp = keys[i0 - 1];
     const uint32_t L = d_counts[2];
-    for (uint32_t idx = blockIdx.x * kThreads + threadIdx.x; idx < L; idx += gridDim.x * kThreads) {
-        const uint32_t curr_tile = keys[idx];
-        if (idx == 0) {
-            ranges[2 * (size_t)curr_tile + 0] = 0u;
-        } else {
-            const uint32_t prev_tile = keys[idx - 1];
-            if (curr_tile != prev_tile) {
-                ranges[2 * (size_t)prev_tile + 1] = idx;
+    for (;;) {
+        if (i0 >= L) break;
+        const uint32_t kk[5] = { kp, k4.x, k4.y, k4.z, k4.w };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t idx = i0 + j;
+            if (idx >= L) break;
+            const uint32_t curr_tile = kk[j + 1];
+            if (idx == 0) {
+                ranges[2 * (size_t)curr_tile + 0] = 0u;
+            } else if (curr_tile != kk[j]) {
+                ranges[2 * (size_t)kk[j] + 1]     = idx;
                 ranges[2 * (size_t)curr_tile + 0] = idx;
             }
+            if (idx == L - 1) ranges[2 * (size_t)curr_tile + 1] = L;
         }
-        if (idx == L - 1) ranges[2 * (size_t)curr_tile + 1] = L;
+        g += gridDim.x * kThreads;
+        i0 = g * 4u;
+        if (i0 >= L) break;
+        if (i0 + 4u <= l_cap) k4 = *reinterpret_cast<const uint4*>(keys + i0);
+        else {
+            k4.x = keys[i0];
+            k4.y = i0 + 1 < L ? keys[i0 + 1] : 0u;
+            k4.z = i0 + 2 < L ? keys[i0 + 2] : 0u;
+            k4.w = 0u;
+        }
+        kp = keys[i0 - 1];
     }
 }
 
@@ -867,7 +935,7 @@ void launch_sh_to_half(int64_t n, const float* src, uint16_t* dst, hipStream_t s
 
 
 
-size_t expand_ws_bytes(int P_cap) { return (size_t)((P_cap + kExpandChunk - 1) / kExpandChunk + 4) * sizeof(uint32_t); }
+size_t expand_ws_bytes(int P_cap) { return (size_t)((P_cap + kExpandChunk - 1) / kExpandChunk + 8) * sizeof(uint32_t); }
 
 bool launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts, uint32_t grid_x,
                    const uint32_t* order, const uint2* rects, uint2* rects_sorted, uint32_t* pair_keys,
@@ -879,9 +947,10 @@ bool launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts
     int64_t cap    = ((int64_t)P_cap + kExpandChunk - 1) / kExpandChunk;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_expand_reduce, dim3((unsigned)blocks), dim3(kThreads), 0, stream, d_counts, order, rects,
-                       rects_sorted, ws);
-    hipLaunchKernelGGL(k_expand_offsets, dim3(1), dim3(1024), 0, stream, d_counts, ws, capacity);
+    hipLaunchKernelGGL(k_expand_reduce, dim3((unsigned)blocks), dim3(kThreads), 0, stream, d_counts, (uint32_t)P_cap, order,
+                       rects, rects_sorted, ws);
+    hipLaunchKernelGGL(k_expand_offsets, dim3(1), dim3(1024), 0, stream, d_counts, ws, (uint32_t)((cap + 3) & ~(int64_t)3),
+                       capacity);
     int64_t lh      = l_hint > 0 ? l_hint : capacity;
     int64_t eblocks = (lh + kEmitWindow - 1) / kEmitWindow;
     if (eblocks > 16384) eblocks = 16384;
@@ -898,17 +967,13 @@ bool launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts
     return hist;
 }
 
-void launch_get_ranges_u32(int64_t L_cap, uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
+void launch_get_ranges_u32(int64_t L_hint, uint32_t l_cap, uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
                            const uint32_t* scan_error_flag, hipStream_t stream, hipEvent_t done)
 {
-    unsigned blocks = blocks_for(L_cap);
-    if (blocks > 4096u) blocks = 4096u;
-    if (done)
-        hipExtLaunchKernelGGL(k_get_ranges_u32, dim3(blocks), dim3(kThreads), 0, stream, nullptr, done, 0, d_counts, keys,
-                              ranges, scan_error_flag);
-    else
-        hipLaunchKernelGGL(k_get_ranges_u32, dim3(blocks), dim3(kThreads), 0, stream, d_counts, keys, ranges,
-                           scan_error_flag);
+    unsigned blocks = blocks_for((L_hint + 3) / 4); // four keys per thread
+    if (blocks > 16384u) blocks = 16384u;
+    hipExtLaunchKernelGGL(k_get_ranges_u32, dim3(blocks), dim3(kThreads), 0, stream, nullptr, done, 0, d_counts, l_cap, keys,
+                          ranges, scan_error_flag);
 }
 
 void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t* list_vid, const uint32_t* vis_index,

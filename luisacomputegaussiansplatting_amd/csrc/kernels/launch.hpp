@@ -103,7 +103,8 @@ void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scal
                           float4* shjac = nullptr);          // non-NULL: 3 x float4 per survivor for the backward
 bool build_records_writes_jacobian(int sh_deg, const float* sh, bool half);
 void launch_sh_to_half(int64_t n, const float* src, uint16_t* dst, hipStream_t stream);
-void launch_get_ranges_u32(int64_t L_cap, uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
+// L_hint sizes the launch (larger live counts are strided); l_cap = entries the key buffer holds
+void launch_get_ranges_u32(int64_t L_hint, uint32_t l_cap, uint32_t* d_counts, const uint32_t* keys, uint32_t* ranges,
                            const uint32_t* scan_error_flag, hipStream_t stream, hipEvent_t done = nullptr);
 void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t* list_vid, const uint32_t* vis_index,
                          uint32_t* list_idx, hipStream_t stream);

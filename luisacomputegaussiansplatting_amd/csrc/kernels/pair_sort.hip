@@ -263,8 +263,7 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys
         if (chunk >= nb) break;
         __syncthreads();
         rex = row_excl[(size_t)tid * row_stride + chunk];
-#pragma unroll
-        for (int r = 0; r < kItems; ++r) {
+        for (int r = 0; r < kItems; ++r) { // (constant trip count: unrolled without being asked)
             const uint32_t i = chunk * kKPB + wave * 64 * kItems + r * 64 + lane;
             key[r]           = i < n ? keys_in[i] : (K)0;
             val[r]           = i < n ? vals_in[i] : 0u;

@@ -398,7 +398,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
                                             /*first_hist_done=*/counted);
     LCGS_TRY(mark(ctx, "tile_sort"));
 
-    launch_get_ranges_u32(hint_L, d_counts, ctx->pairk[where2].as<uint32_t>(), ctx->ranges,
+    launch_get_ranges_u32(hint_L, ctx->pair_capacity, d_counts, ctx->pairk[where2].as<uint32_t>(), ctx->ranges,
                           reinterpret_cast<const uint32_t*>(scan_state + 1), st, deferred ? ctx->ev_ranges : nullptr);
     // tile schedule: the newest complete order if it matches this grid, else computed here
     uint32_t* order_now = nullptr;
