@@ -7,9 +7,9 @@
 // bit-identical per-tile lists:
 //
 //   k_cull_compact       one pass over ALL splats: view transform, near cull, covariance projection,
-//                        conic/radius/rect and the exact opacity-aware pruning of the rect; the indices of
-//                        the survivors are compacted IN INDEX ORDER through a single-pass chained scan
-//                        (decoupled look-back across workgroups, 8-byte self-validating status words).
+//                        conic/radius/rect and the exact opacity-aware pruning of the rect; each 2048-splat
+//                        chunk leaves its survivors IN INDEX ORDER in its own slab, plus the depth sort's
+//                        first digit counts (no cross-workgroup dependency; the sort's first pass compacts).
 //   k_build_records      one DENSE pass over the V survivors: 192-byte SH fetch + colour (the dominant
 //                        stream, paid only for splats that reach the screen) -> packed 48-byte records.
 //   depth sort           32-bit radix sort of the V survivors by depth bits (pair_sort.hip) -- the low
@@ -35,31 +35,6 @@ namespace
 {
 
 constexpr int kThreads = 256;
-
-// ---------------------------------------------------------------------------------------------
-// chained-scan status word: [63:62] status, [61:32] visible count, [31:0] tile count
-// ---------------------------------------------------------------------------------------------
-constexpr uint64_t kStatusInvalid   = 0ull;
-constexpr uint64_t kStatusAggregate = 1ull;
-constexpr uint64_t kStatusInclusive = 2ull;
-
-__device__ __forceinline__ uint64_t pack_state(uint64_t status, uint32_t vis, uint32_t tiles)
-{
-    return (status << 62) | ((uint64_t)(vis & 0x3FFFFFFFu) << 32) | (uint64_t)tiles;
-}
-__device__ __forceinline__ uint64_t state_status(uint64_t s) { return s >> 62; }
-__device__ __forceinline__ uint32_t state_vis(uint64_t s) { return (uint32_t)(s >> 32) & 0x3FFFFFFFu; }
-__device__ __forceinline__ uint32_t state_tiles(uint64_t s) { return (uint32_t)s; }
-
-__device__ __forceinline__ void state_store(uint64_t* p, uint64_t v)
-{
-    // one naturally aligned 8-byte agent-scope store: the word validates itself, no fence needed
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint64_t state_load(const uint64_t* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t& total)
 {
@@ -143,8 +118,8 @@ __device__ __forceinline__ Projected project_splat(const CamParams& cp, float sc
     return r;
 }
 
-// Pass A over ALL splats: project, cull, and compact the survivors' indices IN INDEX ORDER through a
-// single-pass chained scan (decoupled look-back across workgroups).  Writes 12 B per survivor (+ radii on request).
+// Pass A over ALL splats: project, cull, and collect the survivors IN INDEX ORDER chunk by chunk.
+// Writes 16 B per survivor (+ radii on request).
 // A workgroup owns a chunk of kCullItems x 512 consecutive splats and works on it in two phases:
 //   1. every splat: view transform, the reference's near test (exact), and a CONSERVATIVE screen test -- an upper
 //      bound of the reference radius from trace(cov2d) <= (|T0|^2 + |T1|^2) * lambda_max(Sigma), with explicit slack;
@@ -154,14 +129,17 @@ __device__ __forceinline__ Projected project_splat(const CamParams& cp, float sc
 //      rect and opacity-aware pruning, bit for bit the reference's expressions.
 // Results are identical to running phase 2 on everything (that is what RADII = true does, for callers who want
 // the reference's radii array, which is defined for off-screen splats too).
-// The chunk takes ONE ticket -- tickets are handed out in start order, so every predecessor a workgroup waits on
-// is already running, whatever the dispatch order or XCD placement; one returning atomic per 2048 splats keeps
-// the single ticket word far below its ~88 ops/us saturation.
-// scan_state: [0] ticket counter (u32 in the low half), [1] error flag, [2..] per-chunk status words
+// Output: nothing here depends on another workgroup.  The chunk's survivors go, in index order, to the chunk's own
+// 2048-slot slab as 16-byte {depth bits, splat index, pruned rect}; chunk_info[chunk] = {survivors, reference
+// tiles_touched}; and -- the chunk IS the depth sort's first chunk -- counts0[digit][chunk] = how many of its keys
+// carry each value of the sort's first digit.  The dense ids come out of the sort's first pass (pair_sort.hip:
+// k_rowscan_first scans the chunk counts beside the digit rows, k_scatter_first reads the slabs).  An earlier
+// version compacted here through a single-pass chained scan with one ticket per chunk: the pass then took 0.135 ms,
+// 0.105 ms with the look-back cut out -- the chain, not the arithmetic or the traffic, was its largest cost.
 constexpr int kCullThreads = 512; // 8 waves: the per-lane chain of dependent loads is 4 splats long, not 8
 constexpr int kCullWaves   = kCullThreads / 64;
 constexpr int kCullItems   = 4;
-constexpr int kCullChunk   = kCullThreads * kCullItems; // 2048 splats per ticket
+constexpr int kCullChunk   = kCullThreads * kCullItems; // 2048 splats = one chunk of the depth sort's first pass
 
 // Phase-1 test.  Returns false only if the splat certainly emits no pair: behind the near plane (the reference's
 // own test) or bound-of-radius disc entirely off the rasterised tiles.  Any NaN makes every comparison false, i.e.
@@ -219,14 +197,12 @@ __global__ void __launch_bounds__(kCullThreads)
 k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __restrict__ fpp,
                const float* __restrict__ pos,
                const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ opacity,
-               int32_t* __restrict__ radii, uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals,
-               uint32_t* __restrict__ vis_index, uint2* __restrict__ rects, uint64_t* __restrict__ scan_state,
-               uint32_t* __restrict__ d_counts)
+               int32_t* __restrict__ radii, uint4* __restrict__ slab, uint2* __restrict__ chunk_info,
+               uint32_t* __restrict__ counts0, uint32_t stride0, uint32_t mask0)
 {
-    __shared__ uint32_t s_ticket;
     __shared__ uint32_t s_wave_vis[kCullItems][kCullWaves];
     __shared__ uint32_t s_wave_tiles[kCullWaves];
-    __shared__ uint32_t s_prefix_vis;
+    __shared__ uint32_t s_hist[256];
     __shared__ uint16_t s_cand[kCullChunk]; // chunk-local indices of the phase-1 survivors, in index order
 
     if (fpp) { // graph replay: per-call parameters come from device memory
@@ -234,12 +210,9 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
         scale_modifier = fpp->scale_modifier;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_ticket = atomicAdd(reinterpret_cast<uint32_t*>(scan_state), 1u);
-    __syncthreads();
-    const uint32_t bid     = s_ticket;
-    const uint32_t nchunks = gridDim.x;
-    uint64_t*      states  = scan_state + 2;
-    const int64_t  base    = (int64_t)bid * kCullChunk;
+    const uint32_t bid  = blockIdx.x;
+    const int64_t  base = (int64_t)bid * kCullChunk;
+    if (tid < 256) s_hist[tid] = 0;
 
     // ---- phase 1: candidates of the chunk -> s_cand (lane t takes splats t, t + 512, ...: coalesced)
     uint32_t ncand;
@@ -336,67 +309,17 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
 #pragma unroll
     for (int w = 0; w < kCullWaves; ++w) bt += s_wave_tiles[w];
 
-    // ---- chained scan across workgroups (decoupled look-back), done by wave 0
-    if (wave == 0) {
-        uint32_t ex_v = 0, ex_t = 0;
-        if (bid == 0) {
-            if (lane == 0) state_store(&states[0], pack_state(kStatusInclusive, bv, bt));
-        } else {
-            if (lane == 0) state_store(&states[bid], pack_state(kStatusAggregate, bv, bt));
-            int64_t  look  = (int64_t)bid - 1;
-            bool     found = false;
-            uint32_t spins = 0;
-            while (!found) {
-                const int64_t j = look - lane;
-                uint64_t      s = j >= 0 ? state_load(&states[j]) : pack_state(kStatusInclusive, 0u, 0u);
-                // wait until no word in the window (up to the first INCLUSIVE) is still invalid
-                unsigned long long inv = __ballot(state_status(s) == kStatusInvalid);
-                unsigned long long inc = __ballot(state_status(s) == kStatusInclusive);
-                const int first_inc = inc ? (__ffsll((long long)inc) - 1) : 64;
-                const unsigned long long need = first_inc >= 63 ? ~0ull : ((2ull << first_inc) - 1ull);
-                if (inv & need) {
-                    if (++spins > (1u << 22)) { // bounded spin: flag the error and bail out
-                        if (lane == 0) atomicExch(reinterpret_cast<unsigned int*>(scan_state + 1), 1u);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                const bool take = lane <= first_inc;
-                uint32_t   av   = take ? state_vis(s) : 0u;
-                uint32_t   at   = take ? state_tiles(s) : 0u;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    av += __shfl_xor(av, off, 64);
-                    at += __shfl_xor(at, off, 64);
-                }
-                ex_v += av;
-                ex_t += at;
-                if (inc) found = true;
-                else look -= 64;
-            }
-            if (lane == 0) state_store(&states[bid], pack_state(kStatusInclusive, ex_v + bv, ex_t + bt));
-        }
-        if (lane == 0) {
-            s_prefix_vis = ex_v;
-            if (bid == nchunks - 1) {
-                d_counts[0] = ex_v + bv; // V: splats that emit >= 1 pair
-                d_counts[1] = ex_t + bt; // the reference's num_rendered (gs_tile_splatter/impl.cpp:106)
-            }
-        }
-    }
-    __syncthreads();
-
-    const uint32_t prefix = s_prefix_vis;
+    // ---- the chunk's survivors, in index order, into the chunk's own slab; no cross-workgroup dependency
 #pragma unroll
     for (int k = 0; k < kCullItems; ++k) {
         if (!((vis_mask >> k) & 1u)) continue;
-        const uint32_t vid = prefix + my_base[k] + lv[k];
-        sort_keys[vid]     = __float_as_uint(depth[k]);
-        sort_vals[vid]     = vid;
-        vis_index[vid]     = gidx[k];
-        rects[vid]         = rect[k];
+        const uint32_t key = __float_as_uint(depth[k]);
+        slab[base + my_base[k] + lv[k]] = make_uint4(key, gidx[k], rect[k].x, rect[k].y);
+        atomicAdd(&s_hist[key & mask0], 1u);
     }
+    if (tid == 0) chunk_info[bid] = make_uint2(bv, bt);
+    __syncthreads();
+    if (tid < 256) counts0[(size_t)tid * stride0 + bid] = s_hist[tid]; // the depth sort's first count table
 }
 
 // Pass B over the V survivors only (dense: every lane does useful work): re-project (40 B), evaluate the SH
@@ -803,8 +726,8 @@ __global__ void __launch_bounds__(kThreads) k_get_ranges_u32(uint32_t* __restric
                                                                uint32_t* __restrict__ ranges,
                                                                const uint32_t* __restrict__ scan_error_flag)
 {
-    // (also forwards the chained scan's time-out flag into the counter block the host reads back)
-    if (blockIdx.x == 0 && threadIdx.x == 0 && scan_error_flag) d_counts[5] = *scan_error_flag;
+    // (also forwards a time-out flag, if the frame has one, into the counter block the host reads back)
+    if (blockIdx.x == 0 && threadIdx.x == 0) d_counts[5] = scan_error_flag ? *scan_error_flag : 0u;
     uint32_t g  = blockIdx.x * kThreads + threadIdx.x; // group of four keys
     uint32_t i0 = g * 4u;
     uint4    k4 = make_uint4(0, 0, 0, 0);
@@ -863,7 +786,7 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kThreads - 1) / k
 } // namespace
 
 inline unsigned chunks_for(int64_t n) { return (unsigned)((n + kCullChunk - 1) / kCullChunk); }
-size_t fused_scan_state_bytes(int P) { return (size_t)(chunks_for(P) + 2) * sizeof(uint64_t); }
+int    cull_chunk_count(int P) { return (int)chunks_for(P); }
 
 __global__ void k_set_frame_params(FrameParams fp, FrameParams* __restrict__ dst) { *dst = fp; }
 
@@ -873,22 +796,17 @@ void launch_set_frame_params(const FrameParams& fp, FrameParams* d_fp, hipStream
 }
 
 void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const FrameParams* d_fp, const float* pos,
-                         const float* scale,
-                         const float* rotq, const float* opacity, int32_t* radii, uint32_t* sort_keys,
-                         uint32_t* sort_vals, uint32_t* vis_index, uint2* rects, uint64_t* scan_state,
-                         uint32_t* d_counts, hipStream_t stream, hipEvent_t done)
+                         const float* scale, const float* rotq, const float* opacity, int32_t* radii, uint4* slab,
+                         uint2* chunk_info, const DepthSortFirstPass& first, hipStream_t stream)
 {
-    // `done` rides on the dispatch packet itself (completion signal): no separate event-record packet sits between
-    // this kernel and the next one on the stream
-    // (hipExtLaunchKernelGGL with NULL events is an ordinary launch)
     if (radii)
-        hipExtLaunchKernelGGL(k_cull_compact<true>, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, nullptr, done, 0, P,
-                              cp, scale_modifier, d_fp, pos, scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index,
-                              rects, scan_state, d_counts);
+        hipLaunchKernelGGL(k_cull_compact<true>, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, P, cp, scale_modifier,
+                           d_fp, pos, scale, rotq, opacity, radii, slab, chunk_info, first.counts, first.row_stride,
+                           first.mask);
     else
-        hipExtLaunchKernelGGL(k_cull_compact<false>, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, nullptr, done, 0, P,
-                              cp, scale_modifier, d_fp, pos, scale, rotq, opacity, radii, sort_keys, sort_vals, vis_index,
-                              rects, scan_state, d_counts);
+        hipLaunchKernelGGL(k_cull_compact<false>, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, P, cp, scale_modifier,
+                           d_fp, pos, scale, rotq, opacity, radii, slab, chunk_info, first.counts, first.row_stride,
+                           first.mask);
 }
 
 void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const FrameParams* d_fp,

@@ -51,17 +51,28 @@ struct __attribute__((aligned(16))) SplatRecord {
 };
 static_assert(sizeof(SplatRecord) == 48, "SplatRecord must be 48 bytes");
 
-size_t fused_scan_state_bytes(int P);
-// d_counts: [0] V (splats emitting >= 1 pair), [1] reference num_rendered, [2] pairs emitted, [3] overflow flag,
-//           [4] pairs wanted (before clamping to the workspace capacity)
+// ---- the cull pass and the depth sort it feeds
+// Where the cull pass leaves the depth sort's first per-chunk digit counts (pair_sort.hip depth_sort_first_pass).
+struct DepthSortFirstPass {
+    uint32_t  mask;       // first digit = key & mask
+    uint32_t  row_stride; // counts[digit * row_stride + chunk]
+    uint32_t* counts;
+};
+DepthSortFirstPass depth_sort_first_pass(int64_t P, void* sort_ws);
+int    cull_chunk_count(int P); // 2048-splat chunks: slab = 2048 x 16 B per chunk, chunk_info / chunk_base one entry each
 void launch_set_frame_params(const FrameParams& fp, FrameParams* d_fp, hipStream_t stream);
 // d_fp (nullable): when non-NULL the kernels take camera / bg / scale_modifier from device memory (graph replay)
+// slab[chunk * 2048 + r] = {depth bits, splat index, pruned rect} of the chunk's r-th survivor (index order);
+// chunk_info[chunk] = {survivors, reference tiles_touched}
 void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const FrameParams* d_fp, const float* pos,
-                         const float* scale,
-                         const float* rotq, const float* opacity, int32_t* radii, uint32_t* sort_keys,
-                         uint32_t* sort_vals, uint32_t* vis_index, uint2* rects, uint64_t* scan_state,
-                         uint32_t* d_counts, hipStream_t stream,
-                         hipEvent_t done = nullptr); // optional completion event carried by the dispatch itself
+                         const float* scale, const float* rotq, const float* opacity, int32_t* radii, uint4* slab,
+                         uint2* chunk_info, const DepthSortFirstPass& first, hipStream_t stream);
+// d_counts: [0] V (splats emitting >= 1 pair), [1] reference num_rendered (both written by the depth sort's first
+//           row-scan launch), [2] pairs emitted, [3] overflow flag, [4] pairs wanted (before clamping to capacity)
+void launch_depth_sort_from_chunks(int64_t P, int64_t v_hint, const uint4* slab, const uint2* chunk_info,
+                                   uint32_t* chunk_base, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
+                                   uint32_t* vals_b, uint32_t* vis_index, uint2* rects, uint32_t* d_counts, void* sort_ws,
+                                   hipStream_t stream, hipEvent_t fork = nullptr);
 struct PairSortFirstPass;
 size_t expand_ws_bytes(int P_cap);
 // v_hint: expected survivor count (bounds the launch; larger live counts are handled by chunk striding)

@@ -11,6 +11,8 @@
 // are latency-bound here (agent-scope sc1 loads are ~1 us each under load, one ticket atomic saturates at
 // ~88/us), 1.5-2x slower than these three plain launches at V ~ 2.4 M / L ~ 7.5 M.
 // Workgroups stride over chunks, so the grid is bounded (no launch of capacity-sized empty grids).
+#include <hip/hip_ext.h>
+
 #include "launch.hpp"
 
 namespace lcgs
@@ -127,6 +129,222 @@ __global__ void __launch_bounds__(kThreads) k_rowscan(uint32_t* __restrict__ cou
         __syncthreads(); // s_wave is reused by the next round
     }
     if (threadIdx.x == 0) totals[blockIdx.x] = carry_in;
+}
+
+// The depth sort's first pass reads the cull pass's per-chunk slabs instead of a dense array: workgroup c takes
+// chunk c's chunk_info[c].x survivors ({key, splat index, rect} in 16-byte slots, index order), whose dense ids are
+// chunk_base[c] + slot -- the ids the single-pass compaction used to hand out -- and, besides the (key, id) pairs in
+// sorted position, writes the dense vis_index[id] / rects[id] the later stages gather from.
+template <int kItems>
+__global__ void __launch_bounds__(kThreads) k_scatter_first(const uint4* __restrict__ slab,
+                                                              const uint2* __restrict__ chunk_info,
+                                                              const uint32_t* __restrict__ chunk_base,
+                                                              uint32_t* __restrict__ keys_out,
+                                                              uint32_t* __restrict__ vals_out,
+                                                              uint32_t* __restrict__ vis_index,
+                                                              uint2* __restrict__ rects, uint32_t mask, int bits,
+                                                              const uint32_t* __restrict__ row_excl,
+                                                              const uint32_t* __restrict__ totals, uint32_t row_stride)
+{
+    constexpr int kKPB = kThreads * kItems;
+    __shared__ uint32_t s_wave_hist[kWaves][kRadix];
+    __shared__ uint32_t s_global_delta[kRadix];
+    __shared__ uint32_t s_digit_base[kRadix];
+    __shared__ uint32_t s_scan[kWaves];
+    __shared__ uint32_t s_keys[kKPB];
+    __shared__ uint32_t s_vals[kKPB];
+
+    const int      tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t chunk = blockIdx.x;
+    // the chunk's count first (a slab is 40 % full on average: reading only the live slots is worth the round trip),
+    // then everything else at once
+    const uint32_t n_c  = chunk_info[chunk].x;
+    const uint32_t own  = totals[tid];
+    const uint32_t rex  = row_excl[(size_t)tid * row_stride + chunk];
+    const uint32_t vid0 = chunk_base[chunk];
+    uint4          rec[kItems];
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+        const uint32_t li = wave * 64 * kItems + r * 64 + lane;
+        rec[r]            = li < n_c ? slab[(size_t)chunk * kKPB + li] : make_uint4(0u, 0u, 0u, 0u);
+    }
+
+    {
+        uint32_t inc = own;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) s_scan[wave] = inc;
+        __syncthreads();
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w)
+            if (w < wave) carry += s_scan[w];
+        s_digit_base[tid] = carry + inc - own;
+    }
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) s_wave_hist[w][tid] = 0;
+    __syncthreads();
+
+    uint32_t           rank[kItems];
+    volatile uint32_t* my_hist = s_wave_hist[wave];
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+        const uint32_t li    = wave * 64 * kItems + r * 64 + lane;
+        rank[r]              = 0;
+        if ((uint32_t)(wave * 64 * kItems + r * 64) >= n_c) continue; // wave-uniform: the slab is filled from the front
+        const bool     valid = li < n_c;
+        const uint32_t d     = valid ? (rec[r].x & mask) : 0u;
+        unsigned long long peers = __ballot(valid);
+        for (int b = 0; b < bits; ++b) {
+            const bool               bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t below = __popcll(peers & ((1ull << lane) - 1ull));
+        const uint32_t count = __popcll(peers);
+        uint32_t       prev  = 0;
+        if (valid) prev = my_hist[d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && below == 0) my_hist[d] = prev + count;
+        __builtin_amdgcn_wave_barrier();
+        rank[r] = prev + below;
+        if (valid) { // dense copies for the stages that gather by id (coalesced: ids are consecutive in li)
+            vis_index[vid0 + li] = rec[r].y;
+            rects[vid0 + li]     = make_uint2(rec[r].z, rec[r].w);
+        }
+    }
+    __syncthreads();
+
+    uint32_t wave_off[kWaves];
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        wave_off[w] = total;
+        total += s_wave_hist[w][tid];
+    }
+    uint32_t inc = total;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_scan[wave] = inc;
+    __syncthreads();
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w)
+        if (w < wave) carry += s_scan[w];
+    const uint32_t start = carry + inc - total;
+    s_global_delta[tid]  = s_digit_base[tid] + rex - start;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) s_wave_hist[w][tid] = start + wave_off[w];
+    __syncthreads();
+
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+        const uint32_t li = wave * 64 * kItems + r * 64 + lane;
+        if (li < n_c) {
+            const uint32_t pos = s_wave_hist[wave][rec[r].x & mask] + rank[r];
+            s_keys[pos]        = rec[r].x;
+            s_vals[pos]        = vid0 + li;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_c; i += kThreads) {
+        const uint32_t k   = s_keys[i];
+        const uint32_t dst = s_global_delta[k & mask] + i;
+        keys_out[dst]      = k;
+        vals_out[dst]      = s_vals[i];
+    }
+}
+
+// The row scan of the first pass, plus one more workgroup (blockIdx == 256) that turns the per-chunk survivor
+// counts into dense-id bases and publishes V and the reference's num_rendered.  nb is the host-known chunk count.
+__global__ void __launch_bounds__(kThreads) k_rowscan_first(uint32_t* __restrict__ counts, uint32_t nb,
+                                                              uint32_t* __restrict__ totals, uint32_t row_stride,
+                                                              const uint2* __restrict__ chunk_info,
+                                                              uint32_t* __restrict__ chunk_base,
+                                                              uint32_t* __restrict__ d_counts)
+{
+    constexpr int kPer = 16; // one round covers 4096 chunks = 8.4 M splats
+    __shared__ uint32_t s_wave[kWaves], s_wave2[kWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool chunks = blockIdx.x == (uint32_t)kRadix;
+    uint32_t*  row    = counts + (size_t)blockIdx.x * row_stride;
+    uint32_t   carry_in = 0, carry2_in = 0;
+    for (uint32_t base = 0; base < nb; base += kThreads * kPer) {
+        const uint32_t i0 = base + threadIdx.x * kPer;
+        uint32_t       v[kPer], w2[kPer];
+        if (chunks) {
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const uint2 ci = i0 + j < nb ? chunk_info[i0 + j] : make_uint2(0u, 0u);
+                v[j]           = ci.x;
+                w2[j]          = ci.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kPer / 4; ++q) { // row_stride is a multiple of 8: groups of 4 are whole or absent
+                const uint4 a = i0 + 4 * q < row_stride ? *reinterpret_cast<const uint4*>(row + i0 + 4 * q) : make_uint4(0, 0, 0, 0);
+                v[4 * q + 0] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+            }
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                if (i0 + j >= nb) v[j] = 0;
+                w2[j] = 0;
+            }
+        }
+        uint32_t e[kPer], tot = 0, tot2 = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            e[j] = tot;
+            tot += v[j];
+            tot2 += w2[j];
+        }
+        uint32_t inc = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tot2 += __shfl_xor(tot2, off, 64);
+        if (lane == 63) s_wave[wave] = inc;
+        if (lane == 0) s_wave2[wave] = tot2;
+        __syncthreads();
+        uint32_t carry = carry_in, round_total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            if (w < wave) carry += s_wave[w];
+            round_total += s_wave[w];
+            carry2_in += s_wave2[w];
+        }
+        const uint32_t ex = carry + inc - tot;
+        if (chunks) {
+#pragma unroll
+            for (int j = 0; j < kPer; ++j)
+                if (i0 + j < nb) chunk_base[i0 + j] = ex + e[j];
+        } else {
+#pragma unroll
+            for (int q = 0; q < kPer / 4; ++q)
+                if (i0 + 4 * q < row_stride)
+                    *reinterpret_cast<uint4*>(row + i0 + 4 * q) =
+                        make_uint4(ex + e[4 * q], ex + e[4 * q + 1], ex + e[4 * q + 2], ex + e[4 * q + 3]);
+        }
+        carry_in += round_total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (chunks) {
+            d_counts[0] = carry_in;  // V: splats that emit >= 1 pair
+            d_counts[1] = carry2_in; // the reference's num_rendered (gs_tile_splatter/impl.cpp:106)
+        } else {
+            totals[blockIdx.x] = carry_in;
+        }
+    }
 }
 
 template <int kItems, typename K>
@@ -307,6 +525,16 @@ PairSortFirstPass pair_sort_first_pass(int64_t n_cap, int64_t grid_hint, int beg
     return fp;
 }
 
+// The depth sort fed by the cull pass's chunk slabs (see k_scatter_first).  Chunks are the cull pass's 2048 splats.
+DepthSortFirstPass depth_sort_first_pass(int64_t P, void* ws)
+{
+    DepthSortFirstPass fp;
+    fp.mask       = 0xFFu; // 32 key bits in 4 passes of 8
+    fp.row_stride = (uint32_t)row_stride_for(P, 8);
+    fp.counts     = reinterpret_cast<uint32_t*>(ws);
+    return fp;
+}
+
 namespace
 {
 // pass p reads (src_k[p], src_v[p]) and writes (dst_k[p], dst_v[p])
@@ -370,6 +598,31 @@ int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
         run_passes<16, uint32_t>(sk, sv, dk, dv, n_pass, d_n, n_cap, grid_hint, begin_bit, end_bit, ws_, stream,
                                  first_hist_done);
     return n_pass & 1;
+}
+
+// Survivors by depth bits: pass 0 from the slabs into (keys_b, vals_b), passes 1-3 ping-pong; the result ends in
+// (keys_a, vals_a).  d_counts[0] / [1] (V, num_rendered) are written by pass 0's row-scan launch; `fork`, if given,
+// is signalled when pass 0's scatter (which writes vis_index / rects) completes.
+void launch_depth_sort_from_chunks(int64_t P, int64_t v_hint, const uint4* slab, const uint2* chunk_info,
+                                   uint32_t* chunk_base, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
+                                   uint32_t* vals_b, uint32_t* vis_index, uint2* rects, uint32_t* d_counts, void* ws_,
+                                   hipStream_t stream, hipEvent_t fork)
+{
+    if (P <= 0) return;
+    constexpr int  kItems = 8;
+    const uint32_t nb     = (uint32_t)((P + kThreads * kItems - 1) / (kThreads * kItems));
+    const uint32_t stride = (uint32_t)row_stride_for(P, kItems);
+    uint32_t*      counts = reinterpret_cast<uint32_t*>(ws_);
+    uint32_t*      totals = counts + (size_t)stride * kRadix;
+    hipLaunchKernelGGL(k_rowscan_first, dim3(kRadix + 1), dim3(kThreads), 0, stream, counts, nb, totals, stride, chunk_info,
+                       chunk_base, d_counts);
+    hipExtLaunchKernelGGL(k_scatter_first<kItems>, dim3(nb), dim3(kThreads), 0, stream, nullptr, fork, 0, slab, chunk_info,
+                          chunk_base, keys_b, vals_b, vis_index, rects, 0xFFu, 8, counts, totals, stride);
+    const uint32_t* sk[3] = { keys_b, keys_a, keys_b };
+    const uint32_t* sv[3] = { vals_b, vals_a, vals_b };
+    uint32_t*       dk[3] = { keys_a, keys_b, keys_a };
+    uint32_t*       dv[3] = { vals_a, vals_b, vals_a };
+    run_passes<kItems, uint32_t>(sk, sv, dk, dv, 3, d_counts, P, v_hint, 8, 32, ws_, stream);
 }
 
 // The stage-level sort (lcpp DeviceRadixSort::SortPairs<ulong, uint>, call site gs_tile_splatter/impl.cpp:135-143):

@@ -93,10 +93,11 @@ struct lcgs_context {
     bool         use_half_sh = false;
 
     // workspace of the fused frame
+    DeviceBuffer cull_slab, chunk_info, chunk_base; // the cull pass's per-chunk output (fused_forward.hip k_cull_compact)
     DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws[3], counts, sort_ws,
         expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks, shjac;
     bool         last_has_jac = false; // the last keep_state frame stored the colour Jacobian (degree 3)
-    // zero_ws holds what a frame needs zeroed: the chained-scan states of the cull pass and the tile ranges.  Three
+    // zero_ws holds what a frame needs zeroed: the tile ranges.  Three
     // copies rotate: while frame N runs, the auxiliary stream clears the copy of frame N + 2.  Two frames ahead, not
     // one, so that no wait is needed when a frame starts: the fill issued during frame N - 1 sits on the auxiliary
     // stream in front of frame N's record builder, whose completion frame N's renderer waited for -- and frame N + 1
@@ -233,7 +234,7 @@ lcgs_status check_frame_flags(lcgs_context* ctx)
 {
     if (!ctx->last.valid || !ctx->h_counts) return LCGS_OK;
     if (ctx->h_counts[5] != 0) {
-        set_last_error("chained scan timed out (bounded spin expired): the frame is invalid");
+        set_last_error("a device-side wait timed out (bounded spin expired): the frame is invalid");
         return LCGS_ERR_HIP;
     }
     if (ctx->h_counts[3] != 0) {
@@ -273,6 +274,12 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
         LCGS_TRY(ctx->sortk[i].ensure(P * 4));
         LCGS_TRY(ctx->sortv[i].ensure(P * 4));
     }
+    {
+        const size_t chunks = (size_t)cull_chunk_count((int)P);
+        LCGS_TRY(ctx->cull_slab.ensure(chunks * 2048 * 16));
+        LCGS_TRY(ctx->chunk_info.ensure(chunks * 8));
+        LCGS_TRY(ctx->chunk_base.ensure(chunks * 4));
+    }
     LCGS_TRY(ctx->vis_index.ensure(P * 4));
     LCGS_TRY(ctx->rects.ensure(P * 8));
     LCGS_TRY(ctx->rects_sorted.ensure(P * 8));
@@ -287,7 +294,7 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
     }
     const size_t G = (size_t)cp.grid_x * cp.grid_y;
     auto         al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t b0 = al(fused_scan_state_bytes((int)P)), b1 = al(G * 2 * 4);
+    const size_t b0 = 0, b1 = al(G * 2 * 4); // (b0: the chained scan's state block, gone with the scan)
     for (int i = 0; i < 3; ++i) {
         const void* before = ctx->zero_ws[i].ptr;
         LCGS_TRY(ctx->zero_ws[i].ensure(b0 + b1));
@@ -333,7 +340,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     // attributable; otherwise independent work moves to the auxiliary stream (see below).
     const bool overlap  = !ctx->profiling;
     const bool deferred = overlap && !in_capture;
-    // Zeroed per frame: scan states of the cull pass + tile ranges (the reference zero-fills ranges too,
+    // Zeroed per frame: the tile ranges (the reference zero-fills ranges too,
     // gs_tile_splatter/impl.cpp:147).  Normally the auxiliary stream cleared this frame's copy during the last frame.
     const int zb = deferred ? ctx->zero_cur : 0;
     if (!deferred && ctx->aux_pending && !in_capture) {
@@ -345,20 +352,30 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     }
     if (!(deferred && ctx->zero_ready[zb])) LCGS_HIP_CHECK(hipMemsetAsync(ctx->zero_ws[zb].ptr, 0, ctx->zero_bytes, st));
     ctx->zero_ready[zb]  = false;
-    uint64_t* scan_state = ctx->zero_ws[zb].as<uint64_t>();
     ctx->ranges          = reinterpret_cast<uint32_t*>(ctx->zero_ws[zb].as<char>() + ctx->zero_scan_bytes);
+    const DepthSortFirstPass dfirst = depth_sort_first_pass(P, ctx->sort_ws.ptr);
     launch_cull_compact(P, cp, scale_modifier, d_fp, ctx->pos, ctx->scale, ctx->rotq, ctx->opacity, d_radii,
-                        ctx->sortk[0].as<uint32_t>(), ctx->sortv[0].as<uint32_t>(), ctx->vis_index.as<uint32_t>(),
-                        ctx->rects.as<uint2>(), scan_state, d_counts, st, (overlap && !in_capture) ? ctx->ev_fork : nullptr);
+                        ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(), dfirst, st);
     LCGS_TRY(mark(ctx, "cull_compact"));
     const int64_t hint_V = ctx->hint_V > 0 ? ctx->hint_V : P;
     const int64_t hint_L = ctx->hint_L > 0 ? ctx->hint_L : ctx->pair_capacity;
-    // Record building (SH fetch + colour: bandwidth-bound) is independent of the sort chain (latency-bound short
-    // kernels): fork it onto the auxiliary stream so the two overlap; the renderer joins.
+    // survivors by depth bits (the low 32 bits of the reference key), sorted before duplication.  The first pass reads
+    // the cull pass's chunk slabs, hands out the dense ids and writes vis_index / rects; its completion is the fork
+    // point of the record builder.
+    launch_depth_sort_from_chunks(P, hint_V, ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(),
+                                  ctx->chunk_base.as<uint32_t>(), ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
+                                  ctx->sortv[0].as<uint32_t>(), ctx->sortv[1].as<uint32_t>(), ctx->vis_index.as<uint32_t>(),
+                                  ctx->rects.as<uint2>(), d_counts, ctx->sort_ws.ptr, st,
+                                  (overlap && !in_capture) ? ctx->ev_fork : nullptr);
+    const uint32_t* order = ctx->sortv[0].as<uint32_t>();
+    LCGS_TRY(mark(ctx, "depth_sort"));
+    // Record building (SH fetch + colour: bandwidth-bound) is independent of the rest of the sort chain (latency-bound
+    // short kernels): fork it onto the auxiliary stream so the two overlap; the renderer joins.
     hipStream_t rec_stream = overlap ? ctx->aux_stream : st;
-    // (forking later -- after the depth sort or after the duplication -- was measured slower: 1073 / 1048 vs 1094 fps)
     if (overlap) {
-        if (in_capture) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st)); // (otherwise carried by the cull dispatch)
+        // (in a capture the fork is recorded here, after the whole depth sort; otherwise the first pass's scatter
+        //  dispatch carries it)
+        if (in_capture) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
     }
     launch_build_records((int)std::min<int64_t>(P, hint_V), ctx->sh_deg, cp, scale_modifier, d_fp, ctx->pos, ctx->scale,
@@ -374,13 +391,6 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
         ctx->g2d_zeroed = true;
     }
     LCGS_TRY(mark(ctx, "build_records"));
-
-    // survivors by depth bits: the low 32 bits of the reference key, sorted before duplication
-    const int where = launch_pair_sort_u32(ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
-                                           ctx->sortv[0].as<uint32_t>(), ctx->sortv[1].as<uint32_t>(), d_counts + 0, P,
-                                           hint_V, 0, 32, ctx->sort_ws.ptr, st);
-    const uint32_t* order = ctx->sortv[where].as<uint32_t>();
-    LCGS_TRY(mark(ctx, "depth_sort"));
 
     // stable partition by tile id: only ceil(log2 G) key bits are live.  The kernel that writes the pairs also leaves
     // the partition's first per-chunk digit counts in the sort workspace (the depth sort is done with it by then).
@@ -399,7 +409,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     LCGS_TRY(mark(ctx, "tile_sort"));
 
     launch_get_ranges_u32(hint_L, ctx->pair_capacity, d_counts, ctx->pairk[where2].as<uint32_t>(), ctx->ranges,
-                          reinterpret_cast<const uint32_t*>(scan_state + 1), st, deferred ? ctx->ev_ranges : nullptr);
+                          nullptr, st, deferred ? ctx->ev_ranges : nullptr);
     // tile schedule: the newest complete order if it matches this grid, else computed here
     uint32_t* order_now = nullptr;
     if (deferred && ctx->order_G == G) {
@@ -526,7 +536,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     DeviceBuffer* bufs[] = { &ctx->recs, &ctx->sortk[0], &ctx->sortk[1], &ctx->sortv[0], &ctx->sortv[1], &ctx->vis_index,
-                             &ctx->rects, &ctx->rects_sorted, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
+                             &ctx->rects, &ctx->rects_sorted, &ctx->cull_slab, &ctx->chunk_info, &ctx->chunk_base, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
                              &ctx->pairv[1], &ctx->zero_ws[0], &ctx->zero_ws[1], &ctx->zero_ws[2], &ctx->counts, &ctx->sort_ws,
                              &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order[0], &ctx->tile_order[1], &ctx->st_keys_tmp,
                              &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac };
