@@ -139,6 +139,7 @@ __device__ __forceinline__ Projected project_splat(const CamParams& cp, float sc
 constexpr int kCullThreads = 512; // 8 waves: the per-lane chain of dependent loads is 4 splats long, not 8
 constexpr int kCullWaves   = kCullThreads / 64;
 constexpr int kCullItems   = 4;
+constexpr int kCullStaged  = 2 * kCullThreads; // candidates whose inputs stay in LDS between the phases
 constexpr int kCullChunk   = kCullThreads * kCullItems; // 2048 splats = one chunk of the depth sort's first pass
 
 // Phase-1 test.  Returns false only if the splat certainly emits no pair: behind the near plane (the reference's
@@ -204,6 +205,9 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
     __shared__ uint32_t s_wave_tiles[kCullWaves];
     __shared__ uint32_t s_hist[256];
     __shared__ uint16_t s_cand[kCullChunk]; // chunk-local indices of the phase-1 survivors, in index order
+    // the first kCullStaged candidates' inputs (10 floats each, one array per component: conflict-free) so that
+    // phase 2 does not fetch them a second time; later candidates (rare: a chunk averages 820) are read again
+    __shared__ float s_in[RADII ? 1 : 10][RADII ? 1 : kCullStaged];
 
     if (fpp) { // graph replay: per-call parameters come from device memory
         cp             = fpp->cp;
@@ -245,7 +249,16 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
         for (int k = 0; k < kCullItems; ++k) {
 #pragma unroll
             for (int w = 0; w < kCullWaves; ++w) {
-                if (w == wave && ((cmask >> k) & 1u)) s_cand[run + rank[k]] = (uint16_t)(k * kCullThreads + tid);
+                if (w == wave && ((cmask >> k) & 1u)) {
+                    const uint32_t slot = run + rank[k];
+                    s_cand[slot]        = (uint16_t)(k * kCullThreads + tid);
+                    if (slot < (uint32_t)kCullStaged) {
+                        s_in[0][slot] = in[k].px; s_in[1][slot] = in[k].py; s_in[2][slot] = in[k].pz;
+                        s_in[3][slot] = in[k].sx; s_in[4][slot] = in[k].sy; s_in[5][slot] = in[k].sz;
+                        s_in[6][slot] = in[k].q.x; s_in[7][slot] = in[k].q.y; s_in[8][slot] = in[k].q.z;
+                        s_in[9][slot] = in[k].q.w;
+                    }
+                }
                 run += s_wave_vis[k][w];
             }
         }
@@ -272,7 +285,14 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
             if (c < ncand) {
                 const int64_t idx = base + (int64_t)s_cand[c];
                 gidx[k]           = (uint32_t)idx;
-                const SplatIn   in = load_splat(idx, pos, scale, rotq);
+                SplatIn in;
+                if (!RADII && k * kCullThreads < kCullStaged) { // (static per round: rounds 0 and 1 come from LDS)
+                    in.px = s_in[0][c]; in.py = s_in[1][c]; in.pz = s_in[2][c];
+                    in.sx = s_in[3][c]; in.sy = s_in[4][c]; in.sz = s_in[5][c];
+                    in.q  = make_float4(s_in[6][c], s_in[7][c], s_in[8][c], s_in[9][c]);
+                } else {
+                    in = load_splat(idx, pos, scale, rotq);
+                }
                 const float     op = opacity[idx];
                 // keep the compiler from sinking the scale / rotation / opacity loads below the near test: a
                 // candidate always passes it, and one round trip is cheaper than two
