@@ -139,6 +139,7 @@ __device__ __forceinline__ Projected project_splat(const CamParams& cp, float sc
 constexpr int kCullThreads = 512; // 8 waves: the per-lane chain of dependent loads is 4 splats long, not 8
 constexpr int kCullWaves   = kCullThreads / 64;
 constexpr int kCullItems   = 4;
+static_assert(kCullThreads * kCullItems == kCullChunkSplats, "the cull chunk is the depth sort's first chunk");
 constexpr int kCullStaged  = 2 * kCullThreads; // candidates whose inputs stay in LDS between the phases
 constexpr int kCullChunk   = kCullThreads * kCullItems; // 2048 splats = one chunk of the depth sort's first pass
 

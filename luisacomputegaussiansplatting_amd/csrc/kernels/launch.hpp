@@ -53,6 +53,8 @@ static_assert(sizeof(SplatRecord) == 48, "SplatRecord must be 48 bytes");
 
 // ---- the cull pass and the depth sort it feeds
 // Where the cull pass leaves the depth sort's first per-chunk digit counts (pair_sort.hip depth_sort_first_pass).
+// splats per cull workgroup = slots per slab = keys per chunk of the depth sort's first pass (both files assert it)
+constexpr int kCullChunkSplats = 2048;
 struct DepthSortFirstPass {
     uint32_t  mask;       // first digit = key & mask
     uint32_t  row_stride; // counts[digit * row_stride + chunk]

@@ -610,6 +610,7 @@ void launch_depth_sort_from_chunks(int64_t P, int64_t v_hint, const uint4* slab,
 {
     if (P <= 0) return;
     constexpr int  kItems = 8;
+    static_assert(kThreads * kItems == kCullChunkSplats, "one workgroup of the first pass per cull chunk");
     const uint32_t nb     = (uint32_t)((P + kThreads * kItems - 1) / (kThreads * kItems));
     const uint32_t stride = (uint32_t)row_stride_for(P, kItems);
     uint32_t*      counts = reinterpret_cast<uint32_t*>(ws_);
