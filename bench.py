@@ -306,24 +306,33 @@ def main():
             o0 += width * P
         dL = torch.randn(3, H, W, device=dev)
 
-        def train_step():
+        def train_step(collective=True, compact=False):
             r.forward(cam, img, keep_state=True, sync=False)
-            r.backward(dL, views["pos"], views["scale"], views["rotq"], views["sh"], views["opacity"])
-            if dist is not None:
+            r.backward(dL, views["pos"], views["scale"], views["rotq"], views["sh"], views["opacity"], compact=compact)
+            if dist is not None and collective:
                 dist.all_reduce(gbuf)  # sum of the per-view gradients over xGMI
 
-        for _ in range(max(1, args.warmup)):
-            train_step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            train_step()
-        barrier()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
+        def timed_steps(collective, compact=False):
+            for _ in range(max(1, args.warmup)):
+                train_step(collective, compact)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                train_step(collective, compact)
+            barrier()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                tt = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            return el
+
+        el = timed_steps(True)
+        # N > 1: the same steps without the gradient all-reduce, so that the collective's share is visible
+        el_local = timed_steps(False) if dist is not None else None
+        # N = 1: the same step with compact gradient rows (lcgs_render_backward_compact: one row per on-screen splat,
+        # no zero-fill) -- reported beside the dense figure, which stays `value` (an all-reduce needs per-splat rows)
+        el_compact = timed_steps(False, compact=True) if dist is None else None
         r.set_profiling(True)
         r.forward(cam, img, keep_state=True, sync=True)
         r.backward(dL, views["pos"], views["scale"], views["rotq"], views["sh"], views["opacity"])
@@ -333,6 +342,13 @@ def main():
                           "unit": "Msplats/s", "ms_per_step": round(el * 1e3 / args.steps, 4),
                           "grad_allreduce_bytes_per_gpu": 59 * 4 * P if world > 1 else 0,
                           "backward_stages_ms": {k: round(v, 4) for k, v in bwd_stages.items()}}
+        if el_compact is not None:
+            out["fwd_bwd"]["compact_rows"] = {"value": round(P * args.steps / el_compact / 1e6, 1), "unit": "Msplats/s",
+                                              "ms_per_step": round(el_compact * 1e3 / args.steps, 4)}
+        if el_local is not None:
+            out["fwd_bwd"]["without_collective"] = {"value": round(world * P * args.steps / el_local / 1e6, 1),
+                                                    "unit": "Msplats/s",
+                                                    "ms_per_step": round(el_local * 1e3 / args.steps, 4)}
 
         # ---- full training-style step: + the optimiser (gradients -> Adam on the raw parameters -> refreshed
         # activated arrays, lcgs_adam_step), dense and restricted to the splats on screen
@@ -346,8 +362,17 @@ def main():
             mom = [{k: torch.zeros_like(t) for k, t in raw.items()} for _ in range(2)]
             lr = {"pos": 0.0, "sh_dc": 0.0, "sh_rest": 0.0, "opacity": 0.0, "scale": 0.0, "rot": 0.0}  # scene stays put
             out["train_step"] = {}
-            for mode in ("dense", "visible_only"):
+            # "visible_only_compact" (N = 1 only: an all-reduce needs per-splat rows): the backward writes compact
+            # gradient rows (lcgs_render_backward_compact: no zero-fill, consecutive rows) and the optimiser reads them
+            modes = ("dense", "visible_only") + (("visible_only_compact",) if dist is None else ())
+            for mode in modes:
                 def full_step(i):
+                    if mode == "visible_only_compact":
+                        r.forward(cam, img, keep_state=True, sync=False)
+                        r.backward(dL, views["pos"], views["scale"], views["rotq"], views["sh"], views["opacity"],
+                                   compact=True)
+                        r.adam_step(views, raw, mom[0], mom[1], act, i + 1, lr, visible_only=True, compact_grads=True)
+                        return
                     train_step()
                     r.adam_step(views, raw, mom[0], mom[1], act, i + 1, lr, visible_only=(mode == "visible_only"))
                 for i in range(2):

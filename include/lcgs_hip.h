@@ -252,6 +252,16 @@ typedef struct lcgs_grads {
     float* d_dL_dopacity;
 } lcgs_grads;
 LCGS_API lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads);
+/* The same gradients as compact rows: row r of every output belongs to the r-th on-screen splat of that forward
+ * frame (ascending splat index; lcgs_visible_rows names the splats).  Only those rows are written -- consecutive
+ * rows, no zero-fill of the other P - V (the dense variant's stores land on a 39 %-dense row pattern and cost twice
+ * as much).  Buffers need one row per on-screen splat (lcgs_frame_stats.num_visible; P rows always
+ * suffice).  For single-GPU steps: lcgs_adam_step(visible_only = 2) consumes this layout directly; gradients that
+ * are to be summed over views (RCCL all-reduce) need the dense variant. */
+LCGS_API lcgs_status lcgs_render_backward_compact(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads);
+/* Row list of the last forward frame: (*d_rows)[r] = splat index of compact row r, *d_count = address of the
+ * device-side row count.  Context-owned device memory, valid until the context's next forward frame. */
+LCGS_API lcgs_status lcgs_visible_rows(lcgs_context* ctx, const uint32_t** d_rows, const uint32_t** d_count);
 
 /* Optimiser step (the reference only names training on its roadmap, doc/roadmap.md:4).
  * The scene is parameterised as in 3DGS training: raw.pos / raw.sh are the values themselves,
@@ -273,7 +283,8 @@ typedef struct lcgs_adam_config {
     float lr_pos, lr_sh_dc, lr_sh_rest, lr_opacity, lr_scale, lr_rot;
     float beta1, beta2, eps;
     int   step;         /* 1, 2, ... (bias correction) */
-    int   visible_only; /* 0: every splat (dense Adam) */
+    int   visible_only; /* 0: every splat (dense Adam); 1: on-screen splats only, gradients laid out per splat;
+                         * 2: on-screen splats only, gradients in lcgs_render_backward_compact's row layout */
 } lcgs_adam_config;
 LCGS_API lcgs_status lcgs_adam_step(lcgs_context* ctx, int num_gaussians, int sh_degree, const lcgs_adam_config* cfg,
                                     const lcgs_grads* grads, const lcgs_params* raw, const lcgs_params* m,

@@ -139,7 +139,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_sh_process", "lcgs_project_forward", "lcgs_tile_splat_forward", "lcgs_inclusive_sum_u32",
     "lcgs_sort_pairs_u64_u32", "lcgs_scene_bind", "lcgs_scene_upload", "lcgs_render_forward",
     "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists",
-    "lcgs_render_backward", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
+    "lcgs_render_backward", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh",
@@ -479,9 +479,30 @@ class Renderer:
         _check(load_library().lcgs_render_forward_batch(self.ctx._h, C.c_int(n), cam_arr, _f3(bg),
                                                         C.c_float(scale_modifier), ptrs))
 
-    def backward(self, dL_dimg, dpos, dscale, drotq, dsh, dopacity):
+    def backward(self, dL_dimg, dpos, dscale, drotq, dsh, dopacity, compact: bool = False):
+        """lcgs_render_backward; compact=True: lcgs_render_backward_compact (row r = the frame's r-th on-screen
+        splat, see visible_rows; only those rows are written)."""
         g = _Grads(_ptr(dpos), _ptr(dscale), _ptr(drotq), _ptr(dsh), _ptr(dopacity))
-        _check(load_library().lcgs_render_backward(self.ctx._h, _ptr(dL_dimg), C.byref(g)))
+        fn = load_library().lcgs_render_backward_compact if compact else load_library().lcgs_render_backward
+        _check(fn(self.ctx._h, _ptr(dL_dimg), C.byref(g)))
+
+    def visible_rows(self):
+        """lcgs_visible_rows of the last forward frame: (splat index of every compact row, row count) as a device
+        int32 tensor copy (synchronises the context)."""
+        import torch
+
+        rows, count = C.c_void_p(), C.c_void_p()
+        _check(load_library().lcgs_visible_rows(self.ctx._h, C.byref(rows), C.byref(count)))
+        self.ctx.synchronize()
+        n = self.frame_stats()["num_visible"]
+        dev = f"cuda:{self.ctx.device_id}"
+        if n == 0:
+            return torch.empty(0, dtype=torch.int32, device=dev)
+
+        class _View:  # the context-owned device array, seen through the CUDA array interface; cloned before returning
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (int(rows.value), False), "version": 2}
+
+        return torch.as_tensor(_View(), device=dev).clone()
 
     def set_profiling(self, enabled: bool):
         _check(load_library().lcgs_set_profiling(self.ctx._h, C.c_int(1 if enabled else 0)))
@@ -500,14 +521,17 @@ class Renderer:
         _check(load_library().lcgs_debug_last_lists(self.ctx._h, _ptr(d_list), _ptr(d_ranges)))
 
     def adam_step(self, grads: dict, raw: dict, m: dict, v: dict, activated: dict, step: int, lr: dict,
-                  betas=(0.9, 0.999), eps: float = 1e-15, visible_only: bool = False, sh_degree: int = 3):
+                  betas=(0.9, 0.999), eps: float = 1e-15, visible_only: bool = False, sh_degree: int = 3,
+                  compact_grads: bool = False):
         """lcgs_adam_step: gradients w.r.t. the activated values -> Adam on the raw parameters -> refreshed activated
         arrays.  Every dict has the keys pos / scale / rotq / sh / opacity (device tensors); lr has pos, sh_dc,
-        sh_rest, opacity, scale, rot."""
+        sh_rest, opacity, scale, rot.  compact_grads (with visible_only): `grads` hold backward(compact=True) rows."""
+        if compact_grads and not visible_only:
+            raise ValueError("compact gradient rows only exist for the on-screen splats: visible_only must be set")
         keys = ("pos", "scale", "rotq", "sh", "opacity")
         P = int(raw["pos"].shape[0])
         cfg = _AdamConfig(lr["pos"], lr["sh_dc"], lr["sh_rest"], lr["opacity"], lr["scale"], lr["rot"], betas[0], betas[1],
-                          eps, int(step), 1 if visible_only else 0)
+                          eps, int(step), (2 if compact_grads else 1) if visible_only else 0)
         g = _Grads(*[_ptr(grads[k]) for k in keys])
         packs = [_Params(*[_ptr(d[k]) for k in keys]) for d in (raw, m, v, activated)]
         _check(load_library().lcgs_adam_step(self.ctx._h, C.c_int(P), C.c_int(sh_degree), C.byref(cfg), C.byref(g),

@@ -517,7 +517,8 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
                       const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ sh,
                       const uint32_t* __restrict__ vis_index, const uint32_t* __restrict__ d_counts,
                       const float* __restrict__ grads2d, float* __restrict__ dL_dpos, float* __restrict__ dL_dscale,
-                      float* __restrict__ dL_drotq, float* __restrict__ dL_dsh, float* __restrict__ dL_dopacity)
+                      float* __restrict__ dL_drotq, float* __restrict__ dL_dsh, float* __restrict__ dL_dopacity,
+                      int compact)
 {
     __shared__ float4 s_sh[4][64 * 13];
     const uint32_t V = d_counts[0];
@@ -606,13 +607,14 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
             float4 gq;
             geom_backward(cp, scale_modifier, px, py, pz, sc0, sc1, sc2, q, gmx, gmy, gA, gB, gC, gp, gs, gq);
 
+            const size_t orow = compact ? (size_t)vid : (size_t)idx; // compact: row = dense id (see launch.hpp)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                dL_dpos[3 * (size_t)idx + i]   = gp[i];
-                dL_dscale[3 * (size_t)idx + i] = gs[i];
+                dL_dpos[3 * orow + i]   = gp[i];
+                dL_dscale[3 * orow + i] = gs[i];
             }
-            *reinterpret_cast<float4*>(dL_drotq + 4 * (size_t)idx) = gq; // (r,x,y,z)
-            dL_dopacity[idx] = gop;
+            *reinterpret_cast<float4*>(dL_drotq + 4 * orow) = gq; // (r,x,y,z)
+            dL_dopacity[orow] = gop;
         }
 
         // ---- SH gradient rows: 12 consecutive lanes write one splat's 192 contiguous bytes
@@ -623,10 +625,11 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
                 const uint32_t cidx = (uint32_t)i * 64u + lane;
                 const uint32_t slot = cidx / 12u, part = cidx - slot * 12u;
                 const int      sidx = __shfl(idx, (int)slot, 64);
-                if (slot < nvalid) reinterpret_cast<float4*>(dL_dsh + (size_t)sidx * 48)[part] = s_sh[wave][slot * 13u + part];
+                const size_t   orow = compact ? (size_t)(wave_first + slot) : (size_t)sidx;
+                if (slot < nvalid) reinterpret_cast<float4*>(dL_dsh + orow * 48)[part] = s_sh[wave][slot * 13u + part];
             }
         } else if (valid) {
-            float* o = dL_dsh + (size_t)idx * feat * 3;
+            float* o = dL_dsh + (compact ? (size_t)vid : (size_t)idx) * feat * 3;
             for (int k = 0; k < feat * 3; ++k) o[k] = row[k];
         }
     }
@@ -646,7 +649,7 @@ k_preprocess_backward_jac(CamParams cp, float scale_modifier, const float* __res
                           const uint32_t* __restrict__ vis_index, const uint32_t* __restrict__ d_counts,
                           const float* __restrict__ grads2d, const float4* __restrict__ shjac,
                           float* __restrict__ dL_dpos, float* __restrict__ dL_dscale, float* __restrict__ dL_drotq,
-                          float* __restrict__ dL_dsh, float* __restrict__ dL_dopacity)
+                          float* __restrict__ dL_dsh, float* __restrict__ dL_dopacity, int compact)
 {
     __shared__ float s_outer[4][64 * kJacPitch];
     const uint32_t V = d_counts[0];
@@ -693,13 +696,14 @@ k_preprocess_backward_jac(CamParams cp, float scale_modifier, const float* __res
             float  gs[3];
             float4 gq;
             geom_backward(cp, scale_modifier, px, py, pz, sc0, sc1, sc2, q, gmx, gmy, gA, gB, gC, gp, gs, gq);
+            const size_t orow = compact ? (size_t)vid : (size_t)idx; // compact: row = dense id (see launch.hpp)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                dL_dpos[3 * (size_t)idx + i]   = gp[i];
-                dL_dscale[3 * (size_t)idx + i] = gs[i];
+                dL_dpos[3 * orow + i]   = gp[i];
+                dL_dscale[3 * orow + i] = gs[i];
             }
-            *reinterpret_cast<float4*>(dL_drotq + 4 * (size_t)idx) = gq; // (r,x,y,z)
-            dL_dopacity[idx] = gop;
+            *reinterpret_cast<float4*>(dL_drotq + 4 * orow) = gq; // (r,x,y,z)
+            dL_dopacity[orow] = gop;
         }
         __syncthreads();
         // ---- SH gradient rows: 12 consecutive lanes write one splat's 192 contiguous bytes
@@ -716,7 +720,8 @@ k_preprocess_backward_jac(CamParams cp, float scale_modifier, const float* __res
                     const uint32_t f = part * 4u + (uint32_t)e, k = f / 3u, ch = f - 3u * k; // row[k * 3 + ch]
                     v[e]             = o[k] * o[16u + ch];
                 }
-                reinterpret_cast<float4*>(dL_dsh + (size_t)sidx * 48)[part] = make_float4(v[0], v[1], v[2], v[3]);
+                const size_t orow = compact ? (size_t)(wave_first + slot) : (size_t)sidx;
+                reinterpret_cast<float4*>(dL_dsh + orow * 48)[part] = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
         __syncthreads(); // the slab is reused by the next iteration
@@ -756,7 +761,7 @@ void launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp,
                                 const float* scale, const float* rotq, const float* sh, const uint32_t* vis_index,
                                 const uint32_t* d_counts, const float* grads2d, float* dL_dpos, float* dL_dscale,
                                 float* dL_drotq, float* dL_dsh, float* dL_dopacity, hipStream_t stream,
-                                const float4* shjac)
+                                const float4* shjac, bool compact)
 {
     int64_t blocks = (v_hint + 255) / 256;
     if (blocks < 1) blocks = 1;
@@ -764,12 +769,12 @@ void launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp,
     if (shjac && sh_deg == 3 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0) {
         hipLaunchKernelGGL(k_preprocess_backward_jac, dim3((unsigned)blocks), dim3(256), 0, stream, cp, scale_modifier, pos,
                            scale, rotq, vis_index, d_counts, grads2d, shjac, dL_dpos, dL_dscale, dL_drotq, dL_dsh,
-                           dL_dopacity);
+                           dL_dopacity, compact ? 1 : 0);
         return;
     }
     hipLaunchKernelGGL(k_preprocess_backward, dim3((unsigned)blocks), dim3(256), 0, stream, sh_deg, cp, scale_modifier,
                        pos, scale, rotq, sh, vis_index, d_counts, grads2d, dL_dpos, dL_dscale, dL_drotq, dL_dsh,
-                       dL_dopacity);
+                       dL_dopacity, compact ? 1 : 0);
 }
 
 } // namespace lcgs

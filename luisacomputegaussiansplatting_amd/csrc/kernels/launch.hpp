@@ -131,10 +131,11 @@ struct AdamRates {
     float pos, sh_dc, sh_rest, opacity, scale, rot;
 };
 // row_list != NULL: only rows row_list[0 .. *d_row_count) are updated (launch sized for row_hint rows)
+// grad_compact (row_list only): gradient row r belongs to splat row_list[r] (lcgs_render_backward_compact's layout)
 void launch_adam_step(int64_t P, int sh_floats, const uint32_t* row_list, const uint32_t* d_row_count, int64_t row_hint,
                       const AdamArrays& grad, const AdamArrays& raw, const AdamArrays& m, const AdamArrays& v,
                       const AdamArrays& act, const AdamRates& lr, float beta1, float beta2, float eps, int step,
-                      hipStream_t stream);
+                      hipStream_t stream, bool grad_compact = false);
 // byte offsets, inside one vertex record, of the 59 wanted float columns (pos3 dc3 rest45 opacity scale3 rot4)
 struct PlyColumns {
     uint32_t offset[59];
@@ -163,6 +164,10 @@ void   launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& c
                                   const float* scale, const float* rotq, const float* sh, const uint32_t* vis_index,
                                   const uint32_t* d_counts, const float* grads2d, float* dL_dpos, float* dL_dscale,
                                   float* dL_drotq, float* dL_dsh, float* dL_dopacity, hipStream_t stream,
-                                  const float4* shjac = nullptr); // the forward's colour Jacobian rows, if kept
+                                  const float4* shjac = nullptr, // the forward's colour Jacobian rows, if kept
+                                  // compact: output row r belongs to the frame's r-th on-screen splat (dense id r,
+                                  // splat vis_index[r], ascending) instead of row = splat index: consecutive rows, every
+                                  // one written -- no zero-fill, no 39 %-dense store pattern
+                                  bool compact = false);
 
 } // namespace lcgs

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) k_adam_rows(int64_t rows, const uint32_t*
                                                    const uint32_t* __restrict__ d_row_count,
                                                    const float* __restrict__ grad, float* __restrict__ raw,
                                                    float* __restrict__ m, float* __restrict__ v, float* __restrict__ act,
-                                                   int split, float lr0, float lr1, AdamStep a)
+                                                   int split, float lr0, float lr1, AdamStep a, int grad_compact)
 {
     const int64_t n_rows = d_row_count ? (int64_t)*d_row_count : rows;
     const int64_t total  = n_rows * ROW;
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) k_adam_rows(int64_t rows, const uint32_t*
         const int64_t r = e / ROW;
         const int     c = (int)(e - r * ROW);
         const int64_t i = (row_list ? (int64_t)row_list[r] : r) * ROW + c;
-        float         g = grad[i];
+        float         g = grad[grad_compact ? e : i]; // compact gradients: row r of the list, not row of the splat
         if (MODE == 1) g *= act[i];
         if (MODE == 2) {
             const float o = act[i];
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) k_adam_sh48(int64_t rows, const uint32_t*
                                                    const uint32_t* __restrict__ d_row_count,
                                                    const float4* __restrict__ grad, float4* __restrict__ raw,
                                                    float4* __restrict__ m, float4* __restrict__ v, float lr_dc,
-                                                   float lr_rest, AdamStep a)
+                                                   float lr_rest, AdamStep a, int grad_compact)
 {
     const int64_t n_rows = d_row_count ? (int64_t)*d_row_count : rows;
     const int64_t total  = n_rows * 12;
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) k_adam_sh48(int64_t rows, const uint32_t*
         const int64_t r = e / 12;
         const int     c = (int)(e - r * 12);
         const int64_t i = (row_list ? (int64_t)row_list[r] : r) * 12 + c;
-        const float4  g = grad[i];
+        const float4  g = grad[grad_compact ? e : i];
         float4        x = raw[i], mm = m[i], vv = v[i];
         const float   l = c == 0 ? lr_dc : lr_rest; // floats 0..2 of a row are the dc band
         x.x -= adam_update(g.x, mm.x, vv.x, l, a);
@@ -90,12 +90,12 @@ __global__ void __launch_bounds__(256) k_adam_rot(int64_t rows, const uint32_t* 
                                                   const uint32_t* __restrict__ d_row_count,
                                                   const float4* __restrict__ grad, float4* __restrict__ raw,
                                                   float4* __restrict__ m, float4* __restrict__ v, float4* __restrict__ act,
-                                                  float lr, AdamStep a)
+                                                  float lr, AdamStep a, int grad_compact)
 {
     const int64_t n_rows = d_row_count ? (int64_t)*d_row_count : rows;
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * 256) {
         const int64_t i  = row_list ? (int64_t)row_list[r] : r;
-        const float4  g  = grad[i], q = act[i];
+        const float4  g  = grad[grad_compact ? r : i], q = act[i];
         float4        x  = raw[i], mm = m[i], vv = v[i];
         const float   inv_norm = 1.0f / sqrtf(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
         const float   qg       = q.x * g.x + q.y * g.y + q.z * g.z + q.w * g.w;
@@ -124,9 +124,10 @@ unsigned grid_for(int64_t elements)
 void launch_adam_step(int64_t P, int sh_floats, const uint32_t* row_list, const uint32_t* d_row_count, int64_t row_hint,
                       const AdamArrays& grad, const AdamArrays& raw, const AdamArrays& m, const AdamArrays& v,
                       const AdamArrays& act, const AdamRates& lr, float beta1, float beta2, float eps, int step,
-                      hipStream_t stream)
+                      hipStream_t stream, bool grad_compact)
 {
     const int64_t rows = row_list ? row_hint : P;
+    const int     gc   = (grad_compact && row_list) ? 1 : 0;
     if (rows <= 0 && !d_row_count) return;
     AdamStep a;
     a.b1           = beta1;
@@ -136,33 +137,33 @@ void launch_adam_step(int64_t P, int sh_floats, const uint32_t* row_list, const 
     a.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
     const int64_t launch_rows = std::max<int64_t>(rows, 1);
     hipLaunchKernelGGL((k_adam_rows<3, 0>), dim3(grid_for(launch_rows * 3)), dim3(256), 0, stream, rows, row_list, d_row_count,
-                       grad.pos, raw.pos, m.pos, v.pos, act.pos, 3, lr.pos, lr.pos, a);
+                       grad.pos, raw.pos, m.pos, v.pos, act.pos, 3, lr.pos, lr.pos, a, gc);
     hipLaunchKernelGGL((k_adam_rows<3, 1>), dim3(grid_for(launch_rows * 3)), dim3(256), 0, stream, rows, row_list, d_row_count,
-                       grad.scale, raw.scale, m.scale, v.scale, act.scale, 3, lr.scale, lr.scale, a);
+                       grad.scale, raw.scale, m.scale, v.scale, act.scale, 3, lr.scale, lr.scale, a, gc);
     hipLaunchKernelGGL(k_adam_rot, dim3(grid_for(launch_rows)), dim3(256), 0, stream, rows, row_list, d_row_count,
                        reinterpret_cast<const float4*>(grad.rotq), reinterpret_cast<float4*>(raw.rotq),
                        reinterpret_cast<float4*>(m.rotq), reinterpret_cast<float4*>(v.rotq),
-                       reinterpret_cast<float4*>(act.rotq), lr.rot, a);
+                       reinterpret_cast<float4*>(act.rotq), lr.rot, a, gc);
     const bool sh_aligned = ((reinterpret_cast<uintptr_t>(grad.sh) | reinterpret_cast<uintptr_t>(raw.sh) |
                               reinterpret_cast<uintptr_t>(m.sh) | reinterpret_cast<uintptr_t>(v.sh)) & 15) == 0;
     if (sh_floats == 48 && sh_aligned)
         hipLaunchKernelGGL(k_adam_sh48, dim3(grid_for(launch_rows * 12)), dim3(256), 0, stream, rows, row_list, d_row_count,
                            reinterpret_cast<const float4*>(grad.sh), reinterpret_cast<float4*>(raw.sh),
-                           reinterpret_cast<float4*>(m.sh), reinterpret_cast<float4*>(v.sh), lr.sh_dc, lr.sh_rest, a);
+                           reinterpret_cast<float4*>(m.sh), reinterpret_cast<float4*>(v.sh), lr.sh_dc, lr.sh_rest, a, gc);
     else if (sh_floats == 48)
         hipLaunchKernelGGL((k_adam_rows<48, 0>), dim3(grid_for(launch_rows * 48)), dim3(256), 0, stream, rows, row_list,
-                           d_row_count, grad.sh, raw.sh, m.sh, v.sh, act.sh, 3, lr.sh_dc, lr.sh_rest, a);
+                           d_row_count, grad.sh, raw.sh, m.sh, v.sh, act.sh, 3, lr.sh_dc, lr.sh_rest, a, gc);
     else if (sh_floats == 27)
         hipLaunchKernelGGL((k_adam_rows<27, 0>), dim3(grid_for(launch_rows * 27)), dim3(256), 0, stream, rows, row_list,
-                           d_row_count, grad.sh, raw.sh, m.sh, v.sh, act.sh, 3, lr.sh_dc, lr.sh_rest, a);
+                           d_row_count, grad.sh, raw.sh, m.sh, v.sh, act.sh, 3, lr.sh_dc, lr.sh_rest, a, gc);
     else if (sh_floats == 12)
         hipLaunchKernelGGL((k_adam_rows<12, 0>), dim3(grid_for(launch_rows * 12)), dim3(256), 0, stream, rows, row_list,
-                           d_row_count, grad.sh, raw.sh, m.sh, v.sh, act.sh, 3, lr.sh_dc, lr.sh_rest, a);
+                           d_row_count, grad.sh, raw.sh, m.sh, v.sh, act.sh, 3, lr.sh_dc, lr.sh_rest, a, gc);
     else
         hipLaunchKernelGGL((k_adam_rows<3, 0>), dim3(grid_for(launch_rows * 3)), dim3(256), 0, stream, rows, row_list,
-                           d_row_count, grad.sh, raw.sh, m.sh, v.sh, act.sh, 3, lr.sh_dc, lr.sh_rest, a);
+                           d_row_count, grad.sh, raw.sh, m.sh, v.sh, act.sh, 3, lr.sh_dc, lr.sh_rest, a, gc);
     hipLaunchKernelGGL((k_adam_rows<1, 2>), dim3(grid_for(launch_rows)), dim3(256), 0, stream, rows, row_list, d_row_count,
-                       grad.opacity, raw.opacity, m.opacity, v.opacity, act.opacity, 1, lr.opacity, lr.opacity, a);
+                       grad.opacity, raw.opacity, m.opacity, v.opacity, act.opacity, 1, lr.opacity, lr.opacity, a, gc);
 }
 
 } // namespace lcgs

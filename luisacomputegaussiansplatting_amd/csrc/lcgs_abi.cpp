@@ -790,7 +790,8 @@ lcgs_status lcgs_adam_step(lcgs_context* ctx, int num_gaussians, int sh_degree, 
     const AdamArrays g = { grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh, grads->d_dL_dopacity };
     const AdamRates  lr = { cfg->lr_pos, cfg->lr_sh_dc, cfg->lr_sh_rest, cfg->lr_opacity, cfg->lr_scale, cfg->lr_rot };
     launch_adam_step(num_gaussians, (sh_degree + 1) * (sh_degree + 1) * 3, row_list, d_rows, hint, g, pack(raw), pack(m),
-                     pack(v), pack(activated), lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->step, ctx->stream);
+                     pack(v), pack(activated), lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->step, ctx->stream,
+                     /*grad_compact=*/cfg->visible_only == 2);
     LCGS_HIP_CHECK(hipGetLastError());
     return LCGS_OK;
 }
@@ -1120,7 +1121,35 @@ lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t*
     return LCGS_OK;
 }
 
+namespace
+{
+lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads, bool compact);
+}
+
 lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads)
+{
+    return render_backward(ctx, d_dL_dimg, grads, /*compact=*/false);
+}
+
+lcgs_status lcgs_render_backward_compact(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads)
+{
+    return render_backward(ctx, d_dL_dimg, grads, /*compact=*/true);
+}
+
+lcgs_status lcgs_visible_rows(lcgs_context* ctx, const uint32_t** d_rows, const uint32_t** d_count)
+{
+    LCGS_REQUIRE(ctx && d_rows && d_count, "NULL argument");
+    LCGS_REQUIRE(ctx->last.valid, "no frame rendered yet");
+    *d_rows  = ctx->vis_index.as<uint32_t>();
+    *d_count = ctx->counts.as<uint32_t>(); // [0] = on-screen splats of the last frame
+    return LCGS_OK;
+}
+
+} // extern "C"
+
+namespace
+{
+lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads, bool compact)
 {
     LCGS_REQUIRE(ctx && d_dL_dimg && grads, "NULL argument");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
@@ -1138,19 +1167,22 @@ lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, cons
     LCGS_TRY(mark(ctx, "begin"));
     // dense per-splat gradients: splats that did not reach the screen get exact zeros.  The 236 B/splat zero-fill
     // is pure HBM writes and independent of the render-backward: it runs on the auxiliary stream beside it.
-    const bool  overlap = !ctx->profiling;
+    // (Compact rows: every row that exists is written by the preprocess-backward, nothing to clear.)
+    const bool  overlap = !ctx->profiling && !compact;
     hipStream_t zs      = overlap ? ctx->aux_stream : st;
     if (overlap) {
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
     }
-    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dpos, 0, P * 3 * 4, zs));
-    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dscale, 0, P * 3 * 4, zs));
-    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_drotq, 0, P * 4 * 4, zs));
-    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dsh, 0, P * feat * 4, zs));
-    LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dopacity, 0, P * 4, zs));
+    if (!compact) {
+        LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dpos, 0, P * 3 * 4, zs));
+        LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dscale, 0, P * 3 * 4, zs));
+        LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_drotq, 0, P * 4 * 4, zs));
+        LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dsh, 0, P * feat * 4, zs));
+        LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dopacity, 0, P * 4, zs));
+    }
     if (overlap) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
-    if (ctx->g2d_zeroed && overlap) { // cleared during the forward (first backward of this frame only)
+    if (ctx->g2d_zeroed && !ctx->profiling) { // cleared during the forward (first backward of this frame only)
         LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_g2d_zero, 0));
         ctx->g2d_zeroed = false;
     } else {
@@ -1170,7 +1202,7 @@ lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, cons
                                ctx->last.scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->sh,
                                ctx->vis_index.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(),
                                grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh,
-                               grads->d_dL_dopacity, st, ctx->last_has_jac ? ctx->shjac.as<float4>() : nullptr);
+                               grads->d_dL_dopacity, st, ctx->last_has_jac ? ctx->shjac.as<float4>() : nullptr, compact);
     LCGS_TRY(mark(ctx, "preprocess_backward"));
     LCGS_HIP_CHECK(hipGetLastError());
     if (ctx->profiling) {
@@ -1179,5 +1211,4 @@ lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, cons
     }
     return LCGS_OK;
 }
-
-} // extern "C"
+} // namespace

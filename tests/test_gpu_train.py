@@ -114,6 +114,68 @@ def test_adam_visible_only_touches_survivors_only(lcgs):
         assert torch.equal(raw[k][vis], raw_d[k][vis]), k
 
 
+def test_compact_gradient_rows_and_their_optimiser_step(lcgs):
+    """lcgs_render_backward_compact: row r = the r-th on-screen splat (ascending index, lcgs_visible_rows), equal to
+    that splat's row of the dense gradients, nothing else written; lcgs_adam_step(visible_only = 2) on those rows equals
+    the on-screen-only step on the dense gradients bit for bit."""
+    rng = np.random.default_rng(5)
+    P = 30000
+    scene = make_scene(rng, P, log_scale=(-3.9, 0.6))
+    scene["pos"][5000:9000] += 100.0  # culled block in the middle of the index range
+    raw = {"pos": scene["pos"], "scale": np.log(scene["scale"]), "rotq": scene["rotq"] * 1.3, "sh": scene["sh"],
+           "opacity": np.log(scene["opacity"] / (1 - scene["opacity"]))}
+    raw = {k: torch.from_numpy(np.ascontiguousarray(val, dtype=np.float32)).to(DEV) for k, val in raw.items()}
+    act = {k: t.clone() for k, t in _activate(raw).items()}
+    act["pos"], act["sh"] = raw["pos"], raw["sh"]
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.bind_scene(*[act[k] for k in KEYS])
+    W, H = 320, 200
+    cam = lcgs.get_lookat_cam([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+    img = torch.zeros(3, H, W, device=DEV)
+    dL = torch.randn(3, H, W, device=DEV)
+    r.forward(cam, img, keep_state=True, sync=True)
+    dense = {k: torch.full_like(raw[k], 7.0) for k in KEYS}
+    r.backward(dL, *[dense[k] for k in KEYS])
+    rows = r.visible_rows().long()
+    V = r.frame_stats()["num_visible"]
+    assert rows.numel() == V and 0 < V < P
+    assert (rows[1:] > rows[:-1]).all()  # ascending splat index
+    assert not ((rows >= 5000) & (rows < 9000)).any()
+    comp = {k: torch.full_like(raw[k], 7.0) for k in KEYS}  # P rows allocated, V of them used
+    r.backward(dL, *[comp[k] for k in KEYS], compact=True)  # a second backward of the same frame
+    r.ctx.synchronize()
+    for k in KEYS:
+        c, d = comp[k].reshape(P, -1), dense[k].reshape(P, -1)
+        # (pixel-to-splat sums are float atomics: two backward passes of one frame differ in the last bits of the 2-D
+        # gradients, which the geometry Jacobians amplify on ill-conditioned splats -- compare in the norm)
+        err = (c[:V].double() - d[rows].double()).norm() / d[rows].double().norm()
+        assert err <= 1e-4, (k, float(err))
+        assert (c[V:] == 7.0).all(), k  # rows beyond the on-screen count are not touched
+        off = torch.ones(P, dtype=torch.bool, device=DEV)
+        off[rows] = False
+        assert (d[off] == 0).all(), k  # the dense variant: exact zeros elsewhere
+    # optimiser: compact rows (mode 2) vs the same gradients scattered to their splats (mode 1)
+    scattered = {k: torch.zeros_like(raw[k]) for k in KEYS}
+    for k in KEYS:
+        scattered[k].reshape(P, -1)[rows] = comp[k].reshape(P, -1)[:V]
+    state = []
+    for compact in (False, True):
+        rw = {k: t.clone() for k, t in raw.items()}
+        ac = {k: t.clone() for k, t in _activate(rw).items()}
+        ac["pos"], ac["sh"] = rw["pos"], rw["sh"]
+        m = {k: torch.zeros_like(rw[k]) for k in KEYS}
+        v = {k: torch.zeros_like(rw[k]) for k in KEYS}
+        r.adam_step(comp if compact else scattered, rw, m, v, ac, 1, LR, visible_only=True, compact_grads=compact)
+        r.ctx.synchronize()
+        state.append((rw, m, v, ac))
+    for a, b in zip(state[0], state[1]):
+        for k in KEYS:
+            assert torch.equal(a[k], b[k]), k
+    assert not torch.equal(state[0][0]["sh"], raw["sh"])  # and something moved
+    with pytest.raises(ValueError):
+        r.adam_step(comp, raw, m, v, act, 1, LR, visible_only=False, compact_grads=True)
+
+
 def test_autograd_binding_matches_oracle_backward(lcgs, oracle):
     rng = np.random.default_rng(8)
     scene = make_scene(rng, 3000, log_scale=(-3.6, 0.7))
