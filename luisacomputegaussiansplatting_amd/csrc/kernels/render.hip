@@ -1,22 +1,21 @@
 // render.hip -- per-tile front-to-back alpha compositing
 // (m_forward_render_shader, lcgs/src/gs_tile_splatter/shader.cpp:171-288).
 //
-// CDNA4 shape (not the reference's 256-thread block with three block barriers per round):
-//   * one wave64 owns one 16x16 tile; lane l covers column x = l & 15 and the four rows
-//     y = (l >> 4) + {0,4,8,12}.  The four pixels of a lane share dx, cx*dx*dx and cy*dx, so the
-//     per-entry cost is ~8 VALU ops/pixel instead of ~12, and there is no cross-wave barrier at all.
-//   * a round stages 64 list entries: lane l gathers entry l's 36-byte record (mean, conic, opacity,
-//     rgb) with wide loads and parks it in a 3 KiB LDS slab; the inner loop then reads each entry
-//     back with wave-uniform (broadcast, conflict-free) ds_read_b128s.  The colour therefore comes
-//     from LDS too -- the reference re-fetches it from global memory per pixel per contributing
-//     splat (shader.cpp:268-269).
-//   * wave-level early out: a 64-bit ballot of "all four pixels done" ends the tile as soon as every
-//     pixel is saturated (the reference's "collect num_done" at shader.cpp:229 has no code behind it,
-//     so every tile walks its whole list).
-//   * workgroup -> tile mapping is XCD-aware: workgroups are dealt round-robin to the 8 XCDs, so
-//     workgroup b takes tile (b % 8) * ceil(G/8) + b / 8 -- each XCD's private L2 sees one
-//     contiguous band of tile rows and neighbouring tiles (which share most of their splat records)
-//     hit the same L2.
+// CDNA4 shape (not the reference's 256-thread block in which every thread walks every entry):
+//   * k_render_forward_b (the renderer in use): one workgroup of four wave64s per 16x16 tile, wave k owns the 16x4
+//     pixel strip k, one pixel per lane.  A round stages 256 list entries: lane l gathers entry l's 36-byte record
+//     with wide loads, tests it against the four strips (exact "can this splat reach the strip" test) and parks it
+//     in three 16-byte-pitch LDS slabs; the per-strip ballots go to LDS and wave k then walks only the set bits of
+//     "its" masks with scalar bit scans, reading each entry back as wave-uniform (broadcast, conflict-free) LDS
+//     reads.  The colour comes from LDS too -- the reference re-fetches it from global memory per pixel per
+//     contributing splat (shader.cpp:268-269).  Details and measurements: DESIGN.md 4.
+//   * strip-level early out: a finished pixel carries a NaN coordinate (it fails every later test by itself); a
+//     strip whose pixels are all finished retires, a tile whose strips are all retired stops staging (the
+//     reference's "collect num_done" at shader.cpp:229 has no code behind it, so every tile walks its whole list).
+//   * workgroup -> tile: longest-list-first (k_tile_order, from the previous frame's list lengths) when the caller
+//     supplies an order, else XCD-aware blocks of 8x4 tiles dealt round-robin to the 8 XCDs (tile_of_workgroup).
+//   * k_render_forward (LCGS_RENDER_VARIANT=a, a tuning alternative kept for comparison): one wave64 per tile,
+//     lane l = column l & 15 and the four rows (l >> 4) + {0,4,8,12}; 64 entries per round.
 // Numerics: the per-pixel expressions keep the reference's evaluation order with no FMA contraction
 // (-ffp-contract=off); exp() is the hardware v_exp_f32 path (__expf).
 #include <stdlib.h>
