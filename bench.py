@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--no-batch", action="store_true")
     ap.add_argument("--no-stage-path", action="store_true")
     ap.add_argument("--half-sh", action="store_true", help="also time the opt-in f16 SH colour pass")
+    ap.add_argument("--no-spatial", action="store_true", help="skip the spatially re-ordered legs")
     args = ap.parse_args()
 
     import torch
@@ -391,6 +392,42 @@ def main():
                                            "ms_per_step": round(el2 * 1e3 / args.steps, 4)}
             r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
             del act, raw, mom
+
+    # ---- the same frames with the scene in spatial (Morton) order: lcgs_scene_reorder_spatial, an ingest option
+    # (SURVEY 8f rank 1).  Same splats, same image; the splats of a view then sit in runs of consecutive rows instead
+    # of being scattered over every DRAM page.  Reported beside `value` (which stays the file-order figure).
+    if not args.no_spatial:
+        ref_img = torch.empty_like(img)
+        r.forward(cam, ref_img, sync=True)
+        perm = r.reorder_scene_spatial().long()
+        dp = {k: d[k][perm].contiguous() for k in d}  # the caller's copy in the new order (gradients / optimiser legs)
+        r.bind_scene(dp["pos"], dp["scale"], dp["rotq"], dp["sh"], dp["opacity"])
+        n_sp = r.forward(cam, img, sync=True)
+        sp = {"api": "lcgs_scene_reorder_spatial", "num_rendered_equal": bool(n_sp == n_rendered),
+              "image_equal": bool(torch.equal(img, ref_img))}
+        for _ in range(args.warmup):
+            r.forward(cam, img, sync=False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r.forward(cam, img, sync=False)
+        barrier()
+        el_s = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el_s], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el_s = float(tt.item())
+        sp["forward"] = {"value": round(world * args.steps / el_s, 2), "unit": "frames/s",
+                         "ms_per_step": round(el_s * 1e3 / args.steps, 4)}
+        if not args.no_backward:
+            for compact in (False, True):
+                el_b = timed_steps(False, compact=compact)  # (per-view steps; no collective in this leg)
+                sp["fwd_bwd_compact_rows" if compact else "fwd_bwd"] = {
+                    "value": round(world * P * args.steps / el_b / 1e6, 1), "unit": "Msplats/s",
+                    "ms_per_step": round(el_b * 1e3 / args.steps, 4)}
+        out["spatially_ordered"] = sp
+        r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+        del dp, perm, ref_img
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference) on this box's host cores, rank 0, N = 1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

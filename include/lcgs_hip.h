@@ -263,6 +263,17 @@ LCGS_API lcgs_status lcgs_render_backward_compact(lcgs_context* ctx, const float
  * device-side row count.  Context-owned device memory, valid until the context's next forward frame. */
 LCGS_API lcgs_status lcgs_visible_rows(lcgs_context* ctx, const uint32_t** d_rows, const uint32_t** d_count);
 
+/* Spatial order (ingest option; no counterpart in the reference, whose buffers stay in file order).
+ * Re-orders the context's scene along a Morton curve of the positions: afterwards the context renders from its own
+ * re-ordered copy of the five arrays (a scene bound with lcgs_scene_bind is copied, the caller's arrays are left
+ * alone and no longer read).  Splat r of the new order is splat d_perm[r] of the old one (d_perm: P entries, device,
+ * may be NULL); every per-splat output of later calls (radii, gradients, lcgs_visible_rows) follows the new order,
+ * lcgs_scene_pointers returns the new arrays.  Images are unchanged (the blend order is by depth; splats of equal
+ * depth keep their relative order when they coincide in position).  Why: the splats of a view then sit in long runs
+ * of consecutive rows instead of being scattered over every DRAM page (bicycle stand-in: +6 % forward frames/s,
+ * +16 % forward+backward, +28 % on-screen-only training step).  Synchronises the context's stream. */
+LCGS_API lcgs_status lcgs_scene_reorder_spatial(lcgs_context* ctx, uint32_t* d_perm);
+
 /* Optimiser step (the reference only names training on its roadmap, doc/roadmap.md:4).
  * The scene is parameterised as in 3DGS training: raw.pos / raw.sh are the values themselves,
  * scale = exp(raw.scale), opacity = sigmoid(raw.opacity), rotq = raw.rotq / |raw.rotq|.  One call maps the

@@ -141,7 +141,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists",
     "lcgs_render_backward", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png",
-    "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_adam_step",
+    "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh",
 ]
 
@@ -434,6 +434,16 @@ class Renderer:
         self.P, self.sh_degree = P, sh_degree
         _check(load_library().lcgs_scene_bind(self.ctx._h, C.c_int(P), C.c_int(sh_degree), _ptr(pos), _ptr(scale),
                                               _ptr(rotq), _ptr(sh), _ptr(opacity)))
+
+    def reorder_scene_spatial(self):
+        """lcgs_scene_reorder_spatial: the context re-orders its scene along a Morton curve and renders from its own
+        copy from now on.  Returns the permutation (device int32 tensor): new splat r = old splat perm[r]."""
+        import torch
+
+        perm = torch.empty(self.P, dtype=torch.int32, device=f"cuda:{self.ctx.device_id}")
+        _check(load_library().lcgs_scene_reorder_spatial(self.ctx._h, _ptr(perm)))
+        self._keep = None  # the caller's arrays are no longer read
+        return perm
 
     def upload_scene(self, scene: dict, sh_degree: int = 3):
         arrs = [np.ascontiguousarray(scene[k], dtype=np.float32) for k in ("pos", "scale", "rotq", "sh", "opacity")]

@@ -1,6 +1,7 @@
 // lcgs-app -- CLI work-alike of the reference's app/main.cpp on the MI355X library.
 //   lcgs-app --ply <path> [--res WxH] [--out dir] [--world colmap|blender] [--exp_N N] [--backend hip]
 //            [--path fused|stage] [--synth kind:count:seed] [--ingest device|host] [--cameras file]
+//            [--order file|spatial]
 // Same flags (app/main.cpp:52-124; `--key=value` and `--key value`, app/command_parser.hpp:5-79), the same
 // hard-coded look-at camera (app/main.cpp:191-207), the same frame loop (:266-308), the same output:
 // <out>/<ply stem>_<backend>.png, CHW float -> vertically flipped RGB8 with a truncating *255 (:323-339).
@@ -42,6 +43,7 @@ void usage(const char* argv0)
     printf("  --path <fused|stage>     One-submission fused frame (default) or the three stage-level operators\n");
     printf("  --synth <kind:count:seed> Render a synthetic stand-in scene instead of --ply (kind 0 object, 1 unbounded)\n");
     printf("  --ingest <device|host>   De-interleave/activate the PLY on the GPU (default) or on the host\n");
+    printf("  --order <file|spatial>   Keep the splats in file order (default) or re-order them along a Morton curve at load\n");
     printf("  --cameras <file>         Render every camera of the file: `px py pz tx ty tz ux uy uz [fov]` per line\n");
     printf("  --display                Not supported (headless)\n");
 }
@@ -59,7 +61,7 @@ int main(int argc, char** argv)
 {
     unsigned    W = 1600, H = 1063; // app/main.cpp:38
     std::string ply_path = "gsplat.ply", backend = "hip", out_dir = "out", world = "colmap", path = "fused", synth;
-    std::string ingest = "device", cameras_file;
+    std::string ingest = "device", cameras_file, order = "file";
     int         exp_N = 1;
     // parse_command (app/command_parser.hpp:5-79): strip leading dashes, `key=value` or `key value`
     for (int i = 1; i < argc; ++i) {
@@ -102,6 +104,9 @@ int main(int argc, char** argv)
         else if (key == "ingest") {
             if (value != "device" && value != "host") die("Invalid ingest mode: " + value);
             ingest = value;
+        } else if (key == "order") {
+            if (value != "file" && value != "spatial") die("Invalid splat order: " + value);
+            order = value;
         } else if (key == "cameras") cameras_file = value;
         else if (key == "display") die("--display needs a GUI; this build is headless");
         else die("unknown option --" + key);
@@ -155,6 +160,16 @@ int main(int argc, char** argv)
             o_opacity = upload(sc.opacity, (size_t)P);
             d_pos = o_pos; d_scale = o_scale; d_rotq = o_rotq; d_sh = o_sh; d_opacity = o_opacity;
             lcgs::check(lcgs_scene_bind(device.ctx(), P, 3, d_pos.ptr, d_scale.ptr, d_rotq.ptr, d_sh.ptr, d_opacity.ptr));
+        }
+        if (order == "spatial" && P > 0) { // lcgs_scene_reorder_spatial: same image, the splats of a view in runs of rows
+            const float *pp, *ps, *pr, *pf, *po;
+            lcgs::check(lcgs_scene_reorder_spatial(device.ctx(), nullptr));
+            lcgs::check(lcgs_scene_pointers(device.ctx(), nullptr, nullptr, &pp, &ps, &pr, &pf, &po));
+            d_pos     = { const_cast<float*>(pp), (size_t)P * 3 };
+            d_scale   = { const_cast<float*>(ps), (size_t)P * 3 };
+            d_rotq    = { const_cast<float*>(pr), (size_t)P * 4 };
+            d_sh      = { const_cast<float*>(pf), (size_t)P * 48 };
+            d_opacity = { const_cast<float*>(po), (size_t)P };
         }
         printf("scene resident in %.1f ms (%s ingest)\n",
                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_load).count(),

@@ -143,6 +143,13 @@ struct PlyColumns {
 // records [first, first + count) of a PLY payload chunk already in device memory -> activated scene arrays
 void launch_ply_activate(const unsigned char* raw, int64_t first, int64_t count, uint32_t stride, const PlyColumns& cols,
                          float* pos, float* scale, float* rotq, float* sh, float* opacity, hipStream_t stream);
+// spatial (Morton) order of a scene, ingest.hip: position moments (7 doubles per block: sums, sums of squares, count),
+// 30-bit Morton keys + identity values, row gather through a permutation
+int  pos_moment_blocks();
+void launch_pos_moments(int64_t P, const float* pos, double* partial, hipStream_t stream);
+void launch_morton_keys(int64_t P, const float* pos, const float lo[3], const float cells_per_unit[3], uint32_t* keys,
+                        uint32_t* vals, hipStream_t stream);
+void launch_gather_rows(int64_t rows, int row_floats, const uint32_t* perm, const float* src, float* dst, hipStream_t stream);
 void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream);
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "common.hpp"
 #include "kernels/launch.hpp"
@@ -758,6 +759,86 @@ lcgs_status lcgs_scene_upload(lcgs_context* ctx, int num_gaussians, int sh_degre
     LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // app/main.cpp:223
     return lcgs_scene_bind(ctx, num_gaussians, sh_degree, ctx->owned[0].as<float>(), ctx->owned[1].as<float>(),
                            ctx->owned[2].as<float>(), ctx->owned[3].as<float>(), ctx->owned[4].as<float>());
+}
+
+lcgs_status lcgs_scene_reorder_spatial(lcgs_context* ctx, uint32_t* d_perm)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->P == 0) return LCGS_OK;
+    LCGS_REQUIRE(ctx->pos != nullptr, "no scene bound (call lcgs_scene_bind / lcgs_scene_upload / lcgs_scene_load_ply first)");
+    LCGS_TRY(sync_frame(ctx)); // frames in flight still read the old arrays
+    if (ctx->twin) LCGS_TRY(sync_frame(ctx->twin));
+    hipStream_t   st = ctx->stream;
+    const int64_t P  = ctx->P;
+    // ---- the box: mean +- 4 sigma per axis (finite positions only), 1024 cells per axis
+    DeviceBuffer partial;
+    const int    nb = pos_moment_blocks();
+    LCGS_TRY(partial.ensure((size_t)nb * 7 * sizeof(double)));
+    launch_pos_moments(P, ctx->pos, partial.as<double>(), st);
+    std::vector<double> h((size_t)nb * 7);
+    hipError_t          e = hipMemcpyAsync(h.data(), partial.ptr, h.size() * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    partial.release();
+    LCGS_HIP_CHECK(e);
+    double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    for (int b = 0; b < nb; ++b)
+        for (int k = 0; k < 7; ++k) acc[k] += h[(size_t)b * 7 + k];
+    float lo[3] = { 0, 0, 0 }, cells[3] = { 1, 1, 1 };
+    for (int a = 0; a < 3; ++a) {
+        const double n = std::max(acc[6], 1.0), mean = acc[a] / n;
+        const double sd = std::sqrt(std::max(acc[3 + a] / n - mean * mean, 0.0));
+        const double half = std::max(4.0 * sd, 1e-6);
+        lo[a]    = (float)(mean - half);
+        cells[a] = (float)(1024.0 / (2.0 * half));
+    }
+    // ---- keys, stable sort, gather
+    DeviceBuffer keys[2], vals[2], ws, fresh[5];
+    auto         drop = [&]() {
+        for (int i = 0; i < 2; ++i) {
+            keys[i].release();
+            vals[i].release();
+        }
+        ws.release();
+    };
+    lcgs_status s = LCGS_OK;
+    for (int i = 0; i < 2 && s == LCGS_OK; ++i) {
+        s = keys[i].ensure((size_t)P * 4);
+        if (s == LCGS_OK) s = vals[i].ensure((size_t)P * 4);
+    }
+    if (s == LCGS_OK) s = ws.ensure(pair_sort_ws_bytes(P));
+    const size_t feat    = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3;
+    const int    rowf[5] = { 3, 3, 4, (int)feat, 1 };
+    for (int i = 0; i < 5 && s == LCGS_OK; ++i) s = fresh[i].ensure(std::max<size_t>((size_t)P * rowf[i] * 4, 16));
+    if (s != LCGS_OK) {
+        drop();
+        for (DeviceBuffer& b : fresh) b.release();
+        return s;
+    }
+    launch_morton_keys(P, ctx->pos, lo, cells, keys[0].as<uint32_t>(), vals[0].as<uint32_t>(), st);
+    const int where = launch_pair_sort_u32(keys[0].as<uint32_t>(), keys[1].as<uint32_t>(), vals[0].as<uint32_t>(),
+                                           vals[1].as<uint32_t>(), nullptr, P, P, 0, 30, ws.ptr, st);
+    const uint32_t* perm   = vals[where].as<uint32_t>();
+    const float*    src[5] = { ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity };
+    for (int i = 0; i < 5; ++i) launch_gather_rows(P, rowf[i], perm, src[i], fresh[i].as<float>(), st);
+    e = hipGetLastError();
+    if (e == hipSuccess && d_perm) e = hipMemcpyAsync(d_perm, perm, (size_t)P * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    drop();
+    if (e != hipSuccess) {
+        for (DeviceBuffer& b : fresh) b.release();
+        LCGS_HIP_CHECK(e);
+    }
+    // ---- the context now owns (and renders from) the re-ordered copy
+    const bool half = ctx->use_half_sh;
+    for (int i = 0; i < 5; ++i) {
+        ctx->owned[i].release();
+        ctx->owned[i] = fresh[i];
+    }
+    LCGS_TRY(lcgs_scene_bind(ctx, ctx->P, ctx->sh_deg, ctx->owned[0].as<float>(), ctx->owned[1].as<float>(),
+                             ctx->owned[2].as<float>(), ctx->owned[3].as<float>(), ctx->owned[4].as<float>()));
+    if (half) LCGS_TRY(lcgs_scene_use_half_sh(ctx, 1)); // the f16 copy follows the new order
+    return LCGS_OK;
 }
 
 lcgs_status lcgs_adam_step(lcgs_context* ctx, int num_gaussians, int sh_degree, const lcgs_adam_config* cfg,

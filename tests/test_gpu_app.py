@@ -33,6 +33,23 @@ def test_lcgs_app_renders_png(lcgs, oracle, tmp_path, path):
     assert (diff > 1).mean() < 1e-3 and diff.max() <= 2  # 8-bit truncation of values 1e-6 apart may differ by 1
 
 
+@pytest.mark.parametrize("path", ["fused", "stage"])
+def test_lcgs_app_spatial_order_gives_the_same_png(lcgs, tmp_path, path):
+    """--order spatial (lcgs_scene_reorder_spatial at load): byte-identical PNG through both paths."""
+    app = os.path.join(ROOT, "luisacomputegaussiansplatting_amd", "lcgs-app")
+    if not os.path.exists(app):
+        lcgs.build_library()
+    pngs = []
+    for order in ("file", "spatial"):
+        out = str(tmp_path / order)
+        os.makedirs(out)
+        res = subprocess.run([app, "--synth", "1:60000:2001", "--res=480x270", "--out", out, f"--path={path}",
+                              "--order", order], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr
+        pngs.append(open(os.path.join(out, "synth1_60000_hip.png"), "rb").read())
+    assert pngs[0] == pngs[1] and len(pngs[0]) > 1000
+
+
 @pytest.mark.parametrize("ingest", ["device", "host"])
 def test_lcgs_app_ply_ingest_and_camera_batch(lcgs, oracle, tmp_path, ingest):
     """--ply through both ingest paths and a --cameras batch: every view equals the oracle's."""

@@ -86,3 +86,59 @@ def test_device_ingest_errors(lcgs, tmp_path):
     open(bad, "w").write("ply\nformat binary_little_endian 1.0\nelement vertex 5\nproperty float x\nend_header\n")
     with pytest.raises(lcgs.LcgsError):
         r.load_ply(bad)
+
+
+def test_spatial_reorder_keeps_the_image_and_permutes_the_outputs(lcgs, oracle):
+    """lcgs_scene_reorder_spatial: the context's scene becomes old[perm] (perm a permutation, Morton-sorted), the frame
+    is bit-identical, per-splat outputs follow the new order, and the oracle agrees on the permuted scene."""
+    import torch
+    from conftest import make_scene
+    from gpu_util import DEV, assert_image_parity, upload_scene
+
+    rng = np.random.default_rng(21)
+    P = 50000
+    scene = make_scene(rng, P, spread=3.0, log_scale=(-4.2, 0.7))  # the camera sits inside the cloud: most splats are off screen
+    scene["pos"][100:130] = np.array([1e4, -2e5, 3e3], np.float32)  # far outliers must not flatten the grid
+    scene["pos"][200:220] = scene["pos"][200]                        # coincident splats keep their file order
+    pose = ([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1])
+    W, H = 640, 360
+    cam = lcgs.get_lookat_cam(*pose, width=W, height=H)
+    r = lcgs.Renderer(lcgs.Context(0))
+    d = upload_scene(scene)
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    img0 = torch.zeros(3, H, W, device=DEV)
+    rad0 = torch.zeros(P, dtype=torch.int32, device=DEV)
+    n0 = r.forward(cam, img0, radii=rad0, keep_state=True, sync=True)
+    g0 = {k: torch.zeros_like(d[k]) for k in d}
+    dL = torch.randn(3, H, W, device=DEV)
+    r.backward(dL, g0["pos"], g0["scale"], g0["rotq"], g0["sh"], g0["opacity"])
+
+    perm = r.reorder_scene_spatial().long()
+    assert torch.equal(torch.sort(perm).values, torch.arange(P, device=DEV))
+    back = r.download_scene()
+    for k in ("pos", "scale", "rotq", "sh", "opacity"):
+        assert np.array_equal(back[k].reshape(P, -1), scene[k].reshape(P, -1)[perm.cpu().numpy()]), k
+    p20 = perm[(perm >= 200) & (perm < 220)]
+    assert torch.equal(p20, torch.arange(200, 220, device=DEV))  # stable: equal keys stay in file order
+    # for the caller's untouched arrays nothing changed
+    assert np.array_equal(d["pos"].cpu().numpy(), scene["pos"])
+
+    img1 = torch.zeros(3, H, W, device=DEV)
+    rad1 = torch.zeros(P, dtype=torch.int32, device=DEV)
+    n1 = r.forward(cam, img1, radii=rad1, keep_state=True, sync=True)
+    assert n1 == n0 and torch.equal(rad1, rad0[perm])
+    assert torch.equal(img1, img0)  # same per-pixel blend sequence: bit-identical
+    g1 = {k: torch.zeros_like(d[k]) for k in d}
+    r.backward(dL, g1["pos"], g1["scale"], g1["rotq"], g1["sh"], g1["opacity"])
+    for k in g0:
+        a, b = g1[k].reshape(P, -1).double(), g0[k].reshape(P, -1)[perm].double()
+        assert (a - b).norm() <= 1e-4 * b.norm(), k
+    # locality: the on-screen splats now come in runs -- far fewer visible/invisible switches along the index
+    sw0 = int((rad0[1:] > 0).ne(rad0[:-1] > 0).sum())
+    sw1 = int((rad1[1:] > 0).ne(rad1[:-1] > 0).sum())
+    assert sw1 * 4 < sw0, (sw0, sw1)
+    # and the oracle, given the permuted scene, agrees with the frame
+    ps = {k: np.ascontiguousarray(scene[k][perm.cpu().numpy()]) for k in scene}
+    orc = oracle.render(ps, oracle.lookat(*pose, width=W, height=H), ambig_eps=1e-5)
+    assert orc["num_rendered"] == n1 and np.array_equal(orc["radii"], rad1.cpu().numpy())
+    assert_image_parity(img1.cpu().numpy(), orc)
