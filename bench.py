@@ -400,8 +400,7 @@ def main():
         ref_img = torch.empty_like(img)
         r.forward(cam, ref_img, sync=True)
         perm = r.reorder_scene_spatial().long()
-        dp = {k: d[k][perm].contiguous() for k in d}  # the caller's copy in the new order (gradients / optimiser legs)
-        r.bind_scene(dp["pos"], dp["scale"], dp["rotq"], dp["sh"], dp["opacity"])
+        # (forward frames: from the context's own re-ordered copy)
         n_sp = r.forward(cam, img, sync=True)
         sp = {"api": "lcgs_scene_reorder_spatial", "num_rendered_equal": bool(n_sp == n_rendered),
               "image_equal": bool(torch.equal(img, ref_img))}
@@ -420,14 +419,18 @@ def main():
         sp["forward"] = {"value": round(world * args.steps / el_s, 2), "unit": "frames/s",
                          "ms_per_step": round(el_s * 1e3 / args.steps, 4)}
         if not args.no_backward:
+            # the caller's copy in the new order: what a training loop would own (gradients follow it)
+            dp = {k: d[k][perm].contiguous() for k in d}
+            r.bind_scene(dp["pos"], dp["scale"], dp["rotq"], dp["sh"], dp["opacity"])
             for compact in (False, True):
                 el_b = timed_steps(False, compact=compact)  # (per-view steps; no collective in this leg)
                 sp["fwd_bwd_compact_rows" if compact else "fwd_bwd"] = {
                     "value": round(world * P * args.steps / el_b / 1e6, 1), "unit": "Msplats/s",
                     "ms_per_step": round(el_b * 1e3 / args.steps, 4)}
+            del dp
         out["spatially_ordered"] = sp
         r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
-        del dp, perm, ref_img
+        del perm, ref_img
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference) on this box's host cores, rank 0, N = 1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

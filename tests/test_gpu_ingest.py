@@ -128,6 +128,21 @@ def test_spatial_reorder_keeps_the_image_and_permutes_the_outputs(lcgs, oracle):
     n1 = r.forward(cam, img1, radii=rad1, keep_state=True, sync=True)
     assert n1 == n0 and torch.equal(rad1, rad0[perm])
     assert torch.equal(img1, img0)  # same per-pixel blend sequence: bit-identical
+    # other views, without the radii request (the cull pass's two-phase form): same frame, same counts as file order
+    st1 = r.frame_stats()
+    for pose2, res in ((pose, (W, H)), (([0.5, 0.2, 0.6], [3, 2, 0.4], [0, 0, 1]), (333, 201))):
+        cam2 = lcgs.get_lookat_cam(*pose2, width=res[0], height=res[1])
+        a = torch.zeros(3, res[1], res[0], device=DEV)
+        b = torch.full((3, res[1], res[0]), -1.0, device=DEV)
+        fresh = lcgs.Renderer(lcgs.Context(0))
+        fresh.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])  # file order, no bounds
+        na = fresh.forward(cam2, a, sync=True)
+        nb = r.forward(cam2, b, keep_state=True, sync=True)
+        sa, sb_ = fresh.frame_stats(), r.frame_stats()
+        assert na == nb and torch.equal(a, b)
+        assert all(sa[k] == sb_[k] for k in ("num_visible", "num_rendered", "num_pairs")), (sa, sb_)
+    assert r.frame_stats()["num_visible"] < st1["num_visible"]  # (the second pose sits inside the cloud)
+    r.forward(cam, img1, keep_state=True, sync=True)
     g1 = {k: torch.zeros_like(d[k]) for k in d}
     r.backward(dL, g1["pos"], g1["scale"], g1["rotq"], g1["sh"], g1["opacity"])
     for k in g0:
