@@ -1,3 +1,4 @@
+# A/B of prebuilt libraries on one box: gpurun -- bash tools/gpu/ab_compare.sh <tagA> <tagB> (expects gpurun_in/liblcgs_<tag>.so)
 cd $GRAFT_REPO_ROOT
 
 B="python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train-step --no-stage-path"

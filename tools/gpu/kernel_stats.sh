@@ -1,3 +1,4 @@
+# Per-kernel statistics including the stage-level operators: gpurun -- bash tools/gpu/kernel_stats.sh
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/st

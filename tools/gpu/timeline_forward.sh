@@ -1,3 +1,4 @@
+# One forward-only frame as a kernel timeline (rocprofv3 --kernel-trace): gpurun -- bash tools/gpu/timeline_forward.sh
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/tl

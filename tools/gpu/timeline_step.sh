@@ -1,3 +1,4 @@
+# One forward+backward step as a kernel timeline: gpurun -- bash tools/gpu/timeline_step.sh
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/tl2
