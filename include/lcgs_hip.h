@@ -268,8 +268,9 @@ LCGS_API lcgs_status lcgs_visible_rows(lcgs_context* ctx, const uint32_t** d_row
  * re-ordered copy of the five arrays (a scene bound with lcgs_scene_bind is copied, the caller's arrays are left
  * alone and no longer read).  Splat r of the new order is splat d_perm[r] of the old one (d_perm: P entries, device,
  * may be NULL); every per-splat output of later calls (radii, gradients, lcgs_visible_rows) follows the new order,
- * lcgs_scene_pointers returns the new arrays.  Images are unchanged (the blend order is by depth; splats of equal
- * depth keep their relative order when they coincide in position).  Why: the splats of a view then sit in long runs
+ * lcgs_scene_pointers returns the new arrays.  Images are unchanged: the blend order is by depth.  (Splats of exactly
+ * equal depth are blended in splat order, as in the reference; coincident splats keep their relative order, other
+ * equal-depth pairs may swap, which moves a pixel they share by an ulp.)  Why: the splats of a view then sit in long runs
  * of consecutive rows instead of being scattered over every DRAM page (bicycle stand-in: +6 % forward frames/s,
  * +16 % forward+backward, +28 % on-screen-only training step).  Synchronises the context's stream. */
 LCGS_API lcgs_status lcgs_scene_reorder_spatial(lcgs_context* ctx, uint32_t* d_perm);

@@ -127,7 +127,9 @@ def test_spatial_reorder_keeps_the_image_and_permutes_the_outputs(lcgs, oracle):
     rad1 = torch.zeros(P, dtype=torch.int32, device=DEV)
     n1 = r.forward(cam, img1, radii=rad1, keep_state=True, sync=True)
     assert n1 == n0 and torch.equal(rad1, rad0[perm])
-    assert torch.equal(img1, img0)  # same per-pixel blend sequence: bit-identical
+    # same per-pixel blend sequence, hence bit-identical -- except where two splats of exactly equal depth overlap: they
+    # are blended in splat order (as in the reference), which is what changed.  None in this scene.
+    assert torch.equal(img1, img0)
     # other views, without the radii request (the cull pass's two-phase form): same frame, same counts as file order
     st1 = r.frame_stats()
     for pose2, res in ((pose, (W, H)), (([0.5, 0.2, 0.6], [3, 2, 0.4], [0, 0, 1]), (333, 201))):
@@ -139,7 +141,7 @@ def test_spatial_reorder_keeps_the_image_and_permutes_the_outputs(lcgs, oracle):
         na = fresh.forward(cam2, a, sync=True)
         nb = r.forward(cam2, b, keep_state=True, sync=True)
         sa, sb_ = fresh.frame_stats(), r.frame_stats()
-        assert na == nb and torch.equal(a, b)
+        assert na == nb and float((a - b).abs().max()) <= 1e-6
         assert all(sa[k] == sb_[k] for k in ("num_visible", "num_rendered", "num_pairs")), (sa, sb_)
     assert r.frame_stats()["num_visible"] < st1["num_visible"]  # (the second pose sits inside the cloud)
     r.forward(cam, img1, keep_state=True, sync=True)
@@ -157,3 +159,46 @@ def test_spatial_reorder_keeps_the_image_and_permutes_the_outputs(lcgs, oracle):
     orc = oracle.render(ps, oracle.lookat(*pose, width=W, height=H), ambig_eps=1e-5)
     assert orc["num_rendered"] == n1 and np.array_equal(orc["radii"], rad1.cpu().numpy())
     assert_image_parity(img1.cpu().numpy(), orc)
+
+
+def test_spatial_reorder_with_non_finite_and_degenerate_inputs(lcgs):
+    """Non-finite positions (kept out of the box, sorted into cell 0), a scene collapsed to one point (zero-sized box)
+    and P = 1: the permutation stays a bijection and the frame stays the file-order frame (to the last bit or two: see
+    below)."""
+    import torch
+    from conftest import make_scene
+    from gpu_util import DEV, upload_scene
+
+    pose = ([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1])
+    W, H = 200, 120
+    cam = lcgs.get_lookat_cam(*pose, width=W, height=H)
+    rng = np.random.default_rng(31)
+    cases = []
+    s = make_scene(rng, 5000)
+    s["pos"][10] = np.nan
+    s["pos"][500, 1] = np.inf
+    s["pos"][900, 2] = -np.inf
+    s["pos"][1200] = 3e38
+    cases.append(s)
+    s = make_scene(rng, 3000)
+    s["pos"][:] = np.array([0.1, 0.2, 0.5], np.float32)  # every splat at one point: sigma = 0
+    cases.append(s)
+    cases.append(make_scene(rng, 1))
+    for scene in cases:
+        P = scene["pos"].shape[0]
+        d = upload_scene(scene)
+        r = lcgs.Renderer(lcgs.Context(0))
+        r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+        a = torch.full((3, H, W), 0.25, device=DEV)
+        na = r.forward(cam, a, sync=True)
+        perm = r.reorder_scene_spatial().long()
+        assert torch.equal(torch.sort(perm).values, torch.arange(P, device=DEV))
+        b = torch.full((3, H, W), 0.25, device=DEV)
+        nb = r.forward(cam, b, sync=True)
+        # (two splats of exactly equal depth keep their splat order, as in the reference -- and the splat order is what
+        #  changed: where such a pair overlaps, the blend order, hence the last bit, may differ)
+        assert na == nb and float((a - b).abs().max()) <= 1e-6, P
+        back = r.download_scene()
+        pn = perm.cpu().numpy()
+        assert np.array_equal(back["pos"], scene["pos"][pn], equal_nan=True)
+        assert np.array_equal(back["sh"].reshape(P, -1), scene["sh"].reshape(P, -1)[pn])
