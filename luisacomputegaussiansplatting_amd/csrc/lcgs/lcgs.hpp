@@ -230,6 +230,18 @@ public:
     {
         check(lcgs_render_backward(m_dev->ctx(), dL_dimg.ptr, &grads));
     }
+    // the same gradients as compact rows (row r = the frame's r-th on-screen splat, see visible_rows): single-GPU steps
+    void backward_compact(BufferView<float> dL_dimg, const lcgs_grads& grads)
+    {
+        check(lcgs_render_backward_compact(m_dev->ctx(), dL_dimg.ptr, &grads));
+    }
+    // splat index of every compact row and the address of the device-side row count (valid until the next frame)
+    void visible_rows(const uint32_t** d_rows, const uint32_t** d_count)
+    {
+        check(lcgs_visible_rows(m_dev->ctx(), d_rows, d_count));
+    }
+    // Morton order at ingest: the context renders from its own re-ordered copy; d_perm[r] = old index of new splat r
+    void reorder_spatial(uint32_t* d_perm = nullptr) { check(lcgs_scene_reorder_spatial(m_dev->ctx(), d_perm)); }
 
 private:
     Device* m_dev = nullptr;
