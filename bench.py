@@ -87,10 +87,15 @@ def main():
     local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # (LCGS_BENCH_FORCE_DIST=1: a rehearsal hook -- one rank, but through the process group, so that every N > 1 code
+    #  path of this file, collectives included, runs on a one-GPU box)
+    if world > 1 or os.environ.get("LCGS_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     W, H = (int(x) for x in args.res.lower().split("x"))
     dev = torch.device("cuda", local_rank)
