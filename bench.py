@@ -121,6 +121,14 @@ def main():
     r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
     cam = L.get_lookat_cam(*view_pose(rank), width=W, height=H)
     img = torch.zeros(3, H, W, device=dev)
+    if os.environ.get("LCGS_BENCH_SPATIAL_FIRST") == "1":
+        # profiling hook: every leg below runs on the spatially ordered scene (the workload name says so)
+        perm0 = r.reorder_scene_spatial().long()
+        d = {k: d[k][perm0].contiguous() for k in d}
+        scene = {k: np.ascontiguousarray(scene[k][perm0.cpu().numpy()]) for k in d}
+        r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+        workload += " [spatially ordered: LCGS_BENCH_SPATIAL_FIRST]"
+        del perm0
 
     # first frame synchronises: sizes the pair buffers for this view
     n_rendered = r.forward(cam, img, sync=True)
