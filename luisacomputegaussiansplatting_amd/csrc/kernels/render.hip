@@ -389,16 +389,18 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     const float2   eb = *reinterpret_cast<const float2*>(&s_b[idx]);
                     // power = -0.5 (ca dx dx + cc dy dy) - cb dx dy, products left to right (shader.cpp:256); the
                     // x and y halves ride in one packed instruction each
-                    const v2f   d     = (v2f){ea.x, ea.y} - pxy;
-                    const v2f   q     = ((v2f){ea.z, ea.w} * d) * d;
-                    // (on gfx950 a packed op costs two plain ones and v_add/v_mul issue at twice the rate of
-                    // everything else -- tools/microbench/issue_rates.hip -- so the scalar tail must stay scalar:
-                    // the empty asms stop the vectoriser from pairing it up behind extra moves)
-                    float qx = q.x, cross = eb.x * d.x;
+                    // (plain, not packed, arithmetic: on gfx950 a packed op costs two plain ones AND drags a wait state
+                    // behind it -- tools/microbench/issue_rates.hip; the empty asms stop the vectoriser from pairing
+                    // the operations up again.  Renderer 0.227 -> 0.221 ms in same-box A/B runs, same bits.)
+                    float dx = ea.x - pxy.x, dy = ea.y - pxy.y;
+                    asm volatile("" : "+v"(dx), "+v"(dy));
+                    float qx = (ea.z * dx) * dx, cross = eb.x * dx;
                     asm volatile("" : "+v"(qx), "+v"(cross));
-                    float half = -0.5f * (qx + q.y);
+                    float qy = (ea.w * dy) * dy;
+                    asm volatile("" : "+v"(qy));
+                    float half = -0.5f * (qx + qy);
                     asm volatile("" : "+v"(half));
-                    const float power = half - cross * d.y;
+                    const float power = half - cross * dy;
                     const bool  cand  = !(power > 0.0f) & (power >= eb.y);
                     if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue; // scalar test of the lane mask
                     const float4 ec    = s_c[idx]; // one 16-byte read for the survivors of the test
