@@ -268,7 +268,7 @@ def main():
         traffic = None
     # The dominant kernel is VALU-issue-bound, not HBM-bound: beside the mandatory HBM figures, its VALU issue
     # utilisation = wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/r01_pmc_sq.txt) x the average issue
-    # cost of the compositing loop's instruction mix on this part (3.27 cycles: tools/microbench/issue_rates.hip,
+    # cost of the compositing loop's instruction mix on this part (2.96 cycles: tools/microbench/issue_rates.hip,
     # profiles/r01_issue_rates.txt) / (1024 SIMDs x launch duration x 2.4 GHz).
     valu = None
     try:
@@ -277,9 +277,9 @@ def main():
             if line.startswith(stage_kernel.get(dominant, "?") + " "):
                 insts = ast.literal_eval(line[line.index("{"):])["SQ_INSTS_VALU"]
                 if data == "synthetic" and P == P_BICYCLE and (W, H) == (1920, 1080) and dominant == "render":
-                    valu = {"wave_instructions_per_launch": insts, "avg_issue_cycles_per_instruction": 3.27,
+                    valu = {"wave_instructions_per_launch": insts, "avg_issue_cycles_per_instruction": 2.96,
                             "simd_cycles_available": round(1024 * dom_ms * 1e-3 * 2.4e9),
-                            "frac": round(insts * 3.27 / (1024 * dom_ms * 1e-3 * 2.4e9), 4)}
+                            "frac": round(insts * 2.96 / (1024 * dom_ms * 1e-3 * 2.4e9), 4)}
     except Exception:
         valu = None
     roofline = {"kernel": stage_kernel.get(dominant, dominant), "bound": "hbm", "achieved": round(achieved, 1),
