@@ -427,11 +427,15 @@ class Renderer:
         self._keep = []  # keeps bound tensors alive
         self.P = 0
         self.sh_degree = 3
+        # bumped by everything that replaces the state lcgs_render_backward works from (scene binding, a new frame):
+        # render_autograd's backward compares it with the value its own forward left behind
+        self._generation = 0
 
     def bind_scene(self, pos, scale, rotq, sh, opacity, sh_degree: int = 3):
         P = int(pos.shape[0])
         self._keep = [pos, scale, rotq, sh, opacity]
         self.P, self.sh_degree = P, sh_degree
+        self._generation += 1
         _check(load_library().lcgs_scene_bind(self.ctx._h, C.c_int(P), C.c_int(sh_degree), _ptr(pos), _ptr(scale),
                                               _ptr(rotq), _ptr(sh), _ptr(opacity)))
 
@@ -442,6 +446,7 @@ class Renderer:
 
         perm = torch.empty(self.P, dtype=torch.int32, device=f"cuda:{self.ctx.device_id}")
         _check(load_library().lcgs_scene_reorder_spatial(self.ctx._h, _ptr(perm)))
+        self._generation += 1
         self._keep = None  # the caller's arrays are no longer read
         return perm
 
@@ -449,6 +454,7 @@ class Renderer:
         arrs = [np.ascontiguousarray(scene[k], dtype=np.float32) for k in ("pos", "scale", "rotq", "sh", "opacity")]
         P = int(arrs[0].reshape(-1, 3).shape[0])
         self.P, self.sh_degree = P, sh_degree
+        self._generation += 1
         _check(load_library().lcgs_scene_upload(self.ctx._h, C.c_int(P), C.c_int(sh_degree), *[_ptr(a) for a in arrs]))
 
     def load_ply(self, path: str) -> int:
@@ -456,6 +462,7 @@ class Renderer:
         n = C.c_int(0)
         _check(load_library().lcgs_scene_load_ply(self.ctx._h, path.encode(), C.byref(n)))
         self.P, self.sh_degree, self._keep = n.value, 3, []
+        self._generation += 1
         return n.value
 
     def use_half_sh(self, enable: bool = True):
@@ -475,6 +482,7 @@ class Renderer:
     def forward(self, cam: Camera, img, bg=(0.0, 0.0, 0.0), scale_modifier: float = 1.0, radii=None,
                 keep_state: bool = False, sync: bool = True) -> Optional[int]:
         n = C.c_int(0)
+        self._generation += 1
         _check(load_library().lcgs_render_forward(self.ctx._h, C.byref(cam), _f3(bg), C.c_float(scale_modifier),
                                                   _ptr(img), _ptr(radii), C.c_int(1 if keep_state else 0),
                                                   C.byref(n) if sync else None))
@@ -486,6 +494,7 @@ class Renderer:
         assert n == len(imgs)
         cam_arr = (Camera * n)(*cams)
         ptrs = (C.c_void_p * n)(*[_ptr(t).value for t in imgs])
+        self._generation += 1
         _check(load_library().lcgs_render_forward_batch(self.ctx._h, C.c_int(n), cam_arr, _f3(bg),
                                                         C.c_float(scale_modifier), ptrs))
 
@@ -552,7 +561,13 @@ def render_autograd(renderer: "Renderer", cam: Camera, pos, scale, rotq, sh, opa
                     scale_modifier: float = 1.0):
     """Differentiable frame for torch: `img = render_autograd(r, cam, pos, scale, rotq, sh, opacity)` (activated
     parameters, CHW float image); `img.backward(...)` / `torch.autograd.grad` run lcgs_render_backward.  torch is the
-    owner of the tensors and of the autograd graph only; both directions are the HIP kernels."""
+    owner of the tensors and of the autograd graph only; both directions are the HIP kernels.
+
+    lcgs_render_backward differentiates the LAST keep_state frame of the context.  Several render_autograd frames of one
+    renderer may be alive at once (a multi-view loss), or the renderer may have been used for something else between a
+    frame's forward and its backward: the backward notices (the renderer's generation counter has moved), binds its own
+    saved scene again and re-renders its own view with keep_state before differentiating -- the cost of one extra
+    forward instead of gradients silently computed from another view's lists."""
     import torch
 
     class _Fn(torch.autograd.Function):
@@ -566,6 +581,7 @@ def render_autograd(renderer: "Renderer", cam: Camera, pos, scale, rotq, sh, opa
                 img[:] = torch.tensor(bg, device=img.device).view(3, 1, 1)  # nothing drawn: the image is the background
             ctx.shapes = [t.shape for t in (pos, scale, rotq, sh, opacity)]
             ctx.empty = n == 0
+            ctx.generation = renderer._generation
             ctx.save_for_backward(*args)
             return img
 
@@ -573,7 +589,12 @@ def render_autograd(renderer: "Renderer", cam: Camera, pos, scale, rotq, sh, opa
         def backward(ctx, dL_dimg):
             args = ctx.saved_tensors
             grads = [torch.zeros_like(t) for t in args]
-            if not ctx.empty:  # uses the state kept by this renderer's last forward: backward follows its forward
+            if not ctx.empty:
+                if renderer._generation != ctx.generation:  # the renderer's frame state is no longer this frame's
+                    renderer.bind_scene(*args)
+                    scratch = torch.empty(3, cam.height, cam.width, device=args[0].device, dtype=torch.float32)
+                    renderer.forward(cam, scratch, bg=bg, scale_modifier=scale_modifier, keep_state=True, sync=True)
+                    ctx.generation = renderer._generation
                 renderer.backward(dL_dimg.contiguous(), *grads)
             return tuple(g.view(s) for g, s in zip(grads, ctx.shapes))
 

@@ -1,7 +1,7 @@
 // lcgs-app -- CLI work-alike of the reference's app/main.cpp on the MI355X library.
 //   lcgs-app --ply <path> [--res WxH] [--out dir] [--world colmap|blender] [--exp_N N] [--backend hip]
 //            [--path fused|stage] [--synth kind:count:seed] [--ingest device|host] [--cameras file]
-//            [--order file|spatial]
+//            [--order file|spatial] [--pose garden|lego]
 // Same flags (app/main.cpp:52-124; `--key=value` and `--key value`, app/command_parser.hpp:5-79), the same
 // hard-coded look-at camera (app/main.cpp:191-207), the same frame loop (:266-308), the same output:
 // <out>/<ply stem>_<backend>.png, CHW float -> vertically flipped RGB8 with a truncating *255 (:323-339).
@@ -44,6 +44,8 @@ void usage(const char* argv0)
     printf("  --synth <kind:count:seed> Render a synthetic stand-in scene instead of --ply (kind 0 object, 1 unbounded)\n");
     printf("  --ingest <device|host>   De-interleave/activate the PLY on the GPU (default) or on the host\n");
     printf("  --order <file|spatial>   Keep the splats in file order (default) or re-order them along a Morton curve at load\n");
+    printf("  --pose <garden|lego>     The look-at compiled into the reference (garden, app/main.cpp:191-193; default) or the\n"
+           "                           alternative it keeps in a comment for lego / bicycle (app/main.cpp:195-197)\n");
     printf("  --cameras <file>         Render every camera of the file: `px py pz tx ty tz ux uy uz [fov]` per line\n");
     printf("  --display                Not supported (headless)\n");
 }
@@ -61,7 +63,7 @@ int main(int argc, char** argv)
 {
     unsigned    W = 1600, H = 1063; // app/main.cpp:38
     std::string ply_path = "gsplat.ply", backend = "hip", out_dir = "out", world = "colmap", path = "fused", synth;
-    std::string ingest = "device", cameras_file, order = "file";
+    std::string ingest = "device", cameras_file, order = "file", pose = "garden";
     int         exp_N = 1;
     // parse_command (app/command_parser.hpp:5-79): strip leading dashes, `key=value` or `key value`
     for (int i = 1; i < argc; ++i) {
@@ -107,6 +109,9 @@ int main(int argc, char** argv)
         } else if (key == "order") {
             if (value != "file" && value != "spatial") die("Invalid splat order: " + value);
             order = value;
+        } else if (key == "pose") {
+            if (value != "garden" && value != "lego" && value != "bicycle") die("Invalid pose: " + value);
+            pose = value == "garden" ? "garden" : "lego";
         } else if (key == "cameras") cameras_file = value;
         else if (key == "display") die("--display needs a GUI; this build is headless");
         else die("unknown option --" + key);
@@ -179,7 +184,8 @@ int main(int argc, char** argv)
         struct View { float pos[3], target[3], up[3], fov; };
         std::vector<View> views;
         if (cameras_file.empty()) {
-            View v = { { -3.0f, -0.5f, 3.3f }, { 0.0f, 3.0f, 0.5f }, { 0.0f, -1.0f, -1.0f }, 0.0f };
+            View v = { { -3.0f, -0.5f, 3.3f }, { 0.0f, 3.0f, 0.5f }, { 0.0f, -1.0f, -1.0f }, 0.0f }; // app/main.cpp:191-193
+            if (pose == "lego") v = { { -3.0f, -0.5f, 2.3f }, { 0.0f, 0.0f, 0.5f }, { 0.0f, -1.0f, 0.0f }, 0.0f }; // :195-197
             if (world == "blender") { v.up[0] = 0.0f; v.up[1] = 0.0f; v.up[2] = 1.0f; }
             views.push_back(v);
         } else {

@@ -564,7 +564,10 @@ __global__ void __launch_bounds__(kThreads) k_expand_reduce(const uint32_t* __re
 }
 
 // exclusive scan of the block sums in place by one workgroup; d_counts[4] = pairs wanted,
-// [2] = pairs emitted (clamped to the workspace capacity), [3] = overflow flag
+// [2] = pairs emitted (clamped to the workspace capacity), [3] = overflow flag of THIS frame;
+// [6] / [7] are sticky across frames (cleared by the host once read back): frames that overflowed since the last clear,
+// and the largest pair count any of them wanted -- an asynchronous frame's overflow is not lost when the next frame
+// rewrites [3]
 __global__ void __launch_bounds__(1024) k_expand_offsets(uint32_t* __restrict__ d_counts,
                                                            uint32_t* __restrict__ block_sums, uint32_t nb_cap,
                                                            uint32_t capacity)
@@ -614,6 +617,10 @@ __global__ void __launch_bounds__(1024) k_expand_offsets(uint32_t* __restrict__ 
         d_counts[4]      = L;
         d_counts[2]      = L < capacity ? L : capacity;
         d_counts[3]      = L > capacity ? 1u : 0u;
+        if (L > capacity) {
+            d_counts[6] += 1u;
+            if (L > d_counts[7]) d_counts[7] = L;
+        }
     }
 }
 

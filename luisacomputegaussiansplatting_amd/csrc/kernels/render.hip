@@ -23,6 +23,7 @@
 #include <hip/hip_ext.h>
 
 #include "launch.hpp"
+#include "tile_common.hpp"
 
 namespace lcgs
 {
@@ -54,77 +55,7 @@ struct FetchRec {
     }
 };
 
-constexpr int kXcd = 8;
-
-// Conservative "can this splat reach any pixel of the rect?" test, exact up to a safety margin.
-// A pixel receives a contribution only if alpha = min(0.99, o * exp(power)) >= 1/255 with power <= 0
-// (shader.cpp:256-259), i.e. q(d) = ca dx^2 + 2 cb dx dy + cc dy^2 <= t = 2 ln(255 o).  The minimum of the convex
-// quadratic q over the pixel rect [x0,x1] x [y0,y1] is 0 if the mean is inside, else it lies on one of the four
-// edges (a clamped 1-D quadratic each).  `t` already carries its margin; the absolute rounding slack scales with
-// the magnitude of the terms that cancel in q.  Non-finite inputs keep the entry.
-__device__ __forceinline__ bool splat_may_touch_rect(float mx, float my, float ca, float cb, float cc, float t,
-                                                     float x0, float y0, float x1, float y1)
-{
-    if (!(t > 0.0f)) return false; // opacity <= 1/255: alpha < 1/255 everywhere
-    const float ex0 = x0 - mx, ex1 = x1 - mx, ey0 = y0 - my, ey1 = y1 - my; // rect relative to the mean
-    if (ex0 <= 0.0f && ex1 >= 0.0f && ey0 <= 0.0f && ey1 >= 0.0f) return true;
-    if (!(ca > 0.0f) || !(cc > 0.0f)) return true; // degenerate conic: keep
-    // 1-ulp hardware reciprocals are enough: a minimiser that is off by delta raises q by cc*delta^2 (or ca*delta^2),
-    // ~1e-14 relative -- nine orders below the slack applied at the end.
-    const float nb_cc = -cb * __builtin_amdgcn_rcpf(cc), nb_ca = -cb * __builtin_amdgcn_rcpf(ca);
-    float best = 3.0e38f, slack = 0.0f;
-    // vertical edges dx = ex0 / ex1: dy* = -cb dx / cc clamped to [ey0, ey1]
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const float dx = s ? ex1 : ex0;
-        const float dy = fmin_(fmax_(nb_cc * dx, ey0), ey1);
-        const float q1 = ca * dx * dx, q2 = 2.0f * cb * dx * dy, q3 = cc * dy * dy;
-        const float q  = q1 + q2 + q3;
-        if (q < best) {
-            best  = q;
-            slack = fabsf(q1) + fabsf(q2) + fabsf(q3);
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const float dy = s ? ey1 : ey0;
-        const float dx = fmin_(fmax_(nb_ca * dy, ex0), ex1);
-        const float q1 = ca * dx * dx, q2 = 2.0f * cb * dx * dy, q3 = cc * dy * dy;
-        const float q  = q1 + q2 + q3;
-        if (q < best) {
-            best  = q;
-            slack = fabsf(q1) + fabsf(q2) + fabsf(q3);
-        }
-    }
-    if (!(best == best)) return true; // NaN: keep
-    return best - 1e-5f * slack <= t;
-}
-
-// Workgroup -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b lands on XCD b % 8,
-// and is that XCD's (b / 8)-th workgroup).  Tiles are grouped into blocks of 8 x 4 tiles (128 x 64 px: most
-// splats live inside one block, so its tiles share their records in one XCD's L2) and the blocks are dealt
-// round-robin to the XCDs, so every XCD gets an even mix of dense (image centre) and sparse (border) regions.
-// Speed only: any placement gives the same image.
-constexpr uint32_t kBlkW = 8, kBlkH = 4;
-
-__device__ __forceinline__ bool tile_of_workgroup(uint32_t b, uint32_t grid_x, uint32_t grid_y, uint32_t& tx,
-                                                  uint32_t& ty)
-{
-    const uint32_t xcd = b % kXcd, seq = b / kXcd;
-    const uint32_t bw = (grid_x + kBlkW - 1) / kBlkW;
-    const uint32_t blk = xcd + kXcd * (seq / (kBlkW * kBlkH));
-    const uint32_t in  = seq % (kBlkW * kBlkH);
-    tx = (blk % bw) * kBlkW + in % kBlkW;
-    ty = (blk / bw) * kBlkH + in / kBlkW;
-    return tx < grid_x && ty < grid_y;
-}
-
-__host__ __device__ inline uint32_t render_grid_size(uint32_t grid_x, uint32_t grid_y)
-{
-    const uint32_t bw = (grid_x + kBlkW - 1) / kBlkW, bh = (grid_y + kBlkH - 1) / kBlkH;
-    const uint32_t per_xcd = (bw * bh + kXcd - 1) / kXcd; // blocks per XCD
-    return per_xcd * kBlkW * kBlkH * kXcd;
-}
+using namespace tile;
 
 template <typename Fetch>
 __global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, float bg1, float bg2,

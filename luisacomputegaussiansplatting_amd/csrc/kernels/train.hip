@@ -8,6 +8,8 @@
 //   rotq         q = raw / |raw|                          g_raw = (g - q (q . g)) / |raw|
 // Adam as torch.optim.Adam (no weight decay, no amsgrad): m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;
 // raw -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).
+// `act` may alias `raw` for pos / sh (identity activation); when the renderer's arrays are separate buffers they are
+// rewritten too.
 // HBM-bound elementwise work: every array is touched once, 16-byte accesses where the layout allows.  With a row
 // list (the dense ids -> splat index map of the last forward) only the splats that reached the screen are updated
 // ("sparse Adam": their moments are the only ones that change; 2.5x fewer bytes on the bicycle stand-in).
@@ -34,7 +36,7 @@ template <int ROW, int MODE>
 __global__ void __launch_bounds__(256) k_adam_rows(int64_t rows, const uint32_t* __restrict__ row_list,
                                                    const uint32_t* __restrict__ d_row_count,
                                                    const float* __restrict__ grad, float* __restrict__ raw,
-                                                   float* __restrict__ m, float* __restrict__ v, float* __restrict__ act,
+                                                   float* __restrict__ m, float* __restrict__ v, float* act /* may alias raw */,
                                                    int split, float lr0, float lr1, AdamStep a, int grad_compact)
 {
     const int64_t n_rows = d_row_count ? (int64_t)*d_row_count : rows;
@@ -54,6 +56,7 @@ __global__ void __launch_bounds__(256) k_adam_rows(int64_t rows, const uint32_t*
         m[i]   = mm;
         v[i]   = vv;
         raw[i] = x;
+        if (MODE == 0 && act != raw) act[i] = x; // (wave-uniform: the renderer's array is a separate buffer)
         if (MODE == 1) act[i] = expf(x);
         if (MODE == 2) act[i] = 1.0f / (1.0f + expf(-x));
     }
@@ -63,8 +66,9 @@ __global__ void __launch_bounds__(256) k_adam_rows(int64_t rows, const uint32_t*
 __global__ void __launch_bounds__(256) k_adam_sh48(int64_t rows, const uint32_t* __restrict__ row_list,
                                                    const uint32_t* __restrict__ d_row_count,
                                                    const float4* __restrict__ grad, float4* __restrict__ raw,
-                                                   float4* __restrict__ m, float4* __restrict__ v, float lr_dc,
-                                                   float lr_rest, AdamStep a, int grad_compact)
+                                                   float4* __restrict__ m, float4* __restrict__ v,
+                                                   float4* act /* may alias raw */, float lr_dc, float lr_rest, AdamStep a,
+                                                   int grad_compact)
 {
     const int64_t n_rows = d_row_count ? (int64_t)*d_row_count : rows;
     const int64_t total  = n_rows * 12;
@@ -82,6 +86,7 @@ __global__ void __launch_bounds__(256) k_adam_sh48(int64_t rows, const uint32_t*
         raw[i] = x;
         m[i]   = mm;
         v[i]   = vv;
+        if (act != raw) act[i] = x;
     }
 }
 
@@ -145,11 +150,13 @@ void launch_adam_step(int64_t P, int sh_floats, const uint32_t* row_list, const 
                        reinterpret_cast<float4*>(m.rotq), reinterpret_cast<float4*>(v.rotq),
                        reinterpret_cast<float4*>(act.rotq), lr.rot, a, gc);
     const bool sh_aligned = ((reinterpret_cast<uintptr_t>(grad.sh) | reinterpret_cast<uintptr_t>(raw.sh) |
-                              reinterpret_cast<uintptr_t>(m.sh) | reinterpret_cast<uintptr_t>(v.sh)) & 15) == 0;
+                              reinterpret_cast<uintptr_t>(m.sh) | reinterpret_cast<uintptr_t>(v.sh) |
+                              reinterpret_cast<uintptr_t>(act.sh)) & 15) == 0;
     if (sh_floats == 48 && sh_aligned)
         hipLaunchKernelGGL(k_adam_sh48, dim3(grid_for(launch_rows * 12)), dim3(256), 0, stream, rows, row_list, d_row_count,
                            reinterpret_cast<const float4*>(grad.sh), reinterpret_cast<float4*>(raw.sh),
-                           reinterpret_cast<float4*>(m.sh), reinterpret_cast<float4*>(v.sh), lr.sh_dc, lr.sh_rest, a, gc);
+                           reinterpret_cast<float4*>(m.sh), reinterpret_cast<float4*>(v.sh),
+                           reinterpret_cast<float4*>(act.sh), lr.sh_dc, lr.sh_rest, a, gc);
     else if (sh_floats == 48)
         hipLaunchKernelGGL((k_adam_rows<48, 0>), dim3(grid_for(launch_rows * 48)), dim3(256), 0, stream, rows, row_list,
                            d_row_count, grad.sh, raw.sh, m.sh, v.sh, act.sh, 3, lr.sh_dc, lr.sh_rest, a, gc);

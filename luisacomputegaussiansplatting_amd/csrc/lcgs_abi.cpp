@@ -111,14 +111,16 @@ struct lcgs_context {
     DeviceBuffer   frame_params;
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey {
-        const void *pos = nullptr, *img = nullptr, *radii = nullptr;
+        const void *pos = nullptr, *scale = nullptr, *rotq = nullptr, *sh = nullptr, *opacity = nullptr, *sh_half = nullptr,
+                   *img = nullptr, *radii = nullptr;
         int         P = -1, sh_deg = -1, width = 0, height = 0, keep_state = -1;
         int64_t     hint_V = -1, hint_L = -1;
         uint32_t    capacity = 0;
         hipStream_t stream = nullptr;
         bool        operator==(const GraphKey& o) const
         {
-            return pos == o.pos && img == o.img && radii == o.radii && P == o.P && sh_deg == o.sh_deg && width == o.width &&
+            return pos == o.pos && scale == o.scale && rotq == o.rotq && sh == o.sh && opacity == o.opacity &&
+                   sh_half == o.sh_half && img == o.img && radii == o.radii && P == o.P && sh_deg == o.sh_deg && width == o.width &&
                    height == o.height && keep_state == o.keep_state && hint_V == o.hint_V && hint_L == o.hint_L &&
                    capacity == o.capacity && stream == o.stream;
         }
@@ -238,14 +240,21 @@ lcgs_status check_frame_flags(lcgs_context* ctx)
         set_last_error("a device-side wait timed out (bounded spin expired): the frame is invalid");
         return LCGS_ERR_HIP;
     }
-    if (ctx->h_counts[3] != 0) {
-        // the pair workspace was too small for that view: the lists were truncated.  Grow for the next frame.
-        uint64_t want = (uint64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4;
+    if (ctx->h_counts[6] != 0) {
+        // The pair workspace was too small for one or more frames since the last check (the device keeps the count and
+        // the largest demand in sticky words, so a truncated asynchronous frame is not forgotten when later frames
+        // fit): those images are truncated.  Grow for the next frame and clear the record.
+        uint64_t want = (uint64_t)ctx->h_counts[7] + ctx->h_counts[7] / 4;
         if (want > 0x7FFFFFFFull) want = 0x7FFFFFFFull;
-        ctx->pair_capacity = (uint32_t)want;
-        ctx->h_counts[3]   = 0;
-        set_last_error("the last asynchronous frame needed more (tile, splat) pairs than the workspace held; "
-                       "its image is truncated.  The workspace has been grown: render the frame again");
+        ctx->pair_capacity = std::max(ctx->pair_capacity, (uint32_t)want);
+        char buf[320];
+        snprintf(buf, sizeof(buf),
+                 "%u asynchronous frame(s) needed more (tile, splat) pairs than the workspace held (up to %u); their "
+                 "images are truncated.  The workspace has been grown: render those frames again",
+                 ctx->h_counts[6], ctx->h_counts[7]);
+        ctx->h_counts[3] = ctx->h_counts[6] = ctx->h_counts[7] = 0;
+        LCGS_HIP_CHECK(hipMemsetAsync(ctx->counts.as<uint32_t>() + 6, 0, 8, ctx->stream));
+        set_last_error(buf);
         return LCGS_ERR_CAPACITY;
     }
     return LCGS_OK;
@@ -308,7 +317,12 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
     }
     ctx->zero_scan_bytes = b0;
     ctx->zero_bytes      = b0 + b1;
-    LCGS_TRY(ctx->counts.ensure(64));
+    {
+        // the counter block starts zeroed: words [6] / [7] (overflow since the last read-back) are only ever added to
+        const void* before = ctx->counts.ptr;
+        LCGS_TRY(ctx->counts.ensure(64));
+        if (ctx->counts.ptr != before) LCGS_HIP_CHECK(hipMemsetAsync(ctx->counts.ptr, 0, 64, ctx->stream));
+    }
     LCGS_TRY(ctx->sort_ws.ensure(pair_sort_ws_bytes(std::max<int64_t>((int64_t)P, (int64_t)ctx->pair_capacity))));
     LCGS_TRY(ctx->expand_ws.ensure(expand_ws_bytes((int)P)));
     if (keep_state) {
@@ -576,11 +590,13 @@ lcgs_status lcgs_synchronize(lcgs_context* ctx)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
     LCGS_TRY(sync_frame(ctx));
+    lcgs_status twin_status = LCGS_OK;
     if (ctx->twin) {
         LCGS_TRY(sync_frame(ctx->twin));
-        LCGS_TRY(check_frame_flags(ctx->twin));
+        twin_status = check_frame_flags(ctx->twin); // (both workspaces are checked, and grown, by one call)
     }
-    return check_frame_flags(ctx);
+    const lcgs_status own_status = check_frame_flags(ctx);
+    return own_status != LCGS_OK ? own_status : twin_status;
 }
 
 // ---------------------------------------------------------------------------------------------- stages
@@ -1034,6 +1050,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
     if (ctx->P == 0) return LCGS_OK; // nothing to draw: image untouched, like gs_tile_splatter/impl.cpp:109
     LCGS_REQUIRE(ctx->pos != nullptr, "no scene bound (call lcgs_scene_bind / lcgs_scene_upload first)");
     const CamParams cp = make_cam_params(*camera);
+    uint32_t        earlier_truncated = 0; // asynchronous frames before this one that overflowed the pair workspace
     for (int attempt = 0; attempt < 4; ++attempt) {
         LCGS_TRY(ensure_fused_workspace(ctx, cp, keep_state != 0));
         if (ctx->use_graph && !ctx->profiling && ctx->stream != nullptr) { // the legacy NULL stream cannot be captured
@@ -1045,7 +1062,9 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
             fp.scale_modifier = scale_modifier;
             launch_set_frame_params(fp, ctx->frame_params.as<FrameParams>(), ctx->stream);
             lcgs_context::GraphKey key;
-            key.pos = ctx->pos; key.img = d_img; key.radii = d_radii; key.P = ctx->P; key.sh_deg = ctx->sh_deg;
+            key.pos = ctx->pos; key.scale = ctx->scale; key.rotq = ctx->rotq; key.sh = ctx->sh; key.opacity = ctx->opacity;
+            key.sh_half = ctx->use_half_sh ? ctx->sh_half.ptr : nullptr; // (selects the kernel and its coefficient rows)
+            key.img = d_img; key.radii = d_radii; key.P = ctx->P; key.sh_deg = ctx->sh_deg;
             key.width = camera->width; key.height = camera->height; key.keep_state = keep_state != 0;
             key.hint_V = ctx->hint_V; key.hint_L = ctx->hint_L; key.capacity = ctx->pair_capacity; key.stream = ctx->stream;
             if (!ctx->graph_exec || !(key == ctx->graph_key)) {
@@ -1093,14 +1112,31 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
             ctx->hint_V = (int64_t)ctx->h_counts[0] + ctx->h_counts[0] / 4 + 4096;
         if ((int64_t)ctx->h_counts[4] > ctx->hint_L || (int64_t)ctx->h_counts[4] * 2 < ctx->hint_L)
             ctx->hint_L = (int64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4 + 4096;
-        if (ctx->h_counts[3] == 0) return LCGS_OK;
-        // pair buffers were too small for this view: grow and redo the frame
-        uint64_t want = (uint64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4;
-        if (want > 0x7FFFFFFFull) {
-            set_last_error("num_rendered exceeds 2^31 pairs");
+        // overflow bookkeeping: [3] this frame, [6] / [7] every frame since the last read-back (sticky on the device)
+        const bool     own    = ctx->h_counts[3] != 0;
+        const uint32_t sticky = ctx->h_counts[6], sticky_want = ctx->h_counts[7];
+        if (sticky) {
+            ctx->h_counts[6] = ctx->h_counts[7] = 0;
+            LCGS_HIP_CHECK(hipMemsetAsync(ctx->counts.as<uint32_t>() + 6, 0, 8, ctx->stream));
+            uint64_t want = (uint64_t)sticky_want + sticky_want / 4;
+            if (want > 0x7FFFFFFFull) {
+                set_last_error("num_rendered exceeds 2^31 pairs");
+                return LCGS_ERR_CAPACITY;
+            }
+            ctx->pair_capacity = std::max(ctx->pair_capacity, (uint32_t)want);
+        }
+        if (sticky > (own ? 1u : 0u)) earlier_truncated += sticky - (own ? 1u : 0u);
+        if (own) continue; // pair buffers were too small for this view: grown above, redo the frame
+        if (earlier_truncated) {
+            char buf[256];
+            snprintf(buf, sizeof(buf),
+                     "%u earlier asynchronous frame(s) needed more (tile, splat) pairs than the workspace held; their "
+                     "images are truncated (this frame is complete).  The workspace has been grown: render them again",
+                     earlier_truncated);
+            set_last_error(buf);
             return LCGS_ERR_CAPACITY;
         }
-        ctx->pair_capacity = (uint32_t)want;
+        return LCGS_OK;
     }
     set_last_error("pair buffer growth did not converge");
     return LCGS_ERR_CAPACITY;

@@ -16,10 +16,12 @@ def upload_scene(scene):
     return {k: dev(scene[k]) for k in ("pos", "scale", "rotq", "sh", "opacity")}
 
 
-def assert_image_parity(gpu_img, orc, tol=1e-4, max_ambig_frac=2e-3):
+def assert_image_parity(gpu_img, orc, tol=1e-4, max_ambig_frac=1e-4, min_flips_allowed=2):
     """BASELINE tolerance: per-pixel L-inf <= 1e-4.  A pixel whose oracle evaluation came within 1e-5
     (relative) of one of the hard thresholds (alpha < 1/255, T < 1e-4, power > 0) may legitimately flip
-    with a 1-ulp difference in exp(); those pixels are exempt but counted and bounded."""
+    with a 1-ulp difference in exp(); those pixels are exempt but counted, printed and bounded: at most 1e-4 of the
+    frame's pixels (min_flips_allowed is the floor for frames of fewer than 20 000 pixels, where one pixel is already
+    more than 1e-4 of the frame)."""
     ref = orc["img"]
     diff = np.abs(gpu_img - ref).max(axis=0)
     bad = diff > tol
@@ -27,6 +29,10 @@ def assert_image_parity(gpu_img, orc, tol=1e-4, max_ambig_frac=2e-3):
     n_bad_clear = int((bad & ~ambig).sum())
     assert n_bad_clear == 0, (f"{n_bad_clear} unambiguous pixels differ by more than {tol}; "
                               f"max diff {diff[~ambig].max()}")
-    frac = float((bad & ambig).sum()) / diff.size
-    assert frac <= max_ambig_frac, f"{frac:.2e} of the pixels flipped a threshold"
+    n_flipped = int((bad & ambig).sum())
+    print(f"[parity] {diff.shape[1]}x{diff.shape[0]}: threshold-ambiguous pixels {int(ambig.sum())}, "
+          f"flagged-and-different {n_flipped}, max |diff| on unflagged pixels "
+          f"{float(diff[~ambig].max()) if (~ambig).any() else 0.0:.2e}")
+    allowed = max(min_flips_allowed, int(max_ambig_frac * diff.size))
+    assert n_flipped <= allowed, f"{n_flipped} pixels flipped a threshold (allowed: {allowed} of {diff.size})"
     return float(diff[~ambig].max()) if (~ambig).any() else 0.0, int((bad & ambig).sum())

@@ -228,6 +228,14 @@ def test_half_precision_sh_is_opt_in_and_close(lcgs, oracle):
     assert n_half == n_ref  # geometry is untouched
     err = (half - ref).abs()
     assert 0.0 < err.max().item() < 5e-3 and err.mean().item() < 2e-4
+    # against the oracle: the f16 path is the f32 algorithm on coefficients rounded to f16 (round-to-nearest-even, what
+    # numpy's astype does) and widened again -- so the oracle fed those coefficients must agree within the 1e-4 bar
+    scene_h = dict(scene)
+    scene_h["sh"] = scene["sh"].astype(np.float16).astype(np.float32)
+    orc = oracle.render(scene_h, oracle.lookat(*POSE, width=640, height=480), ambig_eps=1e-5)
+    assert n_half == orc["num_rendered"]
+    max_clear, _ = assert_image_parity(half.cpu().numpy(), orc)
+    assert max_clear <= 1e-4
     # camera batches read the same f16 copy
     imgs = [torch.zeros(3, 480, 640, device=DEV) for _ in range(3)]
     r.forward_batch([cam] * 3, imgs)
@@ -323,6 +331,40 @@ def test_asynchronous_overflow_is_reported_at_the_next_sync(lcgs, oracle):
     ref = oracle.render(scene, oracle.lookat(*POSE, width=1920, height=1080), ambig_eps=1e-5)
     assert n == ref["num_rendered"] and n > (1 << 22)
     assert_image_parity(img.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("second_sync", [False, True])
+def test_asynchronous_overflow_is_not_forgotten_when_a_later_frame_fits(lcgs, second_sync):
+    """The overflow record is sticky on the device: an asynchronous frame that was truncated is still reported after a
+    later frame (here a small one that fits) has rewritten the per-frame counters -- by lcgs_synchronize, and by a later
+    synchronising lcgs_render_forward."""
+    rng = np.random.default_rng(13)
+    scene = make_scene(rng, 6000, log_scale=(-1.0, 0.2))  # big splats: L >> max(4 * P, 2^22) at 1080p
+    r = lcgs.Renderer(lcgs.Context(0))
+    d = upload_scene(scene)
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    big = torch.zeros(3, 1080, 1920, device=DEV)
+    small = torch.zeros(3, 64, 64, device=DEV)
+    cam_big = lcgs.get_lookat_cam(*POSE, width=1920, height=1080)
+    cam_small = lcgs.get_lookat_cam(*POSE, width=64, height=64)
+    r.forward(cam_big, big, sync=False)  # truncated
+    with pytest.raises(lcgs.LcgsError) as e:
+        if second_sync:
+            r.forward(cam_small, small, sync=True)  # fits; must still report the earlier frame
+        else:
+            r.forward(cam_small, small, sync=False)
+            r.ctx.synchronize()
+    assert e.value.status == 5 and "truncated" in str(e.value)
+    r.ctx.synchronize()  # reported once, then clear
+    fresh = lcgs.Renderer(lcgs.Context(0))
+    fresh.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    ref_small, ref_big = torch.zeros_like(small), torch.zeros_like(big)
+    fresh.forward(cam_small, ref_small, sync=True)
+    fresh.forward(cam_big, ref_big, sync=True)
+    assert torch.equal(small, ref_small)  # the frame that fitted is complete
+    r.forward(cam_big, big, sync=False)  # the workspace has been grown: the big frame now fits asynchronously
+    r.ctx.synchronize()
+    assert torch.equal(big, ref_big)
 
 
 def test_asynchronous_overflow_inside_a_camera_batch(lcgs):

@@ -47,8 +47,11 @@ def _raw_scene(rng, P):
             "opacity": rng.normal(0, 2, P).astype(np.float32)}
 
 
+@pytest.mark.parametrize("aliased", [True, False])
 @pytest.mark.parametrize("P", [1, 257, 20011])
-def test_adam_step_matches_torch(lcgs, P):
+def test_adam_step_matches_torch(lcgs, P, aliased):
+    """aliased: activated.pos / .sh ARE raw.pos / .sh (identity activation, one array); not aliased: the renderer's
+    arrays are separate buffers and the step has to rewrite them too."""
     rng = np.random.default_rng(P)
     raw0 = _raw_scene(rng, P)
     grads_seq = [{k: (rng.normal(0, 1, raw0[k].shape) * 10.0 ** rng.uniform(-4, 0)).astype(np.float32) for k in KEYS}
@@ -60,7 +63,10 @@ def test_adam_step_matches_torch(lcgs, P):
     m = {k: torch.zeros_like(raw[k]) for k in KEYS}
     v = {k: torch.zeros_like(raw[k]) for k in KEYS}
     act = {k: t.clone() for k, t in _activate(raw).items()}
-    act["pos"], act["sh"] = raw["pos"], raw["sh"]  # raw == activated: one array
+    if aliased:
+        act["pos"], act["sh"] = raw["pos"], raw["sh"]  # raw == activated: one array
+    else:
+        assert act["pos"].data_ptr() != raw["pos"].data_ptr() and act["sh"].data_ptr() != raw["sh"].data_ptr()
     for step, g in enumerate(grads_seq, 1):
         r.adam_step({k: torch.from_numpy(g[k]).to(DEV) for k in KEYS}, raw, m, v, act, step, LR, eps=eps)
     r.ctx.synchronize()
@@ -190,6 +196,28 @@ def test_autograd_binding_matches_oracle_backward(lcgs, oracle):
     ref = oracle.render_backward_full(scene, oracle.lookat(*pose, width=W, height=H), dL.cpu().numpy(), bg=(0.1, 0.2, 0.3))
     for k in KEYS:
         a, b = t[k].grad.cpu().numpy().astype(np.float64), ref[k].astype(np.float64).reshape(t[k].shape)
+        assert np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30) <= 1e-3, k
+
+
+def test_autograd_multi_view_loss_and_interleaved_use(lcgs, oracle):
+    """Two render_autograd frames of ONE renderer alive at once (a two-view loss), plus an unrelated forward in between:
+    each view's backward must differentiate its own frame (the binding re-renders a view whose state was replaced)."""
+    rng = np.random.default_rng(18)
+    scene = make_scene(rng, 3000, log_scale=(-3.6, 0.7))
+    W, H = 128, 96
+    poses = [([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1]), ([2.5, 1.5, 1.0], [0, 0, 0.5], [0, 0, 1])]
+    cams = [lcgs.get_lookat_cam(*p, width=W, height=H) for p in poses]
+    t = {k: torch.from_numpy(scene[k]).to(DEV).requires_grad_(True) for k in KEYS}
+    r = lcgs.Renderer(lcgs.Context(0))
+    imgs = [lcgs.render_autograd(r, c, *[t[k] for k in KEYS], bg=(0.1, 0.2, 0.3)) for c in cams]
+    r.forward(cams[0], torch.zeros(3, H, W, device=DEV), keep_state=False)  # somebody else uses the renderer
+    dLs = [torch.from_numpy(np.random.default_rng(i).normal(size=(3, H, W)).astype(np.float32)).to(DEV) for i in range(2)]
+    sum((img * dL).sum() for img, dL in zip(imgs, dLs)).backward()
+    refs = [oracle.render_backward_full(scene, oracle.lookat(*p, width=W, height=H), dL.cpu().numpy(), bg=(0.1, 0.2, 0.3))
+            for p, dL in zip(poses, dLs)]
+    for k in KEYS:
+        a = t[k].grad.cpu().numpy().astype(np.float64)
+        b = sum(ref[k].astype(np.float64).reshape(t[k].shape) for ref in refs)
         assert np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30) <= 1e-3, k
 
 
