@@ -65,11 +65,16 @@ def main():
     ap.add_argument("--no-stage-path", action="store_true")
     ap.add_argument("--half-sh", action="store_true", help="also time the opt-in f16 SH colour pass")
     ap.add_argument("--no-spatial", action="store_true", help="skip the spatially re-ordered legs")
+    ap.add_argument("--no-moving-camera", action="store_true", help="skip the moving-camera forward leg")
+    ap.add_argument("--collective", choices=("rccl", "torch"), default="rccl",
+                    help="N > 1 gradient collective: the library's own RCCL path (lcgs_comm C ABI, default) or "
+                         "torch.distributed's (cross-check)")
     args = ap.parse_args()
 
     import torch
 
     import luisacomputegaussiansplatting_amd as L
+    import luisacomputegaussiansplatting_amd.multi_gpu as mg
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -154,6 +159,48 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * args.steps / elapsed
+
+    def timed(fn, steps, warm):
+        """warm untimed calls, then `steps` timed ones between barriers; max over ranks; seconds"""
+        for i in range(warm):
+            fn(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(warm + i)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
+    # ---- moving camera: the eight C5 poses (base pose rotated about world-up by k x 45 deg) cycled INSIDE the timed
+    # loop, a different view every frame: the previous frame's tile schedule is stale, V / L change from frame to frame
+    # (launch sizes and buffer hints come from whichever frame synchronised last).  Beside `value`, never instead of it.
+    moving = None
+    if not args.no_moving_camera:
+        cams8 = [L.get_lookat_cam(*view_pose(k), width=W, height=H) for k in range(8)]
+        per_view = []
+        for c in cams8:  # one synchronising frame per view: sizes the pair buffers for the largest of them
+            r.forward(c, img, sync=True)
+            st8 = r.frame_stats()
+            per_view.append({"visible_splats": st8["num_visible"], "tile_pairs_sorted": st8["num_pairs"]})
+        el_m = timed(lambda i: r.forward(cams8[(i + rank) % 8], img, sync=False), args.steps, max(args.warmup, 8))
+        # the same eight views one at a time, each repeated: what a static camera gives on THESE views (the headline
+        # pose is view 0 only), so that the cost of motion is separated from the cost of the other views
+        el_each = []
+        for c in cams8:
+            el_each.append(timed(lambda i, c=c: r.forward(c, img, sync=False), max(8, args.steps // 4), 3) /
+                           max(8, args.steps // 4))
+        static_mean_ms = 1e3 * sum(el_each) / len(el_each)
+        moving = {"value": round(world * args.steps / el_m, 2), "unit": "frames/s",
+                  "ms_per_step": round(el_m * 1e3 / args.steps, 4), "views": 8,
+                  "same_views_static_ms_per_step": round(static_mean_ms, 4),
+                  "motion_overhead": round(el_m * 1e3 / args.steps / static_mean_ms - 1.0, 4),
+                  "per_view": per_view}
+        r.forward(cam, img, sync=True)  # back to the headline view (hints, schedule)
 
     # ---- per-stage device times (HIP events on the context's stream), outside the timed region
     r.set_profiling(True)
@@ -257,13 +304,17 @@ def main():
     dominant = max(acc, key=acc.get) if acc else "render"
     dom_ms = acc.get(dominant, float("nan"))  # HIP events on the stream the kernel is launched on
     achieved = stage_bytes.get(dominant, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    traffic = None
-    try:  # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (profiles/)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        k = pmc.get(stage_kernel.get(dominant, ""))
+    traffic, pmc_all, pmc_source = None, None, None
+    try:  # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (profiles/, newest round)
+        import glob
+
+        pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+        pmc_source = os.path.relpath(pmc_path, ROOT)
+        pmc_all = json.load(open(pmc_path))
+        k = pmc_all["kernels"].get(stage_kernel.get(dominant, ""))
         if k and data == "synthetic" and P == P_BICYCLE and (W, H) == (1920, 1080):
             traffic = {"fetch_bytes_raw": k["fetch_bytes_raw"], "fetch_bytes_x2_corrected": k["fetch_bytes_x2"],
-                       "write_bytes": k["write_bytes"], "source": "profiles/r01_pmc_traffic.json"}
+                       "write_bytes": k["write_bytes"], "source": pmc_source}
     except Exception:
         traffic = None
     # The dominant kernel is VALU-issue-bound, not HBM-bound: beside the mandatory HBM figures, its VALU issue
@@ -273,7 +324,9 @@ def main():
     valu = None
     try:
         import ast
-        for line in open(os.path.join(ROOT, "profiles", "r01_pmc_sq.txt")):
+        import glob
+
+        for line in open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.txt")))[-1]):
             if line.startswith(stage_kernel.get(dominant, "?") + " "):
                 insts = ast.literal_eval(line[line.index("{"):])["SQ_INSTS_VALU"]
                 if data == "synthetic" and P == P_BICYCLE and (W, H) == (1920, 1080) and dominant == "render":
@@ -287,8 +340,31 @@ def main():
                 "algorithmic_bytes_per_launch": stage_bytes.get(dominant, 0), "avg_launch_ms": round(dom_ms, 4),
                 "valu_issue": valu,
                 "note": "the dominant kernel (per-tile compositing) is VALU-issue bound, not HBM bound; see DESIGN.md 4"}
+    # Whole frame, three ways, side by side (none of them is `roofline`, which is the dominant kernel's):
+    #  * survey_model      SURVEY 8(d)'s byte model OF THE REFERENCE ALGORITHM (its L_ref pairs, its 64-bit-key sort passes)
+    #                      / this frame's time: a work-equivalent rate, not bytes this implementation moves;
+    #  * own_algorithmic   the bytes THIS implementation's kernels have to move (DESIGN.md 4 per-unit figures x the
+    #                      measured P, V, L) / the frame time;
+    #  * pmc               what the memory-side counters saw: FETCH_SIZE + WRITE_SIZE summed over one frame's launches
+    #                      (profiles/, same workload), raw and with the gfx950 x2 FETCH_SIZE correction for wide reads.
     frame_bytes = algorithmic_bytes(P, V, Lref, G, W, H)
     frame_gbs = frame_bytes / (ms_per_step * 1e-3) / 1e9
+    own_bytes = sum(stage_bytes.values())
+    frame_views = {"survey_model": {"bytes": frame_bytes, "GB/s": round(frame_gbs, 1), "frac": round(frame_gbs / HBM_PEAK_GBS, 4)},
+                   "own_algorithmic": {"bytes": own_bytes, "GB/s": round(own_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                                       "frac": round(own_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "per_stage_bytes": stage_bytes}}
+    if pmc_all and data == "synthetic" and P == P_BICYCLE and (W, H) == (1920, 1080):
+        fwd_kernels = pmc_all.get("forward_frame_launches")  # {kernel: launches per frame}
+        if fwd_kernels:
+            raw = sum(pmc_all["kernels"][k]["fetch_bytes_raw"] * n for k, n in fwd_kernels.items() if k in pmc_all["kernels"])
+            wr = sum(pmc_all["kernels"][k]["write_bytes"] * n for k, n in fwd_kernels.items() if k in pmc_all["kernels"])
+            sec = ms_per_step * 1e-3
+            frame_views["pmc"] = {"fetch_bytes_raw": raw, "fetch_bytes_x2": 2 * raw, "write_bytes": wr,
+                                  "GB/s_raw": round((raw + wr) / sec / 1e9, 1), "GB/s_x2": round((2 * raw + wr) / sec / 1e9, 1),
+                                  "frac_raw": round((raw + wr) / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                  "frac_x2": round((2 * raw + wr) / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                  "source": pmc_source}
 
     out = {
         "metric": "forward fps @1080p, mip360_bicycle", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
@@ -298,8 +374,7 @@ def main():
                    "tile_pairs_reference": Lref, "tile_pairs_sorted": Lp, "views_per_gpu": 1,
                    "parallelism": f"view-parallel x{world}"},
         "roofline": roofline,
-        "frame_roofline": {"algorithmic_bytes": frame_bytes, "achieved": round(frame_gbs, 1), "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": round(frame_gbs / HBM_PEAK_GBS, 4)},
+        "frame_roofline": {"peak": HBM_PEAK_GBS, "unit": "GB/s", **frame_views},
         "stages_ms": {k: round(v, 4) for k, v in acc.items()},
     }
     if stage_path is not None:
@@ -308,54 +383,66 @@ def main():
         out["half_sh"] = half_sh
     if pipelined is not None:
         out["camera_batch"] = pipelined
+    if moving is not None:
+        out["moving_camera"] = moving
 
-    # ---- forward + backward (+ RCCL all-reduce of the dense per-splat gradients when N > 1): one training-style step
-    # per view; Msplats/s = splats x views / time.  Same barrier / max-over-ranks protocol.
+    # ---- forward + backward (+ the RCCL sum of the dense per-splat gradients when N > 1): one training-style step per
+    # view through the package's view-parallel protocol (luisacomputegaussiansplatting_amd.multi_gpu: the same
+    # ViewParallelTrainer tests/test_distributed.py runs on gloo); Msplats/s = splats x views / time.
+    # Same barrier / max-over-ranks timing.
+    KEYS = mg.KEYS
+    coll = None
     if not args.no_backward:
         gbuf = torch.zeros(59 * P, device=dev)  # pos 3 | scale 3 | rotq 4 | sh 48 | opacity 1, one flat buffer
         o0 = 0
         views = {}
         for name, width in (("pos", 3), ("scale", 3), ("rotq", 4), ("sh", 48), ("opacity", 1)):
-            views[name] = gbuf[o0:o0 + width * P]
+            views[name] = gbuf[o0:o0 + width * P].view(P, width) if width > 1 else gbuf[o0:o0 + P]
             o0 += width * P
         dL = torch.randn(3, H, W, device=dev)
-
-        def train_step(collective=True, compact=False):
-            r.forward(cam, img, keep_state=True, sync=False)
-            r.backward(dL, views["pos"], views["scale"], views["rotq"], views["sh"], views["opacity"], compact=compact)
-            if dist is not None and collective:
-                dist.all_reduce(gbuf)  # sum of the per-view gradients over xGMI
+        if dist is not None:
+            if args.collective == "rccl":
+                def exchange(payload):  # rank 0's 128-byte rendezvous token to everybody, over the process group
+                    t = torch.zeros(128, dtype=torch.uint8, device=dev)
+                    if payload is not None:
+                        t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+                    dist.broadcast(t, 0)
+                    return t.cpu().numpy().tobytes()
+                coll = mg.RcclCollective(ctx, rank, world, exchange)
+            else:
+                coll = mg.TorchCollective(dist, rank, world)
+        engine = mg.HipEngine(r, raw=None, activated=d, lr=None)  # gradients only: no optimiser state
+        tr_sum = mg.ViewParallelTrainer(engine, coll, [cam], views, mode="allreduce" if coll is not None else "local")
+        tr_local = mg.ViewParallelTrainer(engine, None, [cam], views, mode="local")
+        warm = max(1, args.warmup)
 
         def timed_steps(collective, compact=False):
-            for _ in range(max(1, args.warmup)):
-                train_step(collective, compact)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                train_step(collective, compact)
-            barrier()
-            el = time.perf_counter() - t0
-            if dist is not None:
-                tt = torch.tensor([el], device=dev, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                el = float(tt.item())
-            return el
+            engine.compact_rows = compact
+            tr = tr_sum if collective else tr_local
+            el_ = timed(lambda i: tr.step(dL, optimise=False), args.steps, warm)
+            engine.compact_rows = False
+            return el_
 
         el = timed_steps(True)
-        # N > 1: the same steps without the gradient all-reduce, so that the collective's share is visible
+        # N > 1: the same steps without the gradient collective, so that its share is visible
         el_local = timed_steps(False) if dist is not None else None
         # N = 1: the same step with compact gradient rows (lcgs_render_backward_compact: one row per on-screen splat,
-        # no zero-fill) -- reported beside the dense figure, which stays `value` (an all-reduce needs per-splat rows)
+        # no zero-fill) -- reported beside the dense figure, which stays `value` (a sum over views needs per-splat rows)
         el_compact = timed_steps(False, compact=True) if dist is None else None
         r.set_profiling(True)
         r.forward(cam, img, keep_state=True, sync=True)
-        r.backward(dL, views["pos"], views["scale"], views["rotq"], views["sh"], views["opacity"])
+        r.backward(dL, *[views[k] for k in KEYS])
         bwd_stages = r.stage_times()
         r.set_profiling(False)
         out["fwd_bwd"] = {"metric": "fwd+bwd Msplats/s", "value": round(world * P * args.steps / el / 1e6, 1),
                           "unit": "Msplats/s", "ms_per_step": round(el * 1e3 / args.steps, 4),
                           "grad_allreduce_bytes_per_gpu": 59 * 4 * P if world > 1 else 0,
+                          "xgmi_bytes_sent_per_gpu": mg.allreduce_bus_bytes_per_gpu(P, world),
+                          "collective": coll.name if coll is not None else None,
                           "backward_stages_ms": {k: round(v, 4) for k, v in bwd_stages.items()}}
+        if dist is not None:
+            out["fwd_bwd"]["note"] = ("gradient collective: lcgs_grads_allreduce (RCCL, chunked behind the backward's "
+                                      "slices)" if args.collective == "rccl" else "gradient collective: torch.distributed")
         if el_compact is not None:
             out["fwd_bwd"]["compact_rows"] = {"value": round(P * args.steps / el_compact / 1e6, 1), "unit": "Msplats/s",
                                               "ms_per_step": round(el_compact * 1e3 / args.steps, 4)}
@@ -363,48 +450,50 @@ def main():
             out["fwd_bwd"]["without_collective"] = {"value": round(world * P * args.steps / el_local / 1e6, 1),
                                                     "unit": "Msplats/s",
                                                     "ms_per_step": round(el_local * 1e3 / args.steps, 4)}
+        if not args.no_moving_camera:
+            # every rank a different one of the eight C5 views at every step (view_of_rank), collective included
+            cams8 = [L.get_lookat_cam(*view_pose(k), width=W, height=H) for k in range(8)]
+            tr_mov = mg.ViewParallelTrainer(engine, coll, cams8, views, mode="allreduce" if coll is not None else "local")
+            el_mv = timed(lambda i: tr_mov.step(dL, optimise=False), args.steps, max(warm, 8))
+            out["fwd_bwd"]["moving_camera"] = {"value": round(world * P * args.steps / el_mv / 1e6, 1), "unit": "Msplats/s",
+                                               "ms_per_step": round(el_mv * 1e3 / args.steps, 4), "views": 8}
+            r.forward(cam, img, sync=True)
 
         # ---- full training-style step: + the optimiser (gradients -> Adam on the raw parameters -> refreshed
-        # activated arrays, lcgs_adam_step), dense and restricted to the splats on screen
+        # activated arrays).  N = 1: dense, restricted to the on-screen splats, and on compact rows.
+        # N > 1: "allreduce" (lcgs_grads_allreduce + a dense lcgs_adam_step on every rank) and "sharded"
+        # (lcgs_adam_step_sharded: reduce-scatter -> Adam on the own rows -> all-gather of the activated arrays).
         if not args.no_train_step:
             # (on a copy of the scene: exp(log(s)) is not s to the last bit, and the parity block below compares the
             # frame of the pristine scene)
-            act = {k: d[k].clone() for k in ("pos", "scale", "rotq", "sh", "opacity")}
+            act = {k: d[k].clone() for k in KEYS}
             raw = {"pos": act["pos"], "scale": torch.log(act["scale"]), "rotq": act["rotq"].clone(), "sh": act["sh"],
                    "opacity": torch.log(act["opacity"] / (1 - act["opacity"]))}
-            r.bind_scene(act["pos"], act["scale"], act["rotq"], act["sh"], act["opacity"])
-            mom = [{k: torch.zeros_like(t) for k, t in raw.items()} for _ in range(2)]
             lr = {"pos": 0.0, "sh_dc": 0.0, "sh_rest": 0.0, "opacity": 0.0, "scale": 0.0, "rot": 0.0}  # scene stays put
+            eng2 = mg.HipEngine(r, raw=raw, activated=act, lr=lr)  # (binds `act` to the renderer)
             out["train_step"] = {}
-            # "visible_only_compact" (N = 1 only: an all-reduce needs per-splat rows): the backward writes compact
-            # gradient rows (lcgs_render_backward_compact: no zero-fill, consecutive rows) and the optimiser reads them
-            modes = ("dense", "visible_only") + (("visible_only_compact",) if dist is None else ())
+            if dist is None:
+                modes = ("dense", "visible_only", "visible_only_compact")
+            else:
+                modes = ("allreduce", "sharded")
             for mode in modes:
-                def full_step(i):
-                    if mode == "visible_only_compact":
+                if dist is None:
+                    def full_step(i, mode=mode):
+                        compact = mode == "visible_only_compact"
                         r.forward(cam, img, keep_state=True, sync=False)
-                        r.backward(dL, views["pos"], views["scale"], views["rotq"], views["sh"], views["opacity"],
-                                   compact=True)
-                        r.adam_step(views, raw, mom[0], mom[1], act, i + 1, lr, visible_only=True, compact_grads=True)
-                        return
-                    train_step()
-                    r.adam_step(views, raw, mom[0], mom[1], act, i + 1, lr, visible_only=(mode == "visible_only"))
-                for i in range(2):
-                    full_step(i)
-                barrier()
-                t0 = time.perf_counter()
-                for i in range(args.steps):
-                    full_step(i)
-                barrier()
-                el2 = time.perf_counter() - t0
-                if dist is not None:
-                    tt = torch.tensor([el2], device=dev, dtype=torch.float64)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    el2 = float(tt.item())
+                        r.backward(dL, *[views[k] for k in KEYS], compact=compact)
+                        r.adam_step(views, raw, eng2.m, eng2.v, act, i + 1, lr, visible_only=(mode != "dense"),
+                                    compact_grads=compact)
+                else:
+                    tr = mg.ViewParallelTrainer(eng2, coll, [cam], views, mode=mode)
+
+                    def full_step(i, tr=tr):
+                        tr.step(dL, optimise=True)
+                el2 = timed(full_step, args.steps, 2)
                 out["train_step"][mode] = {"value": round(world * P * args.steps / el2 / 1e6, 1), "unit": "Msplats/s",
                                            "ms_per_step": round(el2 * 1e3 / args.steps, 4)}
             r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
-            del act, raw, mom
+            del act, raw, eng2
 
     # ---- the same frames with the scene in spatial (Morton) order: lcgs_scene_reorder_spatial, an ingest option
     # (SURVEY 8f rank 1).  Same splats, same image; the splats of a view then sit in runs of consecutive rows instead
@@ -435,7 +524,7 @@ def main():
             # the caller's copy in the new order: what a training loop would own (gradients follow it)
             dp = {k: d[k][perm].contiguous() for k in d}
             r.bind_scene(dp["pos"], dp["scale"], dp["rotq"], dp["sh"], dp["opacity"])
-            for compact in (False, True):
+            for compact in ((False, True) if dist is None else (False,)):
                 el_b = timed_steps(False, compact=compact)  # (per-view steps; no collective in this leg)
                 sp["fwd_bwd_compact_rows" if compact else "fwd_bwd"] = {
                     "value": round(world * P * args.steps / el_b / 1e6, 1), "unit": "Msplats/s",
@@ -469,6 +558,9 @@ def main():
                          "pixels_over_1e-4": int((diff > 1e-4).sum()), "max_abs_diff": float(diff.max())}
     if rank == 0:
         print(json.dumps(out))
+    if coll is not None:
+        barrier()
+        coll.close()
     if dist is not None:
         dist.destroy_process_group()
 

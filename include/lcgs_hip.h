@@ -280,7 +280,8 @@ LCGS_API lcgs_status lcgs_scene_reorder_spatial(lcgs_context* ctx, uint32_t* d_p
  * scale = exp(raw.scale), opacity = sigmoid(raw.opacity), rotq = raw.rotq / |raw.rotq|.  One call maps the
  * gradients w.r.t. the ACTIVATED values (lcgs_render_backward's outputs, possibly summed over views) to the raw
  * parameters, applies Adam (torch.optim.Adam semantics, per-attribute learning rates, `step` counts from 1) to
- * raw / m / v in place and rewrites the activated arrays (`activated`; pos and sh may alias raw.pos / raw.sh).
+ * raw / m / v in place and rewrites the activated arrays (`activated`; pos and sh may alias raw.pos / raw.sh, or be
+ * separate buffers -- the arrays bound to the renderer -- which are then rewritten too).
  * All pointers are device arrays laid out like the scene (3P, 3P, 4P, P*(deg+1)^2*3, P).
  * visible_only != 0: only the splats that reached the screen in the last lcgs_render_forward of this context are
  * touched ("sparse Adam").  Enqueues on the context's stream. */
@@ -301,6 +302,46 @@ typedef struct lcgs_adam_config {
 LCGS_API lcgs_status lcgs_adam_step(lcgs_context* ctx, int num_gaussians, int sh_degree, const lcgs_adam_config* cfg,
                                     const lcgs_grads* grads, const lcgs_params* raw, const lcgs_params* m,
                                     const lcgs_params* v, const lcgs_params* activated);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU.  No counterpart in the reference, which drives one device (app/main.cpp:162-163).
+ * One process per GPU; the scene is replicated; a batch of views is sharded one view per GPU (no data-path collective in
+ * the forward); the backward's dense per-splat gradients are summed over the ranks by RCCL over xGMI.  RCCL is bound
+ * at run time (the copy the process already carries, else the ROCm installation's); without it these calls fail with
+ * LCGS_ERR_NO_DEVICE and nothing else in the library is affected.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct lcgs_comm lcgs_comm;
+/* The rendezvous token (an ncclUniqueId): made by ONE rank, carried to the others by whatever channel the host has
+ * (a pipe, a file, torch.distributed's store -- lcgs-app and the Python driver show two). */
+typedef struct lcgs_comm_id {
+    char bytes[128];
+} lcgs_comm_id;
+LCGS_API lcgs_status lcgs_comm_unique_id(lcgs_comm_id* out);
+/* Collective over all ranks (ncclCommInitRank).  The communicator is attached to `ctx` (one per context): from then on
+ * lcgs_render_backward runs its per-splat pass as splat-range slices so that lcgs_grads_allreduce can overlap it. */
+LCGS_API lcgs_status lcgs_comm_create(lcgs_context* ctx, const lcgs_comm_id* id, int rank, int world_size,
+                                      lcgs_comm** out);
+LCGS_API lcgs_status lcgs_comm_destroy(lcgs_comm* comm);
+LCGS_API lcgs_status lcgs_comm_info(const lcgs_comm* comm, int* rank, int* world_size);
+/* Row ownership of the sharded step: rank r owns rows [first, first + count) with count = floor(P / N); the last
+ * P mod N rows ("the tail") are kept up to date by every rank. */
+LCGS_API void lcgs_comm_shard_rows(int64_t num_gaussians, int world_size, int rank, int64_t* first, int64_t* count);
+
+/* In-place sum over all ranks of the five dense gradient arrays (lcgs_render_backward's outputs).  Issued on the
+ * communicator's own stream in splat-range chunks, each behind the event of the backward slice that produced its rows, so
+ * the first chunks travel while the backward's tail is still computing; the context's stream then waits for the sums
+ * (enqueue lcgs_adam_step right behind it).  1.45 GB per GPU for the 6.1 M-splat scene: 2 (N-1)/N of that crosses xGMI
+ * per GPU. */
+LCGS_API lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* comm, int num_gaussians, int sh_degree,
+                                          const lcgs_grads* grads);
+/* The whole optimiser step at N > 1 without replicated optimiser work: reduce-scatter of the gradients -> lcgs_adam_step on
+ * the rank's own rows (+ the tail) -> all-gather of the refreshed ACTIVATED arrays.  Same bytes on the wire as
+ * lcgs_grads_allreduce + a dense lcgs_adam_step, exact same arithmetic per row, 1/N of the optimiser's HBM traffic per
+ * GPU.  raw / m / v are authoritative for the own rows (and the tail) only; `activated` is complete on every rank
+ * afterwards.  Dense only (cfg->visible_only must be 0). */
+LCGS_API lcgs_status lcgs_adam_step_sharded(lcgs_context* ctx, lcgs_comm* comm, int num_gaussians, int sh_degree,
+                                            const lcgs_adam_config* cfg, const lcgs_grads* grads, const lcgs_params* raw,
+                                            const lcgs_params* m, const lcgs_params* v, const lcgs_params* activated);
 
 /* ------------------------------------------------------------------------------------------
  * Scene ingest / image egress (host side of `render(ply, camera) -> image`)

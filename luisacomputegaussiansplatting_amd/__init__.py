@@ -8,8 +8,10 @@ that C ABI.  torch is used only as the owner of device memory and streams.
 There is no CPU fallback: every operator raises ``LcgsError`` if the HIP library is missing or no
 gfx950 device is present.
 """
+from . import api  # noqa: F401
 from .api import (  # noqa: F401
     Camera,
+    Comm,
     Context,
     GSProjector,
     GSProjectorInputProxy,
@@ -31,6 +33,7 @@ from .api import (  # noqa: F401
     projection_matrix,
     read_gs_ply,
     render_autograd,
+    shard_rows,
     synth_scene,
     world_to_local_matrix,
     write_png,

@@ -143,6 +143,8 @@ EXPORTED_SYMBOLS = [
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh",
+    "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_shard_rows",
+    "lcgs_grads_allreduce", "lcgs_adam_step_sharded",
 ]
 
 
@@ -169,7 +171,7 @@ def load_library():
         fn = getattr(lib, name)
         if name not in ("lcgs_version", "lcgs_last_error", "lcgs_get_lookat_cam", "lcgs_local_to_world_matrix",
                         "lcgs_world_to_local_matrix", "lcgs_projection_matrix", "lcgs_scene_host_free",
-                        "lcgs_image_to_rgb8"):
+                        "lcgs_image_to_rgb8", "lcgs_comm_shard_rows"):
             fn.restype = C.c_int
     lib.lcgs_get_lookat_cam.restype = None
     lib.lcgs_local_to_world_matrix.restype = None
@@ -177,6 +179,8 @@ def load_library():
     lib.lcgs_projection_matrix.restype = None
     lib.lcgs_scene_host_free.restype = None
     lib.lcgs_image_to_rgb8.restype = None
+    lib.lcgs_comm_shard_rows.restype = None
+    lib.lcgs_comm_shard_rows.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.lcgs_projection_matrix.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
     _lib = lib
     return lib
@@ -555,6 +559,73 @@ class Renderer:
         packs = [_Params(*[_ptr(d[k]) for k in keys]) for d in (raw, m, v, activated)]
         _check(load_library().lcgs_adam_step(self.ctx._h, C.c_int(P), C.c_int(sh_degree), C.byref(cfg), C.byref(g),
                                              *[C.byref(p) for p in packs]))
+
+
+def _adam_config(lr: dict, betas, eps: float, step: int, visible_only: int) -> _AdamConfig:
+    return _AdamConfig(lr["pos"], lr["sh_dc"], lr["sh_rest"], lr["opacity"], lr["scale"], lr["rot"], betas[0], betas[1], eps,
+                       int(step), int(visible_only))
+
+
+_KEYS = ("pos", "scale", "rotq", "sh", "opacity")
+
+
+def shard_rows(num_gaussians: int, world_size: int, rank: int):
+    """lcgs_comm_shard_rows: (first, count) of the rows rank `rank` owns in the sharded optimiser step; the last
+    num_gaussians mod world_size rows (the tail) are kept by every rank.  Pure host arithmetic (no GPU needed)."""
+    first, count = C.c_int64(0), C.c_int64(0)
+    load_library().lcgs_comm_shard_rows(C.c_int64(num_gaussians), C.c_int(world_size), C.c_int(rank), C.byref(first),
+                                        C.byref(count))
+    return first.value, count.value
+
+
+class Comm:
+    """lcgs_comm: the RCCL communicator of a view-parallel job, attached to one context.
+
+    `exchange(payload: bytes | None) -> bytes` carries the 128-byte rendezvous token from rank 0 (which passes it in)
+    to every other rank (which pass None): any broadcast the host has (torch.distributed, a pipe, a file)."""
+
+    def __init__(self, ctx: Context, rank: int, world_size: int, exchange=None):
+        lib = load_library()
+        token = (C.c_char * 128)()
+        if rank == 0:
+            _check(lib.lcgs_comm_unique_id(token))
+        if world_size > 1 or exchange is not None:
+            if exchange is None:
+                raise ValueError("world_size > 1 needs an exchange function for the rendezvous token")
+            got = exchange(bytes(token.raw) if rank == 0 else None)
+            assert len(got) == 128
+            C.memmove(token, got, 128)
+        self.ctx, self.rank, self.world_size = ctx, rank, world_size
+        self._h = C.c_void_p(0)
+        _check(lib.lcgs_comm_create(ctx._h, token, C.c_int(rank), C.c_int(world_size), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load_library().lcgs_comm_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allreduce_grads(self, grads: dict, sh_degree: int = 3):
+        """lcgs_grads_allreduce: in-place sum over the ranks of the five dense gradient arrays (chunked, overlapping the
+        backward's tail); the context's stream waits for the result."""
+        P = int(grads["pos"].shape[0])
+        g = _Grads(*[_ptr(grads[k]) for k in _KEYS])
+        _check(load_library().lcgs_grads_allreduce(self.ctx._h, self._h, C.c_int(P), C.c_int(sh_degree), C.byref(g)))
+
+    def adam_step_sharded(self, grads: dict, raw: dict, m: dict, v: dict, activated: dict, step: int, lr: dict,
+                          betas=(0.9, 0.999), eps: float = 1e-15, sh_degree: int = 3):
+        """lcgs_adam_step_sharded: reduce-scatter -> Adam on the own rows (+ tail) -> all-gather of the activated arrays."""
+        P = int(raw["pos"].shape[0])
+        cfg = _adam_config(lr, betas, eps, step, 0)
+        g = _Grads(*[_ptr(grads[k]) for k in _KEYS])
+        packs = [_Params(*[_ptr(d[k]) for k in _KEYS]) for d in (raw, m, v, activated)]
+        _check(load_library().lcgs_adam_step_sharded(self.ctx._h, self._h, C.c_int(P), C.c_int(sh_degree), C.byref(cfg),
+                                                     C.byref(g), *[C.byref(p) for p in packs]))
 
 
 def render_autograd(renderer: "Renderer", cam: Camera, pos, scale, rotq, sh, opacity, bg=(0.0, 0.0, 0.0),

@@ -1,0 +1,365 @@
+// comm.cpp -- multi-GPU side of the C ABI: one process per GPU, the scene replicated, every rank renders
+// its own view(s); the dense per-splat gradients are summed over the ranks with RCCL over xGMI.  The reference is
+// single-device (app/main.cpp:162-163): everything here is new functionality behind the same boundary.
+//
+// RCCL is bound at run time (dlopen), not at link time: a process that already carries a copy -- torch ships its own
+// librccl.so next to its libamdhip64.so -- keeps using that one (two copies of a HIP-facing runtime in one process do
+// not end well), a process without one loads the ROCm installation's, and liblcgs_hip.so still loads on a machine
+// where RCCL is absent (the lcgs_comm_* calls then fail with a message; nothing else needs it).
+//
+// Two ways through a training step at N > 1, both exact in f32:
+//   lcgs_grads_allreduce     in-place sum of the five dense gradient arrays, issued as splat-range CHUNKS on a
+//                            dedicated stream: the dense backward runs its preprocess pass as slices and records an event
+//                            behind each (lcgs_abi.cpp render_backward), so chunk k is on the wire while slices k+1.. are
+//                            still being computed.  (SURVEY 8e sketched per-attribute chunks; one kernel writes all five
+//                            attributes of a splat, so the chunks are row ranges -- same idea, same bytes.)
+//   lcgs_adam_step_sharded   reduce-scatter -> Adam on the rank's own rows -> all-gather of the refreshed activated
+//                            arrays.  The wire carries what the all-reduce carries ((N-1)/N S out and in per GPU, twice),
+//                            but the optimiser touches P/N rows per GPU instead of P (2.2 ms -> 0.27 ms at N = 8 for the
+//                            bicycle stand-in), and moments / raw parameters are only ever needed for the own rows.
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <new>
+#include <string>
+#include <type_traits>
+
+#include <rccl/rccl.h> // types and enums only: every entry point is resolved with dlsym
+
+#include "../common.hpp"
+#include "../context.hpp"
+
+using namespace lcgs;
+
+namespace
+{
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*)                                                                = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int)                                         = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t)                                                                   = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t)            = nullptr;
+    ncclResult_t (*GroupStart)()                                                                              = nullptr;
+    ncclResult_t (*GroupEnd)()                                                                                = nullptr;
+    const char* (*GetErrorString)(ncclResult_t)                                                               = nullptr;
+    std::string error; // why loading failed
+};
+
+RcclApi& rccl()
+{
+    static RcclApi       api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        for (const char* n : names) // a copy the process already carries (torch's) wins
+            if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char* n : names)
+            if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!api.handle) {
+            const char* e = dlerror();
+            api.error     = std::string("RCCL is not available (dlopen librccl.so.1: ") + (e ? e : "?") + ")";
+            return;
+        }
+        bool ok = true;
+        auto bind = [&](auto& fn, const char* sym) {
+            fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(api.handle, sym));
+            if (!fn) {
+                ok        = false;
+                api.error = std::string("librccl lacks ") + sym;
+            }
+        };
+        bind(api.GetUniqueId, "ncclGetUniqueId");
+        bind(api.CommInitRank, "ncclCommInitRank");
+        bind(api.CommDestroy, "ncclCommDestroy");
+        bind(api.AllReduce, "ncclAllReduce");
+        bind(api.ReduceScatter, "ncclReduceScatter");
+        bind(api.AllGather, "ncclAllGather");
+        bind(api.GroupStart, "ncclGroupStart");
+        bind(api.GroupEnd, "ncclGroupEnd");
+        bind(api.GetErrorString, "ncclGetErrorString");
+        if (!ok) api.handle = nullptr;
+    });
+    return api;
+}
+
+lcgs_status rccl_fail(ncclResult_t r, const char* what, int line)
+{
+    char buf[384];
+    snprintf(buf, sizeof(buf), "RCCL error %d (%s) in `%s` at comm.cpp:%d", (int)r,
+             rccl().GetErrorString ? rccl().GetErrorString(r) : "?", what, line);
+    set_last_error(buf);
+    return LCGS_ERR_HIP;
+}
+
+#define LCGS_RCCL_CHECK(expr)                                              \
+    do {                                                                   \
+        ncclResult_t _r = (expr);                                          \
+        if (_r != ncclSuccess) return rccl_fail(_r, #expr, __LINE__);      \
+    } while (0)
+
+#define LCGS_TRY(expr)                    \
+    do {                                  \
+        lcgs_status _s = (expr);          \
+        if (_s != LCGS_OK) return _s;     \
+    } while (0)
+
+lcgs_status need_rccl()
+{
+    if (rccl().handle) return LCGS_OK;
+    set_last_error(rccl().error.empty() ? "RCCL is not available" : rccl().error);
+    return LCGS_ERR_NO_DEVICE;
+}
+
+struct AttrRows {
+    float* ptr[5];
+    size_t width[5]; // floats per splat: pos 3, scale 3, rotq 4, sh (deg+1)^2*3, opacity 1
+};
+
+AttrRows attr_rows(const lcgs_grads* g, int sh_degree)
+{
+    const size_t feat = (size_t)(sh_degree + 1) * (sh_degree + 1) * 3;
+    return { { g->d_dL_dpos, g->d_dL_dscale, g->d_dL_drotq, g->d_dL_dsh, g->d_dL_dopacity }, { 3, 3, 4, feat, 1 } };
+}
+
+AttrRows attr_rows(const lcgs_params* p, int sh_degree)
+{
+    const size_t feat = (size_t)(sh_degree + 1) * (sh_degree + 1) * 3;
+    return { { p->pos, p->scale, p->rotq, p->sh, p->opacity }, { 3, 3, 4, feat, 1 } };
+}
+
+} // namespace
+
+struct lcgs_comm {
+    lcgs_context* ctx    = nullptr;
+    ncclComm_t    comm   = nullptr;
+    int           rank   = 0, world = 1;
+    hipStream_t   stream = nullptr; // the collectives' own stream: they overlap the compute stream's tail
+    hipEvent_t    ev_in = nullptr, ev_out = nullptr;
+};
+
+namespace lcgs
+{
+void comm_forget_context(lcgs_comm* c)
+{
+    if (!c) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->ctx = nullptr;
+}
+} // namespace lcgs
+
+extern "C" {
+
+lcgs_status lcgs_comm_unique_id(lcgs_comm_id* out)
+{
+    LCGS_REQUIRE(out != nullptr, "out is NULL");
+    static_assert(sizeof(lcgs_comm_id) == sizeof(ncclUniqueId), "lcgs_comm_id must hold an ncclUniqueId");
+    LCGS_TRY(need_rccl());
+    ncclUniqueId id;
+    LCGS_RCCL_CHECK(rccl().GetUniqueId(&id));
+    memcpy(out->bytes, id.internal, sizeof(id.internal));
+    return LCGS_OK;
+}
+
+void lcgs_comm_shard_rows(int64_t num_gaussians, int world_size, int rank, int64_t* first, int64_t* count)
+{
+    // equal shards of floor(P / N) rows; the P mod N rows behind them ("the tail") belong to every rank
+    const int64_t c = world_size > 0 ? num_gaussians / world_size : num_gaussians;
+    if (first) *first = c * rank;
+    if (count) *count = c;
+}
+
+lcgs_status lcgs_comm_create(lcgs_context* ctx, const lcgs_comm_id* id, int rank, int world_size, lcgs_comm** out)
+{
+    LCGS_REQUIRE(ctx && id && out, "NULL argument");
+    *out = nullptr;
+    LCGS_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "rank / world_size out of range");
+    LCGS_REQUIRE(ctx->comm == nullptr, "the context already has a communicator attached");
+    LCGS_TRY(need_rccl());
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    lcgs_comm* c = new (std::nothrow) lcgs_comm();
+    if (!c) return LCGS_ERR_OUT_OF_MEMORY;
+    c->ctx   = ctx;
+    c->rank  = rank;
+    c->world = world_size;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)lcgs_comm_destroy(c);
+        LCGS_HIP_CHECK(e);
+    }
+    ncclUniqueId nid;
+    memcpy(nid.internal, id->bytes, sizeof(nid.internal));
+    ncclResult_t r = rccl().CommInitRank(&c->comm, world_size, nid, rank);
+    if (r != ncclSuccess) {
+        c->comm = nullptr;
+        (void)lcgs_comm_destroy(c);
+        return rccl_fail(r, "ncclCommInitRank", __LINE__);
+    }
+    ctx->comm = c;
+    // chunked all-reduce: the dense backward slices its preprocess pass (tuning hook LCGS_GRAD_SLICES; 1 = one chunk)
+    int slices = 4;
+    if (const char* s = getenv("LCGS_GRAD_SLICES")) slices = atoi(s);
+    ctx->grad_slices = std::min(std::max(slices, 1), kMaxGradSlices);
+    *out = c;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_comm_destroy(lcgs_comm* c)
+{
+    if (!c) return LCGS_OK;
+    if (c->ctx) {
+        (void)hipSetDevice(c->ctx->device);
+        if (c->ctx->comm == c) {
+            c->ctx->comm        = nullptr;
+            c->ctx->grad_slices = 1;
+        }
+    }
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_comm_info(const lcgs_comm* c, int* rank, int* world_size)
+{
+    LCGS_REQUIRE(c != nullptr, "comm is NULL");
+    if (rank) *rank = c->rank;
+    if (world_size) *world_size = c->world;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* c, int num_gaussians, int sh_degree,
+                                 const lcgs_grads* grads)
+{
+    LCGS_REQUIRE(ctx && c && grads, "NULL argument");
+    LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another (or a destroyed) context");
+    LCGS_REQUIRE(num_gaussians >= 0 && sh_degree >= 0 && sh_degree <= 3, "bad num_gaussians / sh_degree");
+    LCGS_REQUIRE(grads->d_dL_dpos && grads->d_dL_dscale && grads->d_dL_drotq && grads->d_dL_dsh && grads->d_dL_dopacity,
+                 "NULL gradient buffer");
+    if (num_gaussians == 0) return LCGS_OK;
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    const AttrRows a = attr_rows(grads, sh_degree);
+    const int64_t  P = num_gaussians;
+    // chunks = the slices the last dense backward recorded for these very arrays; else one chunk behind the stream's tail
+    const bool chunked = ctx->slices_recorded > 1 && ctx->slices_of == (const void*)grads->d_dL_dpos && ctx->P == num_gaussians;
+    const int  K       = chunked ? ctx->slices_recorded : 1;
+    if (!chunked) {
+        LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    }
+    for (int k = 0; k < K; ++k) {
+        if (chunked) LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, ctx->ev_slice[k], 0));
+        const int64_t r0 = (int64_t)(((uint64_t)P * (uint64_t)k) / (uint64_t)K);       // (k_slice_bounds' split)
+        const int64_t r1 = (int64_t)(((uint64_t)P * (uint64_t)(k + 1)) / (uint64_t)K);
+        if (r1 <= r0) continue;
+        LCGS_RCCL_CHECK(rccl().GroupStart());
+        for (int i = 0; i < 5; ++i) {
+            float* p = a.ptr[i] + (size_t)r0 * a.width[i];
+            ncclResult_t r = rccl().AllReduce(p, p, (size_t)(r1 - r0) * a.width[i], ncclFloat32, ncclSum, c->comm, c->stream);
+            if (r != ncclSuccess) {
+                (void)rccl().GroupEnd();
+                return rccl_fail(r, "ncclAllReduce", __LINE__);
+            }
+        }
+        LCGS_RCCL_CHECK(rccl().GroupEnd());
+    }
+    ctx->slices_recorded = 0; // consumed
+    // whatever the caller enqueues next on the context's stream (the optimiser) sees the sums
+    LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
+    LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_adam_step_sharded(lcgs_context* ctx, lcgs_comm* c, int num_gaussians, int sh_degree,
+                                   const lcgs_adam_config* cfg, const lcgs_grads* grads, const lcgs_params* raw,
+                                   const lcgs_params* m, const lcgs_params* v, const lcgs_params* activated)
+{
+    LCGS_REQUIRE(ctx && c && cfg && grads && raw && m && v && activated, "NULL argument");
+    LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another context");
+    LCGS_REQUIRE(cfg->visible_only == 0, "the sharded step is dense (per-splat rows): visible_only must be 0");
+    LCGS_REQUIRE(num_gaussians >= 0 && sh_degree >= 0 && sh_degree <= 3, "bad num_gaussians / sh_degree");
+    if (num_gaussians == 0) return LCGS_OK;
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t P = num_gaussians, N = c->world;
+    int64_t       first = 0, count = 0;
+    lcgs_comm_shard_rows(P, c->world, c->rank, &first, &count);
+    const int64_t  tail0 = count * N, tail = P - tail0; // rows every rank keeps (fewer than N)
+    const AttrRows g = attr_rows(grads, sh_degree), act = attr_rows(activated, sh_degree);
+    for (int i = 0; i < 5; ++i) LCGS_REQUIRE(g.ptr[i] && act.ptr[i], "NULL device pointer");
+
+    // ---- 1. reduce-scatter: rank r ends up with the summed gradient rows [r c, (r + 1) c); the tail is all-reduced
+    LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
+    LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    ctx->slices_recorded = 0;
+    LCGS_RCCL_CHECK(rccl().GroupStart());
+    for (int i = 0; i < 5; ++i) {
+        ncclResult_t r = ncclSuccess;
+        if (count > 0)
+            r = rccl().ReduceScatter(g.ptr[i], g.ptr[i] + (size_t)first * g.width[i], (size_t)count * g.width[i], ncclFloat32,
+                                     ncclSum, c->comm, c->stream);
+        if (r == ncclSuccess && tail > 0) {
+            float* t = g.ptr[i] + (size_t)tail0 * g.width[i];
+            r        = rccl().AllReduce(t, t, (size_t)tail * g.width[i], ncclFloat32, ncclSum, c->comm, c->stream);
+        }
+        if (r != ncclSuccess) {
+            (void)rccl().GroupEnd();
+            return rccl_fail(r, "ncclReduceScatter", __LINE__);
+        }
+    }
+    LCGS_RCCL_CHECK(rccl().GroupEnd());
+    LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
+    LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
+
+    // ---- 2. Adam on the own rows (and on the tail, identically on every rank): lcgs_adam_step on row sub-ranges
+    auto sub = [&](const lcgs_params* p, int64_t row) {
+        const AttrRows a = attr_rows(p, sh_degree);
+        lcgs_params    o;
+        o.pos = a.ptr[0] + (size_t)row * a.width[0]; o.scale = a.ptr[1] + (size_t)row * a.width[1];
+        o.rotq = a.ptr[2] + (size_t)row * a.width[2]; o.sh = a.ptr[3] + (size_t)row * a.width[3];
+        o.opacity = a.ptr[4] + (size_t)row * a.width[4];
+        return o;
+    };
+    auto step_rows = [&](int64_t row, int64_t rows) -> lcgs_status {
+        if (rows <= 0) return LCGS_OK;
+        lcgs_grads gg = { g.ptr[0] + (size_t)row * g.width[0], g.ptr[1] + (size_t)row * g.width[1],
+                          g.ptr[2] + (size_t)row * g.width[2], g.ptr[3] + (size_t)row * g.width[3],
+                          g.ptr[4] + (size_t)row * g.width[4] };
+        const lcgs_params r_ = sub(raw, row), m_ = sub(m, row), v_ = sub(v, row), a_ = sub(activated, row);
+        return lcgs_adam_step(ctx, (int)rows, sh_degree, cfg, &gg, &r_, &m_, &v_, &a_);
+    };
+    LCGS_TRY(step_rows(first, count));
+    LCGS_TRY(step_rows(tail0, tail));
+
+    // ---- 3. all-gather of the refreshed ACTIVATED rows (what every rank's renderer reads).  Raw parameters and moments
+    // stay authoritative on their owner only (plus the tail everywhere).
+    LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
+    LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    if (count > 0) {
+        LCGS_RCCL_CHECK(rccl().GroupStart());
+        for (int i = 0; i < 5; ++i) {
+            ncclResult_t r = rccl().AllGather(act.ptr[i] + (size_t)first * act.width[i], act.ptr[i],
+                                              (size_t)count * act.width[i], ncclFloat32, c->comm, c->stream);
+            if (r != ncclSuccess) {
+                (void)rccl().GroupEnd();
+                return rccl_fail(r, "ncclAllGather", __LINE__);
+            }
+        }
+        LCGS_RCCL_CHECK(rccl().GroupEnd());
+    }
+    LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
+    LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
+    return LCGS_OK;
+}
+
+} // extern "C"

@@ -460,19 +460,21 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
                       const uint32_t* __restrict__ vis_index, const uint32_t* __restrict__ d_counts,
                       const float* __restrict__ grads2d, float* __restrict__ dL_dpos, float* __restrict__ dL_dscale,
                       float* __restrict__ dL_drotq, float* __restrict__ dL_dsh, float* __restrict__ dL_dopacity,
-                      int compact)
+                      int compact, const uint32_t* __restrict__ slice_bounds, int slice)
 {
     __shared__ float4 s_sh[4][64 * 13];
-    const uint32_t V = d_counts[0];
+    // the survivors (dense ids) this launch covers: all of them, or slice `slice` of a splat-range split (k_slice_bounds)
+    const uint32_t v0 = slice_bounds ? slice_bounds[slice] : 0u;
+    const uint32_t V  = slice_bounds ? slice_bounds[slice + 1] : d_counts[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int feat = (sh_deg + 1) * (sh_deg + 1);
     const bool staged = sh_deg == 3 && ((reinterpret_cast<uintptr_t>(sh) & 15) == 0) &&
                         ((reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0);
-    for (uint32_t blk = blockIdx.x; blk * 256u < V; blk += gridDim.x) {
-        const uint32_t vid   = blk * 256u + threadIdx.x;
+    for (uint32_t blk = blockIdx.x; v0 + blk * 256u < V; blk += gridDim.x) {
+        const uint32_t vid   = v0 + blk * 256u + threadIdx.x;
         const bool     valid = vid < V;
         const int      idx   = (int)vis_index[valid ? vid : V - 1];
-        const uint32_t wave_first = blk * 256u + wave * 64u;
+        const uint32_t wave_first = v0 + blk * 256u + wave * 64u;
         const uint32_t nvalid     = wave_first < V ? ((V - wave_first) < 64u ? (V - wave_first) : 64u) : 0u;
         float*         row = reinterpret_cast<float*>(&s_sh[wave][lane * 13]); // this lane's 48 floats (+4 pad)
         // Every global operand of this splat is requested here, together with the SH rows below: one memory round
@@ -591,17 +593,19 @@ k_preprocess_backward_jac(CamParams cp, float scale_modifier, const float* __res
                           const uint32_t* __restrict__ vis_index, const uint32_t* __restrict__ d_counts,
                           const float* __restrict__ grads2d, const float4* __restrict__ shjac,
                           float* __restrict__ dL_dpos, float* __restrict__ dL_dscale, float* __restrict__ dL_drotq,
-                          float* __restrict__ dL_dsh, float* __restrict__ dL_dopacity, int compact)
+                          float* __restrict__ dL_dsh, float* __restrict__ dL_dopacity, int compact,
+                          const uint32_t* __restrict__ slice_bounds, int slice)
 {
     __shared__ float s_outer[4][64 * kJacPitch];
-    const uint32_t V = d_counts[0];
+    const uint32_t v0 = slice_bounds ? slice_bounds[slice] : 0u; // (see k_preprocess_backward)
+    const uint32_t V  = slice_bounds ? slice_bounds[slice + 1] : d_counts[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t blk = blockIdx.x; blk * 256u < V; blk += gridDim.x) {
-        const uint32_t vid   = blk * 256u + threadIdx.x;
+    for (uint32_t blk = blockIdx.x; v0 + blk * 256u < V; blk += gridDim.x) {
+        const uint32_t vid   = v0 + blk * 256u + threadIdx.x;
         const bool     valid = vid < V;
         const uint32_t vsafe = valid ? vid : V - 1;
         const int      idx   = (int)vis_index[vsafe];
-        const uint32_t wave_first = blk * 256u + wave * 64u;
+        const uint32_t wave_first = v0 + blk * 256u + wave * 64u;
         const uint32_t nvalid     = wave_first < V ? ((V - wave_first) < 64u ? (V - wave_first) : 64u) : 0u;
         const float4* g2 = reinterpret_cast<const float4*>(grads2d + (size_t)vsafe * kG2D);
         const float4  q0 = g2[0], q1 = g2[1];
@@ -699,24 +703,54 @@ void launch_render_backward(const CamParams& cp, const float bg[3], const uint32
                        bg[1], bg[2], ranges, point_list, recs, final_T, n_contrib, dL_dimg, grads2d, tile_order, strip_masks, d_counts);
 }
 
+// Splat-range slices of the survivors (for the chunked gradient all-reduce, lcgs_grads_allreduce): the dense ids are
+// handed out in ascending splat index, so the survivors whose splat index lies in [k P / K, (k + 1) P / K) are the
+// dense ids [bounds[k], bounds[k + 1]).  One lane per boundary: lower_bound over vis_index[0, V).
+__global__ void __launch_bounds__(64) k_slice_bounds(const uint32_t* __restrict__ vis_index,
+                                                     const uint32_t* __restrict__ d_counts, uint32_t P, int slices,
+                                                     uint32_t* __restrict__ bounds)
+{
+    const int k = threadIdx.x;
+    if (k > slices) return;
+    const uint32_t V = d_counts[0];
+    uint32_t       lo = 0, hi = V; // first dense id whose splat index >= target
+    if (k == slices) lo = V;
+    else {
+        const uint32_t target = (uint32_t)(((uint64_t)P * (uint64_t)k) / (uint64_t)slices);
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (vis_index[mid] < target) lo = mid + 1;
+            else hi = mid;
+        }
+    }
+    bounds[k] = lo;
+}
+
+void launch_slice_bounds(const uint32_t* vis_index, const uint32_t* d_counts, int64_t P, int slices, uint32_t* bounds,
+                         hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_slice_bounds, dim3(1), dim3(64), 0, stream, vis_index, d_counts, (uint32_t)P, slices, bounds);
+}
+
 void launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
                                 const float* scale, const float* rotq, const float* sh, const uint32_t* vis_index,
                                 const uint32_t* d_counts, const float* grads2d, float* dL_dpos, float* dL_dscale,
                                 float* dL_drotq, float* dL_dsh, float* dL_dopacity, hipStream_t stream,
-                                const float4* shjac, bool compact)
+                                const float4* shjac, bool compact, const uint32_t* slice_bounds, int slice, int slices)
 {
-    int64_t blocks = (v_hint + 255) / 256;
+    // (a slice's launch is sized for its share of the hint; larger live counts are strided)
+    int64_t blocks = (v_hint / (slice_bounds ? slices : 1) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 65536) blocks = 65536;
     if (shjac && sh_deg == 3 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0) {
         hipLaunchKernelGGL(k_preprocess_backward_jac, dim3((unsigned)blocks), dim3(256), 0, stream, cp, scale_modifier, pos,
                            scale, rotq, vis_index, d_counts, grads2d, shjac, dL_dpos, dL_dscale, dL_drotq, dL_dsh,
-                           dL_dopacity, compact ? 1 : 0);
+                           dL_dopacity, compact ? 1 : 0, slice_bounds, slice);
         return;
     }
     hipLaunchKernelGGL(k_preprocess_backward, dim3((unsigned)blocks), dim3(256), 0, stream, sh_deg, cp, scale_modifier,
                        pos, scale, rotq, sh, vis_index, d_counts, grads2d, dL_dpos, dL_dscale, dL_drotq, dL_dsh,
-                       dL_dopacity, compact ? 1 : 0);
+                       dL_dopacity, compact ? 1 : 0, slice_bounds, slice);
 }
 
 } // namespace lcgs

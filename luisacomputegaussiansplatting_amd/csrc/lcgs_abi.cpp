@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "context.hpp"
 #include "kernels/launch.hpp"
 
 namespace lcgs
@@ -72,8 +73,6 @@ using namespace lcgs;
 
 namespace
 {
-constexpr int kMaxEvents = LCGS_MAX_STAGES + 1;
-
 inline int ceil_log2_u32(uint32_t v)
 {
     int b = 0;
@@ -81,99 +80,6 @@ inline int ceil_log2_u32(uint32_t v)
     return b;
 }
 } // namespace
-
-struct lcgs_context {
-    int         device = 0;
-    hipStream_t stream = nullptr;
-
-    // scene (lcgs_scene_bind / lcgs_scene_upload)
-    int          P = 0, sh_deg = 3;
-    const float *pos = nullptr, *scale = nullptr, *rotq = nullptr, *sh = nullptr, *opacity = nullptr;
-    DeviceBuffer owned[5];
-    DeviceBuffer sh_half;            // opt-in f16 copy of sh for the fused forward's colour pass (lcgs_scene_use_half_sh)
-    bool         use_half_sh = false;
-
-    // workspace of the fused frame
-    DeviceBuffer cull_slab, chunk_info, chunk_base; // the cull pass's per-chunk output (fused_forward.hip k_cull_compact)
-    DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws[3], counts, sort_ws,
-        expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks, shjac;
-    bool         last_has_jac = false; // the last keep_state frame stored the colour Jacobian (degree 3)
-    // zero_ws holds what a frame needs zeroed: the tile ranges.  Three
-    // copies rotate: while frame N runs, the auxiliary stream clears the copy of frame N + 2.  Two frames ahead, not
-    // one, so that no wait is needed when a frame starts: the fill issued during frame N - 1 sits on the auxiliary
-    // stream in front of frame N's record builder, whose completion frame N's renderer waited for -- and frame N + 1
-    // starts behind that renderer.
-    size_t    zero_scan_bytes = 0, zero_bytes = 0;
-    int       zero_cur        = 0;
-    bool      zero_ready[3]   = { false, false, false };
-    uint32_t* ranges          = nullptr; // tile ranges of the last frame (inside zero_ws[...])
-    // device-resident per-call parameters + the captured frame graph (replayed while its key is unchanged)
-    DeviceBuffer   frame_params;
-    hipGraphExec_t graph_exec = nullptr;
-    struct GraphKey {
-        const void *pos = nullptr, *scale = nullptr, *rotq = nullptr, *sh = nullptr, *opacity = nullptr, *sh_half = nullptr,
-                   *img = nullptr, *radii = nullptr;
-        int         P = -1, sh_deg = -1, width = 0, height = 0, keep_state = -1;
-        int64_t     hint_V = -1, hint_L = -1;
-        uint32_t    capacity = 0;
-        hipStream_t stream = nullptr;
-        bool        operator==(const GraphKey& o) const
-        {
-            return pos == o.pos && scale == o.scale && rotq == o.rotq && sh == o.sh && opacity == o.opacity &&
-                   sh_half == o.sh_half && img == o.img && radii == o.radii && P == o.P && sh_deg == o.sh_deg && width == o.width &&
-                   height == o.height && keep_state == o.keep_state && hint_V == o.hint_V && hint_L == o.hint_L &&
-                   capacity == o.capacity && stream == o.stream;
-        }
-    } graph_key;
-    // Longest-list-first tile schedule: a scheduling hint, so a frame uses the order derived from the PREVIOUS
-    // frame's list lengths (computed on the auxiliary stream while that frame rendered); only the first frame of a
-    // resolution computes its own order in line.
-    DeviceBuffer tile_order[2];
-    int          order_cur = 0;  // tile_order[order_cur] is the newest complete order ...
-    uint32_t     order_G   = 0;  // ... valid for this many tiles (0: none yet)
-    uint32_t*    last_tile_order = nullptr; // the order the last frame rendered with (reused by the backward)
-    bool use_graph = false; // opt-in (LCGS_GRAPH=1): measured no gain on MI355X, the short kernels are GPU-latency-bound
-    // second stream: work that is independent of the sort chain (record building; gradient zero-fill) overlaps it
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_ranges = nullptr, ev_aux_done = nullptr, ev_render = nullptr,
-                ev_counts = nullptr;
-    bool        aux_pending = false, counts_pending = false;
-    // keep_state frames clear the 2-D gradient rows on the auxiliary stream (beside the renderer) so that the backward
-    // does not start with a 40 us zero-fill; consumed by the first backward of that frame
-    hipEvent_t  ev_g2d_zero = nullptr;
-    bool        g2d_zeroed  = false;
-    // lcgs_render_forward_batch: a sibling context (own workspace, own streams) that renders every other view, so
-    // that one view's latency-bound sort chain overlaps the other's bandwidth- and VALU-bound kernels
-    lcgs_context* twin         = nullptr;
-    hipStream_t   twin_stream  = nullptr; // owned
-    hipEvent_t    ev_batch_fork = nullptr, ev_batch_join = nullptr;
-    // launch-size hints from the last synchronised frame (live counts stay on the device; larger counts are
-    // still handled correctly by chunk striding)
-    int64_t hint_V = 0, hint_L = 0;
-    // workspace of the stage-level path / primitives
-    DeviceBuffer st_keys_tmp, st_vals_tmp, st_sort_temp, st_scan_temp, st_scalar;
-    uint32_t     pair_capacity = 0;
-    uint32_t*    h_counts      = nullptr; // pinned, 8 x u32
-
-    // state of the last forward (for backward and stats)
-    struct {
-        bool      valid = false;
-        bool      has_state = false;
-        CamParams cp;
-        float     bg[3];
-        float     scale_modifier;
-        int       list_buf = 0; // pairv[list_buf] holds the sorted per-tile lists (dense ids)
-    } last;
-    lcgs_frame_stats stats{};
-
-    // per-stage timing
-    bool             profiling = false;
-    hipEvent_t       events[kMaxEvents]{};
-    bool             events_created = false;
-    int              n_marks        = 0;
-    const char*      mark_names[kMaxEvents]{};
-    lcgs_stage_times times{};
-};
 
 namespace lcgs
 {
@@ -537,6 +443,10 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
 {
     if (!ctx) return LCGS_OK;
     (void)hipSetDevice(ctx->device);
+    if (ctx->comm) {
+        comm_forget_context(ctx->comm); // (drains the communicator's stream; the caller still owns and destroys it)
+        ctx->comm = nullptr;
+    }
     if (ctx->twin) {
         ctx->twin->sh_half.ptr = nullptr; // borrowed from this context
         (void)lcgs_destroy(ctx->twin);
@@ -566,6 +476,9 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
                            ctx->ev_g2d_zero })
         if (ev) (void)hipEventDestroy(ev);
     ctx->frame_params.release();
+    ctx->slice_bounds.release();
+    for (hipEvent_t ev : ctx->ev_slice)
+        if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->events_created)
         for (auto& ev : ctx->events) (void)hipEventDestroy(ev);
@@ -1291,6 +1204,16 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
     }
+    // dense rows with a communicator attached: the preprocess pass runs as splat-range slices so that the gradient
+    // all-reduce (lcgs_grads_allreduce) can start on the first rows while the later ones are still being computed
+    const bool sliced = !compact && ctx->grad_slices > 1 && P >= 4096;
+    if (sliced) {
+        LCGS_TRY(ctx->slice_bounds.ensure((lcgs::kMaxGradSlices + 1) * sizeof(uint32_t)));
+        for (int k = 0; k < ctx->grad_slices; ++k)
+            if (!ctx->ev_slice[k]) LCGS_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_slice[k], hipEventDisableTiming));
+        launch_slice_bounds(ctx->vis_index.as<uint32_t>(), ctx->counts.as<uint32_t>(), (int64_t)P, ctx->grad_slices,
+                            ctx->slice_bounds.as<uint32_t>(), zs); // (before the fill: ev_join / stream order covers it)
+    }
     if (!compact) {
         LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dpos, 0, P * 3 * 4, zs));
         LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dscale, 0, P * 3 * 4, zs));
@@ -1315,11 +1238,18 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
                            ctx->counts.as<uint32_t>());
     LCGS_TRY(mark(ctx, "render_backward"));
     if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
-    launch_preprocess_backward(ctx->hint_V > 0 ? ctx->hint_V : (int64_t)P, ctx->sh_deg, ctx->last.cp,
-                               ctx->last.scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->sh,
-                               ctx->vis_index.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(),
-                               grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh,
-                               grads->d_dL_dopacity, st, ctx->last_has_jac ? ctx->shjac.as<float4>() : nullptr, compact);
+    const int slices = (sliced ? ctx->grad_slices : 1);
+    for (int k = 0; k < slices; ++k) {
+        launch_preprocess_backward(ctx->hint_V > 0 ? ctx->hint_V : (int64_t)P, ctx->sh_deg, ctx->last.cp,
+                                   ctx->last.scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->sh,
+                                   ctx->vis_index.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(),
+                                   grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh,
+                                   grads->d_dL_dopacity, st, ctx->last_has_jac ? ctx->shjac.as<float4>() : nullptr, compact,
+                                   sliced ? ctx->slice_bounds.as<uint32_t>() : nullptr, k, slices);
+        if (sliced) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_slice[k], st));
+    }
+    ctx->slices_recorded = sliced ? slices : 0;
+    ctx->slices_of       = sliced ? grads->d_dL_dpos : nullptr;
     LCGS_TRY(mark(ctx, "preprocess_backward"));
     LCGS_HIP_CHECK(hipGetLastError());
     if (ctx->profiling) {

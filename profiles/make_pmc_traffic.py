@@ -32,6 +32,13 @@ for k in fetch:
     wb = write.get(k, (0, 0))[0] * 1024
     out["kernels"][k] = {"launches": n, "fetch_bytes_raw": round(fb), "fetch_bytes_x2": round(2 * fb), "write_bytes": round(wb)}
     lines.append("%-24s %8d %14.1f %14.1f %14.1f" % (k, n, fb / 1e6, 2 * fb / 1e6, wb / 1e6))
+# launches per forward frame (k_cull_compact runs once per frame, forward-only and keep_state frames alike); the backward's
+# and the optimiser's kernels are not part of the forward frame
+frames = out["kernels"].get("k_cull_compact", {}).get("launches", 0)
+not_forward = ("k_render_backward", "k_preprocess_backward", "k_zero_grads2d", "k_adam", "k_slice_bounds", "k_tile_order")
+if frames:
+    out["forward_frame_launches"] = {k: round(v["launches"] / frames) for k, v in out["kernels"].items()
+                                     if not k.startswith(not_forward) and round(v["launches"] / frames) >= 1}
 json.dump(out, open(sys.argv[3] + ".json", "w"), indent=1)
 open(sys.argv[3] + ".txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

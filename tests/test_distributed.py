@@ -1,7 +1,9 @@
-"""The N > 1 path on CPU: two gloo ranks shard the views (one view per rank, scene replicated) and all-reduce the
-dense per-splat gradient buffer -- the same host-side protocol bench.py runs over RCCL, with the oracle standing in
-for the GPU kernels (no GPU here).  Checks: sharding covers every view exactly once, the reduced gradient equals the
-single-process sum over all views, and the max-over-ranks timing reduction works."""
+"""The N > 1 path on CPU: two gloo ranks run the PACKAGE's view-parallel protocol
+(luisacomputegaussiansplatting_amd.multi_gpu: ViewParallelTrainer + TorchCollective + shard_rows / view_of_rank -- the
+very classes bench.py drives over RCCL), with a CPU stand-in for the engine only: the oracle computes a view's gradients
+and a numpy restatement of lcgs_adam_step's arithmetic applies the update (no GPU here).  Checks: the views of a step
+are disjoint and cover the batch; both collective modes ("allreduce", "sharded") leave every rank with the parameters a
+single process gets from the summed gradients; row ownership incl. the P mod N tail; max-over-ranks timing."""
 import os
 import socket
 import sys
@@ -10,6 +12,10 @@ import numpy as np
 import pytest
 
 from conftest import ROOT
+
+KEYS = ("pos", "scale", "rotq", "sh", "opacity")
+LR = {"pos": 1.6e-3, "sh_dc": 2.5e-2, "sh_rest": 1.25e-3, "opacity": 5e-2, "scale": 5e-3, "rot": 1e-2}
+P, W, H, N_VIEWS, STEPS = 301, 48, 32, 4, 2  # P is odd: the sharded step has a one-row tail at N = 2
 
 
 def _free_port():
@@ -20,14 +26,97 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_views, out_dir):
+def _poses():
+    sys.path.insert(0, ROOT)
+    from bench import view_pose
+
+    return [view_pose(v) for v in range(N_VIEWS)]
+
+
+def _raw_scene():
+    from conftest import make_scene
+
+    s = make_scene(np.random.default_rng(0), P, log_scale=(-3.4, 0.6))
+    return {"pos": s["pos"], "scale": np.log(s["scale"]), "rotq": s["rotq"] * 1.3, "sh": s["sh"],
+            "opacity": np.log(s["opacity"] / (1 - s["opacity"]))}
+
+
+def _activate(raw):
+    return {"pos": raw["pos"], "scale": np.exp(raw["scale"]),
+            "rotq": raw["rotq"] / np.linalg.norm(raw["rotq"], axis=1, keepdims=True), "sh": raw["sh"],
+            "opacity": 1.0 / (1.0 + np.exp(-raw["opacity"]))}
+
+
+class OracleEngine:
+    """CPU stand-in for multi_gpu.HipEngine: same interface, torch CPU tensors, the oracle as the kernels."""
+
+    def __init__(self, oracle, raw_np, dL_of_view):
+        import torch
+
+        self.o = oracle
+        self.raw = {k: torch.from_numpy(np.ascontiguousarray(raw_np[k], dtype=np.float32)) for k in KEYS}
+        act = _activate(raw_np)
+        self.activated = {k: torch.from_numpy(np.ascontiguousarray(act[k], dtype=np.float32)) for k in KEYS}
+        self.activated["pos"], self.activated["sh"] = self.raw["pos"], self.raw["sh"]  # identity activation: one array
+        self.m = {k: torch.zeros_like(self.raw[k]) for k in KEYS}
+        self.v = {k: torch.zeros_like(self.raw[k]) for k in KEYS}
+        self.dL_of_view = dL_of_view
+        self.views_rendered = []
+
+    def forward_backward(self, cam, dL_dimg, grads, bg=(0.0, 0.0, 0.0)):
+        import torch
+
+        view, ocam = cam
+        self.views_rendered.append(view)
+        scene = {k: self.activated[k].numpy() for k in KEYS}
+        g = self.o.render_backward_full(scene, ocam, self.dL_of_view(view))
+        for k in KEYS:
+            grads[k].copy_(torch.from_numpy(g[k].reshape(grads[k].shape).astype(np.float32)))
+
+    def adam(self, grads, step, rows=None, b1=0.9, b2=0.999, eps=1e-15):
+        """lcgs_adam_step (csrc/kernels/train.hip) restated: activated-space gradients -> raw-space -> Adam -> activate."""
+        first, count = rows if rows is not None else (0, P)
+        if count <= 0:
+            return
+        sl = slice(first, first + count)
+        bc1, bc2 = 1.0 - b1 ** step, np.sqrt(1.0 - b2 ** step)
+        for k in KEYS:
+            g = grads[k][sl].numpy().astype(np.float32).reshape(count, -1)
+            raw, m, v = (d[k][sl].numpy().reshape(count, -1) for d in (self.raw, self.m, self.v))
+            act = self.activated[k][sl].numpy().reshape(count, -1)
+            if k == "scale":
+                g = g * act
+            elif k == "opacity":
+                g = g * act * (1 - act)
+            elif k == "rotq":
+                g = (g - act * (act * g).sum(1, keepdims=True)) / np.linalg.norm(raw, axis=1, keepdims=True)
+            lr = np.full(g.shape[1], LR.get(k, 0.0), np.float32)
+            if k == "sh":
+                lr[:3], lr[3:] = LR["sh_dc"], LR["sh_rest"]
+            if k == "rotq":
+                lr[:] = LR["rot"]
+            m[:] = b1 * m + (1 - b1) * g
+            v[:] = b2 * v + (1 - b2) * g * g
+            raw -= (lr / bc1) * m / (np.sqrt(v) / bc2 + eps)
+            if k == "scale":
+                act[:] = np.exp(raw)
+            elif k == "opacity":
+                act[:] = 1.0 / (1.0 + np.exp(-raw))
+            elif k == "rotq":
+                act[:] = raw / np.linalg.norm(raw, axis=1, keepdims=True)
+
+
+def _dL(view):
+    return np.random.default_rng(100 + view).normal(size=(3, H, W)).astype(np.float32)
+
+
+def _worker(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
 
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from bench import view_pose
-    from conftest import make_scene
+    import luisacomputegaussiansplatting_amd.multi_gpu as mg
     from oracle import Oracle
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,50 +124,86 @@ def _worker(rank, world, port, n_views, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     o = Oracle("f32")
     o.set_threads(2)
-    scene = make_scene(np.random.default_rng(0), 300, log_scale=(-3.4, 0.6))  # replicated on every rank
-    P, W, H = 300, 48, 32
-    gbuf = torch.zeros(59 * P)
-    mine = [v for v in range(n_views) if v % world == rank]  # one view per rank per step
-    for v in mine:
-        cam = o.lookat(*view_pose(v), width=W, height=H)
-        dL = np.random.default_rng(100 + v).normal(size=(3, H, W)).astype(np.float32)
-        g = o.render_backward_full(scene, cam, dL)
-        flat = np.concatenate([g[k].reshape(-1) for k in ("pos", "scale", "rotq", "sh", "opacity")])
-        gbuf += torch.from_numpy(flat)
-    dist.all_reduce(gbuf)
+    cams = [(v, o.lookat(*p, width=W, height=H)) for v, p in enumerate(_poses())]
+    for mode in ("allreduce", "sharded"):
+        engine = OracleEngine(o, _raw_scene(), _dL)  # the scene is replicated on every rank
+        grads = {k: torch.zeros_like(engine.raw[k]) for k in KEYS}
+        trainer = mg.ViewParallelTrainer(engine, mg.TorchCollective(dist, rank, world), cams, grads, mode=mode)
+        for _ in range(STEPS):
+            trainer.step(None)
+        np.savez(os.path.join(out_dir, f"{mode}_{rank}.npz"), views=np.array(engine.views_rendered),
+                 **{f"act_{k}": engine.activated[k].numpy() for k in KEYS},
+                 **{f"raw_{k}": engine.raw[k].numpy() for k in KEYS})
+    # bench.py's timing reduction: max over ranks
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        np.save(os.path.join(out_dir, "reduced.npy"), gbuf.numpy())
         np.save(os.path.join(out_dir, "tmax.npy"), t.numpy())
-    np.save(os.path.join(out_dir, f"views_{rank}.npy"), np.array(mine))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_view_sharding_and_gradient_allreduce_gloo(tmp_path):
+def test_shard_rows_and_view_assignment(lcgs):
+    import luisacomputegaussiansplatting_amd.multi_gpu as mg
+
+    for P_, N in ((301, 2), (6_131_954, 8), (7, 8), (0, 4), (4096, 4)):
+        spans = [lcgs.api.shard_rows(P_, N, r) for r in range(N)]
+        c = P_ // N
+        assert spans == [(r * c, c) for r in range(N)]  # equal shards; the P mod N rows behind them are the tail
+        assert P_ - c * N < N
+    for N in (1, 2, 4, 8):
+        for step in range(3):
+            views = [mg.view_of_rank(step, r, N, 8) for r in range(N)]
+            assert len(set(views)) == N  # one view per rank, no view twice in a step
+        assert sorted(mg.view_of_rank(s, r, N, 8) for s in range(8 // N) for r in range(N)) == list(range(8))
+    assert mg.allreduce_bus_bytes_per_gpu(6_131_954, 8) == 2 * 7 * 59 * 4 * 6_131_954 // 8
+    assert mg.allreduce_bus_bytes_per_gpu(6_131_954, 1) == 0
+
+
+def test_view_parallel_protocol_on_two_gloo_ranks(tmp_path, oracle):
+    import torch
     import torch.multiprocessing as mp
 
-    world, n_views = 2, 4
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, n_views, str(tmp_path)), nprocs=world, join=True)
-    views = np.concatenate([np.load(tmp_path / f"views_{r}.npy") for r in range(world)])
-    assert sorted(views.tolist()) == list(range(n_views))
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert np.load(tmp_path / "tmax.npy")[0] == pytest.approx(0.2)
-    # single-process reference: sum over all views
-    sys.path.insert(0, ROOT)
-    from bench import view_pose
-    from conftest import make_scene
-    from oracle import Oracle
 
-    o = Oracle("f32")
-    scene = make_scene(np.random.default_rng(0), 300, log_scale=(-3.4, 0.6))
-    total = np.zeros(59 * 300, np.float64)
-    for v in range(n_views):
-        cam = o.lookat(*view_pose(v), width=48, height=32)
-        dL = np.random.default_rng(100 + v).normal(size=(3, 32, 48)).astype(np.float32)
-        g = o.render_backward_full(scene, cam, dL)
-        total += np.concatenate([g[k].reshape(-1) for k in ("pos", "scale", "rotq", "sh", "opacity")])
-    red = np.load(tmp_path / "reduced.npy")
-    assert np.abs(red).max() > 0
-    assert np.allclose(red, total, rtol=1e-4, atol=1e-5 * np.abs(total).max())
+    # single-process reference: per step, the gradients of the step's views summed, then one dense Adam step
+    cams = [(v, oracle.lookat(*p, width=W, height=H)) for v, p in enumerate(_poses())]
+    ref = OracleEngine(oracle, _raw_scene(), _dL)
+    g = {k: torch.zeros_like(ref.raw[k]) for k in KEYS}
+    for step in range(STEPS):
+        total = {k: torch.zeros_like(ref.raw[k]) for k in KEYS}
+        for r in range(world):
+            ref.forward_backward(cams[(step * world + r) % N_VIEWS], None, g)
+            for k in KEYS:
+                total[k] += g[k]
+        ref.adam(total, step + 1)
+
+    res = {(m, r): np.load(tmp_path / f"{m}_{r}.npz") for m in ("allreduce", "sharded") for r in range(world)}
+    for m in ("allreduce", "sharded"):
+        views = np.stack([res[(m, r)]["views"] for r in range(world)], axis=1)  # [step, rank]
+        assert views.tolist() == [[0, 1], [2, 3]]  # disjoint per step, the batch covered after STEPS steps
+        for r in range(world):
+            for k in KEYS:
+                a, b = res[(m, r)][f"act_{k}"], ref.activated[k].numpy()
+                assert np.abs(b).max() > 0
+                # (sum order differs between all_reduce and the single process: fp32 round-off only)
+                assert np.allclose(a, b, rtol=2e-4, atol=2e-6 * np.abs(b).max()), (m, r, k, np.abs(a - b).max())
+        # every rank holds the same activated scene afterwards
+        for k in KEYS:
+            assert np.array_equal(res[(m, 0)][f"act_{k}"], res[(m, 1)][f"act_{k}"]), (m, k)
+    # something was learnt (the update is not a no-op)
+    assert not np.allclose(ref.activated["opacity"].numpy(), _activate(_raw_scene())["opacity"].astype(np.float32))
+    # sharded: raw parameters are authoritative on their owner (and on the tail) only
+    sys.path.insert(0, ROOT)
+    import luisacomputegaussiansplatting_amd as L
+
+    for r in range(world):
+        first, count = L.api.shard_rows(P, world, r)
+        own = np.r_[first:first + count, count * world:P]
+        for k in ("scale", "opacity", "rotq"):
+            a, b = res[("sharded", r)][f"raw_{k}"][own], ref.raw[k].numpy()[own]
+            assert np.allclose(a, b, rtol=2e-4, atol=2e-6 * np.abs(b).max()), (r, k)
+        other = np.setdiff1d(np.arange(P), own)
+        assert np.array_equal(res[("sharded", r)]["raw_scale"][other], _raw_scene()["scale"][other].astype(np.float32))

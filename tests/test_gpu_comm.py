@@ -1,0 +1,177 @@
+"""`-m gpu`: the multi-GPU side of the C ABI (lcgs_comm_*) on the one GPU a box has -- a communicator of world
+size 1 takes every call through RCCL itself (run-time binding, the communicator's stream, the slice events of the chunked
+all-reduce, the reduce-scatter / all-gather of the sharded step); what a rank count above 1 adds is RCCL's own business.
+The N > 1 host protocol is covered on CPU (tests/test_distributed.py, same classes, gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import luisacomputegaussiansplatting_amd.multi_gpu as mg
+from conftest import ROOT, make_scene
+from gpu_util import DEV, upload_scene
+
+pytestmark = pytest.mark.gpu
+
+KEYS = mg.KEYS
+POSE = ([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1])
+LR = {"pos": 1.6e-4, "sh_dc": 2.5e-3, "sh_rest": 1.25e-4, "opacity": 5e-2, "scale": 5e-3, "rot": 1e-3}
+
+
+def _raw_act(scene):
+    act = upload_scene(scene)
+    raw = {"pos": act["pos"], "scale": torch.log(act["scale"]), "rotq": act["rotq"] * 1.3, "sh": act["sh"],
+           "opacity": torch.log(act["opacity"] / (1 - act["opacity"]))}
+    return raw, act
+
+
+def _grads_like(act, fill=7.0):
+    return {k: torch.full_like(act[k], fill) for k in KEYS}
+
+
+def test_sliced_backward_and_chunked_allreduce_leave_the_gradients_unchanged(lcgs, oracle):
+    """With a communicator attached the dense backward runs its per-splat pass as splat-range slices (the chunks of
+    lcgs_grads_allreduce): same gradients as the unsliced backward (up to the order of the render-backward's float
+    atomics, which differs from run to run anyway), and a world of one sums to itself."""
+    rng = np.random.default_rng(5)
+    P = 30000
+    scene = make_scene(rng, P, log_scale=(-3.8, 0.7))
+    scene["pos"][:4000] += 100.0  # a run of culled splats: some slices hold few survivors
+    cam = lcgs.get_lookat_cam(*POSE, width=400, height=300)
+    dL = torch.randn(3, 300, 400, device=DEV)
+    d = upload_scene(scene)
+    plain = lcgs.Renderer(lcgs.Context(0))
+    plain.bind_scene(*[d[k] for k in KEYS])
+    img = torch.zeros(3, 300, 400, device=DEV)
+    plain.forward(cam, img, keep_state=True)
+    g0 = _grads_like(d)
+    plain.backward(dL, *[g0[k] for k in KEYS])
+    plain.ctx.synchronize()
+
+    ctx = lcgs.Context(0)
+    r = lcgs.Renderer(ctx)
+    r.bind_scene(*[d[k] for k in KEYS])
+    comm = lcgs.Comm(ctx, 0, 1)
+    for _ in range(2):  # twice: slice events are re-recorded per backward
+        g1 = _grads_like(d)
+        r.forward(cam, img, keep_state=True)
+        r.backward(dL, *[g1[k] for k in KEYS])
+        comm.allreduce_grads(g1)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        for k in KEYS:
+            a, b = g1[k].double(), g0[k].double()
+            assert float((a - b).norm() / b.norm()) <= 2e-4, k  # (float-atomic order; the bar is 1e-3)
+            assert torch.equal(g0[k] == 0, g1[k] == 0), k  # the same rows are written, the same stay zero
+    # an all-reduce of arrays no sliced backward wrote (one chunk behind the stream's tail) works too
+    g2 = {k: g0[k].clone() for k in KEYS}
+    comm.allreduce_grads(g2)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    assert all(torch.equal(g0[k], g2[k]) for k in KEYS)
+    # and against the oracle (BASELINE tolerance)
+    ref = oracle.render_backward_full(scene, oracle.lookat(*POSE, width=400, height=300), dL.cpu().numpy())
+    for k in KEYS:
+        a, b = g1[k].cpu().numpy().astype(np.float64).ravel(), ref[k].astype(np.float64).ravel()
+        assert np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30) <= 1e-3, k
+    comm.close()
+
+
+@pytest.mark.parametrize("P", [4097, 20000])
+def test_sharded_adam_step_equals_the_dense_step(lcgs, P):
+    rng = np.random.default_rng(P)
+    scene = make_scene(rng, P)
+    results = []
+    for sharded in (False, True):
+        raw, act = _raw_act(scene)
+        m = {k: torch.zeros_like(raw[k]) for k in KEYS}
+        v = {k: torch.zeros_like(raw[k]) for k in KEYS}
+        ctx = lcgs.Context(0)
+        r = lcgs.Renderer(ctx)
+        comm = lcgs.Comm(ctx, 0, 1) if sharded else None
+        for step in (1, 2):
+            g = {k: torch.from_numpy(np.random.default_rng(step).normal(size=tuple(raw[k].shape)).astype(np.float32)).to(DEV)
+                 for k in KEYS}
+            if sharded:
+                comm.adam_step_sharded(g, raw, m, v, act, step, LR, eps=1e-8)
+            else:
+                r.adam_step(g, raw, m, v, act, step, LR, eps=1e-8)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        results.append((raw, m, v, act))
+        if comm is not None:
+            comm.close()
+    for a, b in zip(*results):
+        for k in KEYS:
+            assert torch.equal(a[k], b[k]), k
+
+
+def test_view_parallel_trainer_on_the_hip_engine(lcgs):
+    """The package protocol end to end on the GPU: ViewParallelTrainer + HipEngine + RcclCollective (world 1), both
+    collective modes, against the same steps without any collective.  (Not bit for bit: the render-backward sums with
+    float atomics, so two runs differ in the last place, and Adam turns the sign of a near-zero gradient into a step of
+    +-lr; the bound below is that step, and almost every element has to agree far more closely.)"""
+    rng = np.random.default_rng(11)
+    scene = make_scene(rng, 20000, log_scale=(-3.8, 0.7))
+    cams = [lcgs.get_lookat_cam([-3 * np.cos(a), -0.5 + 3 * np.sin(a), 2.3], [0, 0, 0.5], [0, 0, 1], width=320, height=240)
+            for a in (0.0, 0.4, 0.8)]
+    dL = torch.randn(3, 240, 320, device=DEV)
+    outs = {}
+    for mode in ("local", "allreduce", "sharded"):
+        raw, act = _raw_act(scene)
+        ctx = lcgs.Context(0)
+        eng = mg.HipEngine(lcgs.Renderer(ctx), raw, act, LR, eps=1e-8)
+        coll = None if mode == "local" else mg.RcclCollective(ctx, 0, 1)
+        tr = mg.ViewParallelTrainer(eng, coll, cams, _grads_like(act, 0.0), mode=mode)
+        for _ in range(4):
+            tr.step(dL)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        outs[mode] = {k: raw[k].clone() for k in KEYS}
+        if coll is not None:
+            coll.close()
+    assert not torch.equal(outs["local"]["opacity"], _raw_act(scene)[0]["opacity"])  # it trained
+    lr_of = {"pos": LR["pos"], "scale": LR["scale"], "rotq": LR["rot"], "sh": LR["sh_dc"], "opacity": LR["opacity"]}
+    for mode in ("allreduce", "sharded"):
+        for k in KEYS:
+            diff = (outs[mode][k] - outs["local"][k]).abs()
+            assert float(diff.max()) <= 2.02 * 4 * lr_of[k], (mode, k, float(diff.max()))
+            assert float((diff > 0.05 * lr_of[k]).float().mean()) < 0.01, (mode, k)
+
+
+def test_comm_argument_checks(lcgs):
+    ctx = lcgs.Context(0)
+    comm = lcgs.Comm(ctx, 0, 1)
+    with pytest.raises(lcgs.LcgsError):
+        lcgs.Comm(ctx, 0, 1)  # one communicator per context
+    other = lcgs.Context(0)
+    z = {k: torch.zeros(s, device=DEV) for k, s in zip(KEYS, ((8, 3), (8, 3), (8, 4), (8, 48), (8,)))}
+    with pytest.raises(ValueError):
+        lcgs.Comm(other, 1, 2)  # world > 1 needs a way to carry the rendezvous token
+    comm.allreduce_grads(z)
+    ctx.synchronize()
+    comm.close()
+    lcgs.Comm(ctx, 0, 1).close()  # detached again: a new one may be attached
+
+
+@pytest.mark.parametrize("collective", ["rccl", "torch"])
+def test_bench_runs_every_multi_gpu_code_path_on_one_rank(collective):
+    """bench.py with LCGS_BENCH_FORCE_DIST=1: one rank, but through the process group and the gradient collectives -- every
+    N > 1 branch of the file runs (the driver launches the real N = 2, 4, 8 on a whole node)."""
+    env = dict(os.environ, LCGS_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--splats", "200000", "--res", "640x480", "--steps",
+                          "3", "--warmup", "1", "--no-cpu-baseline", "--no-stage-path", "--no-spatial", "--collective",
+                          collective], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [x for x in res.stdout.splitlines() if x.startswith("{")][-1]
+    out = json.loads(line)
+    fb = out["fwd_bwd"]
+    assert fb["value"] > 0 and fb["without_collective"]["value"] > 0 and fb["moving_camera"]["value"] > 0
+    assert ("rccl" in fb["collective"]) == (collective == "rccl")
+    assert set(out["train_step"]) == {"allreduce", "sharded"}
+    assert all(v["value"] > 0 for v in out["train_step"].values())
+    assert out["moving_camera"]["value"] > 0 and len(out["moving_camera"]["per_view"]) == 8
