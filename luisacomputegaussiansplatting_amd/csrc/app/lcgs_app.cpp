@@ -1,7 +1,7 @@
 // lcgs-app -- CLI work-alike of the reference's app/main.cpp on the MI355X library.
 //   lcgs-app --ply <path> [--res WxH] [--out dir] [--world colmap|blender] [--exp_N N] [--backend hip]
 //            [--path fused|stage] [--synth kind:count:seed] [--ingest device|host] [--cameras file]
-//            [--order file|spatial] [--pose garden|lego]
+//            [--order file|spatial] [--pose garden|lego] [--gpus N] [--backward]
 // Same flags (app/main.cpp:52-124; `--key=value` and `--key value`, app/command_parser.hpp:5-79), the same
 // hard-coded look-at camera (app/main.cpp:191-207), the same frame loop (:266-308), the same output:
 // <out>/<ply stem>_<backend>.png, CHW float -> vertically flipped RGB8 with a truncating *255 (:323-339).
@@ -9,7 +9,14 @@
 // Beyond the reference: the PLY is de-interleaved and activated on the device
 // (--ingest device, default; `host` = the reference's read_gs_ply order of work), and --cameras <file> renders a
 // batch of views of the resident scene (one `px py pz  tx ty tz  ux uy uz [fov]` line per camera, `#` comments),
-// writing <stem>_<backend>_<k>.png per view.
+// writing <stem>_<backend>_<k>.png per view.  --gpus N shards the views of --cameras over N GPUs, one process per GPU
+// (view k on rank k mod N; every rank holds the whole scene; no collective in the forward), and --backward adds, per
+// round of N views, each rank's backward (dL/dimg = 1) and the RCCL sum of the dense per-splat gradients over the ranks
+// (lcgs_grads_allreduce), printing the norms of the summed gradients -- the multi-view batch of SURVEY 8e driven from C++.
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <cmath>
 #include <sys/stat.h>
 
 #include <chrono>
@@ -17,6 +24,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -47,6 +56,8 @@ void usage(const char* argv0)
     printf("  --pose <garden|lego>     The look-at compiled into the reference (garden, app/main.cpp:191-193; default) or the\n"
            "                           alternative it keeps in a comment for lego / bicycle (app/main.cpp:195-197)\n");
     printf("  --cameras <file>         Render every camera of the file: `px py pz tx ty tz ux uy uz [fov]` per line\n");
+    printf("  --gpus <N>               Shard the views of --cameras over N GPUs (one process per GPU; default 1)\n");
+    printf("  --backward               Per round of views: backward (dL/dimg = 1) + RCCL sum of the gradients over the GPUs\n");
     printf("  --display                Not supported (headless)\n");
 }
 
@@ -64,7 +75,8 @@ int main(int argc, char** argv)
     unsigned    W = 1600, H = 1063; // app/main.cpp:38
     std::string ply_path = "gsplat.ply", backend = "hip", out_dir = "out", world = "colmap", path = "fused", synth;
     std::string ingest = "device", cameras_file, order = "file", pose = "garden";
-    int         exp_N = 1;
+    int         exp_N = 1, gpus = 1;
+    bool        backward = false;
     // parse_command (app/command_parser.hpp:5-79): strip leading dashes, `key=value` or `key value`
     for (int i = 1; i < argc; ++i) {
         std::string arg = argv[i];
@@ -113,6 +125,11 @@ int main(int argc, char** argv)
             if (value != "garden" && value != "lego" && value != "bicycle") die("Invalid pose: " + value);
             pose = value == "garden" ? "garden" : "lego";
         } else if (key == "cameras") cameras_file = value;
+        else if (key == "gpus") {
+            if (value.empty()) die("--gpus requires a value");
+            gpus = std::stoi(value);
+            if (gpus < 1 || gpus > 64) die("--gpus out of range");
+        } else if (key == "backward") backward = true;
         else if (key == "display") die("--display needs a GUI; this build is headless");
         else die("unknown option --" + key);
     }
@@ -124,8 +141,61 @@ int main(int argc, char** argv)
     if (ep != std::string::npos) ply_name = ply_name.substr(0, ep);
     mkdir(out_dir.c_str(), 0755);
 
+    // ---- one process per GPU: the launcher forks the ranks BEFORE anything touches the GPU and hands every rank > 0 a
+    // pipe on which rank 0 will send the communicator's rendezvous token
+    int rank = 0;
+    std::vector<int> token_write; // rank 0: write ends towards ranks 1 .. N-1
+    int              token_read = -1;
+    if (gpus > 1) {
+        if (cameras_file.empty()) die("--gpus N shards the views of a --cameras file");
+        if (path != "fused") die("--gpus N uses the fused frame (--path fused)");
+        std::vector<int> rd(gpus, -1), wr(gpus, -1);
+        for (int r = 1; r < gpus; ++r) {
+            int fds[2];
+            if (pipe(fds) != 0) die("pipe() failed");
+            rd[r] = fds[0];
+            wr[r] = fds[1];
+        }
+        std::vector<pid_t> kids;
+        for (int r = 0; r < gpus; ++r) {
+            fflush(stdout);
+            fflush(stderr);
+            pid_t pid = fork();
+            if (pid < 0) die("fork() failed");
+            if (pid == 0) {
+                rank = r;
+                for (int q = 1; q < gpus; ++q) {
+                    if (r == 0) {
+                        close(rd[q]);
+                        token_write.push_back(wr[q]);
+                    } else {
+                        close(wr[q]);
+                        if (q == r) token_read = rd[q];
+                        else close(rd[q]);
+                    }
+                }
+                kids.clear();
+                break;
+            }
+            kids.push_back(pid);
+        }
+        if (!kids.empty()) { // the launcher: wait for the ranks, exit with the first failure
+            for (int q = 1; q < gpus; ++q) {
+                close(rd[q]);
+                close(wr[q]);
+            }
+            int rc = 0;
+            for (pid_t k : kids) {
+                int st = 0;
+                if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : 1;
+            }
+            return rc;
+        }
+    }
+    const bool root = rank == 0;
+
     try {
-        lcgs::Device device(0);
+        lcgs::Device device(rank);
         // ---- scene: read_gs_ply (app/main.cpp:165-167) or a synthetic stand-in
         lcgs_scene_host sc{};
         std::vector<float> spos, sfeat, sop, sscale, srot;
@@ -147,7 +217,7 @@ int main(int argc, char** argv)
             lcgs::check(lcgs_ply_read(ply_path.c_str(), &sc));
             P = sc.num_gaussians;
         }
-        printf("num_gaussians: %d\n", P);
+        if (root) printf("num_gaussians: %d\n", P);
         // the five device arrays of app/main.cpp:180-186, 216-223 (owned here, or by the context after a device ingest)
         lcgs::Buffer<float>     o_pos, o_scale, o_rotq, o_sh, o_opacity;
         lcgs::BufferView<float> d_pos, d_scale, d_rotq, d_sh, d_opacity;
@@ -176,7 +246,7 @@ int main(int argc, char** argv)
             d_sh      = { const_cast<float*>(pf), (size_t)P * 48 };
             d_opacity = { const_cast<float*>(po), (size_t)P };
         }
-        printf("scene resident in %.1f ms (%s ingest)\n",
+        if (root) printf("scene resident in %.1f ms (%s ingest)\n",
                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_load).count(),
                !synth.empty() ? "synthetic" : ingest.c_str());
 
@@ -243,7 +313,76 @@ int main(int argc, char** argv)
             lcgs::check(lcgs_write_png(img_name.c_str(), (int)W, (int)H, rgb.data()));
             printf("result saved in %s\n", img_name.c_str());
         };
-        if (!cameras_file.empty() && path == "fused" && exp_N == 1) {
+        if (gpus > 1 || backward) {
+            // ---- a multi-view batch sharded over the GPUs: view k belongs to rank k mod N; one round = N
+            // views, one per rank.  Forward: no collective.  --backward: each rank differentiates its view (dL/dimg = 1,
+            // i.e. the gradient of the image sum) and the dense per-splat gradients are summed over the ranks by RCCL.
+            if (path != "fused") die("--backward uses the fused frame (--path fused)");
+            std::unique_ptr<lcgs::Comm> comm;
+            if (backward) {
+                lcgs_comm_id id{};
+                if (root) {
+                    id = lcgs::Comm::unique_id();
+                    for (int fd : token_write)
+                        if (write(fd, id.bytes, sizeof(id.bytes)) != (ssize_t)sizeof(id.bytes)) die("cannot send the communicator token");
+                } else if (read(token_read, id.bytes, sizeof(id.bytes)) != (ssize_t)sizeof(id.bytes))
+                    die("cannot receive the communicator token");
+                comm.reset(new lcgs::Comm(device, id, rank, gpus));
+            }
+            lcgs::Scene         scene(device);
+            lcgs::Buffer<float> g_pos, g_scale, g_rotq, g_sh, g_op, d_ones;
+            lcgs_grads          grads{};
+            const size_t        widths[5] = { 3, 3, 4, 48, 1 };
+            if (backward) {
+                g_pos = lcgs::Buffer<float>((size_t)P * 3); g_scale = lcgs::Buffer<float>((size_t)P * 3);
+                g_rotq = lcgs::Buffer<float>((size_t)P * 4); g_sh = lcgs::Buffer<float>((size_t)P * 48);
+                g_op = lcgs::Buffer<float>((size_t)P);
+                grads = { g_pos.data(), g_scale.data(), g_rotq.data(), g_sh.data(), g_op.data() };
+                std::vector<float> ones((size_t)W * H * 3, 1.0f);
+                d_ones = upload(ones.data(), ones.size());
+            }
+            const size_t rounds = (views.size() + (size_t)gpus - 1) / (size_t)gpus;
+            auto         t0     = std::chrono::steady_clock::now();
+            for (size_t round = 0; round < rounds; ++round) {
+                const size_t vi   = round * (size_t)gpus + (size_t)rank;
+                const bool   mine = vi < views.size();
+                int          n    = 0;
+                if (mine) {
+                    lcgs::Camera cam = make_camera(views[vi]);
+                    n                = scene.render(cam, d_img, bg, 1.0f, backward);
+                    save_view(d_img.data(), vi);
+                }
+                if (!backward) continue;
+                float* gp[5] = { g_pos.data(), g_scale.data(), g_rotq.data(), g_sh.data(), g_op.data() };
+                if (mine && n > 0) scene.backward(d_ones, grads);
+                else // no view for this rank in the last round (or an empty frame): it contributes zeros to the sum
+                    for (int a = 0; a < 5; ++a)
+                        if (hipMemsetAsync(gp[a], 0, (size_t)P * widths[a] * 4, nullptr) != hipSuccess) die("memset failed");
+                if (!(mine && n > 0) && hipDeviceSynchronize() != hipSuccess) die("sync failed");
+                comm->allreduce(P, grads);
+                device.synchronize();
+                if (root) { // the norms of the summed gradients: identical on every rank
+                    static const char* names[5] = { "pos", "scale", "rotq", "sh", "opacity" };
+                    printf("round %zu (%d view%s): grad_l2", round, (int)std::min<size_t>(gpus, views.size() - round * gpus),
+                           gpus > 1 ? "s" : "");
+                    for (int a = 0; a < 5; ++a) {
+                        std::vector<float> h((size_t)P * widths[a]);
+                        if (hipMemcpy(h.data(), gp[a], h.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) die("D2H copy failed");
+                        double acc = 0.0;
+                        for (float x : h) acc += (double)x * x;
+                        printf(" %s %.9e", names[a], std::sqrt(acc));
+                    }
+                    printf("\n");
+                }
+            }
+            device.synchronize();
+            double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (root)
+                printf("exp time: %.3f ms\n%zu views on %d GPU%s%s\n", ms, views.size(), gpus, gpus > 1 ? "s" : "",
+                       backward ? ", gradients summed over the GPUs" : "");
+            views.clear(); // done
+        }
+        if (!cameras_file.empty() && path == "fused" && exp_N == 1 && !views.empty()) {
             // the whole camera file as one batch: two frames in flight (lcgs_render_forward_batch)
             lcgs::Scene               scene(device);
             std::vector<lcgs::Camera> cams;

@@ -247,4 +247,40 @@ private:
     Device* m_dev = nullptr;
 };
 
+// The RCCL communicator of a view-parallel job (one process per GPU): gradient sums over the ranks.
+// `id` is made by one rank (Comm::unique_id) and carried to the others by the host (lcgs-app: pipes from the launcher).
+class Comm
+{
+public:
+    static lcgs_comm_id unique_id()
+    {
+        lcgs_comm_id id;
+        check(lcgs_comm_unique_id(&id));
+        return id;
+    }
+    Comm(Device& device, const lcgs_comm_id& id, int rank, int world_size) : m_dev(&device)
+    {
+        check(lcgs_comm_create(device.ctx(), &id, rank, world_size, &m_comm));
+    }
+    Comm(const Comm&)            = delete;
+    Comm& operator=(const Comm&) = delete;
+    ~Comm() { lcgs_comm_destroy(m_comm); }
+    // in-place sum over the ranks of the dense gradients of lcgs_render_backward (chunked behind its slices)
+    void allreduce(int num_gaussians, const lcgs_grads& grads, int sh_degree = 3)
+    {
+        check(lcgs_grads_allreduce(m_dev->ctx(), m_comm, num_gaussians, sh_degree, &grads));
+    }
+    // reduce-scatter -> Adam on the own rows -> all-gather of the activated arrays
+    void adam_step_sharded(int num_gaussians, const lcgs_adam_config& cfg, const lcgs_grads& grads, const lcgs_params& raw,
+                           const lcgs_params& m, const lcgs_params& v, const lcgs_params& activated, int sh_degree = 3)
+    {
+        check(lcgs_adam_step_sharded(m_dev->ctx(), m_comm, num_gaussians, sh_degree, &cfg, &grads, &raw, &m, &v, &activated));
+    }
+    lcgs_comm* handle() const { return m_comm; }
+
+private:
+    Device*    m_dev  = nullptr;
+    lcgs_comm* m_comm = nullptr;
+};
+
 } // namespace lcgs

@@ -85,3 +85,33 @@ def test_lcgs_app_ply_ingest_and_camera_batch(lcgs, oracle, tmp_path, ingest):
         diff = np.abs(png.astype(int) - ref.astype(int))
         # device ingest: exp() within 2 ulp of the host's moves a few pixels by one 8-bit step
         assert (diff > 1).mean() < 2e-3 and diff.max() <= (3 if ingest == "device" else 2)
+
+
+def test_lcgs_app_view_sharded_backward_with_gradient_sum(lcgs, oracle, tmp_path):
+    """--gpus 1 --backward: the multi-view batch driver of SURVEY 8e from C++ (lcgs.hpp -> C ABI): per round, the view's
+    backward with dL/dimg = 1 and lcgs_grads_allreduce over the (here: one) rank; the printed norms of the summed
+    gradients equal the oracle's for every view.  (More ranks need more GPUs than a box has: the rank launcher -- fork
+    before any HIP call, rendezvous token over pipes -- only runs with --gpus > 1.)"""
+    import re
+
+    app = os.path.join(ROOT, "luisacomputegaussiansplatting_amd", "lcgs-app")
+    P, W, H = 8000, 256, 192
+    views = [([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1]), ([2.5, 1.5, 1.0], [0, 0, 0.5], [0, 0, 1])]
+    cams = str(tmp_path / "cams.txt")
+    with open(cams, "w") as f:
+        for p, t, u in views:
+            f.write(" ".join(str(x) for x in p + t + u) + "\n")
+    out = str(tmp_path / "out")
+    res = subprocess.run([app, "--synth", f"0:{P}:1001", f"--res={W}x{H}", "--out", out, "--cameras", cams, "--gpus", "1",
+                          "--backward"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    rounds = re.findall(r"round (\d+) \(1 view\): grad_l2 pos (\S+) scale (\S+) rotq (\S+) sh (\S+) opacity (\S+)", res.stdout)
+    assert len(rounds) == len(views), res.stdout
+    scene = lcgs.synth_scene(0, 1001, P)
+    dL = np.ones((3, H, W), np.float32)
+    for (k, *norms), (p, t, u) in zip(rounds, views):
+        ref = oracle.render_backward_full(scene, oracle.lookat(p, t, u, width=W, height=H), dL)
+        for name, got in zip(("pos", "scale", "rotq", "sh", "opacity"), norms):
+            want = float(np.linalg.norm(ref[name].astype(np.float64)))
+            assert abs(float(got) - want) <= 1e-3 * want, (k, name, got, want)
+        assert os.path.exists(os.path.join(out, f"synth0_{P}_hip_{k}.png"))
