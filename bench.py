@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--no-batch", action="store_true")
     ap.add_argument("--no-stage-path", action="store_true")
     ap.add_argument("--half-sh", action="store_true", help="also time the opt-in f16 SH colour pass")
-    ap.add_argument("--no-spatial", action="store_true", help="skip the spatially re-ordered legs")
+    ap.add_argument("--no-spatial", action="store_true", help="skip the file-order legs (the scene is kept in spatial order)")
     ap.add_argument("--no-moving-camera", action="store_true", help="skip the moving-camera forward leg")
     ap.add_argument("--collective", choices=("rccl", "torch"), default="rccl",
                     help="N > 1 gradient collective: the library's own RCCL path (lcgs_comm C ABI, default) or "
@@ -104,36 +104,36 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     W, H = (int(x) for x in args.res.lower().split("x"))
     dev = torch.device("cuda", local_rank)
+    KEYS = mg.KEYS
 
-    # ---- scene (replicated on every GPU)
+    # ---- scene (replicated on every GPU), through the library's own ingest: the context owns the device arrays and keeps
+    # them in spatial (Morton) order, its default for scenes it owns (lcgs_set_ingest_order; same images -- the blend
+    # order is by depth).  The file-order figure is reported beside `value` (`file_order`).
     data = "synthetic"
+    side = torch.cuda.Stream(device=dev)  # a dedicated (non-NULL) HIP stream for the context
+    torch.cuda.set_stream(side)
+    ctx = L.Context(local_rank, side.cuda_stream)
+    r = L.Renderer(ctx)
     if args.ply and os.path.exists(args.ply):
-        scene = L.read_gs_ply(args.ply)
+        r.load_ply(args.ply)  # records -> GPU -> activated arrays (lcgs_scene_load_ply)
+        scene = L.read_gs_ply(args.ply)  # host copy, file order: the CPU baseline's input
         scene.pop("sh_degree", None)
         workload = os.path.basename(args.ply)
         data = "real"
     else:
         scene = L.synth_scene(1, 2001, args.splats)
+        # host arrays -> context-owned device arrays (lcgs_scene_upload); LCGS_BENCH_FILE_ORDER=1 is a profiling hook:
+        # every leg then runs on the file-order scene (the workload name says so)
+        file_order = os.environ.get("LCGS_BENCH_FILE_ORDER") == "1"
+        r.upload_scene(scene, order="file" if file_order else None)
         workload = f"mip360_bicycle stand-in: synth_unbounded(seed=2001, P={args.splats})"
+    workload += " [ingest order: file (LCGS_BENCH_FILE_ORDER)]" if r.permutation() is None else \
+                " [ingest order: spatial (library default)]"
     P = scene["pos"].shape[0]
-    d = {k: torch.from_numpy(scene[k]).to(dev) for k in ("pos", "scale", "rotq", "sh", "opacity")}
+    d = r.scene_tensors()  # torch views of the context's arrays (the order the library keeps them in)
     torch.cuda.synchronize(dev)
-    # a dedicated (non-NULL) HIP stream: the library replays the frame as a captured hipGraph on it
-    side = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(side)
-    ctx = L.Context(local_rank, side.cuda_stream)
-    r = L.Renderer(ctx)
-    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
     cam = L.get_lookat_cam(*view_pose(rank), width=W, height=H)
     img = torch.zeros(3, H, W, device=dev)
-    if os.environ.get("LCGS_BENCH_SPATIAL_FIRST") == "1":
-        # profiling hook: every leg below runs on the spatially ordered scene (the workload name says so)
-        perm0 = r.reorder_scene_spatial().long()
-        d = {k: d[k][perm0].contiguous() for k in d}
-        scene = {k: np.ascontiguousarray(scene[k][perm0.cpu().numpy()]) for k in d}
-        r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
-        workload += " [spatially ordered: LCGS_BENCH_SPATIAL_FIRST]"
-        del perm0
 
     # first frame synchronises: sizes the pair buffers for this view
     n_rendered = r.forward(cam, img, sync=True)
@@ -390,7 +390,6 @@ def main():
     # view through the package's view-parallel protocol (luisacomputegaussiansplatting_amd.multi_gpu: the same
     # ViewParallelTrainer tests/test_distributed.py runs on gloo); Msplats/s = splats x views / time.
     # Same barrier / max-over-ranks timing.
-    KEYS = mg.KEYS
     coll = None
     if not args.no_backward:
         gbuf = torch.zeros(59 * P, device=dev)  # pos 3 | scale 3 | rotq 4 | sh 48 | opacity 1, one flat buffer
@@ -495,44 +494,28 @@ def main():
             r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
             del act, raw, eng2
 
-    # ---- the same frames with the scene in spatial (Morton) order: lcgs_scene_reorder_spatial, an ingest option
-    # (SURVEY 8f rank 1).  Same splats, same image; the splats of a view then sit in runs of consecutive rows instead
-    # of being scattered over every DRAM page.  Reported beside `value` (which stays the file-order figure).
+    # ---- the same frames with the splats in FILE order (caller-bound arrays in the order of the file: for this stand-in
+    # i.i.d., the worst case -- a view's splats are scattered over every DRAM page).  Same splats, same image.
     if not args.no_spatial:
         ref_img = torch.empty_like(img)
         r.forward(cam, ref_img, sync=True)
-        perm = r.reorder_scene_spatial().long()
-        # (forward frames: from the context's own re-ordered copy)
-        n_sp = r.forward(cam, img, sync=True)
-        sp = {"api": "lcgs_scene_reorder_spatial", "num_rendered_equal": bool(n_sp == n_rendered),
+        df = {k: torch.from_numpy(np.ascontiguousarray(scene[k], dtype=np.float32)).to(dev) for k in KEYS}
+        r.bind_scene(*[df[k] for k in KEYS])
+        n_fo = r.forward(cam, img, sync=True)
+        fo = {"api": "lcgs_scene_bind of file-order arrays", "num_rendered_equal": bool(n_fo == n_rendered),
               "image_equal": bool(torch.equal(img, ref_img))}
-        for _ in range(args.warmup):
-            r.forward(cam, img, sync=False)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            r.forward(cam, img, sync=False)
-        barrier()
-        el_s = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([el_s], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el_s = float(tt.item())
-        sp["forward"] = {"value": round(world * args.steps / el_s, 2), "unit": "frames/s",
+        el_s = timed(lambda i: r.forward(cam, img, sync=False), args.steps, args.warmup)
+        fo["forward"] = {"value": round(world * args.steps / el_s, 2), "unit": "frames/s",
                          "ms_per_step": round(el_s * 1e3 / args.steps, 4)}
         if not args.no_backward:
-            # the caller's copy in the new order: what a training loop would own (gradients follow it)
-            dp = {k: d[k][perm].contiguous() for k in d}
-            r.bind_scene(dp["pos"], dp["scale"], dp["rotq"], dp["sh"], dp["opacity"])
             for compact in ((False, True) if dist is None else (False,)):
                 el_b = timed_steps(False, compact=compact)  # (per-view steps; no collective in this leg)
-                sp["fwd_bwd_compact_rows" if compact else "fwd_bwd"] = {
+                fo["fwd_bwd_compact_rows" if compact else "fwd_bwd"] = {
                     "value": round(world * P * args.steps / el_b / 1e6, 1), "unit": "Msplats/s",
                     "ms_per_step": round(el_b * 1e3 / args.steps, 4)}
-            del dp
-        out["spatially_ordered"] = sp
-        r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
-        del perm, ref_img
+        out["file_order"] = fo
+        r.bind_scene(*[d[k] for k in KEYS])
+        del df, ref_img
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference) on this box's host cores, rank 0, N = 1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

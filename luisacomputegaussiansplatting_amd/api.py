@@ -143,7 +143,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh",
-    "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_shard_rows",
+    "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_shard_rows",
     "lcgs_grads_allreduce", "lcgs_adam_step_sharded",
 ]
 
@@ -454,20 +454,51 @@ class Renderer:
         self._keep = None  # the caller's arrays are no longer read
         return perm
 
-    def upload_scene(self, scene: dict, sh_degree: int = 3):
+    def upload_scene(self, scene: dict, sh_degree: int = 3, order: Optional[str] = None):
+        """lcgs_scene_upload: host arrays -> device copies owned by the context, kept in spatial order by default
+        (order="file" keeps the given order); see permutation() / scene_tensors()."""
+        if order is not None:
+            _check(load_library().lcgs_set_ingest_order(self.ctx._h, C.c_int({"file": 0, "spatial": 1}[order])))
         arrs = [np.ascontiguousarray(scene[k], dtype=np.float32) for k in ("pos", "scale", "rotq", "sh", "opacity")]
         P = int(arrs[0].reshape(-1, 3).shape[0])
         self.P, self.sh_degree = P, sh_degree
         self._generation += 1
         _check(load_library().lcgs_scene_upload(self.ctx._h, C.c_int(P), C.c_int(sh_degree), *[_ptr(a) for a in arrs]))
 
-    def load_ply(self, path: str) -> int:
-        """read_gs_ply + upload with the de-interleave / activations on the device (lcgs_scene_load_ply)."""
+    def load_ply(self, path: str, order: Optional[str] = None) -> int:
+        """read_gs_ply + upload with the de-interleave / activations on the device (lcgs_scene_load_ply).  order:
+        "spatial" (the library's default: the context keeps its scene along a Morton curve) or "file"."""
+        if order is not None:
+            _check(load_library().lcgs_set_ingest_order(self.ctx._h, C.c_int({"file": 0, "spatial": 1}[order])))
         n = C.c_int(0)
         _check(load_library().lcgs_scene_load_ply(self.ctx._h, path.encode(), C.byref(n)))
         self.P, self.sh_degree, self._keep = n.value, 3, []
         self._generation += 1
         return n.value
+
+    def _device_view(self, ptr: int, shape, typestr: str):
+        """a torch tensor ALIASING context-owned device memory (no copy; valid while the context keeps that array)"""
+        import torch
+
+        class _View:
+            __cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+        return torch.as_tensor(_View(), device=f"cuda:{self.ctx.device_id}")
+
+    def scene_tensors(self) -> dict:
+        """lcgs_scene_pointers as torch tensors aliasing the bound arrays (the context's own after load_ply / a re-order)."""
+        ptrs = [C.c_void_p() for _ in range(5)]
+        n, deg = C.c_int(0), C.c_int(0)
+        _check(load_library().lcgs_scene_pointers(self.ctx._h, C.byref(n), C.byref(deg), *[C.byref(p) for p in ptrs]))
+        P, feat = n.value, (deg.value + 1) ** 2 * 3
+        shapes = {"pos": (P, 3), "scale": (P, 3), "rotq": (P, 4), "sh": (P, feat), "opacity": (P,)}
+        return {k: self._device_view(p.value, shapes[k], "<f4") for k, p in zip(("pos", "scale", "rotq", "sh", "opacity"), ptrs)}
+
+    def permutation(self):
+        """lcgs_scene_permutation: int32 device tensor, [r] = file index of splat r; None while in file / caller order."""
+        p = C.c_void_p()
+        _check(load_library().lcgs_scene_permutation(self.ctx._h, C.byref(p)))
+        return self._device_view(p.value, (self.P,), "<i4") if p.value else None
 
     def use_half_sh(self, enable: bool = True):
         """lcgs_scene_use_half_sh: opt-in f16 copy of the SH coefficients for the fused forward (outside the 1e-4 bar)."""

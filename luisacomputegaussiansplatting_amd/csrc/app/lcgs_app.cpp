@@ -52,7 +52,8 @@ void usage(const char* argv0)
     printf("  --path <fused|stage>     One-submission fused frame (default) or the three stage-level operators\n");
     printf("  --synth <kind:count:seed> Render a synthetic stand-in scene instead of --ply (kind 0 object, 1 unbounded)\n");
     printf("  --ingest <device|host>   De-interleave/activate the PLY on the GPU (default) or on the host\n");
-    printf("  --order <file|spatial>   Keep the splats in file order (default) or re-order them along a Morton curve at load\n");
+    printf("  --order <file|spatial>   Keep the splats in file order, or re-order them along a Morton curve at load (same image;\n"
+           "                           default: spatial for a PLY ingested on the device -- the library's default --, else file)\n");
     printf("  --pose <garden|lego>     The look-at compiled into the reference (garden, app/main.cpp:191-193; default) or the\n"
            "                           alternative it keeps in a comment for lego / bicycle (app/main.cpp:195-197)\n");
     printf("  --cameras <file>         Render every camera of the file: `px py pz tx ty tz ux uy uz [fov]` per line\n");
@@ -74,7 +75,7 @@ int main(int argc, char** argv)
 {
     unsigned    W = 1600, H = 1063; // app/main.cpp:38
     std::string ply_path = "gsplat.ply", backend = "hip", out_dir = "out", world = "colmap", path = "fused", synth;
-    std::string ingest = "device", cameras_file, order = "file", pose = "garden";
+    std::string ingest = "device", cameras_file, order = "auto", pose = "garden";
     int         exp_N = 1, gpus = 1;
     bool        backward = false;
     // parse_command (app/command_parser.hpp:5-79): strip leading dashes, `key=value` or `key value`
@@ -211,8 +212,11 @@ int main(int argc, char** argv)
             sc = { P, 3, spos.data(), sfeat.data(), sop.data(), sscale.data(), srot.data() };
             ply_name = "synth" + std::to_string(kind) + "_" + std::to_string(count);
         } else if (ingest == "device") {
-            lcgs::check(lcgs_scene_load_ply(device.ctx(), ply_path.c_str(), &P)); // records -> GPU -> activated arrays
+            // records -> GPU -> activated arrays; the context keeps its scene in spatial order unless --order file
+            lcgs::check(lcgs_set_ingest_order(device.ctx(), order == "file" ? LCGS_ORDER_FILE : LCGS_ORDER_SPATIAL));
+            lcgs::check(lcgs_scene_load_ply(device.ctx(), ply_path.c_str(), &P));
             on_device = true;
+            if (order != "file") order = "done";
         } else {
             lcgs::check(lcgs_ply_read(ply_path.c_str(), &sc));
             P = sc.num_gaussians;

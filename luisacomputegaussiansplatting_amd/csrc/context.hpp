@@ -26,6 +26,11 @@ struct lcgs_context {
     int          P = 0, sh_deg = 3;
     const float *pos = nullptr, *scale = nullptr, *rotq = nullptr, *sh = nullptr, *opacity = nullptr;
     DeviceBuffer owned[5];
+    // Splat order of a context-owned scene: lcgs_scene_load_ply re-orders along a Morton curve unless told otherwise
+    // (lcgs_set_ingest_order); scene_perm[r] = file index of splat r while perm_valid (lcgs_scene_permutation)
+    int          ingest_order = 1; // LCGS_ORDER_SPATIAL
+    DeviceBuffer scene_perm;
+    bool         perm_valid = false;
     DeviceBuffer sh_half;            // opt-in f16 copy of sh for the fused forward's colour pass (lcgs_scene_use_half_sh)
     bool         use_half_sh = false;
 

@@ -14,8 +14,7 @@
 //     reference's "collect num_done" at shader.cpp:229 has no code behind it, so every tile walks its whole list).
 //   * workgroup -> tile: longest-list-first (k_tile_order, from the previous frame's list lengths) when the caller
 //     supplies an order, else XCD-aware blocks of 8x4 tiles dealt round-robin to the 8 XCDs (tile_of_workgroup).
-//   * k_render_forward (LCGS_RENDER_VARIANT=a, a tuning alternative kept for comparison): one wave64 per tile,
-//     lane l = column l & 15 and the four rows (l >> 4) + {0,4,8,12}; 64 entries per round.
+//   (A one-wave64-per-tile variant was kept as a tuning hook through round 1; measured slower at every size, removed.)
 // Numerics: the per-pixel expressions keep the reference's evaluation order with no FMA contraction
 // (-ffp-contract=off); exp() is the hardware v_exp_f32 path (__expf).
 #include <stdlib.h>
@@ -57,152 +56,8 @@ struct FetchRec {
 
 using namespace tile;
 
-template <typename Fetch>
-__global__ void __launch_bounds__(64) k_render_forward(CamParams cp, float bg0, float bg1, float bg2,
-                                                            const FrameParams* __restrict__ fpp,
-                                                         const uint32_t* __restrict__ ranges,
-                                                         const uint32_t* __restrict__ point_list, Fetch fetch,
-                                                         float* __restrict__ img, float* __restrict__ final_T,
-                                                         uint32_t* __restrict__ n_contrib,
-                                                         const uint32_t* __restrict__ d_counts)
-{
-    __shared__ float4 s_a[64]; // mean.x, mean.y, conic.x, conic.y
-    __shared__ float4 s_b[64]; // conic.z, opacity, r, g
-    __shared__ float4 s_c[64]; // b, power floor (-t/2), list position + 1 (bits), strip mask (bits)
-
-    if (fpp) { // graph replay: per-call parameters come from device memory
-        cp  = fpp->cp;
-        bg0 = fpp->bg[0];
-        bg1 = fpp->bg[1];
-        bg2 = fpp->bg[2];
-    }
-    uint32_t tx, ty;
-    if (!tile_of_workgroup(blockIdx.x, cp.grid_x, cp.grid_y, tx, ty)) return;
-    const uint32_t tile = ty * cp.grid_x + tx;
-    // num_rendered == 0: nothing is drawn and the image is left untouched (gs_tile_splatter/impl.cpp:109)
-    if (d_counts && d_counts[1] == 0u) return;
-
-    const uint32_t lane = threadIdx.x;
-    const uint32_t px  = tx * kBlockX + (lane & 15u);
-    const uint32_t py0 = ty * kBlockY + (lane >> 4);
-    float          pxf = (float)px;
-    const float    rx0 = (float)(tx * kBlockX), ry0 = (float)(ty * kBlockY);
-    const float    rx1 = rx0 + (float)(kBlockX - 1);
-
-    // T > 0: pixel live; T < 0: pixel finished (saturated or outside the image), |T| is its transmittance.
-    float    pyf[4], T[4], Cr[4], Cg[4], Cb[4];
-    uint32_t last_contrib[4];
-    uint32_t live = 0;       // wave-uniform count of live pixels
-    uint32_t live_strips = 0; // wave-uniform: bit k set while strip k still has a live pixel
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t py = py0 + 4u * k;
-        pyf[k]            = (float)py;
-        const bool inside = (px < cp.width) && (py < cp.height);
-        T[k]              = inside ? 1.0f : -1.0f;
-        Cr[k] = Cg[k] = Cb[k] = 0.0f;
-        last_contrib[k]       = 0u;
-        const unsigned long long in_mask = __ballot(inside);
-        live += __popcll(in_mask);
-        if (in_mask) live_strips |= 1u << k;
-        asm volatile("" : "+v"(pyf[k])); // keep the converted coordinate in a register (no re-conversion per entry)
-    }
-    asm volatile("" : "+v"(pxf));
-
-    const uint32_t range_start = ranges[2 * (size_t)tile + 0];
-    const uint32_t range_end   = ranges[2 * (size_t)tile + 1];
-
-    // software pipeline: the gather of round r+1 is in flight while round r is composited
-    float4 na = make_float4(0, 0, 0, 0), nb = make_float4(0, 0, 0, 0);
-    float  nc = 0.0f;
-    if (range_start + lane < range_end) fetch(point_list[range_start + lane], na, nb, nc);
-
-    for (uint32_t base = range_start; base < range_end && live != 0u; base += 64u) {
-        // ---- stage: test each entry against the four 16x4 strips of the tile, compact survivors in list order
-        const uint32_t e    = base + lane;
-        const bool     have = e < range_end;
-        const float4   a = na, b = nb;
-        const float    c = nc;
-        // t = 2 ln(255 o) with a relative + absolute safety margin (exp/log rounding)
-        const float t = have ? (2.0f * __logf(255.0f * b.y)) * 1.0001f + 2e-4f : -1.0f;
-        uint32_t    kmask = 0;
-        if (have) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float y0 = ry0 + 4.0f * k;
-                if (splat_may_touch_rect(a.x, a.y, a.z, a.w, b.x, t, rx0, y0, rx1, y0 + 3.0f)) kmask |= 1u << k;
-            }
-        }
-        const bool               keep = kmask != 0u;
-        const unsigned long long mask = __ballot(keep);
-        const uint32_t slot = __popcll(mask & ((1ull << lane) - 1ull));
-        const uint32_t cnt  = __popcll(mask);
-        __syncthreads(); // previous round's readers are done with the slab
-        if (keep) {
-            s_a[slot] = a;
-            s_b[slot] = b;
-            s_c[slot] = make_float4(c, -0.5f * t, __uint_as_float(e - range_start + 1u), __uint_as_float(kmask));
-        }
-        const uint32_t en = e + 64u;
-        if (en < range_end) fetch(point_list[en], na, nb, nc);
-        __syncthreads();
-
-        float4 ea = s_a[0], eb = s_b[0], ec = s_c[0];
-        for (uint32_t j = 0; j < cnt && live != 0u; ++j) {
-            const float4 ca = ea, cb4 = eb, cc4 = ec;
-            const uint32_t jn = (j + 1u < cnt) ? j + 1u : j;
-            ea = s_a[jn]; // LDS reads of the next entry overlap this entry's arithmetic
-            eb = s_b[jn];
-            ec = s_c[jn];
-            const uint32_t contributor = __float_as_uint(cc4.z);
-            const uint32_t strips      = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cc4.w)) & live_strips;
-            const float    dx          = ca.x - pxf;
-            const float    cxdxdx      = ca.z * dx * dx; // con_o.x * d.x * d.x
-            const float    cydx        = ca.w * dx;      // con_o.y * d.x
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!((strips >> k) & 1u)) continue; // scalar: this 16x4 strip is out of the splat's reach
-                const float dy    = ca.y - pyf[k];
-                const float power = -0.5f * (cxdxdx + cb4.x * dy * dy) - cydx * dy; // shader.cpp:256
-                const bool  cand  = (T[k] > 0.0f) && !(power > 0.0f) && (power >= cc4.y);
-                if (!__any(cand)) continue;
-                const float alpha  = fmin_(0.99f, cb4.y * __expf(power));
-                const bool  valid  = cand && !(alpha < 1.0f / 255.0f);
-                const float test_T = T[k] * (1.0f - alpha);
-                const bool  sat    = valid && (test_T < 0.0001f);
-                const bool  upd    = valid && !sat;
-                const float w      = upd ? T[k] * alpha : 0.0f;
-                Cr[k]              = Cr[k] + w * cb4.z;
-                Cg[k]              = Cg[k] + w * cb4.w;
-                Cb[k]              = Cb[k] + w * cc4.x;
-                T[k]               = upd ? test_T : (sat ? -T[k] : T[k]);
-                last_contrib[k]    = upd ? contributor : last_contrib[k];
-                const unsigned long long sm = __ballot(sat);
-                if (sm) { // rare: some pixel of this strip just saturated
-                    live -= __popcll(sm);
-                    if (!__any(T[k] > 0.0f)) live_strips &= ~(1u << k); // the whole 16x4 strip is finished
-                }
-            }
-        }
-    }
-
-    const size_t hw = (size_t)cp.width * cp.height;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t py = py0 + 4u * k;
-        if (!((px < cp.width) && (py < cp.height))) continue;
-        const float  Tk  = fabsf(T[k]);
-        const size_t pix = (size_t)px + (size_t)cp.width * py;
-        img[pix]          = bg0 * Tk + Cr[k]; // shader.cpp:279-286, planar CHW
-        img[pix + hw]     = bg1 * Tk + Cg[k];
-        img[pix + 2 * hw] = bg2 * Tk + Cb[k];
-        if (final_T) final_T[pix] = Tk;
-        if (n_contrib) n_contrib[pix] = last_contrib[k];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Variant B: one workgroup (4 wave64s) per tile, wave k owns the 16x4 strip k, one pixel per lane.
+// One workgroup (4 wave64s) per tile, wave k owns the 16x4 strip k, one pixel per lane.
 // The heaviest tiles set the kernel's critical path; splitting a tile over four waves shortens it 4x and gives
 // the dispatcher four times as many independent wave-sized work items to balance.  A round stages 256 list
 // entries: every lane fetches one entry, tests it against the four strips, and the per-strip ballots (one
@@ -430,11 +285,7 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
                    uint8_t* strip_masks = nullptr, hipEvent_t done = nullptr)
 {
     if (cp.grid_x * cp.grid_y == 0) return;
-    static const int variant = [] {
-        const char* v = getenv("LCGS_RENDER_VARIANT"); // tuning hook: "a" = wave per tile, default = workgroup per tile
-        return (v && v[0] == 'a') ? 0 : 1;
-    }();
-    if (variant == 1) {
+    {
         const dim3 grid(render_grid_size(cp.grid_x, cp.grid_y));
         // (`done`, when given, is carried by the dispatch packet: no separate event-record packet behind the kernel)
         if (final_T || n_contrib)
@@ -445,10 +296,7 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
             hipExtLaunchKernelGGL((k_render_forward_b<Fetch, false>), grid, dim3(256), 0, stream, nullptr, done, 0, cp, bg[0],
                                   bg[1], bg[2], d_fp, ranges, point_list, fetch, img, final_T, n_contrib, d_counts,
                                   tile_order, (uint8_t*)nullptr);
-        return;
     }
-    hipLaunchKernelGGL(k_render_forward<Fetch>, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(64), 0, stream, cp, bg[0], bg[1], bg[2], d_fp, ranges,
-                       point_list, fetch, img, final_T, n_contrib, d_counts);
 }
 
 } // namespace
@@ -477,11 +325,7 @@ void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uin
                   stream, strip_masks, done);
 }
 
-// true when the forward renderer in use fills strip_masks (the workgroup-per-tile variant does)
-bool render_forward_writes_strip_masks()
-{
-    const char* v = getenv("LCGS_RENDER_VARIANT");
-    return !(v && v[0] == 'a');
-}
+// the forward renderer fills strip_masks whenever it keeps backward state
+bool render_forward_writes_strip_masks() { return true; }
 
 } // namespace lcgs

@@ -477,6 +477,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
         if (ev) (void)hipEventDestroy(ev);
     ctx->frame_params.release();
     ctx->slice_bounds.release();
+    ctx->scene_perm.release();
     for (hipEvent_t ev : ctx->ev_slice)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -665,6 +666,22 @@ lcgs_status lcgs_scene_bind(lcgs_context* ctx, int num_gaussians, int sh_degree,
     ctx->opacity = d_opacity;
     ctx->last.valid = false;
     ctx->use_half_sh = false; // a new scene: the f16 copy (if any) is stale
+    ctx->perm_valid  = false; // the caller's arrays, the caller's order
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_set_ingest_order(lcgs_context* ctx, int order)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(order == LCGS_ORDER_FILE || order == LCGS_ORDER_SPATIAL, "order must be LCGS_ORDER_FILE or LCGS_ORDER_SPATIAL");
+    ctx->ingest_order = order;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_scene_permutation(lcgs_context* ctx, const uint32_t** d_perm)
+{
+    LCGS_REQUIRE(ctx && d_perm, "NULL argument");
+    *d_perm = ctx->perm_valid ? ctx->scene_perm.as<uint32_t>() : nullptr;
     return LCGS_OK;
 }
 
@@ -686,8 +703,11 @@ lcgs_status lcgs_scene_upload(lcgs_context* ctx, int num_gaussians, int sh_degre
             LCGS_HIP_CHECK(hipMemcpyAsync(ctx->owned[i].ptr, src[i], sizes[i], hipMemcpyHostToDevice, ctx->stream));
     }
     LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // app/main.cpp:223
-    return lcgs_scene_bind(ctx, num_gaussians, sh_degree, ctx->owned[0].as<float>(), ctx->owned[1].as<float>(),
-                           ctx->owned[2].as<float>(), ctx->owned[3].as<float>(), ctx->owned[4].as<float>());
+    LCGS_TRY(lcgs_scene_bind(ctx, num_gaussians, sh_degree, ctx->owned[0].as<float>(), ctx->owned[1].as<float>(),
+                             ctx->owned[2].as<float>(), ctx->owned[3].as<float>(), ctx->owned[4].as<float>()));
+    // a scene the context owns is kept in spatial order unless the caller asked for the given one (lcgs_set_ingest_order)
+    if (ctx->ingest_order == LCGS_ORDER_SPATIAL && num_gaussians > 0) LCGS_TRY(lcgs_scene_reorder_spatial(ctx, nullptr));
+    return LCGS_OK;
 }
 
 lcgs_status lcgs_scene_reorder_spatial(lcgs_context* ctx, uint32_t* d_perm)
@@ -751,21 +771,48 @@ lcgs_status lcgs_scene_reorder_spatial(lcgs_context* ctx, uint32_t* d_perm)
     const float*    src[5] = { ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity };
     for (int i = 0; i < 5; ++i) launch_gather_rows(P, rowf[i], perm, src[i], fresh[i].as<float>(), st);
     e = hipGetLastError();
+    DeviceBuffer kept_perm;
+    if (e == hipSuccess && kept_perm.ensure((size_t)P * 4) != LCGS_OK) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMemcpyAsync(kept_perm.ptr, perm, (size_t)P * 4, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && d_perm) e = hipMemcpyAsync(d_perm, perm, (size_t)P * 4, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     drop();
     if (e != hipSuccess) {
         for (DeviceBuffer& b : fresh) b.release();
+        kept_perm.release();
         LCGS_HIP_CHECK(e);
     }
     // ---- the context now owns (and renders from) the re-ordered copy
-    const bool half = ctx->use_half_sh;
+    const bool half = ctx->use_half_sh, had_perm = ctx->perm_valid;
     for (int i = 0; i < 5; ++i) {
         ctx->owned[i].release();
         ctx->owned[i] = fresh[i];
     }
     LCGS_TRY(lcgs_scene_bind(ctx, ctx->P, ctx->sh_deg, ctx->owned[0].as<float>(), ctx->owned[1].as<float>(),
                              ctx->owned[2].as<float>(), ctx->owned[3].as<float>(), ctx->owned[4].as<float>()));
+    // the permutation stays with the context (composed with an earlier one: file index of every row)
+    if (had_perm) {
+        DeviceBuffer composed;
+        lcgs_status  cs = composed.ensure((size_t)P * 4);
+        if (cs == LCGS_OK) {
+            launch_gather_rows(P, 1, kept_perm.as<uint32_t>(), ctx->scene_perm.as<float>(), composed.as<float>(), st);
+            hipError_t ce = hipStreamSynchronize(st);
+            kept_perm.release();
+            if (ce != hipSuccess) {
+                composed.release();
+                LCGS_HIP_CHECK(ce);
+            }
+            ctx->scene_perm.release();
+            ctx->scene_perm = composed;
+        } else {
+            kept_perm.release();
+            return cs;
+        }
+    } else {
+        ctx->scene_perm.release();
+        ctx->scene_perm = kept_perm;
+    }
+    ctx->perm_valid = true;
     if (half) LCGS_TRY(lcgs_scene_use_half_sh(ctx, 1)); // the f16 copy follows the new order
     return LCGS_OK;
 }
@@ -873,7 +920,7 @@ lcgs_status lcgs_scene_load_ply(lcgs_context* ctx, const char* path, int* num_ga
         lcgs_status s = lcgs_scene_upload(ctx, h.num_gaussians, h.sh_degree, h.pos, h.scale, h.rotq, h.feature, h.opacity);
         if (num_gaussians) *num_gaussians = h.num_gaussians;
         lcgs_scene_host_free(&h);
-        return s;
+        return s; // (lcgs_scene_upload applied the ingest order)
     }
     const int64_t N = probe.num_vertices;
     LCGS_REQUIRE(N < (1 << 30), "too many vertices");
@@ -946,8 +993,11 @@ lcgs_status lcgs_scene_load_ply(lcgs_context* ctx, const char* path, int* num_ga
         }
     }
     if (num_gaussians) *num_gaussians = (int)N;
-    return lcgs_scene_bind(ctx, (int)N, 3, ctx->owned[0].as<float>(), ctx->owned[1].as<float>(), ctx->owned[2].as<float>(),
-                           ctx->owned[3].as<float>(), ctx->owned[4].as<float>());
+    LCGS_TRY(lcgs_scene_bind(ctx, (int)N, 3, ctx->owned[0].as<float>(), ctx->owned[1].as<float>(), ctx->owned[2].as<float>(),
+                             ctx->owned[3].as<float>(), ctx->owned[4].as<float>()));
+    // a scene the context owns is kept in spatial order unless the caller asked for the file's (lcgs_set_ingest_order)
+    if (ctx->ingest_order == LCGS_ORDER_SPATIAL && N > 0) LCGS_TRY(lcgs_scene_reorder_spatial(ctx, nullptr));
+    return LCGS_OK;
 }
 
 lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, const float bg_color[3],

@@ -31,8 +31,48 @@ def test_device_ingest_matches_host_reader_on_golden_ply(lcgs, golden_dir):
     path = os.path.join(golden_dir, "tiny_scene.ply")
     host = lcgs.read_gs_ply(path)
     r = lcgs.Renderer(lcgs.Context(0))
-    assert r.load_ply(path) == host["pos"].shape[0]
+    assert r.load_ply(path, order="file") == host["pos"].shape[0]
     _compare(r.download_scene(), host)
+    assert r.permutation() is None
+
+
+def test_load_ply_keeps_the_scene_in_spatial_order_by_default(lcgs, tmp_path):
+    """lcgs_scene_load_ply's default (lcgs_set_ingest_order: LCGS_ORDER_SPATIAL): the context's arrays are the file's rows
+    through lcgs_scene_permutation, the frame equals the file-order frame, per-splat outputs follow the new order; a second
+    re-order composes the permutation; binding caller arrays drops it."""
+    rng = np.random.default_rng(77)
+    P = 40000
+    path = str(tmp_path / "s.ply")
+    lcgs.write_ply_raw(path, rng.normal(0, 0.9, (P, 3)) + [0, 0, 0.5], rng.normal(0.3, 0.8, (P, 3)),
+                       rng.normal(0, 0.1, (P, 45)), rng.normal(0, 2.5, P), rng.normal(-4.0, 0.8, (P, 3)),
+                       rng.normal(size=(P, 4)))
+    cam = lcgs.get_lookat_cam([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1], width=320, height=240)
+    rf = lcgs.Renderer(lcgs.Context(0))
+    rf.load_ply(path, order="file")
+    file_scene = rf.download_scene()
+    img_f, rad_f = torch.zeros(3, 240, 320, device=DEV), torch.zeros(P, dtype=torch.int32, device=DEV)
+    n_f = rf.forward(cam, img_f, radii=rad_f)
+    rs = lcgs.Renderer(lcgs.Context(0))
+    assert rs.load_ply(path) == P  # the default
+    for rep in range(2):
+        perm = rs.permutation()
+        assert perm is not None
+        pn = perm.cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.sort(pn), np.arange(P))
+        got = rs.download_scene()
+        for k in ("pos", "scale", "rotq", "sh", "opacity"):
+            assert np.array_equal(got[k], file_scene[k][pn]), (rep, k)
+        t = rs.scene_tensors()  # aliases of the context's arrays
+        assert np.array_equal(t["pos"].cpu().numpy(), got["pos"]) and t["sh"].shape == (P, 48)
+        img_s, rad_s = torch.zeros(3, 240, 320, device=DEV), torch.zeros(P, dtype=torch.int32, device=DEV)
+        assert rs.forward(cam, img_s, radii=rad_s) == n_f
+        assert torch.equal(img_s, img_f)
+        assert np.array_equal(rad_s.cpu().numpy(), rad_f.cpu().numpy()[pn])
+        if rep == 0:
+            rs.reorder_scene_spatial()  # once more: already sorted, the kept permutation is the composition
+    d = {k: torch.from_numpy(file_scene[k]).to(DEV) for k in file_scene}
+    rs.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    assert rs.permutation() is None
 
 
 @pytest.mark.parametrize("P", [0, 1, 63, 64, 65, 100003])
@@ -44,8 +84,9 @@ def test_device_ingest_sizes_and_render(lcgs, tmp_path, P):
                        rng.normal(0, 0.1, (P, 45)), rng.normal(0, 2.5, P), rng.normal(-4.0, 0.8, (P, 3)), rot)
     host = lcgs.read_gs_ply(path)
     r = lcgs.Renderer(lcgs.Context(0))
-    assert r.load_ply(path) == P
+    assert r.load_ply(path, order="file") == P
     if P == 0:
+        assert lcgs.Renderer(lcgs.Context(0)).load_ply(path) == 0  # (and the default order on an empty file)
         return
     _compare(r.download_scene(), host)
     # the loaded scene renders; against the host-loaded scene the image differs only through the <= 2 ulp of exp()
@@ -72,7 +113,7 @@ def test_device_ingest_falls_back_for_ascii(lcgs, tmp_path):
             f.write(" ".join(repr(float(v)) for v in row) + "\n")
     host = lcgs.read_gs_ply(path)
     r = lcgs.Renderer(lcgs.Context(0))
-    assert r.load_ply(path) == 7
+    assert r.load_ply(path, order="file") == 7
     dev = r.download_scene()
     for k in ("pos", "sh", "rotq", "scale", "opacity"):
         assert np.array_equal(dev[k], host[k].reshape(dev[k].shape))  # same host code path

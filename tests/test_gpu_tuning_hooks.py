@@ -1,7 +1,7 @@
-"""`-m gpu`: the two opt-in tuning hooks stay correct -- LCGS_GRAPH=1 (the fused frame captured once and replayed as
-a hipGraph, per-call parameters read from device memory) and LCGS_RENDER_VARIANT=a (one wave64 per tile instead of
-one workgroup per tile).  Neither is the default (measured: no gain); both must still produce the reference frame,
-so the fused-frame and backward parity suites run once more under each."""
+"""`-m gpu`: the opt-in tuning hook LCGS_GRAPH=1 (the fused frame captured once and replayed as a hipGraph, per-call
+parameters read from device memory) stays correct.  It is not the default (measured: no gain, the short kernels are
+GPU-latency-bound, not host-bound) but must still produce the reference frame, so the fused-frame parity suite runs once
+more under it."""
 import os
 import subprocess
 import sys
@@ -12,10 +12,10 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
-FILES = ["tests/test_gpu_fused.py", "tests/test_gpu_backward.py", "tests/test_gpu_sh_degrees.py"]
+FILES = ["tests/test_gpu_fused.py", "tests/test_gpu_backward.py"]
 
 
-@pytest.mark.parametrize("hook", [{"LCGS_GRAPH": "1"}, {"LCGS_RENDER_VARIANT": "a"}], ids=["hipgraph", "wave_per_tile"])
+@pytest.mark.parametrize("hook", [{"LCGS_GRAPH": "1"}], ids=["hipgraph"])
 def test_parity_suites_under_tuning_hook(hook):
     env = dict(os.environ, **hook)
     res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + FILES,
