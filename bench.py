@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--no-batch", action="store_true")
     ap.add_argument("--no-stage-path", action="store_true")
     ap.add_argument("--half-sh", action="store_true", help="also time the opt-in f16 SH colour pass")
+    ap.add_argument("--lod", type=int, default=0, help="also time the opt-in footprint cull (lcgs_set_lod) at this radius")
     ap.add_argument("--no-spatial", action="store_true", help="skip the file-order legs (the scene is kept in spatial order)")
     ap.add_argument("--no-moving-camera", action="store_true", help="skip the moving-camera forward leg")
     ap.add_argument("--collective", choices=("rccl", "torch"), default="rccl",
@@ -289,6 +290,22 @@ def main():
         r.use_half_sh(False)
         r.forward(cam, img, sync=True)
 
+    # ---- opt-in footprint (LOD) cull (changes the image, never `value`)
+    lod = None
+    if args.lod > 0:
+        ref_img = img.clone()
+        r.set_lod(args.lod)
+        n_lod = r.forward(cam, img, sync=True)
+        st_lod = r.frame_stats()
+        el_l = timed(lambda i: r.forward(cam, img, sync=False), args.steps, args.warmup)
+        lod = {"min_radius_px": args.lod, "value": round(world * args.steps / el_l, 2), "unit": "frames/s",
+               "num_rendered": int(n_lod), "visible_splats": st_lod["num_visible"], "tile_pairs_sorted": st_lod["num_pairs"],
+               "max_abs_diff_vs_unculled": float((img - ref_img).abs().max().item()),
+               "mean_abs_diff_vs_unculled": float((img - ref_img).abs().mean().item())}
+        r.set_lod(0)
+        r.forward(cam, img, sync=True)
+        del ref_img
+
     V, Lref, Lp, G = stats["num_visible"], stats["num_rendered"], stats["num_pairs"], stats["num_tiles"]
     # Algorithmic bytes per launch of each stage = per-unit figure x units
     stage_bytes = {
@@ -381,6 +398,8 @@ def main():
         out["stage_path"] = stage_path
     if half_sh is not None:
         out["half_sh"] = half_sh
+    if lod is not None:
+        out["lod"] = lod
     if pipelined is not None:
         out["camera_batch"] = pipelined
     if moving is not None:

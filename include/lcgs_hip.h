@@ -205,6 +205,15 @@ LCGS_API lcgs_status lcgs_scene_pointers(lcgs_context* ctx, int* num_gaussians, 
  * the backward and the stage-level operators keep reading the f32 coefficients.  enable == 0 returns to f32. */
 LCGS_API lcgs_status lcgs_scene_use_half_sh(lcgs_context* ctx, int enable);
 
+/* Opt-in footprint (level-of-detail) cull for the fused frame (the reference only names LOD on its
+ * roadmap, doc/roadmap.md:8).  min_radius_px > 0: a splat whose reference radius -- ceil(3 sqrt(lambda_max)) in pixels,
+ * gs_tile_splatter/shader.cpp:145-148 -- is below it is treated as touching no tile (radius 0, not counted in
+ * num_rendered, no gradient).  The low-pass filter and the max(0.1, .) under the root make 3 the smallest radius a splat
+ * can have (3 sqrt(0.3 + sqrt(0.1)) = 2.35), so 4 drops exactly the splats at that floor.  This changes the image (a quality / speed trade): it is outside the 1e-4
+ * parity bar against the unculled frame by construction, never the default, and the stage-level operators ignore it.
+ * 0 switches it off. */
+LCGS_API lcgs_status lcgs_set_lod(lcgs_context* ctx, int min_radius_px);
+
 /* Copies the bound scene to host arrays sized like lcgs_scene_upload's inputs (NULL outputs are skipped). */
 LCGS_API lcgs_status lcgs_scene_download(lcgs_context* ctx, float* h_pos, float* h_scale, float* h_rotq, float* h_sh,
                                          float* h_opacity);

@@ -143,7 +143,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh",
-    "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_shard_rows",
+    "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_set_lod", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_shard_rows",
     "lcgs_grads_allreduce", "lcgs_adam_step_sharded",
 ]
 
@@ -503,6 +503,11 @@ class Renderer:
     def use_half_sh(self, enable: bool = True):
         """lcgs_scene_use_half_sh: opt-in f16 copy of the SH coefficients for the fused forward (outside the 1e-4 bar)."""
         _check(load_library().lcgs_scene_use_half_sh(self.ctx._h, C.c_int(1 if enable else 0)))
+
+    def set_lod(self, min_radius_px: int):
+        """lcgs_set_lod: opt-in footprint cull (0 = off): splats whose reference radius is below min_radius_px pixels are
+        dropped from the fused frame.  Changes the image; never the default."""
+        _check(load_library().lcgs_set_lod(self.ctx._h, C.c_int(int(min_radius_px))))
 
     def download_scene(self) -> dict:
         """Host copies of the bound scene (same keys and shapes as read_gs_ply)."""

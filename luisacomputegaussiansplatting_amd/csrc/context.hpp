@@ -28,6 +28,7 @@ struct lcgs_context {
     DeviceBuffer owned[5];
     // Splat order of a context-owned scene: lcgs_scene_load_ply re-orders along a Morton curve unless told otherwise
     // (lcgs_set_ingest_order); scene_perm[r] = file index of splat r while perm_valid (lcgs_scene_permutation)
+    int          lod_min_radius = 0; // lcgs_set_lod: opt-in footprint cull of the fused frame (0 = off)
     int          ingest_order = 1; // LCGS_ORDER_SPATIAL
     DeviceBuffer scene_perm;
     bool         perm_valid = false;

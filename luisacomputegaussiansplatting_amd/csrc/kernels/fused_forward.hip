@@ -102,6 +102,10 @@ __device__ __forceinline__ Projected project_splat(const CamParams& cp, float sc
     cam_clamp(cp, v, t);
     ewa_cov2d(cp, Sig, t, true, cov2d);
     conic_and_radius(cov2d[0], cov2d[1], cov2d[2], true, cp.width, cp.height, r.conic, r.radius, filt);
+    if (r.radius < cp.lod_min_radius) { // opt-in footprint cull (lcgs_set_lod; never taken at the default 0)
+        r.radius = 0;
+        return r;
+    }
     r.pix_x = ndc2pix(ndc[0], cp.width);
     r.pix_y = ndc2pix(ndc[1], cp.height);
     uint32_t fmin[2], fmax[2], tmin[2], tmax[2];

@@ -50,6 +50,9 @@ struct CamParams {
     float focalx, focaly;
     uint32_t width, height;
     uint32_t grid_x, grid_y;
+    // opt-in footprint cull of the fused frame (lcgs_set_lod; 0 = off = the reference's behaviour): a splat whose reference
+    // radius (pixels, gs_tile_splatter/shader.cpp:148) is below this is treated as if it touched no tile
+    int32_t lod_min_radius;
 };
 
 // Per-call parameters of the fused frame, kept in DEVICE memory so that a captured hipGraph of the frame stays

@@ -670,6 +670,15 @@ lcgs_status lcgs_scene_bind(lcgs_context* ctx, int num_gaussians, int sh_degree,
     return LCGS_OK;
 }
 
+lcgs_status lcgs_set_lod(lcgs_context* ctx, int min_radius_px)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(min_radius_px >= 0 && min_radius_px <= 4096, "min_radius_px out of range");
+    ctx->lod_min_radius = min_radius_px;
+    if (ctx->twin) ctx->twin->lod_min_radius = min_radius_px;
+    return LCGS_OK;
+}
+
 lcgs_status lcgs_set_ingest_order(lcgs_context* ctx, int order)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
@@ -1012,7 +1021,8 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
     if (num_rendered) *num_rendered = 0;
     if (ctx->P == 0) return LCGS_OK; // nothing to draw: image untouched, like gs_tile_splatter/impl.cpp:109
     LCGS_REQUIRE(ctx->pos != nullptr, "no scene bound (call lcgs_scene_bind / lcgs_scene_upload first)");
-    const CamParams cp = make_cam_params(*camera);
+    CamParams cp      = make_cam_params(*camera);
+    cp.lod_min_radius = ctx->lod_min_radius;
     uint32_t        earlier_truncated = 0; // asynchronous frames before this one that overflowed the pair workspace
     for (int attempt = 0; attempt < 4; ++attempt) {
         LCGS_TRY(ensure_fused_workspace(ctx, cp, keep_state != 0));
@@ -1129,7 +1139,8 @@ lcgs_status lcgs_render_forward_batch(lcgs_context* ctx, int num_views, const lc
         lcgs_context* t = ctx->twin;
         if (t->pos != ctx->pos || t->P != ctx->P || t->sh != ctx->sh || t->sh_deg != ctx->sh_deg)
             LCGS_TRY(lcgs_scene_bind(t, ctx->P, ctx->sh_deg, ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity));
-        t->use_half_sh = false;
+        t->use_half_sh    = false;
+        t->lod_min_radius = ctx->lod_min_radius;
         if (ctx->use_half_sh) { // the sibling reads the same f16 copy (not owned: never grown or freed through it)
             t->sh_half.ptr   = ctx->sh_half.ptr;
             t->sh_half.bytes = 0;

@@ -85,6 +85,10 @@ class Oracle:
     def set_smooth(self, on: bool) -> None:
         self.lib.orc_set_smooth(C.c_int(1 if on else 0))
 
+    def set_lod_min_radius(self, px: int) -> None:
+        """the product's opt-in lcgs_set_lod rule restated for orc_render (0 = off, the reference's behaviour)"""
+        self.lib.orc_set_lod_min_radius(C.c_int(px))
+
     def get_threads(self) -> int:
         return int(self.lib.orc_get_threads())
 

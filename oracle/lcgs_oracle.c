@@ -44,6 +44,11 @@ static int g_threads = 0;
 int orc_g_smooth = 0;
 void orc_set_smooth(int on) { orc_g_smooth = on; }
 
+/* BUILD-DEFINED opt-in rule (no reference counterpart; doc/roadmap.md:8 only names LOD): orc_render treats a splat whose
+ * radius (:148) is below this many pixels as touching no tile.  0 = off = the reference's behaviour. */
+static int g_lod_min_radius = 0;
+void orc_set_lod_min_radius(int px) { g_lod_min_radius = px; }
+
 int orc_sizeof_real(void) { return (int)sizeof(real); }
 
 void orc_set_threads(int n)
@@ -711,6 +716,12 @@ int64_t orc_render(int P, int sh_deg, const real* pos, const real* scale, const 
     /* size the pair buffers exactly: run allocate+scan once on copies?  Cheaper: allocate in place,
      * scan, then allocate the pair buffers (the reference pre-allocates 20M, main.cpp:245). */
     orc_allocate_tiles(P, width, height, depth, means_2d, covs_2d, tiles, my_radii, 1);
+    if (g_lod_min_radius > 0)
+        for (int idx = 0; idx < P; ++idx)
+            if (my_radii[idx] < g_lod_min_radius) {
+                my_radii[idx] = 0; /* copy_with_keys skips radius <= 0 (shader.cpp:41-42) */
+                tiles[idx]    = 0u;
+            }
     orc_inclusive_sum(P, tiles, offsets);
     {
         int64_t L = P > 0 ? (int64_t)(int32_t)offsets[P - 1] : 0;

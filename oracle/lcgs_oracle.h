@@ -125,6 +125,8 @@ int64_t orc_tile_splatter_forward(int P, int width, int height, const real bg[3]
 
 /* app/main.cpp:266-308 in one call with clean semantics (intermediates zero-initialised).
  * Returns num_rendered (or -1 on allocation failure).  img is CHW, 3*H*W. */
+/* build-defined opt-in footprint cull for orc_render (0 = off): see lcgs_oracle.c */
+void orc_set_lod_min_radius(int px);
 int64_t orc_render(int P, int sh_deg, const real* pos, const real* scale, const real* rotq,
                    const real* sh, const real* opacity,
                    const orc_camera* cam, const real bg[3], real scale_modifier,

@@ -50,7 +50,9 @@ def test_bench_refuses_to_run_without_a_gpu():
 
 
 def test_committed_default_bench_line_has_the_contract_fields():
-    path = os.path.join(ROOT, "profiles", "r01_bench_default.json")
+    import glob
+
+    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")))[-1]  # the newest round's
     d = json.loads(open(path).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -61,3 +63,8 @@ def test_committed_default_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    if "r01" not in os.path.basename(path):  # round 2 on: the whole-frame roofline is reported three ways, side by side
+        fr = d["frame_roofline"]
+        assert {"survey_model", "own_algorithmic"} <= set(fr) and fr["peak"] == 8000.0
+        assert fr["own_algorithmic"]["bytes"] == sum(fr["own_algorithmic"]["per_stage_bytes"].values())
+        assert "moving_camera" in d and "file_order" in d

@@ -10,7 +10,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out/prof
 mkdir -p $O
-CMD="bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-batch --no-train-step --no-stage-path --no-spatial"
+CMD="bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-batch --no-train-step --no-stage-path --no-spatial --no-moving-camera"
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 echo "bench done" && cut -c1-200 $O/bench_default.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-spatial > $O/stats.log 2>&1 || exit 1
