@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 def test_parity_suites_with_poisoned_workspace():
     env = dict(os.environ, LCGS_POISON="1")
     files = ["tests/test_gpu_fused.py", "tests/test_gpu_backward.py", "tests/test_gpu_train.py",
-             "tests/test_gpu_sh_degrees.py", "tests/test_gpu_random_sweep.py"]
+             "tests/test_gpu_sh_degrees.py", "tests/test_gpu_random_sweep.py", "tests/test_gpu_comm.py",
+             "tests/test_gpu_lod.py", "tests/test_gpu_ingest.py"]
     res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + files,
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
