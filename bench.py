@@ -476,6 +476,18 @@ def main():
             out["fwd_bwd"]["moving_camera"] = {"value": round(world * P * args.steps / el_mv / 1e6, 1), "unit": "Msplats/s",
                                                "ms_per_step": round(el_mv * 1e3 / args.steps, 4), "views": 8}
             r.forward(cam, img, sync=True)
+            if dist is not None:
+                # the answer to a collective that costs several views' worth of compute: B views per GPU and step,
+                # their gradients accumulated (lcgs_render_backward_accumulate), ONE gradient sum per step
+                B = 4
+                tr_acc = mg.ViewParallelTrainer(engine, coll, cams8, views, mode="allreduce", views_per_step=B)
+                acc_steps = max(2, args.steps // B)
+                el_acc = timed(lambda i: tr_acc.step(dL, optimise=False), acc_steps, 2)
+                out["fwd_bwd"]["views_per_gpu_and_step_4"] = {
+                    "value": round(world * P * B * acc_steps / el_acc / 1e6, 1), "unit": "Msplats/s",
+                    "ms_per_step": round(el_acc * 1e3 / acc_steps, 4), "views_per_step": world * B,
+                    "note": "one gradient collective per step of 4 views per GPU"}
+                r.forward(cam, img, sync=True)
 
         # ---- full training-style step: + the optimiser (gradients -> Adam on the raw parameters -> refreshed
         # activated arrays).  N = 1: dense, restricted to the on-screen splats, and on compact rows.

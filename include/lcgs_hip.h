@@ -272,6 +272,10 @@ typedef struct lcgs_grads {
     float* d_dL_dopacity;
 } lcgs_grads;
 LCGS_API lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads);
+/* The same dense gradients ADDED to what the arrays hold (no zero-fill): the second and later views of a multi-view batch
+ * whose first view went through lcgs_render_backward.  One optimiser step (and, on several GPUs, one gradient collective)
+ * per batch instead of per view: B views per GPU amortise the 1.45 GB all-reduce B times. */
+LCGS_API lcgs_status lcgs_render_backward_accumulate(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads);
 /* The same gradients as compact rows: row r of every output belongs to the r-th on-screen splat of that forward
  * frame (ascending splat index; lcgs_visible_rows names the splats).  Only those rows are written -- consecutive
  * rows, no zero-fill of the other P - V (the dense variant's stores land on a 39 %-dense row pattern and cost twice

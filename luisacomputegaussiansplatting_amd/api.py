@@ -139,7 +139,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_sh_process", "lcgs_project_forward", "lcgs_tile_splat_forward", "lcgs_inclusive_sum_u32",
     "lcgs_sort_pairs_u64_u32", "lcgs_scene_bind", "lcgs_scene_upload", "lcgs_render_forward",
     "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists",
-    "lcgs_render_backward", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
+    "lcgs_render_backward", "lcgs_render_backward_accumulate", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh",
@@ -538,11 +538,16 @@ class Renderer:
         _check(load_library().lcgs_render_forward_batch(self.ctx._h, C.c_int(n), cam_arr, _f3(bg),
                                                         C.c_float(scale_modifier), ptrs))
 
-    def backward(self, dL_dimg, dpos, dscale, drotq, dsh, dopacity, compact: bool = False):
+    def backward(self, dL_dimg, dpos, dscale, drotq, dsh, dopacity, compact: bool = False, accumulate: bool = False):
         """lcgs_render_backward; compact=True: lcgs_render_backward_compact (row r = the frame's r-th on-screen
-        splat, see visible_rows; only those rows are written)."""
+        splat, see visible_rows; only those rows are written); accumulate=True: lcgs_render_backward_accumulate (dense
+        rows added to what the arrays hold: a further view of a multi-view batch)."""
+        if compact and accumulate:
+            raise ValueError("compact rows belong to one frame: they cannot be accumulated over views")
         g = _Grads(_ptr(dpos), _ptr(dscale), _ptr(drotq), _ptr(dsh), _ptr(dopacity))
-        fn = load_library().lcgs_render_backward_compact if compact else load_library().lcgs_render_backward
+        lib = load_library()
+        fn = lib.lcgs_render_backward_compact if compact else (lib.lcgs_render_backward_accumulate if accumulate
+                                                               else lib.lcgs_render_backward)
         _check(fn(self.ctx._h, _ptr(dL_dimg), C.byref(g)))
 
     def visible_rows(self):

@@ -454,15 +454,43 @@ __device__ __forceinline__ void geom_backward(const CamParams& cp, float scale_m
 // (cooperative 16-byte loads, 12 lanes per 192-byte row), the SH gradient row is written back IN PLACE into the
 // slab as it is produced (so it never lives in registers next to the geometry Jacobians) and leaves as coalesced
 // 16-byte stores.
+// the four geometry rows of one splat; accumulate: add to what the arrays hold (a further view of a multi-view batch)
+__device__ __forceinline__ void store_geometry_rows(size_t orow, bool accumulate, const float gp[3], const float gs[3],
+                                                    float4 gq, float gop, float* __restrict__ dL_dpos,
+                                                    float* __restrict__ dL_dscale, float* __restrict__ dL_drotq,
+                                                    float* __restrict__ dL_dopacity)
+{
+    float4* rq = reinterpret_cast<float4*>(dL_drotq + 4 * orow); // (r,x,y,z)
+    if (accumulate) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            dL_dpos[3 * orow + i] += gp[i];
+            dL_dscale[3 * orow + i] += gs[i];
+        }
+        const float4 o = *rq;
+        *rq            = make_float4(o.x + gq.x, o.y + gq.y, o.z + gq.z, o.w + gq.w);
+        dL_dopacity[orow] += gop;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            dL_dpos[3 * orow + i]   = gp[i];
+            dL_dscale[3 * orow + i] = gs[i];
+        }
+        *rq               = gq;
+        dL_dopacity[orow] = gop;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const float* __restrict__ pos,
                       const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ sh,
                       const uint32_t* __restrict__ vis_index, const uint32_t* __restrict__ d_counts,
                       const float* __restrict__ grads2d, float* __restrict__ dL_dpos, float* __restrict__ dL_dscale,
                       float* __restrict__ dL_drotq, float* __restrict__ dL_dsh, float* __restrict__ dL_dopacity,
-                      int compact, const uint32_t* __restrict__ slice_bounds, int slice)
+                      int mode, const uint32_t* __restrict__ slice_bounds, int slice)
 {
     __shared__ float4 s_sh[4][64 * 13];
+    const bool compact = (mode & 1) != 0, accumulate = (mode & 2) != 0; // (see launch_preprocess_backward)
     // the survivors (dense ids) this launch covers: all of them, or slice `slice` of a splat-range split (k_slice_bounds)
     const uint32_t v0 = slice_bounds ? slice_bounds[slice] : 0u;
     const uint32_t V  = slice_bounds ? slice_bounds[slice + 1] : d_counts[0];
@@ -552,13 +580,7 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
             geom_backward(cp, scale_modifier, px, py, pz, sc0, sc1, sc2, q, gmx, gmy, gA, gB, gC, gp, gs, gq);
 
             const size_t orow = compact ? (size_t)vid : (size_t)idx; // compact: row = dense id (see launch.hpp)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                dL_dpos[3 * orow + i]   = gp[i];
-                dL_dscale[3 * orow + i] = gs[i];
-            }
-            *reinterpret_cast<float4*>(dL_drotq + 4 * orow) = gq; // (r,x,y,z)
-            dL_dopacity[orow] = gop;
+            store_geometry_rows(orow, accumulate, gp, gs, gq, gop, dL_dpos, dL_dscale, dL_drotq, dL_dopacity);
         }
 
         // ---- SH gradient rows: 12 consecutive lanes write one splat's 192 contiguous bytes
@@ -570,11 +592,19 @@ k_preprocess_backward(int sh_deg, CamParams cp, float scale_modifier, const floa
                 const uint32_t slot = cidx / 12u, part = cidx - slot * 12u;
                 const int      sidx = __shfl(idx, (int)slot, 64);
                 const size_t   orow = compact ? (size_t)(wave_first + slot) : (size_t)sidx;
-                if (slot < nvalid) reinterpret_cast<float4*>(dL_dsh + orow * 48)[part] = s_sh[wave][slot * 13u + part];
+                if (slot < nvalid) {
+                    float4* dst = reinterpret_cast<float4*>(dL_dsh + orow * 48) + part;
+                    float4  v   = s_sh[wave][slot * 13u + part];
+                    if (accumulate) {
+                        const float4 o = *dst;
+                        v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+                    }
+                    *dst = v;
+                }
             }
         } else if (valid) {
             float* o = dL_dsh + (compact ? (size_t)vid : (size_t)idx) * feat * 3;
-            for (int k = 0; k < feat * 3; ++k) o[k] = row[k];
+            for (int k = 0; k < feat * 3; ++k) o[k] = accumulate ? o[k] + row[k] : row[k];
         }
     }
 }
@@ -593,10 +623,11 @@ k_preprocess_backward_jac(CamParams cp, float scale_modifier, const float* __res
                           const uint32_t* __restrict__ vis_index, const uint32_t* __restrict__ d_counts,
                           const float* __restrict__ grads2d, const float4* __restrict__ shjac,
                           float* __restrict__ dL_dpos, float* __restrict__ dL_dscale, float* __restrict__ dL_drotq,
-                          float* __restrict__ dL_dsh, float* __restrict__ dL_dopacity, int compact,
+                          float* __restrict__ dL_dsh, float* __restrict__ dL_dopacity, int mode,
                           const uint32_t* __restrict__ slice_bounds, int slice)
 {
     __shared__ float s_outer[4][64 * kJacPitch];
+    const bool compact = (mode & 1) != 0, accumulate = (mode & 2) != 0;
     const uint32_t v0 = slice_bounds ? slice_bounds[slice] : 0u; // (see k_preprocess_backward)
     const uint32_t V  = slice_bounds ? slice_bounds[slice + 1] : d_counts[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -643,13 +674,7 @@ k_preprocess_backward_jac(CamParams cp, float scale_modifier, const float* __res
             float4 gq;
             geom_backward(cp, scale_modifier, px, py, pz, sc0, sc1, sc2, q, gmx, gmy, gA, gB, gC, gp, gs, gq);
             const size_t orow = compact ? (size_t)vid : (size_t)idx; // compact: row = dense id (see launch.hpp)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                dL_dpos[3 * orow + i]   = gp[i];
-                dL_dscale[3 * orow + i] = gs[i];
-            }
-            *reinterpret_cast<float4*>(dL_drotq + 4 * orow) = gq; // (r,x,y,z)
-            dL_dopacity[orow] = gop;
+            store_geometry_rows(orow, accumulate, gp, gs, gq, gop, dL_dpos, dL_dscale, dL_drotq, dL_dopacity);
         }
         __syncthreads();
         // ---- SH gradient rows: 12 consecutive lanes write one splat's 192 contiguous bytes
@@ -667,7 +692,12 @@ k_preprocess_backward_jac(CamParams cp, float scale_modifier, const float* __res
                     v[e]             = o[k] * o[16u + ch];
                 }
                 const size_t orow = compact ? (size_t)(wave_first + slot) : (size_t)sidx;
-                reinterpret_cast<float4*>(dL_dsh + orow * 48)[part] = make_float4(v[0], v[1], v[2], v[3]);
+                float4*      dst  = reinterpret_cast<float4*>(dL_dsh + orow * 48) + part;
+                if (accumulate) {
+                    const float4 o = *dst;
+                    v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                }
+                *dst = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
         __syncthreads(); // the slab is reused by the next iteration
@@ -736,8 +766,10 @@ void launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp,
                                 const float* scale, const float* rotq, const float* sh, const uint32_t* vis_index,
                                 const uint32_t* d_counts, const float* grads2d, float* dL_dpos, float* dL_dscale,
                                 float* dL_drotq, float* dL_dsh, float* dL_dopacity, hipStream_t stream,
-                                const float4* shjac, bool compact, const uint32_t* slice_bounds, int slice, int slices)
+                                const float4* shjac, bool compact, const uint32_t* slice_bounds, int slice, int slices,
+                                bool accumulate)
 {
+    const int mode = (compact ? 1 : 0) | (accumulate ? 2 : 0);
     // (a slice's launch is sized for its share of the hint; larger live counts are strided)
     int64_t blocks = (v_hint / (slice_bounds ? slices : 1) + 255) / 256;
     if (blocks < 1) blocks = 1;
@@ -745,12 +777,12 @@ void launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp,
     if (shjac && sh_deg == 3 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0) {
         hipLaunchKernelGGL(k_preprocess_backward_jac, dim3((unsigned)blocks), dim3(256), 0, stream, cp, scale_modifier, pos,
                            scale, rotq, vis_index, d_counts, grads2d, shjac, dL_dpos, dL_dscale, dL_drotq, dL_dsh,
-                           dL_dopacity, compact ? 1 : 0, slice_bounds, slice);
+                           dL_dopacity, mode, slice_bounds, slice);
         return;
     }
     hipLaunchKernelGGL(k_preprocess_backward, dim3((unsigned)blocks), dim3(256), 0, stream, sh_deg, cp, scale_modifier,
                        pos, scale, rotq, sh, vis_index, d_counts, grads2d, dL_dpos, dL_dscale, dL_drotq, dL_dsh,
-                       dL_dopacity, compact ? 1 : 0, slice_bounds, slice);
+                       dL_dopacity, mode, slice_bounds, slice);
 }
 
 } // namespace lcgs

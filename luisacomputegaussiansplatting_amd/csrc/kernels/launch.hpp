@@ -178,7 +178,9 @@ void   launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& c
                                   bool compact = false,
                                   // slice_bounds != NULL: only the survivors [slice_bounds[slice], slice_bounds[slice + 1])
                                   // (a splat-range slice, see launch_slice_bounds; `slices` sizes the launch)
-                                  const uint32_t* slice_bounds = nullptr, int slice = 0, int slices = 1);
+                                  const uint32_t* slice_bounds = nullptr, int slice = 0, int slices = 1,
+                                  // accumulate: ADD the rows to what the arrays hold (dense rows of a further view)
+                                  bool accumulate = false);
 // bounds[0 .. slices]: dense-id boundaries of the splat-index ranges [k P / slices, (k + 1) P / slices), k < slices <= 63
 void   launch_slice_bounds(const uint32_t* vis_index, const uint32_t* d_counts, int64_t P, int slices, uint32_t* bounds,
                            hipStream_t stream);

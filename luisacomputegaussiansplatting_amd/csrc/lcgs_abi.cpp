@@ -1214,7 +1214,8 @@ lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t*
 
 namespace
 {
-lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads, bool compact);
+lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads, bool compact,
+                            bool accumulate = false);
 }
 
 lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads)
@@ -1225,6 +1226,11 @@ lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, cons
 lcgs_status lcgs_render_backward_compact(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads)
 {
     return render_backward(ctx, d_dL_dimg, grads, /*compact=*/true);
+}
+
+lcgs_status lcgs_render_backward_accumulate(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads)
+{
+    return render_backward(ctx, d_dL_dimg, grads, /*compact=*/false, /*accumulate=*/true);
 }
 
 lcgs_status lcgs_visible_rows(lcgs_context* ctx, const uint32_t** d_rows, const uint32_t** d_count)
@@ -1240,7 +1246,8 @@ lcgs_status lcgs_visible_rows(lcgs_context* ctx, const uint32_t** d_rows, const 
 
 namespace
 {
-lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads, bool compact)
+lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads, bool compact,
+                            bool accumulate)
 {
     LCGS_REQUIRE(ctx && d_dL_dimg && grads, "NULL argument");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
@@ -1259,7 +1266,8 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
     // dense per-splat gradients: splats that did not reach the screen get exact zeros.  The 236 B/splat zero-fill
     // is pure HBM writes and independent of the render-backward: it runs on the auxiliary stream beside it.
     // (Compact rows: every row that exists is written by the preprocess-backward, nothing to clear.)
-    const bool  overlap = !ctx->profiling && !compact;
+    // accumulate: the arrays hold the sum of earlier views of the batch -- no fill, the rows are added to
+    const bool  overlap = !ctx->profiling && !compact && !accumulate;
     hipStream_t zs      = overlap ? ctx->aux_stream : st;
     if (overlap) {
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));
@@ -1275,7 +1283,7 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
         launch_slice_bounds(ctx->vis_index.as<uint32_t>(), ctx->counts.as<uint32_t>(), (int64_t)P, ctx->grad_slices,
                             ctx->slice_bounds.as<uint32_t>(), zs); // (before the fill: ev_join / stream order covers it)
     }
-    if (!compact) {
+    if (!compact && !accumulate) {
         LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dpos, 0, P * 3 * 4, zs));
         LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dscale, 0, P * 3 * 4, zs));
         LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_drotq, 0, P * 4 * 4, zs));
@@ -1306,7 +1314,7 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
                                    ctx->vis_index.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(),
                                    grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh,
                                    grads->d_dL_dopacity, st, ctx->last_has_jac ? ctx->shjac.as<float4>() : nullptr, compact,
-                                   sliced ? ctx->slice_bounds.as<uint32_t>() : nullptr, k, slices);
+                                   sliced ? ctx->slice_bounds.as<uint32_t>() : nullptr, k, slices, accumulate);
         if (sliced) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_slice[k], st));
     }
     ctx->slices_recorded = sliced ? slices : 0;

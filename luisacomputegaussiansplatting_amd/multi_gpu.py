@@ -30,8 +30,8 @@ GRAD_FLOATS_PER_SPLAT = sum(ROW_FLOATS.values())  # 59
 
 
 def view_of_rank(step: int, rank: int, world_size: int, num_views: int) -> int:
-    """Which view of the batch a rank renders at a step: consecutive views to consecutive ranks, the window sliding by
-    world_size per step (every view is visited when the steps cover the batch)."""
+    """Which view of the batch a rank renders at a (micro-)step: consecutive views to consecutive ranks, the window
+    sliding by world_size per step (every view is visited when the steps cover the batch)."""
     return (step * world_size + rank) % num_views
 
 
@@ -122,13 +122,14 @@ class HipEngine:
         self.compact_rows = False  # N = 1 only: lcgs_render_backward_compact (row r = the frame's r-th on-screen splat)
         renderer.bind_scene(*[activated[k] for k in KEYS])
 
-    def forward_backward(self, cam, dL_dimg, grads: dict, bg=(0.0, 0.0, 0.0)):
+    def forward_backward(self, cam, dL_dimg, grads: dict, bg=(0.0, 0.0, 0.0), accumulate: bool = False):
+        """one view: frame + its gradients into `grads` (accumulate: added to what they hold)"""
         import torch
 
         if self._img is None or tuple(self._img.shape) != (3, cam.height, cam.width):
             self._img = torch.empty(3, cam.height, cam.width, device=dL_dimg.device, dtype=torch.float32)
         self.r.forward(cam, self._img, bg=bg, keep_state=True, sync=False)
-        self.r.backward(dL_dimg, *[grads[k] for k in KEYS], compact=self.compact_rows)
+        self.r.backward(dL_dimg, *[grads[k] for k in KEYS], compact=self.compact_rows, accumulate=accumulate)
 
     def adam(self, grads: dict, step: int, rows=None):
         if self.raw is None:
@@ -151,10 +152,16 @@ class HipEngine:
 class ViewParallelTrainer:
     """One training step per call: this rank's view -> forward + backward -> gradient collective -> optimiser."""
 
-    def __init__(self, engine, collective, cameras: Sequence, grads: dict, mode: str = "allreduce"):
+    def __init__(self, engine, collective, cameras: Sequence, grads: dict, mode: str = "allreduce",
+                 views_per_step: int = 1):
+        """views_per_step: views each rank renders (and whose gradients it accumulates) per optimiser step -- one
+        collective per step, so B views per GPU amortise the gradient exchange B times."""
         if mode not in ("allreduce", "sharded", "local"):
             raise ValueError(mode)
+        if views_per_step < 1:
+            raise ValueError("views_per_step must be >= 1")
         self.engine, self.coll, self.cameras, self.grads, self.mode = engine, collective, list(cameras), grads, mode
+        self.views_per_step = views_per_step
         self.rank = collective.rank if collective is not None else 0
         self.world_size = collective.world_size if collective is not None else 1
         self.steps_done = 0
@@ -164,8 +171,9 @@ class ViewParallelTrainer:
 
     def step(self, dL_dimg, optimise: bool = True):
         """forward + backward of this rank's view, the collective, and (optimise=True) the Adam update."""
-        cam = self.camera_for_step(self.steps_done)
-        self.engine.forward_backward(cam, dL_dimg, self.grads)
+        for j in range(self.views_per_step):  # this rank's views of the step: the first overwrites, the others add
+            cam = self.camera_for_step(self.steps_done * self.views_per_step + j)
+            self.engine.forward_backward(cam, dL_dimg, self.grads, accumulate=j > 0)
         self.steps_done += 1
         if self.mode == "local" or self.coll is None:
             if optimise:

@@ -63,7 +63,7 @@ class OracleEngine:
         self.dL_of_view = dL_of_view
         self.views_rendered = []
 
-    def forward_backward(self, cam, dL_dimg, grads, bg=(0.0, 0.0, 0.0)):
+    def forward_backward(self, cam, dL_dimg, grads, bg=(0.0, 0.0, 0.0), accumulate=False):
         import torch
 
         view, ocam = cam
@@ -71,7 +71,11 @@ class OracleEngine:
         scene = {k: self.activated[k].numpy() for k in KEYS}
         g = self.o.render_backward_full(scene, ocam, self.dL_of_view(view))
         for k in KEYS:
-            grads[k].copy_(torch.from_numpy(g[k].reshape(grads[k].shape).astype(np.float32)))
+            t = torch.from_numpy(g[k].reshape(grads[k].shape).astype(np.float32))
+            if accumulate:
+                grads[k].add_(t)
+            else:
+                grads[k].copy_(t)
 
     def adam(self, grads, step, rows=None, b1=0.9, b2=0.999, eps=1e-15):
         """lcgs_adam_step (csrc/kernels/train.hip) restated: activated-space gradients -> raw-space -> Adam -> activate."""
@@ -125,12 +129,17 @@ def _worker(rank, world, port, out_dir):
     o = Oracle("f32")
     o.set_threads(2)
     cams = [(v, o.lookat(*p, width=W, height=H)) for v, p in enumerate(_poses())]
-    for mode in ("allreduce", "sharded"):
+    for mode in ("allreduce", "sharded", "allreduce_2views"):
         engine = OracleEngine(o, _raw_scene(), _dL)  # the scene is replicated on every rank
         grads = {k: torch.zeros_like(engine.raw[k]) for k in KEYS}
-        trainer = mg.ViewParallelTrainer(engine, mg.TorchCollective(dist, rank, world), cams, grads, mode=mode)
-        for _ in range(STEPS):
+        if mode == "allreduce_2views":  # two views per rank and optimiser step: gradients accumulate, ONE collective
+            trainer = mg.ViewParallelTrainer(engine, mg.TorchCollective(dist, rank, world), cams, grads, mode="allreduce",
+                                             views_per_step=2)
             trainer.step(None)
+        else:
+            trainer = mg.ViewParallelTrainer(engine, mg.TorchCollective(dist, rank, world), cams, grads, mode=mode)
+            for _ in range(STEPS):
+                trainer.step(None)
         np.savez(os.path.join(out_dir, f"{mode}_{rank}.npz"), views=np.array(engine.views_rendered),
                  **{f"act_{k}": engine.activated[k].numpy() for k in KEYS},
                  **{f"raw_{k}": engine.raw[k].numpy() for k in KEYS})
@@ -193,6 +202,20 @@ def test_view_parallel_protocol_on_two_gloo_ranks(tmp_path, oracle):
         # every rank holds the same activated scene afterwards
         for k in KEYS:
             assert np.array_equal(res[(m, 0)][f"act_{k}"], res[(m, 1)][f"act_{k}"]), (m, k)
+    # two views per rank and step: one step over all four views = one dense Adam step on the sum of their gradients
+    ref2 = OracleEngine(oracle, _raw_scene(), _dL)
+    total = {k: torch.zeros_like(ref2.raw[k]) for k in KEYS}
+    for v in range(N_VIEWS):
+        ref2.forward_backward(cams[v], None, g)
+        for k in KEYS:
+            total[k] += g[k]
+    ref2.adam(total, 1)
+    for r in range(world):
+        got = np.load(tmp_path / f"allreduce_2views_{r}.npz")
+        assert got["views"].tolist() == [r, 2 + r]  # micro-step j of the step: view j * world + rank
+        for k in KEYS:
+            b = ref2.activated[k].numpy()
+            assert np.allclose(got[f"act_{k}"], b, rtol=2e-4, atol=2e-6 * np.abs(b).max()), (r, k)
     # something was learnt (the update is not a no-op)
     assert not np.allclose(ref.activated["opacity"].numpy(), _activate(_raw_scene())["opacity"].astype(np.float32))
     # sharded: raw parameters are authoritative on their owner (and on the tail) only

@@ -97,3 +97,30 @@ def test_backward_of_an_empty_frame_is_all_zeros(lcgs):
     r.backward(torch.randn(3, 48, 64, device=DEV), g["pos"], g["scale"], g["rotq"], g["sh"], g["opacity"])
     r.ctx.synchronize()
     assert all((t == 0).all() for t in g.values())
+
+
+def test_backward_accumulate_sums_the_views_of_a_batch(lcgs, oracle):
+    """lcgs_render_backward_accumulate: the second view's dense gradients are ADDED to the first view's (no zero-fill):
+    the arrays then hold the sum the oracle gives for the two views."""
+    rng = np.random.default_rng(19)
+    P, W, H = 20000, 320, 240
+    scene = make_scene(rng, P, log_scale=(-3.8, 0.7))
+    poses = [POSE, ([2.5, 1.5, 1.0], [0, 0, 0.5], [0, 0, 1])]
+    d = upload_scene(scene)
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    img = torch.zeros(3, H, W, device=DEV)
+    keys = ("pos", "scale", "rotq", "sh", "opacity")
+    g = {k: torch.full_like(d[k], 7.0) for k in keys}
+    dLs = [np.random.default_rng(i).normal(size=(3, H, W)).astype(np.float32) for i in range(2)]
+    for j, pose in enumerate(poses):
+        r.forward(lcgs.get_lookat_cam(*pose, width=W, height=H), img, keep_state=True, sync=False)
+        r.backward(dev(dLs[j]), *[g[k] for k in keys], accumulate=j > 0)
+    r.ctx.synchronize()
+    refs = [oracle.render_backward_full(scene, oracle.lookat(*p, width=W, height=H), dL) for p, dL in zip(poses, dLs)]
+    for k in keys:
+        a = g[k].cpu().numpy().astype(np.float64).ravel()
+        b = sum(ref[k].astype(np.float64).ravel() for ref in refs)
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 1e-3, k
+    with pytest.raises(ValueError):
+        r.backward(dev(dLs[0]), *[g[k] for k in keys], compact=True, accumulate=True)
