@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--lod", type=int, default=0, help="also time the opt-in footprint cull (lcgs_set_lod) at this radius")
     ap.add_argument("--no-spatial", action="store_true", help="skip the file-order legs (the scene is kept in spatial order)")
     ap.add_argument("--no-moving-camera", action="store_true", help="skip the moving-camera forward leg")
+    ap.add_argument("--grad-transport", choices=("f32", "f16"), default="f32",
+                    help="N > 1, --collective rccl: the gradient all-reduce's wire format (f16 is opt-in: half the bytes, "
+                         "about sqrt(N) x 5e-4 relative error; never the default)")
     ap.add_argument("--collective", choices=("rccl", "torch"), default="rccl",
                     help="N > 1 gradient collective: the library's own RCCL path (lcgs_comm C ABI, default) or "
                          "torch.distributed's (cross-check)")
@@ -427,6 +430,8 @@ def main():
                     dist.broadcast(t, 0)
                     return t.cpu().numpy().tobytes()
                 coll = mg.RcclCollective(ctx, rank, world, exchange)
+                if args.grad_transport != "f32":
+                    coll.comm.set_transport(args.grad_transport)
             else:
                 coll = mg.TorchCollective(dist, rank, world)
         engine = mg.HipEngine(r, raw=None, activated=d, lr=None)  # gradients only: no optimiser state
@@ -461,6 +466,7 @@ def main():
         if dist is not None:
             out["fwd_bwd"]["note"] = ("gradient collective: lcgs_grads_allreduce (RCCL, chunked behind the backward's "
                                       "slices)" if args.collective == "rccl" else "gradient collective: torch.distributed")
+            out["fwd_bwd"]["grad_transport"] = args.grad_transport if args.collective == "rccl" else "f32"
         if el_compact is not None:
             out["fwd_bwd"]["compact_rows"] = {"value": round(P * args.steps / el_compact / 1e6, 1), "unit": "Msplats/s",
                                               "ms_per_step": round(el_compact * 1e3 / args.steps, 4)}

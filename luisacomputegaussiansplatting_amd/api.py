@@ -143,7 +143,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh",
-    "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_set_lod", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_shard_rows",
+    "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_set_lod", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_set_transport", "lcgs_comm_shard_rows",
     "lcgs_grads_allreduce", "lcgs_adam_step_sharded",
 ]
 
@@ -650,6 +650,10 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+    def set_transport(self, transport: str):
+        """lcgs_comm_set_transport: "f32" (default, exact) or "f16" (opt-in: half the bytes, ~sqrt(N) x 5e-4 relative)"""
+        _check(load_library().lcgs_comm_set_transport(self._h, C.c_int({"f32": 0, "f16": 1}[transport])))
 
     def allreduce_grads(self, grads: dict, sh_degree: int = 3):
         """lcgs_grads_allreduce: in-place sum over the ranks of the five dense gradient arrays (chunked, overlapping the

@@ -32,6 +32,7 @@
 
 #include "../common.hpp"
 #include "../context.hpp"
+#include "../kernels/launch.hpp"
 
 using namespace lcgs;
 
@@ -142,6 +143,9 @@ struct lcgs_comm {
     int           rank   = 0, world = 1;
     hipStream_t   stream = nullptr; // the collectives' own stream: they overlap the compute stream's tail
     hipEvent_t    ev_in = nullptr, ev_out = nullptr;
+    // opt-in f16 transport (lcgs_comm_set_transport): staging for the packed gradients and the five scales
+    int          transport = LCGS_TRANSPORT_F32;
+    DeviceBuffer packed, scales; // 59 P halfs; 5 magnitudes | 5 scales | 5 inverses (floats)
 };
 
 namespace lcgs
@@ -224,10 +228,20 @@ lcgs_status lcgs_comm_destroy(lcgs_comm* c)
     }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
+    c->packed.release();
+    c->scales.release();
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_out) (void)hipEventDestroy(c->ev_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_comm_set_transport(lcgs_comm* c, int transport)
+{
+    LCGS_REQUIRE(c != nullptr, "comm is NULL");
+    LCGS_REQUIRE(transport == LCGS_TRANSPORT_F32 || transport == LCGS_TRANSPORT_F16, "unknown transport");
+    c->transport = transport;
     return LCGS_OK;
 }
 
@@ -251,6 +265,37 @@ lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* c, int num_gaussi
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     const AttrRows a = attr_rows(grads, sh_degree);
     const int64_t  P = num_gaussians;
+    if (c->transport == LCGS_TRANSPORT_F16) {
+        // Opt-in: the sum crosses the wire as f16 with one power-of-two scale per attribute, agreed by all ranks (the
+        // magnitudes are max-reduced first).  One chunk behind the backward's tail: the scales need every row.
+        size_t total = 0, start[5]; // (halfs; every attribute's region starts 16-byte aligned: vector stores on that side)
+        for (int i = 0; i < 5; ++i) {
+            start[i] = total;
+            total += ((size_t)P * a.width[i] + 7) & ~(size_t)7;
+        }
+        const void* had = c->packed.ptr;
+        LCGS_TRY(c->packed.ensure(total * 2));
+        if (c->packed.ptr != had) LCGS_HIP_CHECK(hipMemsetAsync(c->packed.ptr, 0, total * 2, c->stream)); // the padding is summed too
+        LCGS_TRY(c->scales.ensure(16 * sizeof(float)));
+        float*    amax  = c->scales.as<float>();
+        float*    scale = amax + 5;
+        float*    inv   = amax + 10;
+        uint16_t* pk    = c->packed.as<uint16_t>();
+        LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+        ctx->slices_recorded = 0;
+        LCGS_HIP_CHECK(hipMemsetAsync(amax, 0, 5 * sizeof(float), c->stream));
+        for (int i = 0; i < 5; ++i) launch_absmax(a.ptr[i], (size_t)P * a.width[i], reinterpret_cast<uint32_t*>(amax + i), c->stream);
+        LCGS_RCCL_CHECK(rccl().AllReduce(amax, amax, 5, ncclFloat32, ncclMax, c->comm, c->stream));
+        launch_transport_scales(amax, c->world, scale, inv, c->stream);
+        for (int i = 0; i < 5; ++i) launch_pack_f16(a.ptr[i], (size_t)P * a.width[i], scale + i, pk + start[i], c->stream);
+        LCGS_RCCL_CHECK(rccl().AllReduce(pk, pk, total, ncclFloat16, ncclSum, c->comm, c->stream));
+        for (int i = 0; i < 5; ++i) launch_unpack_f16(pk + start[i], (size_t)P * a.width[i], inv + i, a.ptr[i], c->stream);
+        LCGS_HIP_CHECK(hipGetLastError());
+        LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
+        return LCGS_OK;
+    }
     // chunks = the slices the last dense backward recorded for these very arrays; else one chunk behind the stream's tail
     const bool chunked = ctx->slices_recorded > 1 && ctx->slices_of == (const void*)grads->d_dL_dpos && ctx->P == num_gaussians;
     const int  K       = chunked ? ctx->slices_recorded : 1;

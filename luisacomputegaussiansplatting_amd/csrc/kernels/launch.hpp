@@ -160,6 +160,14 @@ void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uin
 // kept); the backward takes them instead of repeating the tests
 bool render_forward_writes_strip_masks();
 
+// ---- comm_pack.hip : the opt-in f16 transport of the gradient all-reduce (host/comm.cpp) ----
+// |max| of n floats, atomically max-ed into *d_out_bits (float bits; zero it first)
+void launch_absmax(const float* x, size_t n, uint32_t* d_out_bits, hipStream_t stream);
+// five power-of-two scales (and their inverses) from the five all-reduced magnitudes: max * scale <= 16384 / world
+void launch_transport_scales(const float* d_absmax5, int world, float* d_scale5, float* d_inv5, hipStream_t stream);
+void launch_pack_f16(const float* x, size_t n, const float* d_scale, uint16_t* out, hipStream_t stream);
+void launch_unpack_f16(const uint16_t* in, size_t n, const float* d_inv, float* x, hipStream_t stream);
+
 // ---- backward.hip ----
 size_t grads2d_bytes(int64_t V_cap);
 void   launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t stream);

@@ -81,6 +81,50 @@ def test_sliced_backward_and_chunked_allreduce_leave_the_gradients_unchanged(lcg
     comm.close()
 
 
+def test_f16_transport_is_opt_in_and_rounds_once(lcgs):
+    """lcgs_comm_set_transport(F16): per-attribute power-of-two scales from the (max-reduced) magnitudes, f16 on the wire.
+    At world size 1 the sum is the value itself, so what comes back is each gradient rounded once to f16 at its
+    attribute's scale: zeros stay exact zeros, the relative error in the norm is a few 1e-4, nothing overflows -- also
+    for magnitudes far outside f16's own range and for unaligned array offsets."""
+    rng = np.random.default_rng(3)
+    P = 30001  # odd: the arrays carved from one flat buffer start at unaligned offsets
+    ctx = lcgs.Context(0)
+    comm = lcgs.Comm(ctx, 0, 1)
+    flat = torch.zeros(59 * P, device=DEV)
+    widths = {"pos": 3, "scale": 3, "rotq": 4, "sh": 48, "opacity": 1}
+    mags = {"pos": 1e-7, "scale": 3e4, "rotq": 1.0, "sh": 1e-3, "opacity": 5e9}
+    g, o = {}, 0
+    for k, w in widths.items():
+        g[k] = flat[o:o + w * P].view(P, w) if w > 1 else flat[o:o + P]
+        o += w * P
+        vals = rng.normal(size=tuple(g[k].shape)) * mags[k] * 10.0 ** rng.uniform(-3, 0, size=tuple(g[k].shape))
+        vals[rng.random(size=tuple(g[k].shape)) < 0.6] = 0.0  # most rows of a view's gradient are zero
+        g[k].copy_(torch.from_numpy(vals.astype(np.float32)))
+    before = {k: g[k].clone() for k in KEYS}
+    comm.allreduce_grads(g)  # default transport: exact
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    assert all(torch.equal(g[k], before[k]) for k in KEYS)
+    comm.set_transport("f16")
+    comm.allreduce_grads(g)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    for k in KEYS:
+        a, b = g[k].double(), before[k].double()
+        assert torch.isfinite(a).all(), k
+        assert torch.equal(g[k] == 0, before[k] == 0) or float(((g[k] == 0) & (before[k] != 0)).float().mean()) < 1e-2, k
+        assert (g[k][before[k] == 0] == 0).all(), k  # zeros stay exact zeros
+        rel = float((a - b).norm() / b.norm())
+        assert 0.0 < rel <= 6e-4, (k, rel)  # one f16 rounding (2^-11) of each value, nothing more
+    comm.set_transport("f32")
+    again = {k: g[k].clone() for k in KEYS}
+    comm.allreduce_grads(g)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    assert all(torch.equal(g[k], again[k]) for k in KEYS)
+    comm.close()
+
+
 @pytest.mark.parametrize("P", [4097, 20000])
 def test_sharded_adam_step_equals_the_dense_step(lcgs, P):
     rng = np.random.default_rng(P)
