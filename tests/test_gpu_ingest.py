@@ -101,6 +101,36 @@ def test_device_ingest_sizes_and_render(lcgs, tmp_path, P):
     assert (img - img2).abs().max().item() < 5e-3 and (img - img2).abs().mean().item() < 1e-5
 
 
+def test_upload_keeps_the_scene_in_spatial_order_by_default_too(lcgs, oracle):
+    """lcgs_scene_upload (host arrays -> context-owned copies) follows the same ingest order as lcgs_scene_load_ply; the
+    oracle frame of the ORIGINAL arrays is the yardstick for both orders."""
+    from conftest import make_scene
+    from gpu_util import assert_image_parity
+
+    rng = np.random.default_rng(4)
+    scene = make_scene(rng, 50000, spread=1.5, log_scale=(-4.0, 0.8))
+    pose = ([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1])
+    cam = lcgs.get_lookat_cam(*pose, width=400, height=300)
+    orc = oracle.render(scene, oracle.lookat(*pose, width=400, height=300), ambig_eps=1e-5)
+    imgs = {}
+    for order in (None, "file"):
+        r = lcgs.Renderer(lcgs.Context(0))
+        r.upload_scene(scene, order=order)
+        img, radii = torch.zeros(3, 300, 400, device=DEV), torch.zeros(50000, dtype=torch.int32, device=DEV)
+        assert r.forward(cam, img, radii=radii) == orc["num_rendered"]
+        perm = r.permutation()
+        assert (perm is None) == (order == "file")
+        rad = radii.cpu().numpy()
+        if perm is not None:
+            back = np.empty_like(rad)
+            back[perm.cpu().numpy().astype(np.int64)] = rad
+            rad = back
+        assert np.array_equal(rad, orc["radii"])
+        assert_image_parity(img.cpu().numpy(), orc)
+        imgs[order] = img
+    assert torch.equal(imgs[None], imgs["file"])
+
+
 def test_device_ingest_falls_back_for_ascii(lcgs, tmp_path):
     path = str(tmp_path / "a.ply")
     names = (["x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(45)] + ["opacity"] +
