@@ -230,3 +230,63 @@ def test_view_parallel_protocol_on_two_gloo_ranks(tmp_path, oracle):
             assert np.allclose(a, b, rtol=2e-4, atol=2e-6 * np.abs(b).max()), (r, k)
         other = np.setdiff1d(np.arange(P), own)
         assert np.array_equal(res[("sharded", r)]["raw_scale"][other], _raw_scene()["scale"][other].astype(np.float32))
+
+
+def _worker_c5(rank, world, port, out_dir):
+    """BASELINE config C5 in miniature: 8 ranks, the 8 C5 views (one per rank), one optimiser step, both collective modes."""
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import luisacomputegaussiansplatting_amd.multi_gpu as mg
+    from bench import view_pose
+    from oracle import Oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    o = Oracle("f32")
+    o.set_threads(1)
+    cams = [(v, o.lookat(*view_pose(v), width=W, height=H)) for v in range(8)]
+    for mode in ("allreduce", "sharded"):
+        engine = OracleEngine(o, _raw_scene(), _dL)
+        grads = {k: torch.zeros_like(engine.raw[k]) for k in KEYS}
+        trainer = mg.ViewParallelTrainer(engine, mg.TorchCollective(dist, rank, world), cams, grads, mode=mode)
+        trainer.step(None)
+        np.savez(os.path.join(out_dir, f"c5_{mode}_{rank}.npz"), views=np.array(engine.views_rendered),
+                 **{f"act_{k}": engine.activated[k].numpy() for k in KEYS})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c5_shape_eight_ranks_eight_views_on_gloo(tmp_path, oracle):
+    """The host protocol at the node's full width (the kernels' part is per-rank and identical to N = 1): 8 ranks x 1 view,
+    P = 301 -> shards of 37 rows and a 5-row tail; every rank ends with the scene a single process gets from one dense Adam
+    step on the sum of the eight views' gradients."""
+    import torch
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, ROOT)
+    from bench import view_pose
+
+    world = 8
+    mp.spawn(_worker_c5, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    cams = [(v, oracle.lookat(*view_pose(v), width=W, height=H)) for v in range(8)]
+    ref = OracleEngine(oracle, _raw_scene(), _dL)
+    g = {k: torch.zeros_like(ref.raw[k]) for k in KEYS}
+    total = {k: torch.zeros_like(ref.raw[k]) for k in KEYS}
+    for v in range(8):
+        ref.forward_backward(cams[v], None, g)
+        for k in KEYS:
+            total[k] += g[k]
+    ref.adam(total, 1)
+    for mode in ("allreduce", "sharded"):
+        outs = [np.load(tmp_path / f"c5_{mode}_{r}.npz") for r in range(world)]
+        assert [o_["views"].tolist() for o_ in outs] == [[r] for r in range(world)]  # one view per rank, all eight covered
+        for r in range(world):
+            for k in KEYS:
+                b = ref.activated[k].numpy()
+                assert np.allclose(outs[r][f"act_{k}"], b, rtol=3e-4, atol=3e-6 * np.abs(b).max()), (mode, r, k)
+                assert np.array_equal(outs[r][f"act_{k}"], outs[0][f"act_{k}"]), (mode, r, k)  # replicas stay identical
