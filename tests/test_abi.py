@@ -103,3 +103,23 @@ def test_png_writer(lcgs, tmp_path):
 
     back = np.array(Image.open(path))
     assert np.array_equal(back, rgb)
+
+
+def test_comm_entry_points_without_a_gpu(lcgs):
+    """The multi-GPU entry points that need no device: the rendezvous token (RCCL bound at run time -- the copy torch
+    carries), row ownership, and argument checks that fail before anything touches a GPU."""
+    import ctypes as C
+
+    lib = lcgs.load_library()
+    a, b = (C.c_char * 128)(), (C.c_char * 128)()
+    st = lib.lcgs_comm_unique_id(a)
+    if st == 0:  # RCCL present (it is in this image): two tokens differ, and are not all zeros
+        assert lib.lcgs_comm_unique_id(b) == 0
+        assert bytes(a.raw) != bytes(b.raw) and any(a.raw)
+    else:  # no RCCL on this machine: a clean status and a message, nothing else breaks
+        assert st == 3 and b"RCCL" in lib.lcgs_last_error()
+    assert lib.lcgs_comm_unique_id(None) == 1  # LCGS_ERR_INVALID_ARG
+    h = C.c_void_p(0)
+    assert lib.lcgs_comm_create(None, a, C.c_int(0), C.c_int(1), C.byref(h)) == 1 and not h.value
+    assert lib.lcgs_comm_destroy(None) == 0
+    assert lcgs.shard_rows(10, 4, 3) == (6, 2)  # floor(10 / 4) rows each; rows 8, 9 are the tail every rank keeps
