@@ -192,7 +192,12 @@ lcgs_status lcgs_comm_create(lcgs_context* ctx, const lcgs_comm_id* id, int rank
     c->ctx   = ctx;
     c->rank  = rank;
     c->world = world_size;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // highest dispatch priority: the collective's workgroups should get their slots as soon as a chunk is ready, not queue
+    // behind the backward's remaining slices (the auxiliary stream of the context has the LOWEST, for the opposite reason)
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // hi = numerically smallest = highest priority
+    hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi);
+    if (e != hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
     if (e != hipSuccess) {
