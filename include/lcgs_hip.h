@@ -412,6 +412,11 @@ LCGS_API void lcgs_image_to_rgb8(int width, int height, const float* h_img_chw, 
 /* Same on the device (d_img CHW float -> d_rgb HWC uint8), enqueued on the context's stream. */
 LCGS_API lcgs_status lcgs_image_to_rgb8_device(lcgs_context* ctx, int width, int height, const float* d_img_chw,
                                                uint8_t* d_rgb);
+/* The simplest photometric loss for the training step (the reference only names training on its roadmap,
+ * doc/roadmap.md:4): *d_loss = mean((img - target)^2) over the 3*H*W samples, d_dL_dimg = its gradient 2 (img - target) /
+ * (3 H W) -- what lcgs_render_backward takes.  All device pointers; enqueued on the context's stream. */
+LCGS_API lcgs_status lcgs_l2_loss_backward(lcgs_context* ctx, int width, int height, const float* d_img_chw,
+                                           const float* d_target_chw, float* d_dL_dimg, float* d_loss);
 /* stbi_write_png(name, w, h, 3, data, 0) (app/main.cpp:339): 8-bit RGB PNG (stored deflate blocks). */
 LCGS_API lcgs_status lcgs_write_png(const char* path, int width, int height, const uint8_t* h_rgb);
 

@@ -140,7 +140,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_sort_pairs_u64_u32", "lcgs_scene_bind", "lcgs_scene_upload", "lcgs_render_forward",
     "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists",
     "lcgs_render_backward", "lcgs_render_backward_accumulate", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
-    "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png",
+    "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png", "lcgs_l2_loss_backward",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh",
     "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_set_lod", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_set_transport", "lcgs_comm_shard_rows",
@@ -549,6 +549,12 @@ class Renderer:
         fn = lib.lcgs_render_backward_compact if compact else (lib.lcgs_render_backward_accumulate if accumulate
                                                                else lib.lcgs_render_backward)
         _check(fn(self.ctx._h, _ptr(dL_dimg), C.byref(g)))
+
+    def l2_loss_backward(self, img, target, dL_dimg, loss):
+        """lcgs_l2_loss_backward: loss[0] = mean((img - target)^2), dL_dimg = 2 (img - target) / numel (device tensors)"""
+        _, H, W = img.shape
+        _check(load_library().lcgs_l2_loss_backward(self.ctx._h, C.c_int(W), C.c_int(H), _ptr(img), _ptr(target),
+                                                    _ptr(dL_dimg), _ptr(loss)))
 
     def visible_rows(self):
         """lcgs_visible_rows of the last forward frame: (splat index of every compact row, row count) as a device

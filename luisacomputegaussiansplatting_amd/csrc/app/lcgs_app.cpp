@@ -1,7 +1,7 @@
 // lcgs-app -- CLI work-alike of the reference's app/main.cpp on the MI355X library.
 //   lcgs-app --ply <path> [--res WxH] [--out dir] [--world colmap|blender] [--exp_N N] [--backend hip]
 //            [--path fused|stage] [--synth kind:count:seed] [--ingest device|host] [--cameras file]
-//            [--order file|spatial] [--pose garden|lego] [--gpus N] [--backward]
+//            [--order file|spatial] [--pose garden|lego] [--gpus N] [--backward] [--fit K]
 // Same flags (app/main.cpp:52-124; `--key=value` and `--key value`, app/command_parser.hpp:5-79), the same
 // hard-coded look-at camera (app/main.cpp:191-207), the same frame loop (:266-308), the same output:
 // <out>/<ply stem>_<backend>.png, CHW float -> vertically flipped RGB8 with a truncating *255 (:323-339).
@@ -59,6 +59,9 @@ void usage(const char* argv0)
     printf("  --cameras <file>         Render every camera of the file: `px py pz tx ty tz ux uy uz [fov]` per line\n");
     printf("  --gpus <N>               Shard the views of --cameras over N GPUs (one process per GPU; default 1)\n");
     printf("  --backward               Per round of views: backward (dL/dimg = 1) + RCCL sum of the gradients over the GPUs\n");
+    printf("  --fit <K>                Training without a Python binding (doc/roadmap.md:4), as a demonstration: the loaded scene's\n"
+           "                           frame is the target, opacities and base colours are perturbed, K optimiser steps\n"
+           "                           (forward, L2 loss, backward, Adam) pull them back; prints the loss per step\n");
     printf("  --display                Not supported (headless)\n");
 }
 
@@ -76,7 +79,7 @@ int main(int argc, char** argv)
     unsigned    W = 1600, H = 1063; // app/main.cpp:38
     std::string ply_path = "gsplat.ply", backend = "hip", out_dir = "out", world = "colmap", path = "fused", synth;
     std::string ingest = "device", cameras_file, order = "auto", pose = "garden";
-    int         exp_N = 1, gpus = 1;
+    int         exp_N = 1, gpus = 1, fit_steps = 0;
     bool        backward = false;
     // parse_command (app/command_parser.hpp:5-79): strip leading dashes, `key=value` or `key value`
     for (int i = 1; i < argc; ++i) {
@@ -131,6 +134,11 @@ int main(int argc, char** argv)
             gpus = std::stoi(value);
             if (gpus < 1 || gpus > 64) die("--gpus out of range");
         } else if (key == "backward") backward = true;
+        else if (key == "fit") {
+            if (value.empty()) die("--fit requires a value");
+            fit_steps = std::stoi(value);
+            if (fit_steps < 1 || fit_steps > 100000) die("--fit out of range");
+        }
         else if (key == "display") die("--display needs a GUI; this build is headless");
         else die("unknown option --" + key);
     }
@@ -317,6 +325,64 @@ int main(int argc, char** argv)
             lcgs::check(lcgs_write_png(img_name.c_str(), (int)W, (int)H, rgb.data()));
             printf("result saved in %s\n", img_name.c_str());
         };
+        if (fit_steps > 0) {
+            // ---- "training without python binding" (doc/roadmap.md:4) through the C ABI only: the scene's own frame is the
+            // target; the optimiser starts from perturbed opacities / base colours and has to find its way back.
+            if (gpus > 1) die("--fit runs on one GPU");
+            const size_t n3 = (size_t)P * 3, n4 = (size_t)P * 4, n48 = (size_t)P * 48;
+            std::vector<float> h_pos(n3), h_scale(n3), h_rotq(n4), h_sh(n48), h_op(P);
+            lcgs::check(lcgs_scene_download(device.ctx(), h_pos.data(), h_scale.data(), h_rotq.data(), h_sh.data(), h_op.data()));
+            lcgs::Camera cam = make_camera(views[0]);
+            lcgs::Scene  scene(device);
+            lcgs::Buffer<float> d_target((size_t)W * H * 3), d_dL((size_t)W * H * 3), d_loss(1);
+            scene.render(cam, d_target, bg);
+            // raw 3DGS parameters (log-scale, opacity logit, un-normalised quaternion) of the PERTURBED scene
+            std::vector<float> r_scale(n3), r_op(P);
+            for (size_t i = 0; i < n3; ++i) r_scale[i] = std::log(h_scale[i]);
+            for (int i = 0; i < P; ++i) {
+                const float o = std::min(std::max(h_op[i], 1e-6f), 1.0f - 1e-6f);
+                r_op[i]       = std::log(o / (1.0f - o)) - 1.0f; // every splat more transparent than it should be
+                h_op[i]       = 1.0f / (1.0f + std::exp(-r_op[i]));
+            }
+            for (int i = 0; i < P; ++i)
+                for (int c = 0; c < 3; ++c) h_sh[(size_t)i * 48 + c] += 0.3f * ((float)((i * 3 + c) % 7) / 3.0f - 1.0f);
+            lcgs::Buffer<float> a_pos = upload(h_pos.data(), n3), a_scale = upload(h_scale.data(), n3),
+                                a_rotq = upload(h_rotq.data(), n4), a_sh = upload(h_sh.data(), n48), a_op = upload(h_op.data(), (size_t)P);
+            lcgs::Buffer<float> w_scale = upload(r_scale.data(), n3), w_rotq = upload(h_rotq.data(), n4), w_op = upload(r_op.data(), (size_t)P);
+            auto zeros = [&](size_t n) {
+                lcgs::Buffer<float> b(n);
+                if (hipMemset(b.data(), 0, n * sizeof(float)) != hipSuccess) die("memset failed");
+                return b;
+            };
+            lcgs::Buffer<float> g[5] = { zeros(n3), zeros(n3), zeros(n4), zeros(n48), zeros((size_t)P) };
+            lcgs::Buffer<float> m[5] = { zeros(n3), zeros(n3), zeros(n4), zeros(n48), zeros((size_t)P) };
+            lcgs::Buffer<float> v[5] = { zeros(n3), zeros(n3), zeros(n4), zeros(n48), zeros((size_t)P) };
+            scene.bind(P, a_pos, a_scale, a_rotq, a_sh, a_op);
+            const lcgs_grads  grads = { g[0].data(), g[1].data(), g[2].data(), g[3].data(), g[4].data() };
+            const lcgs_params raw = { a_pos.data(), w_scale.data(), w_rotq.data(), a_sh.data(), w_op.data() }; // pos / sh: raw == activated
+            const lcgs_params act = { a_pos.data(), a_scale.data(), a_rotq.data(), a_sh.data(), a_op.data() };
+            const lcgs_params mm = { m[0].data(), m[1].data(), m[2].data(), m[3].data(), m[4].data() };
+            const lcgs_params vv = { v[0].data(), v[1].data(), v[2].data(), v[3].data(), v[4].data() };
+            lcgs_adam_config cfg = { 0.0f, 2.5e-2f, 0.0f, 5e-2f, 0.0f, 0.0f, 0.9f, 0.999f, 1e-15f, 1, 0 }; // opacity + dc only
+            auto t0 = std::chrono::steady_clock::now();
+            float first_loss = 0.0f, loss = 0.0f;
+            for (int it = 0; it < fit_steps; ++it) {
+                scene.render(cam, d_img, bg, 1.0f, /*keep_state=*/true);
+                lcgs::check(lcgs_l2_loss_backward(device.ctx(), (int)W, (int)H, d_img.data(), d_target.data(), d_dL.data(), d_loss.data()));
+                scene.backward(d_dL, grads);
+                cfg.step = it + 1;
+                lcgs::check(lcgs_adam_step(device.ctx(), P, 3, &cfg, &grads, &raw, &mm, &vv, &act));
+                device.synchronize();
+                if (hipMemcpy(&loss, d_loss.data(), sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) die("D2H copy failed");
+                if (it == 0) first_loss = loss;
+                printf("step %d loss %.6e\n", it + 1, loss);
+            }
+            double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            printf("fit: loss %.6e -> %.6e in %d steps (%.3f ms per step)\n", first_loss, loss, fit_steps, ms / fit_steps);
+            scene.render(cam, d_img, bg);
+            save_view(d_img.data(), 0);
+            views.clear(); // done
+        }
         if (gpus > 1 || backward) {
             // ---- a multi-view batch sharded over the GPUs: view k belongs to rank k mod N; one round = N
             // views, one per rank.  Forward: no collective.  --backward: each rank differentiates its view (dL/dimg = 1,

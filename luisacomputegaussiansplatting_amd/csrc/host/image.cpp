@@ -65,9 +65,49 @@ __global__ void k_image_to_rgb8(int w, int h, const float* __restrict__ img, uin
     for (int c = 0; c < 3; ++c) rgb[p * 3 + c] = (uint8_t)(int)(img[c * hw + idx] * 255.0f);
 }
 
+// mean squared error of two images and its gradient (2 (a - b) / n); the partial sums of a workgroup go out as one atomic
+__global__ void __launch_bounds__(256) k_l2_loss_backward(int64_t n, const float* __restrict__ img,
+                                                          const float* __restrict__ target, float* __restrict__ dL,
+                                                          float* __restrict__ loss)
+{
+    __shared__ float s_w[4];
+    const float      inv = 1.0f / (float)n;
+    float            acc = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = img[i] - target[i];
+        dL[i]         = 2.0f * d * inv;
+        acc += d * d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (s_w[0] + s_w[1] + s_w[2] + s_w[3]) * inv);
+}
+
 } // namespace
 
 extern "C" {
+
+lcgs_status lcgs_l2_loss_backward(lcgs_context* ctx, int width, int height, const float* d_img_chw,
+                                  const float* d_target_chw, float* d_dL_dimg, float* d_loss)
+{
+    if (!ctx || !d_img_chw || !d_target_chw || !d_dL_dimg || !d_loss || width <= 0 || height <= 0) {
+        lcgs::set_last_error("lcgs_l2_loss_backward: invalid argument");
+        return LCGS_ERR_INVALID_ARG;
+    }
+    const int64_t n  = (int64_t)width * height * 3;
+    hipStream_t   st = lcgs::context_stream(ctx);
+    hipError_t    e  = hipMemsetAsync(d_loss, 0, sizeof(float), st);
+    if (e != hipSuccess) return lcgs::hip_fail(e, "hipMemsetAsync(loss)", __FILE__, __LINE__);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_l2_loss_backward, dim3((unsigned)blocks), dim3(256), 0, st, n, d_img_chw, d_target_chw, d_dL_dimg,
+                       d_loss);
+    e = hipGetLastError();
+    if (e != hipSuccess) return lcgs::hip_fail(e, "k_l2_loss_backward", __FILE__, __LINE__);
+    return LCGS_OK;
+}
 
 void lcgs_image_to_rgb8(int width, int height, const float* h_img_chw, uint8_t* h_rgb)
 {

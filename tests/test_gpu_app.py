@@ -115,3 +115,38 @@ def test_lcgs_app_view_sharded_backward_with_gradient_sum(lcgs, oracle, tmp_path
             want = float(np.linalg.norm(ref[name].astype(np.float64)))
             assert abs(float(got) - want) <= 1e-3 * want, (k, name, got, want)
         assert os.path.exists(os.path.join(out, f"synth0_{P}_hip_{k}.png"))
+
+
+def test_lcgs_app_fit_trains_through_the_c_abi_only(lcgs, tmp_path):
+    """--fit K: "training without python binding" (doc/roadmap.md:4) -- forward, lcgs_l2_loss_backward, lcgs_render_backward,
+    lcgs_adam_step in a C++ loop.  The target is the scene's own frame and the start a perturbed copy, so the loss has to
+    fall, and by a lot."""
+    import re
+
+    app = os.path.join(ROOT, "luisacomputegaussiansplatting_amd", "lcgs-app")
+    res = subprocess.run([app, "--synth", "0:20000:1001", "--res=320x240", "--out", str(tmp_path), "--world", "blender",
+                          "--pose", "lego", "--fit", "30"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    losses = [float(x) for x in re.findall(r"step \d+ loss (\S+)", res.stdout)]
+    assert len(losses) == 30 and all(np.isfinite(losses))
+    assert losses[0] > 1e-5, "the perturbation must be visible in the first loss"
+    assert losses[-1] < 0.25 * losses[0], (losses[0], losses[-1])
+    assert min(losses[-5:]) <= min(losses[:5])
+    assert os.path.exists(os.path.join(str(tmp_path), "synth0_20000_hip.png"))
+
+
+def test_l2_loss_backward_matches_torch(lcgs):
+    import torch
+
+    r = lcgs.Renderer(lcgs.Context(0))
+    H, W = 37, 53
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    img = torch.rand(3, H, W, device="cuda:0", generator=g)
+    tgt = torch.rand(3, H, W, device="cuda:0", generator=g)
+    dL, loss = torch.empty_like(img), torch.full((1,), 9.0, device="cuda:0")
+    r.l2_loss_backward(img, tgt, dL, loss)
+    r.ctx.synchronize()
+    torch.cuda.synchronize()
+    ref = ((img.double() - tgt.double()) ** 2).mean()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * float(ref)
+    assert torch.allclose(dL, (2.0 * (img - tgt) / img.numel()), rtol=1e-6, atol=1e-12)
