@@ -107,7 +107,7 @@ class _StageTimes(C.Structure):
 
 class _FrameStats(C.Structure):
     _fields_ = [("num_gaussians", C.c_int64), ("num_visible", C.c_int64), ("num_rendered", C.c_int64),
-                ("num_pairs", C.c_int64), ("num_tiles", C.c_int64)]
+                ("num_pairs", C.c_int64), ("num_tiles", C.c_int64), ("equal_depth_unresolved", C.c_int64)]
 
 
 class _Grads(C.Structure):

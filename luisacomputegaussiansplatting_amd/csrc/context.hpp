@@ -31,12 +31,14 @@ struct lcgs_context {
     int          lod_min_radius = 0; // lcgs_set_lod: opt-in footprint cull of the fused frame (0 = off)
     int          ingest_order = 1; // LCGS_ORDER_SPATIAL
     DeviceBuffer scene_perm;
-    bool         perm_valid = false;
+    bool         perm_valid = false;      // the BOUND arrays are owned[] in the order scene_perm describes
+    bool         perm_for_owned = false;  // scene_perm describes the current contents of owned[] (bound or not)
     DeviceBuffer sh_half;            // opt-in f16 copy of sh for the fused forward's colour pass (lcgs_scene_use_half_sh)
     bool         use_half_sh = false;
 
     // workspace of the fused frame
     DeviceBuffer cull_slab, chunk_info, chunk_base; // the cull pass's per-chunk output (fused_forward.hip k_cull_compact)
+    DeviceBuffer tie_list; // re-ordered scenes: equal-depth runs the depth sort looks at again (kernels/tie_order.hpp)
     DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws[3], counts, sort_ws,
         expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks, shjac;
     bool         last_has_jac = false; // the last keep_state frame stored the colour Jacobian (degree 3)

@@ -519,7 +519,7 @@ constexpr int kExpandChunk = kThreads * kExpandSub;  // 1024 survivors
 __device__ __forceinline__ uint32_t rect_tiles(uint2 rc) { return (rc.y & 0xFFFFu) * (rc.y >> 16); }
 
 __global__ void __launch_bounds__(kThreads) k_expand_reduce(const uint32_t* __restrict__ d_counts, uint32_t v_cap,
-                                                              const uint32_t* __restrict__ order,
+                                                              const uint32_t* __restrict__ order, uint32_t id_mask,
                                                               const uint2* __restrict__ rects,
                                                               uint2* __restrict__ rects_sorted,
                                                               uint32_t* __restrict__ block_sums)
@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(kThreads) k_expand_reduce(const uint32_t* __re
 #pragma unroll
         for (int s = 0; s < kExpandSub; ++s) { // the one random gather (four in flight); emit reads the sorted copy
             const uint32_t k = chunk * kExpandChunk + s * kThreads + threadIdx.x;
-            rc[s]            = k < V ? rects[src[s]] : make_uint2(0u, 0u);
+            rc[s]            = k < V ? rects[src[s] & id_mask] : make_uint2(0u, 0u);
         }
         uint32_t sum = 0;
 #pragma unroll
@@ -637,7 +637,7 @@ constexpr int kEmitWindow = 4096;
 
 template <bool HIST>
 __global__ void __launch_bounds__(kThreads) k_expand_emit(const uint32_t* __restrict__ d_counts, uint32_t grid_x,
-                                                            const uint32_t* __restrict__ order,
+                                                            const uint32_t* __restrict__ order, uint32_t id_mask,
                                                             const uint2* __restrict__ rects_sorted,
                                                             const uint32_t* __restrict__ block_offsets,
                                                             uint32_t* __restrict__ pair_keys,
@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(kThreads) k_expand_emit(const uint32_t* __rest
                 uint32_t       count = 0;
                 if (k < V) {
                     const uint2 rc = rects_sorted[k];
-                    s_vid[j]       = order[k];
+                    s_vid[j]       = order[k] & id_mask;
                     s_xy[j]        = rc.x;
                     s_w[j]         = rc.y & 0xFFFFu;
                     count          = (rc.y & 0xFFFFu) * (rc.y >> 16);
@@ -890,7 +890,7 @@ size_t expand_ws_bytes(int P_cap) { return (size_t)((P_cap + kExpandChunk - 1) /
 bool launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts, uint32_t grid_x,
                    const uint32_t* order, const uint2* rects, uint2* rects_sorted, uint32_t* pair_keys,
                    uint32_t* pair_vals, uint32_t capacity, uint32_t* ws, hipStream_t stream,
-                   const PairSortFirstPass* first_pass)
+                   const PairSortFirstPass* first_pass, uint32_t id_mask)
 {
     int64_t hint   = v_hint > 0 ? v_hint : P_cap;
     int64_t blocks = (hint + kExpandChunk - 1) / kExpandChunk;
@@ -898,7 +898,7 @@ bool launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_expand_reduce, dim3((unsigned)blocks), dim3(kThreads), 0, stream, d_counts, (uint32_t)P_cap, order,
-                       rects, rects_sorted, ws);
+                       id_mask, rects, rects_sorted, ws);
     hipLaunchKernelGGL(k_expand_offsets, dim3(1), dim3(1024), 0, stream, d_counts, ws, (uint32_t)((cap + 3) & ~(int64_t)3),
                        capacity);
     int64_t lh      = l_hint > 0 ? l_hint : capacity;
@@ -909,11 +909,11 @@ bool launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts
                       (first_pass->keys_per_chunk == kEmitWindow || first_pass->keys_per_chunk * 2 == kEmitWindow);
     if (hist)
         hipLaunchKernelGGL(k_expand_emit<true>, dim3((unsigned)eblocks), dim3(kThreads), 0, stream, d_counts, grid_x, order,
-                           rects_sorted, ws, pair_keys, pair_vals, first_pass->shift, first_pass->mask,
+                           id_mask, rects_sorted, ws, pair_keys, pair_vals, first_pass->shift, first_pass->mask,
                            (uint32_t)first_pass->keys_per_chunk, first_pass->counts, first_pass->row_stride);
     else
         hipLaunchKernelGGL(k_expand_emit<false>, dim3((unsigned)eblocks), dim3(kThreads), 0, stream, d_counts, grid_x, order,
-                           rects_sorted, ws, pair_keys, pair_vals, 0, 0u, (uint32_t)kEmitWindow, (uint32_t*)nullptr, 0u);
+                           id_mask, rects_sorted, ws, pair_keys, pair_vals, 0, 0u, (uint32_t)kEmitWindow, (uint32_t*)nullptr, 0u);
     return hist;
 }
 
@@ -926,6 +926,7 @@ void launch_get_ranges_u32(int64_t L_hint, uint32_t l_cap, uint32_t* d_counts, c
                           ranges, scan_error_flag);
 }
 
+// d_counts[9] accumulates the members of equal-depth runs beyond the cap (zeroed per frame by k_rowscan_first)
 void launch_map_to_index(int64_t L_cap, const uint32_t* d_counts, const uint32_t* list_vid, const uint32_t* vis_index,
                          uint32_t* list_idx, hipStream_t stream)
 {

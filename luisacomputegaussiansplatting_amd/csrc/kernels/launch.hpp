@@ -55,6 +55,7 @@ static_assert(sizeof(SplatRecord) == 48, "SplatRecord must be 48 bytes");
 // Where the cull pass leaves the depth sort's first per-chunk digit counts (pair_sort.hip depth_sort_first_pass).
 // splats per cull workgroup = slots per slab = keys per chunk of the depth sort's first pass (both files assert it)
 constexpr int kCullChunkSplats = 2048;
+struct TieOrder; // tie_order.hpp
 struct DepthSortFirstPass {
     uint32_t  mask;       // first digit = key & mask
     uint32_t  row_stride; // counts[digit * row_stride + chunk]
@@ -74,7 +75,13 @@ void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const
 void launch_depth_sort_from_chunks(int64_t P, int64_t v_hint, const uint4* slab, const uint2* chunk_info,
                                    uint32_t* chunk_base, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
                                    uint32_t* vals_b, uint32_t* vis_index, uint2* rects, uint32_t* d_counts, void* sort_ws,
-                                   hipStream_t stream, hipEvent_t fork = nullptr);
+                                   hipStream_t stream, hipEvent_t fork = nullptr,
+                                   // re-ordered scenes: equal depths come out in FILE order (tie_order.hpp); the sorted
+                                   // values then carry a file-index tag above their id_bits -- readers mask it off
+                                   const TieOrder* tie = nullptr);
+size_t tie_list_entries(int64_t P);     // words of the run list (TieOrder::list + its shared tail) for a scene of P splats
+size_t tie_overflow_offset(int64_t P);  // where the tail begins
+size_t tie_overflow_entries(int64_t P); // and how many entries it holds
 struct PairSortFirstPass;
 size_t expand_ws_bytes(int P_cap);
 // v_hint: expected survivor count (bounds the launch; larger live counts are handled by chunk striding)
@@ -82,7 +89,8 @@ size_t expand_ws_bytes(int P_cap);
 bool launch_expand(int P_cap, int64_t v_hint, int64_t l_hint, uint32_t* d_counts, uint32_t grid_x,
                    const uint32_t* order, const uint2* rects, uint2* rects_sorted, uint32_t* pair_keys,
                    uint32_t* pair_vals, uint32_t capacity, uint32_t* ws, hipStream_t stream,
-                   const PairSortFirstPass* first_pass = nullptr); // non-NULL: also leave the tile sort's first counts
+                   const PairSortFirstPass* first_pass = nullptr, // non-NULL: also leave the tile sort's first counts
+                   uint32_t id_mask = 0xFFFFFFFFu); // the bits of an `order` entry that are the dense id
 
 // ---- pair_sort.hip : stable radix sort of (u32 key, u32 value) pairs, count in device memory ----
 size_t pair_sort_ws_bytes(int64_t n_cap);

@@ -19,6 +19,7 @@
 #include "common.hpp"
 #include "context.hpp"
 #include "kernels/launch.hpp"
+#include "kernels/tie_order.hpp"
 
 namespace lcgs
 {
@@ -197,6 +198,7 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
         LCGS_TRY(ctx->chunk_base.ensure(chunks * 4));
     }
     LCGS_TRY(ctx->vis_index.ensure(P * 4));
+    if (ctx->perm_valid) LCGS_TRY(ctx->tie_list.ensure(tie_list_entries((int64_t)P) * 4));
     LCGS_TRY(ctx->rects.ensure(P * 8));
     LCGS_TRY(ctx->rects_sorted.ensure(P * 8));
     if (ctx->pair_capacity == 0) {
@@ -283,11 +285,26 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     // survivors by depth bits (the low 32 bits of the reference key), sorted before duplication.  The first pass reads
     // the cull pass's chunk slabs, hands out the dense ids and writes vis_index / rects; its completion is the fork
     // point of the record builder.
+    // a scene the context re-ordered: equal depths must still blend in ascending FILE index, as in the reference
+    // (kernels/tie_order.hpp); the sorted values then carry a file-index tag above the dense id's id_bits
+    TieOrder tie;
+    uint32_t id_mask = 0xFFFFFFFFu;
+    if (ctx->perm_valid) {
+        tie.d_counts  = d_counts;
+        tie.list      = ctx->tie_list.as<uint32_t>();
+        tie.overflow  = tie.list + tie_overflow_offset(P);
+        tie.overflow_cap = (uint32_t)tie_overflow_entries(P);
+        tie.vis_index = ctx->vis_index.as<uint32_t>();
+        tie.perm      = ctx->scene_perm.as<uint32_t>();
+        tie.id_bits   = (uint32_t)std::max(1, ceil_log2_u32((uint32_t)P));
+        tie.tag_shift = 2u * tie.id_bits > 32u ? 2u * tie.id_bits - 32u : 0u;
+        id_mask       = (1u << tie.id_bits) - 1u;
+    }
     launch_depth_sort_from_chunks(P, hint_V, ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(),
                                   ctx->chunk_base.as<uint32_t>(), ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
                                   ctx->sortv[0].as<uint32_t>(), ctx->sortv[1].as<uint32_t>(), ctx->vis_index.as<uint32_t>(),
                                   ctx->rects.as<uint2>(), d_counts, ctx->sort_ws.ptr, st,
-                                  (overlap && !in_capture) ? ctx->ev_fork : nullptr);
+                                  (overlap && !in_capture) ? ctx->ev_fork : nullptr, ctx->perm_valid ? &tie : nullptr);
     const uint32_t* order = ctx->sortv[0].as<uint32_t>();
     LCGS_TRY(mark(ctx, "depth_sort"));
     // Record building (SH fetch + colour: bandwidth-bound) is independent of the rest of the sort chain (latency-bound
@@ -320,7 +337,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     const bool counted =
         launch_expand(P, hint_V, hint_L, d_counts, cp.grid_x, order, ctx->rects.as<uint2>(), ctx->rects_sorted.as<uint2>(),
                       ctx->pairk[0].as<uint32_t>(), ctx->pairv[0].as<uint32_t>(), ctx->pair_capacity,
-                      ctx->expand_ws.as<uint32_t>(), st, &first);
+                      ctx->expand_ws.as<uint32_t>(), st, &first, id_mask);
     LCGS_TRY(mark(ctx, "expand"));
 
     const int where2 = launch_pair_sort_u32(ctx->pairk[0].as<uint32_t>(), ctx->pairk[1].as<uint32_t>(),
@@ -370,11 +387,11 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     if (deferred) {
         // the counter read-back leaves through the auxiliary stream: the next frame does not queue behind it
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_render, 0)); // (carried by the render dispatch)
-        LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, d_counts, 32, hipMemcpyDeviceToHost, ctx->aux_stream));
+        LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, d_counts, 40, hipMemcpyDeviceToHost, ctx->aux_stream));
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_counts, ctx->aux_stream));
         ctx->counts_pending = true;
     } else {
-        LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, d_counts, 32, hipMemcpyDeviceToHost, st));
+        LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, d_counts, 40, hipMemcpyDeviceToHost, st));
     }
     ctx->last.valid          = true;
     ctx->last.has_state      = keep_state;
@@ -448,7 +465,8 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
         ctx->comm = nullptr;
     }
     if (ctx->twin) {
-        ctx->twin->sh_half.ptr = nullptr; // borrowed from this context
+        ctx->twin->sh_half.ptr    = nullptr; // borrowed from this context
+        ctx->twin->scene_perm.ptr = nullptr; // likewise
         (void)lcgs_destroy(ctx->twin);
         ctx->twin = nullptr;
     }
@@ -477,6 +495,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
         if (ev) (void)hipEventDestroy(ev);
     ctx->frame_params.release();
     ctx->slice_bounds.release();
+    ctx->tie_list.release();
     ctx->scene_perm.release();
     for (hipEvent_t ev : ctx->ev_slice)
         if (ev) (void)hipEventDestroy(ev);
@@ -666,7 +685,11 @@ lcgs_status lcgs_scene_bind(lcgs_context* ctx, int num_gaussians, int sh_degree,
     ctx->opacity = d_opacity;
     ctx->last.valid = false;
     ctx->use_half_sh = false; // a new scene: the f16 copy (if any) is stale
-    ctx->perm_valid  = false; // the caller's arrays, the caller's order
+    // the caller's arrays, the caller's order -- unless these ARE the context's own re-ordered arrays (bound again after
+    // something else was): their permutation, and with it the reference's order of equal depths, still applies
+    ctx->perm_valid = ctx->perm_for_owned && num_gaussians > 0 && d_pos == ctx->owned[0].as<float>() &&
+                      d_scale == ctx->owned[1].as<float>() && d_rotq == ctx->owned[2].as<float>() &&
+                      d_sh == ctx->owned[3].as<float>() && d_opacity == ctx->owned[4].as<float>();
     return LCGS_OK;
 }
 
@@ -706,6 +729,7 @@ lcgs_status lcgs_scene_upload(lcgs_context* ctx, int num_gaussians, int sh_degre
     const size_t feat     = (size_t)(sh_degree + 1) * (sh_degree + 1) * 3;
     const size_t sizes[5] = { P * 3 * 4, P * 3 * 4, P * 4 * 4, P * feat * 4, P * 4 };
     const float* src[5]   = { h_pos, h_scale, h_rotq, h_sh, h_opacity };
+    ctx->perm_for_owned = false; // owned[] is rewritten in the given order
     for (int i = 0; i < 5; ++i) {
         LCGS_TRY(ctx->owned[i].ensure(std::max<size_t>(sizes[i], 16)));
         if (sizes[i])
@@ -821,7 +845,8 @@ lcgs_status lcgs_scene_reorder_spatial(lcgs_context* ctx, uint32_t* d_perm)
         ctx->scene_perm.release();
         ctx->scene_perm = kept_perm;
     }
-    ctx->perm_valid = true;
+    ctx->perm_valid     = true;
+    ctx->perm_for_owned = true;
     if (half) LCGS_TRY(lcgs_scene_use_half_sh(ctx, 1)); // the f16 copy follows the new order
     return LCGS_OK;
 }
@@ -933,6 +958,7 @@ lcgs_status lcgs_scene_load_ply(lcgs_context* ctx, const char* path, int* num_ga
     }
     const int64_t N = probe.num_vertices;
     LCGS_REQUIRE(N < (1 << 30), "too many vertices");
+    ctx->perm_for_owned = false; // owned[] is rewritten in the file's order
     const size_t sizes[5] = { (size_t)N * 3 * 4, (size_t)N * 3 * 4, (size_t)N * 4 * 4, (size_t)N * 48 * 4, (size_t)N * 4 };
     for (int i = 0; i < 5; ++i) LCGS_TRY(ctx->owned[i].ensure(std::max<size_t>(sizes[i], 16)));
     if (N > 0) {
@@ -1077,6 +1103,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
         ctx->stats.num_rendered  = ctx->h_counts[1];
         ctx->stats.num_pairs     = ctx->h_counts[2];
         ctx->stats.num_tiles     = (int64_t)cp.grid_x * cp.grid_y;
+        ctx->stats.equal_depth_unresolved = ctx->perm_valid ? ctx->h_counts[9] : 0;
         if (num_rendered) *num_rendered = (int)ctx->h_counts[1];
         if (ctx->h_counts[5] != 0) return check_frame_flags(ctx);
         // launch-size hints for the following asynchronous frames
@@ -1141,6 +1168,10 @@ lcgs_status lcgs_render_forward_batch(lcgs_context* ctx, int num_views, const lc
             LCGS_TRY(lcgs_scene_bind(t, ctx->P, ctx->sh_deg, ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity));
         t->use_half_sh    = false;
         t->lod_min_radius = ctx->lod_min_radius;
+        // the sibling renders the same (possibly re-ordered) arrays: it borrows their permutation for the order of equal depths
+        t->scene_perm.ptr   = ctx->scene_perm.ptr;
+        t->scene_perm.bytes = 0;
+        t->perm_valid       = ctx->perm_valid;
         if (ctx->use_half_sh) { // the sibling reads the same f16 copy (not owned: never grown or freed through it)
             t->sh_half.ptr   = ctx->sh_half.ptr;
             t->sh_half.bytes = 0;
@@ -1189,6 +1220,7 @@ lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* out)
     ctx->stats.num_rendered  = ctx->h_counts[1];
     ctx->stats.num_pairs     = ctx->h_counts[2];
     ctx->stats.num_tiles     = (int64_t)ctx->last.cp.grid_x * ctx->last.cp.grid_y;
+    ctx->stats.equal_depth_unresolved = ctx->perm_valid ? ctx->h_counts[9] : 0;
     *out                     = ctx->stats;
     return LCGS_OK;
 }

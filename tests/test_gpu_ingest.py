@@ -273,3 +273,130 @@ def test_spatial_reorder_with_non_finite_and_degenerate_inputs(lcgs):
         pn = perm.cpu().numpy()
         assert np.array_equal(back["pos"], scene["pos"][pn], equal_nan=True)
         assert np.array_equal(back["sh"].reshape(P, -1), scene["sh"].reshape(P, -1)[pn])
+
+
+def _plane_scene(rng, P):
+    """P overlapping splats on the plane x = 0, seen head-on by an axis-aligned camera: every view depth is exactly 5.0"""
+    from conftest import make_scene
+
+    scene = make_scene(rng, P, spread=0.25, log_scale=(-2.6, 0.3))
+    scene["pos"][:, 0] = 0.0
+    scene["pos"][:, 2] += 0.0
+    scene["opacity"][:] = rng.uniform(0.3, 0.8, P).astype(np.float32)
+    return scene
+
+
+PLANE_POSE = ([-5.0, 0.0, 0.5], [0.0, 0.0, 0.5], [0.0, 0.0, 1.0])
+
+
+def test_equal_depths_blend_in_file_order_after_the_spatial_reorder(lcgs, oracle):
+    """The reference's stable sort on (tile, depth bits) blends splats of exactly equal depth in ascending FILE index
+    (gs_tile_splatter/impl.cpp:135-143).  A context-owned scene is re-ordered along a Morton curve by default; the pass
+    behind the depth sort must put every run of equal depths back into file order -- here ALL depths are equal and the
+    splats overlap heavily, so any other order gives a visibly different image."""
+    from gpu_util import assert_image_parity
+
+    rng = np.random.default_rng(91)
+    scene = _plane_scene(rng, 900)
+    W, H = 320, 240
+    cam = lcgs.get_lookat_cam(*PLANE_POSE, width=W, height=H)
+    orc = oracle.render(scene, oracle.lookat(*PLANE_POSE, width=W, height=H), ambig_eps=1e-5)
+    assert orc["num_rendered"] > 3000
+    imgs = {}
+    for order in ("file", None):
+        r = lcgs.Renderer(lcgs.Context(0))
+        r.upload_scene(scene, order=order)
+        img = torch.zeros(3, H, W, device=DEV)
+        assert r.forward(cam, img) == orc["num_rendered"]
+        assert r.frame_stats()["equal_depth_unresolved"] == 0
+        assert_image_parity(img.cpu().numpy(), orc)
+        imgs[order] = img
+        if order is None:  # and through the camera-batch sibling, which borrows the permutation
+            pair = [torch.zeros(3, H, W, device=DEV) for _ in range(2)]
+            r.forward_batch([cam, cam], pair)
+            r.ctx.synchronize()
+            assert torch.equal(pair[0], img) and torch.equal(pair[1], img)
+            # binding the context's own arrays again keeps the permutation (and with it the order of equal depths)
+            t = r.scene_tensors()
+            r.bind_scene(t["pos"], t["scale"], t["rotq"], t["sh"], t["opacity"])
+            assert r.permutation() is not None
+            again = torch.zeros(3, H, W, device=DEV)
+            r.forward(cam, again)
+            assert torch.equal(again, img)
+    assert torch.equal(imgs["file"], imgs[None])
+    # the order matters here: the same splats in reversed file order are a different image
+    rev = {k: np.ascontiguousarray(v[::-1]) for k, v in scene.items()}
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.upload_scene(rev, order="file")
+    other = torch.zeros(3, H, W, device=DEV)
+    r.forward(cam, other)
+    assert (other - imgs["file"]).abs().max().item() > 1e-2
+
+
+def test_equal_depth_runs_beyond_the_cap_are_reported(lcgs, oracle):
+    """More than 4096 splats at exactly one depth: the re-ordered scene keeps its own order inside that run and says so
+    (lcgs_frame_stats.equal_depth_unresolved); the file-order scene stays exact."""
+    from gpu_util import assert_image_parity
+
+    rng = np.random.default_rng(92)
+    scene = _plane_scene(rng, 6000)
+    W, H = 256, 192
+    cam = lcgs.get_lookat_cam(*PLANE_POSE, width=W, height=H)
+    orc = oracle.render(scene, oracle.lookat(*PLANE_POSE, width=W, height=H), ambig_eps=1e-5)
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.upload_scene(scene)
+    img = torch.zeros(3, H, W, device=DEV)
+    assert r.forward(cam, img) == orc["num_rendered"]
+    st = r.frame_stats()
+    assert st["equal_depth_unresolved"] == st["num_visible"] > 4096
+    rf = lcgs.Renderer(lcgs.Context(0))
+    rf.upload_scene(scene, order="file")
+    imgf = torch.zeros(3, H, W, device=DEV)
+    rf.forward(cam, imgf)
+    assert rf.frame_stats()["equal_depth_unresolved"] == 0
+    assert_image_parity(imgf.cpu().numpy(), orc)
+
+
+def _frame_lists_in_file_indices(lcgs, scene, cam, order):
+    """per-tile lists of one fused frame, every entry as the splat's FILE index"""
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.upload_scene(scene, order=order)
+    img = torch.zeros(3, cam.height, cam.width, device=DEV)
+    n = r.forward(cam, img)
+    st = r.frame_stats()
+    lst = torch.zeros(max(st["num_pairs"], 1), dtype=torch.int32, device=DEV)
+    rng_ = torch.zeros(st["num_tiles"] * 2, dtype=torch.int32, device=DEV)
+    r.last_lists(lst, rng_)
+    lst = lst[:st["num_pairs"]].cpu().numpy().astype(np.int64)
+    perm = r.permutation()
+    if perm is not None:
+        lst = perm.cpu().numpy().astype(np.int64)[lst]
+    return n, st, lst, rng_.cpu().numpy(), img
+
+
+@pytest.mark.parametrize("levels", [20000, 1500, 60, 7])
+def test_equal_depth_runs_of_every_length_keep_the_file_order(lcgs, levels):
+    """Depths quantised to `levels` planes in a 60 K-splat scene: runs of 2-3 equal depths (put right inside the last
+    radix pass), of dozens (listed, ranked by a workgroup), of thousands (many of them crossing the sort's 2048-key
+    chunks) and -- 7 levels -- beyond the cap.  The re-ordered scene must yield the file-order scene's per-tile lists
+    entry for entry (as file indices), and the same image bit for bit."""
+    from conftest import make_scene
+
+    rng = np.random.default_rng(400 + levels)
+    P = 60000
+    scene = make_scene(rng, P, spread=1.2, log_scale=(-4.0, 0.3))
+    x = scene["pos"][:, 0]
+    scene["pos"][:, 0] = (np.round((x - x.min()) / (x.max() - x.min()) * (levels - 1)) / (levels - 1) * 2.0 - 1.0) \
+        .astype(np.float32)  # the camera looks along +x: the view depth is x + 5, equal x = equal depth bits
+    W, H = 320, 240
+    cam = lcgs.get_lookat_cam(*PLANE_POSE, width=W, height=H)
+    n_f, st_f, list_f, rng_f, img_f = _frame_lists_in_file_indices(lcgs, scene, cam, "file")
+    n_s, st_s, list_s, rng_s, img_s = _frame_lists_in_file_indices(lcgs, scene, cam, None)
+    assert n_f == n_s and st_f["num_pairs"] == st_s["num_pairs"] > 20000
+    assert np.array_equal(rng_f, rng_s)
+    if levels == 7:  # ~8.5 K splats per depth: left in the context's order, and reported
+        assert st_s["equal_depth_unresolved"] > 4096 * 6
+        return
+    assert st_s["equal_depth_unresolved"] == 0
+    assert np.array_equal(list_f, list_s)
+    assert torch.equal(img_f, img_s)
