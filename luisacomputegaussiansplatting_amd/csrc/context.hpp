@@ -38,7 +38,6 @@ struct lcgs_context {
 
     // workspace of the fused frame
     DeviceBuffer cull_slab, chunk_info, chunk_base; // the cull pass's per-chunk output (fused_forward.hip k_cull_compact)
-    DeviceBuffer tie_list; // re-ordered scenes: equal-depth runs the depth sort looks at again (kernels/tie_order.hpp)
     DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws[3], counts, sort_ws,
         expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks, shjac;
     bool         last_has_jac = false; // the last keep_state frame stored the colour Jacobian (degree 3)

@@ -79,9 +79,6 @@ void launch_depth_sort_from_chunks(int64_t P, int64_t v_hint, const uint4* slab,
                                    // re-ordered scenes: equal depths come out in FILE order (tie_order.hpp); the sorted
                                    // values then carry a file-index tag above their id_bits -- readers mask it off
                                    const TieOrder* tie = nullptr);
-size_t tie_list_entries(int64_t P);     // words of the run list (TieOrder::list + its shared tail) for a scene of P splats
-size_t tie_overflow_offset(int64_t P);  // where the tail begins
-size_t tie_overflow_entries(int64_t P); // and how many entries it holds
 struct PairSortFirstPass;
 size_t expand_ws_bytes(int P_cap);
 // v_hint: expected survivor count (bounds the launch; larger live counts are handled by chunk striding)

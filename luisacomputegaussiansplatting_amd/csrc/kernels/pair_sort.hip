@@ -349,28 +349,21 @@ __global__ void __launch_bounds__(kThreads) k_rowscan_first(uint32_t* __restrict
         if (chunks) {
             d_counts[0] = carry_in;  // V: splats that emit >= 1 pair
             d_counts[1] = carry2_in; // the reference's num_rendered (gs_tile_splatter/impl.cpp:106)
-            d_counts[kCountTieUnresolved] = 0u; // (tie_order.hpp: this frame's launches add to the two)
-            d_counts[kCountTieListed]     = 0u;
+            d_counts[kCountTieUnresolved] = 0u; // (tie_order.hpp: k_fix_equal_depth_order adds to it)
         } else {
             totals[blockIdx.x] = carry_in;
         }
     }
 }
 
-// TIES (the depth sort's last pass over a re-ordered scene, see tie_order.hpp): the chunk sits in LDS sorted by its full
-// key -- the input is sorted by the bits below this pass's digit -- so equal keys are neighbours there.  Runs of up to
-// kTieRunShort members are put into file order in LDS; longer ones, and keys that may continue in the neighbouring chunk
-// (they share the low bits of this chunk's first / last input key, and so does the key across the boundary), are listed
-// by output position for k_fix_listed_runs.
-template <int kItems, typename K, bool TIES = false>
+template <int kItems, typename K>
 __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys_in,
                                                         const uint32_t* __restrict__ vals_in,
                                                         K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                         const uint32_t* __restrict__ d_n, uint32_t n_cap, int shift,
                                                         uint32_t mask,
                                                         int bits, const uint32_t* __restrict__ row_excl,
-                                                        const uint32_t* __restrict__ totals, uint32_t row_stride,
-                                                        TieOrder tie)
+                                                        const uint32_t* __restrict__ totals, uint32_t row_stride)
 {
     constexpr int kKPB = kThreads * kItems;
     __shared__ uint32_t s_wave_hist[kWaves][kRadix];
@@ -379,8 +372,6 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys
     __shared__ uint32_t s_scan[kWaves];
     __shared__ K        s_keys[kKPB];
     __shared__ uint32_t s_vals[kKPB];
-    __shared__ K        s_edge[2]; // TIES: the chunk's first and last input key
-    __shared__ uint32_t s_nlist;   // TIES: runs this chunk listed
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // everything the first chunk needs is requested before the element count arrives (capacity-guarded)
@@ -394,11 +385,6 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys
         const uint32_t i = chunk * kKPB + wave * 64 * kItems + r * 64 + lane;
         key[r]           = i < n_cap ? keys_in[i] : (K)0;
         val[r]           = i < n_cap ? vals_in[i] : 0u;
-    }
-    K before = (K)0, after = (K)0; // TIES: the input keys either side of the chunk (wave-uniform loads)
-    if (TIES) {
-        if (chunk > 0) before = keys_in[(size_t)chunk * kKPB - 1];
-        if ((size_t)(chunk + 1) * kKPB < n_cap) after = keys_in[(size_t)(chunk + 1) * kKPB];
     }
     const uint32_t n  = d_n ? *d_n : n_cap;
     const uint32_t nb = (n + kKPB - 1) / kKPB;
@@ -493,78 +479,7 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys
                 s_vals[pos]        = val[r];
             }
         }
-        if (TIES) {
-            if (tid == 0) {
-                s_edge[0] = key[0];
-                s_nlist   = 0;
-            }
-            if (tid == kThreads - 1) s_edge[1] = key[kItems - 1]; // (the chunk's last input key if the chunk is full)
-        }
         __syncthreads();
-        if (TIES) {
-            const K    low    = ((K)1 << shift) - (K)1; // the bits the earlier passes sorted on
-            const K    kf     = s_edge[0], kl = s_edge[1];
-            const bool flag_l = block_base > 0 && ((before ^ kf) & low) == 0; // a run may have begun in the chunk before
-            const bool flag_r = block_base + kKPB < n && ((after ^ kl) & low) == 0; // ... or go on in the next
-            // position i = tid + 256 r.  Runs of two that cannot cross a chunk boundary are settled at once; whatever
-            // needs more than that is noted in `slow` and taken up below, one at a time
-            uint32_t slow = 0;
-#pragma unroll 2
-            for (int r = 0; r < kItems; ++r) {
-                const uint32_t i  = tid + r * kThreads;
-                const K        k  = s_keys[i];
-                const K        k0 = s_keys[i > 0 ? i - 1 : 0];
-                const K        k2 = s_keys[i + 1 < (uint32_t)kKPB ? i + 1 : i];
-                const K        k3 = s_keys[i + 2 < (uint32_t)kKPB ? i + 2 : i];
-                const bool     head  = i < in_block && !(i > 0 && k0 == k); // the first of its key in this chunk acts
-                const bool     two   = i + 1 < in_block && k2 == k;
-                const bool     three = two && i + 2 < in_block && k3 == k;
-                const bool     edge  = (flag_l && ((k ^ kf) & low) == 0) || (flag_r && ((k ^ kl) & low) == 0);
-                if (head && two && !three && !edge) { // two splats whose depths round to the same float: the usual run
-                    const uint32_t a = s_vals[i], b = s_vals[i + 1];
-                    if (tie_before(b, a, tie.id_bits, tie.vis_index, tie.perm)) {
-                        s_vals[i]     = b;
-                        s_vals[i + 1] = a;
-                    }
-                }
-                slow |= (head && (three || edge) ? 1u : 0u) << r;
-            }
-            while (slow) {
-                const uint32_t r = (uint32_t)__ffs((int)slow) - 1u;
-                slow &= slow - 1u;
-                const uint32_t i = tid + r * kThreads;
-                const K        k = s_keys[i];
-                uint32_t       m = 1;
-                while (i + m < in_block && m <= kTieRunShort && s_keys[i + m] == k) ++m;
-                const bool edge = (flag_l && ((k ^ kf) & low) == 0) || (flag_r && ((k ^ kl) & low) == 0);
-                if (edge || m > kTieRunShort) { // to be looked at again in the output, where the run is in one piece
-                    const uint32_t dst  = s_global_delta[(uint32_t)(k >> shift) & mask] + i;
-                    const uint32_t slot = atomicAdd(&s_nlist, 1u);
-                    if (slot < kTieChunkSlots) {
-                        tie.list[(size_t)chunk * kTieChunkLine + 1 + slot] = dst;
-                    } else { // (rare: a chunk with many such keys) the shared tail of the list
-                        const uint32_t o = atomicAdd(&tie.d_counts[kCountTieListed], 1u);
-                        if (o < tie.overflow_cap) tie.overflow[o] = dst;
-                        else atomicAdd(&tie.d_counts[kCountTieUnresolved], m); // (a list this long has never been seen)
-                    }
-                    continue;
-                }
-                for (uint32_t j = 0; j + 1 < m; ++j) { // selection sort: a handful of members
-                    const uint32_t vj   = s_vals[i + j];
-                    uint32_t       best = j, vb = vj;
-                    for (uint32_t q = j + 1; q < m; ++q) {
-                        const uint32_t vc = s_vals[i + q];
-                        if (tie_before(vc, vb, tie.id_bits, tie.vis_index, tie.perm)) best = q, vb = vc;
-                    }
-                    if (best != j) {
-                        s_vals[i + j]    = vb;
-                        s_vals[i + best] = vj;
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid == 0) tie.list[(size_t)chunk * kTieChunkLine] = s_nlist < kTieChunkSlots ? s_nlist : kTieChunkSlots;
-        }
         for (uint32_t i = tid; i < in_block; i += kThreads) {
             const K        k   = s_keys[i];
             const uint32_t dst = s_global_delta[(uint32_t)(k >> shift) & mask] + i;
@@ -580,101 +495,150 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys
             key[r]           = i < n ? keys_in[i] : (K)0;
             val[r]           = i < n ? vals_in[i] : 0u;
         }
-        if (TIES) {
-            before = keys_in[(size_t)chunk * kKPB - 1];
-            if ((size_t)(chunk + 1) * kKPB < n) after = keys_in[(size_t)(chunk + 1) * kKPB];
-        }
     }
 }
 
-// The runs the last pass listed (TIES above), each by the output position of the first member its chunk held: chunk c's
-// line of the list is {count, positions...}; chunks with more entries than a line holds put the rest on the shared
-// tail.  One wave per chunk line.  A position whose left neighbour has the same key is not the run's first -- the chunk
-// before listed that one -- and is skipped.  A run of fewer than 64 members is ranked in registers, by the tags if
-// they are all different (no further loads: two round trips in all); longer ones through LDS.
-__device__ void fix_listed_run(uint32_t lo, uint32_t V, const uint32_t* __restrict__ keys, uint32_t* vals,
-                               const TieOrder& tie, uint32_t* s_f, uint32_t* s_v)
+// Equal depths in a re-ordered scene (tie_order.hpp): puts every run of equal keys of the sorted survivors back into
+// file order, in place.  Only the first member of a run does anything: a lane reads kTieLane consecutive keys and their
+// neighbours (requested before the survivor count arrives), and values only if one of its elements starts a run.
+//   run of 2 (nearly all)      compare the tags, swap in place
+//   run of 3 .. kTieRunShort   selection sort in place by the first member's lane
+//   longer, up to kTieRunCap   the first member's workgroup ranks the members by file index through LDS
+//   longer still               left in the context's order and counted in d_counts[kCountTieUnresolved]
+constexpr uint32_t kTieLane = 8;                   // elements per lane: the whole frame is resident at once
+constexpr uint32_t kTieSpan = kThreads * kTieLane; // elements per workgroup step
+
+__global__ void __launch_bounds__(kThreads) k_fix_equal_depth_order(const uint32_t* __restrict__ keys, uint32_t* vals,
+                                                                      uint32_t v_cap, TieOrder tie)
 {
-    const uint32_t lane = threadIdx.x;
-    if (lo >= V) return;
-    const uint32_t kprev = lo > 0 ? keys[lo - 1] : 0u;
-    const bool     in    = lo + lane < V;
-    const uint32_t kj    = in ? keys[lo + lane] : 0u;
-    const uint32_t vj    = in ? vals[lo + lane] : 0u;
-    const uint32_t k     = __shfl(kj, 0, 64);
-    if (lo > 0 && kprev == k) return;
+    __shared__ uint32_t s_n, s_len;
+    __shared__ uint32_t s_head[kTieSpan / (kTieRunShort + 1u) + 4u]; // long runs start >= kTieRunShort + 1 apart
+    __shared__ uint32_t s_f[kTieRunCap];
+    const uint32_t tid     = threadIdx.x;
     const uint32_t id_mask = (1u << tie.id_bits) - 1u;
-    const unsigned long long members = __ballot(in && kj == k);
-    if (~members != 0ull) { // the run ends among these 64
-        const uint32_t m = (uint32_t)__ffsll((long long)~members) - 1u;
-        if (m <= 1u) return;
-        uint32_t mine = vj >> tie.id_bits;
-        for (int round = 0; round < 2; ++round) {
-            uint32_t rank = 0;
-            bool     same = false;
-            for (uint32_t q = 0; q < m; ++q) {
-                const uint32_t t = __shfl(mine, (int)q, 64);
-                rank += t < mine ? 1u : 0u;
-                same |= t == mine && q != lane;
+    // keys i0 - 1 .. i0 + kTieLane + 1 around the lane's elements; v_cap is a multiple of 4 or the tail goes one by one
+    auto load_keys = [&](uint32_t i0, uint32_t limit, uint32_t (&kk)[kTieLane + 3]) {
+#pragma unroll
+        for (uint32_t g = 0; g < kTieLane; g += 4) {
+            if (i0 + g + 4u <= limit) {
+                const uint4 k4 = *reinterpret_cast<const uint4*>(keys + i0 + g);
+                kk[g + 1] = k4.x, kk[g + 2] = k4.y, kk[g + 3] = k4.z, kk[g + 4] = k4.w;
+            } else {
+#pragma unroll
+                for (uint32_t e = 0; e < 4; ++e) kk[g + e + 1] = i0 + g + e < limit ? keys[i0 + g + e] : 0u;
             }
-            if (!__any(same && lane < m)) {
-                if (lane < m) vals[lo + rank] = vj;
-                return;
+        }
+        kk[0]            = (i0 > 0u && i0 <= limit) ? keys[i0 - 1u] : 0u;
+        kk[kTieLane + 1] = i0 + kTieLane < limit ? keys[i0 + kTieLane] : 0u;
+        kk[kTieLane + 2] = i0 + kTieLane + 1u < limit ? keys[i0 + kTieLane + 1u] : 0u;
+    };
+    uint32_t base = blockIdx.x * kTieSpan;
+    uint32_t kk[kTieLane + 3];
+    load_keys(base + tid * kTieLane, v_cap, kk); // (entries beyond the live count are never compared)
+    const uint32_t V = tie.d_counts[0];
+    for (; base < V; base += gridDim.x * kTieSpan) { // (workgroup-uniform)
+        const uint32_t i0 = base + tid * kTieLane;
+        if (base != blockIdx.x * kTieSpan) load_keys(i0, V, kk);
+        if (tid == 0) {
+            s_n   = 0;
+            s_len = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        // element e starts a run: its left neighbour differs, its right one does not
+        uint32_t heads = 0, more = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < kTieLane; ++e) {
+            const uint32_t i = i0 + e;
+            const bool     h = i + 1u < V && kk[e + 1] == kk[e + 2] && !(i > 0u && kk[e] == kk[e + 1]);
+            const bool     t = i + 2u < V && kk[e + 2] == kk[e + 3]; // a third member
+            heads |= (h ? 1u : 0u) << e;
+            more |= (h && t ? 1u : 0u) << e;
+        }
+        if (heads) {
+            // the values of the lane's elements and of the one after them: all a run of two needs
+            uint32_t vv[kTieLane + 1];
+#pragma unroll
+            for (uint32_t g = 0; g < kTieLane; g += 4) {
+                if (i0 + g + 4u <= V) {
+                    const uint4 v4 = *reinterpret_cast<const uint4*>(vals + i0 + g);
+                    vv[g] = v4.x, vv[g + 1] = v4.y, vv[g + 2] = v4.z, vv[g + 3] = v4.w;
+                } else {
+#pragma unroll
+                    for (uint32_t e = 0; e < 4; ++e) vv[g + e] = i0 + g + e < V ? vals[i0 + g + e] : 0u;
+                }
             }
-            // equal tags among the members: the full file indices (distinct)
-            mine = lane < m ? tie.perm[tie.vis_index[vj & id_mask]] : 0u;
+            vv[kTieLane] = i0 + kTieLane < V ? vals[i0 + kTieLane] : 0u;
+#pragma unroll
+            for (uint32_t e = 0; e < kTieLane; ++e) { // two splats whose depths round to the same float: the usual run
+                if (((heads & ~more) >> e) & 1u) {
+                    if (tie_before(vv[e + 1], vv[e], tie.id_bits, tie.vis_index, tie.perm)) {
+                        vals[i0 + e]      = vv[e + 1];
+                        vals[i0 + e + 1u] = vv[e];
+                    }
+                }
+            }
+            while (more) { // (rare) three members or more
+                const uint32_t e = (uint32_t)__ffs((int)more) - 1u;
+                more &= more - 1u;
+                const uint32_t i = i0 + e, k = keys[i];
+                uint32_t       hi = i + 2u;
+                while (hi + 1u < V && hi - i < kTieRunShort && keys[hi + 1u] == k) ++hi;
+                const uint32_t m = hi - i + 1u;
+                if (m > kTieRunShort) { // (at least that long) left to the workgroup, below
+                    s_head[atomicAdd(&s_n, 1u)] = i;
+                    continue;
+                }
+                for (uint32_t j = 0; j + 1u < m; ++j) { // (one lane, same addresses: its loads see its stores)
+                    const uint32_t vj   = vals[i + j];
+                    uint32_t       best = j, vb = vj;
+                    for (uint32_t q = j + 1u; q < m; ++q) {
+                        const uint32_t vc = vals[i + q];
+                        if (tie_before(vc, vb, tie.id_bits, tie.vis_index, tie.perm)) best = q, vb = vc;
+                    }
+                    if (best != j) {
+                        vals[i + j]    = vb;
+                        vals[i + best] = vj;
+                    }
+                }
+            }
         }
-        return;
-    }
-    uint32_t m = 64u; // at least: measure on
-    for (;;) {
-        const bool               more = lo + m + lane < V && keys[lo + m + lane] == k;
-        const unsigned long long b    = __ballot(more);
-        if (~b != 0ull) {
-            m += (uint32_t)__ffsll((long long)~b) - 1u;
-            break;
+        __syncthreads();
+        const uint32_t n_long = s_n;
+        for (uint32_t r = 0; r < n_long; ++r) { // (rare) runs of more than kTieRunShort members: all 256 lanes on each
+            const uint32_t lo = s_head[r], k = keys[lo];
+            for (uint32_t off = 1u;; off += kThreads) { // the run's length: the first position that is not a member
+                const uint32_t j    = off + tid;
+                const bool     stop = lo + j >= V || keys[lo + j] != k;
+                if (stop) atomicMin(&s_len, j);
+                if (__syncthreads_or(stop)) break;
+            }
+            const uint32_t m = s_len;
+            if (m > kTieRunCap) {
+                if (tid == 0) atomicAdd(&tie.d_counts[kCountTieUnresolved], m);
+            } else {
+                uint32_t own[kTieRunCap / kThreads]; // the members this lane ranks (read before anything is written)
+#pragma unroll
+                for (uint32_t t = 0; t < kTieRunCap / kThreads; ++t) {
+                    const uint32_t j = tid + t * kThreads;
+                    own[t]           = j < m ? vals[lo + j] : 0u;
+                    if (j < m) s_f[j] = tie.perm[tie.vis_index[own[t] & id_mask]];
+                }
+                __syncthreads();
+#pragma unroll
+                for (uint32_t t = 0; t < kTieRunCap / kThreads; ++t) {
+                    const uint32_t j = tid + t * kThreads;
+                    if (j >= m) break;
+                    const uint32_t mine = s_f[j];
+                    uint32_t       rank = 0;
+                    for (uint32_t q = 0; q < m; ++q) rank += s_f[q] < mine ? 1u : 0u; // (file indices are distinct)
+                    vals[lo + rank] = own[t];
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_len = 0xFFFFFFFFu;
+            __syncthreads();
         }
-        m += 64u; // (a run beyond the cap is still measured: its length is what gets reported)
     }
-    if (m > kTieRunCap) {
-        if (lane == 0) atomicAdd(&tie.d_counts[kCountTieUnresolved], m);
-        return;
-    }
-    for (uint32_t j = lane; j < m; j += 64u) {
-        const uint32_t v = vals[lo + j];
-        s_v[j]           = v;
-        s_f[j]           = tie.perm[tie.vis_index[v & id_mask]];
-    }
-    __syncthreads();
-    for (uint32_t j = lane; j < m; j += 64u) {
-        const uint32_t f    = s_f[j];
-        uint32_t       rank = 0;
-        for (uint32_t q = 0; q < m; ++q) rank += s_f[q] < f ? 1u : 0u; // (file indices are distinct)
-        vals[lo + rank] = s_v[j];
-    }
-    __syncthreads(); // s_f / s_v are reused
-}
-
-template <int kKPB>
-__global__ void __launch_bounds__(64) k_fix_listed_runs(const uint32_t* __restrict__ keys, uint32_t* vals, TieOrder tie,
-                                                          uint32_t nb_cap)
-{
-    __shared__ uint32_t s_f[kTieRunCap], s_v[kTieRunCap];
-    const uint32_t lane = threadIdx.x;
-    // the first chunk's line is requested before the survivor count arrives
-    uint32_t       chunk = blockIdx.x;
-    uint32_t       line  = (chunk < nb_cap && lane < kTieChunkLine) ? tie.list[(size_t)chunk * kTieChunkLine + lane] : 0u;
-    const uint32_t V      = tie.d_counts[0];
-    const uint32_t n_over = tie.d_counts[kCountTieListed] < tie.overflow_cap ? tie.d_counts[kCountTieListed] : tie.overflow_cap;
-    const uint32_t nb     = (V + kKPB - 1) / kKPB;
-    while (chunk < nb) { // (everything here is wave-uniform; the workgroup is one wave)
-        uint32_t count = __shfl(line, 0, 64);
-        if (count > kTieChunkSlots) count = kTieChunkSlots;
-        for (uint32_t s = 0; s < count; ++s) fix_listed_run(__shfl(line, (int)(1 + s), 64), V, keys, vals, tie, s_f, s_v);
-        chunk += gridDim.x;
-        if (chunk < nb) line = lane < kTieChunkLine ? tie.list[(size_t)chunk * kTieChunkLine + lane] : 0u;
-    }
-    for (uint32_t r = blockIdx.x; r < n_over; r += gridDim.x) fix_listed_run(tie.overflow[r], V, keys, vals, tie, s_f, s_v);
 }
 
 } // namespace
@@ -729,7 +693,7 @@ namespace
 template <int kItems, typename K>
 void run_passes(const K* const* src_k, const uint32_t* const* src_v, K* const* dst_k, uint32_t* const* dst_v, int n_pass,
                 const uint32_t* d_n, int64_t n_cap, int64_t grid_hint, int begin_bit, int end_bit, void* ws_,
-                hipStream_t stream, bool first_hist_done = false, const TieOrder* tie = nullptr)
+                hipStream_t stream, bool first_hist_done = false)
 {
     constexpr int kKPB   = kThreads * kItems;
     const int64_t nb_cap = (n_cap + kKPB - 1) / kKPB;
@@ -751,16 +715,8 @@ void run_passes(const K* const* src_k, const uint32_t* const* src_v, K* const* d
             hipLaunchKernelGGL((k_hist<kItems, K>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, src_k[p], d_n,
                                n_host, shift, mask, counts, stride);
         hipLaunchKernelGGL(k_rowscan<kItems>, dim3(kRadix), dim3(kThreads), 0, stream, counts, d_n, n_host, totals, stride);
-        if constexpr (kItems == 8 && sizeof(K) == 4) { // (the depth sort)
-            if (tie && p == n_pass - 1) {
-                hipLaunchKernelGGL((k_scatter<kItems, K, true>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, src_k[p],
-                               src_v[p], dst_k[p], dst_v[p], d_n, n_host, shift, mask, bits, counts, totals, stride, *tie);
-                shift += bits;
-                continue;
-            }
-        }
-        hipLaunchKernelGGL((k_scatter<kItems, K, false>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, src_k[p],
-                           src_v[p], dst_k[p], dst_v[p], d_n, n_host, shift, mask, bits, counts, totals, stride, TieOrder{});
+        hipLaunchKernelGGL((k_scatter<kItems, K>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, src_k[p], src_v[p],
+                           dst_k[p], dst_v[p], d_n, n_host, shift, mask, bits, counts, totals, stride);
         shift += bits;
     }
 }
@@ -796,12 +752,6 @@ int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
     return n_pass & 1;
 }
 
-// One line per 2048-key chunk of the depth sort plus a shared tail of P / 16 + 1024 entries -- far more than any frame
-// has used (a few hundred entries in all at 2.4 M survivors); a frame that overflows it reports the rest as unresolved.
-size_t tie_list_entries(int64_t P) { return (size_t)tie_overflow_offset(P) + (size_t)tie_overflow_entries(P); }
-size_t tie_overflow_offset(int64_t P) { return (size_t)((P + 2047) / 2048) * kTieChunkLine; }
-size_t tie_overflow_entries(int64_t P) { return (size_t)(P / 16 + 1024); }
-
 // Survivors by depth bits: pass 0 from the slabs into (keys_b, vals_b), passes 1-3 ping-pong; the result ends in
 // (keys_a, vals_a).  d_counts[0] / [1] (V, num_rendered) are written by pass 0's row-scan launch; `fork`, if given,
 // is signalled when pass 0's scatter (which writes vis_index / rects) completes.
@@ -826,13 +776,12 @@ void launch_depth_sort_from_chunks(int64_t P, int64_t v_hint, const uint4* slab,
     const uint32_t* sv[3] = { vals_b, vals_a, vals_b };
     uint32_t*       dk[3] = { keys_a, keys_b, keys_a };
     uint32_t*       dv[3] = { vals_a, vals_b, vals_a };
-    run_passes<kItems, uint32_t>(sk, sv, dk, dv, 3, d_counts, P, v_hint, 8, 32, ws_, stream, false, tie);
-    if (tie) // the runs the last pass could not settle inside a chunk (a few hundred; the launch is mostly its latency)
-    {
-        int64_t blocks = ((v_hint > 0 ? v_hint : P) + kThreads * kItems - 1) / (kThreads * kItems);
-        if (blocks > (int64_t)nb) blocks = nb;
-        hipLaunchKernelGGL(k_fix_listed_runs<kThreads * kItems>, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(64), 0,
-                           stream, keys_a, vals_a, *tie, nb);
+    run_passes<kItems, uint32_t>(sk, sv, dk, dv, 3, d_counts, P, v_hint, 8, 32, ws_, stream);
+    if (tie) {
+        int64_t blocks = ((v_hint > 0 ? v_hint : P) + kTieSpan - 1) / kTieSpan; // (larger live counts are strided)
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(k_fix_equal_depth_order, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(kThreads), 0, stream,
+                           keys_a, vals_a, (uint32_t)P, *tie);
     }
 }
 

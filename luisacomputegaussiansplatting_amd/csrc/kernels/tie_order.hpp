@@ -9,13 +9,12 @@
 //   * the sorted VALUES carry, above the id_bits of the dense id, the top (32 - id_bits) bits of the splat's file index
 //     (written by the first pass, carried by the others for nothing): two members of a run are almost always ordered
 //     by those tags alone; only equal tags (one pair in 2^(32 - id_bits)) gather the full index perm[vis_index[id]];
-//   * the LAST radix pass holds each chunk in LDS in fully sorted order, so runs of up to kTieRunShort members that lie
-//     inside one chunk are fixed there, before they are written out, at no memory traffic;
-//   * what is left -- longer runs, and runs that may continue in the neighbouring chunk -- goes onto a list of output
-//     positions that one small launch works through (k_fix_listed_runs): runs of up to kTieRunCap members are ranked
-//     through LDS; longer ones stay in the context's order and are counted (lcgs_frame_stats.equal_depth_unresolved):
-//     only a scene with thousands of splats at exactly one depth -- a plane seen head-on by an axis-aligned camera --
-//     gets there, and LCGS_ORDER_FILE is exact for those.
+//   * one pass over the sorted keys (k_fix_equal_depth_order, pair_sort.hip) finds the runs; only the first member of a
+//     run does anything, in place: runs of two -- nearly all -- are a compare and a swap, runs of up to kTieRunShort a
+//     selection sort by one lane, runs of up to kTieRunCap members are ranked by their workgroup through LDS; longer
+//     ones stay in the context's order and are counted (lcgs_frame_stats.equal_depth_unresolved): only a scene with
+//     thousands of splats at exactly one depth -- a plane seen head-on by an axis-aligned camera -- gets there, and
+//     LCGS_ORDER_FILE is exact for those.
 // Readers of the sorted order mask the values with (1 << id_bits) - 1.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -26,22 +25,12 @@ namespace lcgs
 {
 
 constexpr uint32_t kTieRunCap   = 4096; // longest run that is put back into file order
-constexpr uint32_t kTieRunShort = 16;   // runs up to this length are resolved inside the last radix pass
+constexpr uint32_t kTieRunShort = 16;   // runs up to this length are resolved by their first member alone
 
-// d_counts slots of the frame's counter block used here
-constexpr int kCountTieUnresolved = 9;  // members of runs left in the context's order
-constexpr int kCountTieListed     = 10; // entries on the shared tail of the run list
-
-// the run list: one line of kTieChunkLine words per chunk of the last radix pass -- {count, positions ...} -- and a
-// shared tail for chunks that list more than a line holds
-constexpr uint32_t kTieChunkLine  = 16;
-constexpr uint32_t kTieChunkSlots = kTieChunkLine - 1;
+constexpr int kCountTieUnresolved = 9; // d_counts slot: members of runs left in the context's order
 
 struct TieOrder { // (all device pointers)
-    uint32_t*       d_counts     = nullptr;
-    uint32_t*       list         = nullptr; // output positions of the first member (in its chunk) of a run to look at again
-    uint32_t*       overflow     = nullptr; // the shared tail; d_counts[kCountTieListed] counts its entries
-    uint32_t        overflow_cap = 0;
+    uint32_t*       d_counts  = nullptr;
     const uint32_t* vis_index = nullptr; // dense id -> index of the splat in the context's arrays
     const uint32_t* perm      = nullptr; // that index -> file index
     uint32_t        id_bits   = 32;

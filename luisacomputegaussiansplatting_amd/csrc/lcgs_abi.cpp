@@ -198,7 +198,6 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
         LCGS_TRY(ctx->chunk_base.ensure(chunks * 4));
     }
     LCGS_TRY(ctx->vis_index.ensure(P * 4));
-    if (ctx->perm_valid) LCGS_TRY(ctx->tie_list.ensure(tie_list_entries((int64_t)P) * 4));
     LCGS_TRY(ctx->rects.ensure(P * 8));
     LCGS_TRY(ctx->rects_sorted.ensure(P * 8));
     if (ctx->pair_capacity == 0) {
@@ -291,9 +290,6 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     uint32_t id_mask = 0xFFFFFFFFu;
     if (ctx->perm_valid) {
         tie.d_counts  = d_counts;
-        tie.list      = ctx->tie_list.as<uint32_t>();
-        tie.overflow  = tie.list + tie_overflow_offset(P);
-        tie.overflow_cap = (uint32_t)tie_overflow_entries(P);
         tie.vis_index = ctx->vis_index.as<uint32_t>();
         tie.perm      = ctx->scene_perm.as<uint32_t>();
         tie.id_bits   = (uint32_t)std::max(1, ceil_log2_u32((uint32_t)P));
@@ -495,7 +491,6 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
         if (ev) (void)hipEventDestroy(ev);
     ctx->frame_params.release();
     ctx->slice_bounds.release();
-    ctx->tie_list.release();
     ctx->scene_perm.release();
     for (hipEvent_t ev : ctx->ev_slice)
         if (ev) (void)hipEventDestroy(ev);
