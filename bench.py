@@ -19,6 +19,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -70,6 +71,8 @@ def main():
     ap.add_argument("--grad-transport", choices=("f32", "f16"), default="f32",
                     help="N > 1, --collective rccl: the gradient all-reduce's wire format (f16 is opt-in: half the bytes, "
                          "about sqrt(N) x 5e-4 relative error; never the default)")
+    ap.add_argument("--leg-timeout", type=float, default=600.0,
+                    help="N > 1: seconds the legs after the forward measurement may take before the line is printed without them")
     ap.add_argument("--collective", choices=("rccl", "torch"), default="rccl",
                     help="N > 1 gradient collective: the library's own RCCL path (lcgs_comm C ABI, default) or "
                          "torch.distributed's (cross-check)")
@@ -312,11 +315,13 @@ def main():
     V, Lref, Lp, G = stats["num_visible"], stats["num_rendered"], stats["num_pairs"], stats["num_tiles"]
     # Algorithmic bytes per launch of each stage = per-unit figure x units
     stage_bytes = {
-        "cull_compact": 12 * P + 32 * int(0.55 * P) + 20 * V,   # pos for all, scale/rot/opacity for the ~55 % in front
+        "cull_compact": 40 * P + 4 * V + 16 * V,  # pos/scale/rotq of every splat, opacity of the candidates (~V), slab slots
         "build_records": (4 + 44 + 192) * V + 48 * V,
-        "depth_sort": 4 * 20 * V,
+        # first pass from the 16-byte slab slots (+ dense index / rect writes), three 20-byte passes, and -- re-ordered
+        # scenes -- the equal-depth pass (keys, about a third of the values)
+        "depth_sort": (16 + 20 + 3 * 20) * V + (6 * V if r.permutation() is not None else 0),
         "expand": 12 * V + 8 * V + 8 * Lp,
-        "tile_sort": 2 * 20 * Lp,
+        "tile_sort": (16 + 20) * Lp,  # the first pass's counts come from the emitter
         "ranges": 4 * Lp + 8 * G,
         "render": 40 * Lp + 12 * W * H,
     }
@@ -408,151 +413,188 @@ def main():
     if moving is not None:
         out["moving_camera"] = moving
 
+    # ---- N > 1 insurance.  The legs below (RCCL communicator of the library, collectives, sharded optimiser) have only
+    # ever run on one GPU (`LCGS_BENCH_FORCE_DIST=1`) and on gloo: on a real multi-GPU node a rank that fails alone
+    # leaves the others waiting in a collective.  The forward measurement above is complete at this point, so a
+    # watchdog prints the line with what has been measured (plus `error`) instead of hanging the whole run.
+    printed = threading.Lock()
+    watchdog = None
+
+    def emit(error=None):
+        if not printed.acquire(blocking=False):
+            return
+        if error is not None:
+            out["error"] = error
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        def give_up():
+            done = printed.locked()  # (the line is out: only the teardown is stuck)
+            emit(f"the legs after the forward measurement did not finish within {args.leg_timeout} s on rank {rank}")
+            sys.stdout.flush()
+            os._exit(0 if rank == 0 or done else 1)
+        watchdog = threading.Timer(args.leg_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
     # ---- forward + backward (+ the RCCL sum of the dense per-splat gradients when N > 1): one training-style step per
     # view through the package's view-parallel protocol (luisacomputegaussiansplatting_amd.multi_gpu: the same
     # ViewParallelTrainer tests/test_distributed.py runs on gloo); Msplats/s = splats x views / time.
     # Same barrier / max-over-ranks timing.
     coll = None
-    if not args.no_backward:
-        gbuf = torch.zeros(59 * P, device=dev)  # pos 3 | scale 3 | rotq 4 | sh 48 | opacity 1, one flat buffer
-        o0 = 0
-        views = {}
-        for name, width in (("pos", 3), ("scale", 3), ("rotq", 4), ("sh", 48), ("opacity", 1)):
-            views[name] = gbuf[o0:o0 + width * P].view(P, width) if width > 1 else gbuf[o0:o0 + P]
-            o0 += width * P
-        dL = torch.randn(3, H, W, device=dev)
-        if dist is not None:
-            if args.collective == "rccl":
-                def exchange(payload):  # rank 0's 128-byte rendezvous token to everybody, over the process group
-                    t = torch.zeros(128, dtype=torch.uint8, device=dev)
-                    if payload is not None:
-                        t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
-                    dist.broadcast(t, 0)
-                    return t.cpu().numpy().tobytes()
-                coll = mg.RcclCollective(ctx, rank, world, exchange)
-                if args.grad_transport != "f32":
-                    coll.comm.set_transport(args.grad_transport)
-            else:
-                coll = mg.TorchCollective(dist, rank, world)
-        engine = mg.HipEngine(r, raw=None, activated=d, lr=None)  # gradients only: no optimiser state
-        tr_sum = mg.ViewParallelTrainer(engine, coll, [cam], views, mode="allreduce" if coll is not None else "local")
-        tr_local = mg.ViewParallelTrainer(engine, None, [cam], views, mode="local")
-        warm = max(1, args.warmup)
-
-        def timed_steps(collective, compact=False):
-            engine.compact_rows = compact
-            tr = tr_sum if collective else tr_local
-            el_ = timed(lambda i: tr.step(dL, optimise=False), args.steps, warm)
-            engine.compact_rows = False
-            return el_
-
-        el = timed_steps(True)
-        # N > 1: the same steps without the gradient collective, so that its share is visible
-        el_local = timed_steps(False) if dist is not None else None
-        # N = 1: the same step with compact gradient rows (lcgs_render_backward_compact: one row per on-screen splat,
-        # no zero-fill) -- reported beside the dense figure, which stays `value` (a sum over views needs per-splat rows)
-        el_compact = timed_steps(False, compact=True) if dist is None else None
-        r.set_profiling(True)
-        r.forward(cam, img, keep_state=True, sync=True)
-        r.backward(dL, *[views[k] for k in KEYS])
-        bwd_stages = r.stage_times()
-        r.set_profiling(False)
-        out["fwd_bwd"] = {"metric": "fwd+bwd Msplats/s", "value": round(world * P * args.steps / el / 1e6, 1),
-                          "unit": "Msplats/s", "ms_per_step": round(el * 1e3 / args.steps, 4),
-                          "grad_allreduce_bytes_per_gpu": 59 * 4 * P if world > 1 else 0,
-                          "xgmi_bytes_sent_per_gpu": mg.allreduce_bus_bytes_per_gpu(P, world),
-                          "collective": coll.name if coll is not None else None,
-                          "backward_stages_ms": {k: round(v, 4) for k, v in bwd_stages.items()}}
-        if dist is not None:
-            out["fwd_bwd"]["note"] = ("gradient collective: lcgs_grads_allreduce (RCCL, chunked behind the backward's "
-                                      "slices)" if args.collective == "rccl" else "gradient collective: torch.distributed")
-            out["fwd_bwd"]["grad_transport"] = args.grad_transport if args.collective == "rccl" else "f32"
-        if el_compact is not None:
-            out["fwd_bwd"]["compact_rows"] = {"value": round(P * args.steps / el_compact / 1e6, 1), "unit": "Msplats/s",
-                                              "ms_per_step": round(el_compact * 1e3 / args.steps, 4)}
-        if el_local is not None:
-            out["fwd_bwd"]["without_collective"] = {"value": round(world * P * args.steps / el_local / 1e6, 1),
-                                                    "unit": "Msplats/s",
-                                                    "ms_per_step": round(el_local * 1e3 / args.steps, 4)}
-        if not args.no_moving_camera:
-            # every rank a different one of the eight C5 views at every step (view_of_rank), collective included
-            cams8 = [L.get_lookat_cam(*view_pose(k), width=W, height=H) for k in range(8)]
-            tr_mov = mg.ViewParallelTrainer(engine, coll, cams8, views, mode="allreduce" if coll is not None else "local")
-            el_mv = timed(lambda i: tr_mov.step(dL, optimise=False), args.steps, max(warm, 8))
-            out["fwd_bwd"]["moving_camera"] = {"value": round(world * P * args.steps / el_mv / 1e6, 1), "unit": "Msplats/s",
-                                               "ms_per_step": round(el_mv * 1e3 / args.steps, 4), "views": 8}
-            r.forward(cam, img, sync=True)
+    try:
+        if dist is not None and os.environ.get("LCGS_BENCH_INJECT_LEG_FAILURE") == "1":  # (test hook)
+            raise RuntimeError("injected failure of the gradient legs")
+        if not args.no_backward:
+            gbuf = torch.zeros(59 * P, device=dev)  # pos 3 | scale 3 | rotq 4 | sh 48 | opacity 1, one flat buffer
+            o0 = 0
+            views = {}
+            for name, width in (("pos", 3), ("scale", 3), ("rotq", 4), ("sh", 48), ("opacity", 1)):
+                views[name] = gbuf[o0:o0 + width * P].view(P, width) if width > 1 else gbuf[o0:o0 + P]
+                o0 += width * P
+            dL = torch.randn(3, H, W, device=dev)
             if dist is not None:
-                # the answer to a collective that costs several views' worth of compute: B views per GPU and step,
-                # their gradients accumulated (lcgs_render_backward_accumulate), ONE gradient sum per step
-                B = 4
-                tr_acc = mg.ViewParallelTrainer(engine, coll, cams8, views, mode="allreduce", views_per_step=B)
-                acc_steps = max(2, args.steps // B)
-                el_acc = timed(lambda i: tr_acc.step(dL, optimise=False), acc_steps, 2)
-                out["fwd_bwd"]["views_per_gpu_and_step_4"] = {
-                    "value": round(world * P * B * acc_steps / el_acc / 1e6, 1), "unit": "Msplats/s",
-                    "ms_per_step": round(el_acc * 1e3 / acc_steps, 4), "views_per_step": world * B,
-                    "note": "one gradient collective per step of 4 views per GPU"}
-                r.forward(cam, img, sync=True)
-
-        # ---- full training-style step: + the optimiser (gradients -> Adam on the raw parameters -> refreshed
-        # activated arrays).  N = 1: dense, restricted to the on-screen splats, and on compact rows.
-        # N > 1: "allreduce" (lcgs_grads_allreduce + a dense lcgs_adam_step on every rank) and "sharded"
-        # (lcgs_adam_step_sharded: reduce-scatter -> Adam on the own rows -> all-gather of the activated arrays).
-        if not args.no_train_step:
-            # (on a copy of the scene: exp(log(s)) is not s to the last bit, and the parity block below compares the
-            # frame of the pristine scene)
-            act = {k: d[k].clone() for k in KEYS}
-            raw = {"pos": act["pos"], "scale": torch.log(act["scale"]), "rotq": act["rotq"].clone(), "sh": act["sh"],
-                   "opacity": torch.log(act["opacity"] / (1 - act["opacity"]))}
-            lr = {"pos": 0.0, "sh_dc": 0.0, "sh_rest": 0.0, "opacity": 0.0, "scale": 0.0, "rot": 0.0}  # scene stays put
-            eng2 = mg.HipEngine(r, raw=raw, activated=act, lr=lr)  # (binds `act` to the renderer)
-            out["train_step"] = {}
-            if dist is None:
-                modes = ("dense", "visible_only", "visible_only_compact")
-            else:
-                modes = ("allreduce", "sharded")
-            for mode in modes:
-                if dist is None:
-                    def full_step(i, mode=mode):
-                        compact = mode == "visible_only_compact"
-                        r.forward(cam, img, keep_state=True, sync=False)
-                        r.backward(dL, *[views[k] for k in KEYS], compact=compact)
-                        r.adam_step(views, raw, eng2.m, eng2.v, act, i + 1, lr, visible_only=(mode != "dense"),
-                                    compact_grads=compact)
+                if args.collective == "rccl":
+                    def exchange(payload):  # rank 0's 128-byte rendezvous token to everybody, over the process group
+                        t = torch.zeros(128, dtype=torch.uint8, device=dev)
+                        if payload is not None:
+                            t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+                        dist.broadcast(t, 0)
+                        return t.cpu().numpy().tobytes()
+                    coll = mg.RcclCollective(ctx, rank, world, exchange)
+                    if args.grad_transport != "f32":
+                        coll.comm.set_transport(args.grad_transport)
                 else:
-                    tr = mg.ViewParallelTrainer(eng2, coll, [cam], views, mode=mode)
+                    coll = mg.TorchCollective(dist, rank, world)
+            engine = mg.HipEngine(r, raw=None, activated=d, lr=None)  # gradients only: no optimiser state
+            tr_sum = mg.ViewParallelTrainer(engine, coll, [cam], views, mode="allreduce" if coll is not None else "local")
+            tr_local = mg.ViewParallelTrainer(engine, None, [cam], views, mode="local")
+            warm = max(1, args.warmup)
 
-                    def full_step(i, tr=tr):
-                        tr.step(dL, optimise=True)
-                el2 = timed(full_step, args.steps, 2)
-                out["train_step"][mode] = {"value": round(world * P * args.steps / el2 / 1e6, 1), "unit": "Msplats/s",
-                                           "ms_per_step": round(el2 * 1e3 / args.steps, 4)}
-            r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
-            del act, raw, eng2
+            def timed_steps(collective, compact=False):
+                engine.compact_rows = compact
+                tr = tr_sum if collective else tr_local
+                el_ = timed(lambda i: tr.step(dL, optimise=False), args.steps, warm)
+                engine.compact_rows = False
+                return el_
+
+            el = timed_steps(True)
+            # N > 1: the same steps without the gradient collective, so that its share is visible
+            el_local = timed_steps(False) if dist is not None else None
+            # N = 1: the same step with compact gradient rows (lcgs_render_backward_compact: one row per on-screen splat,
+            # no zero-fill) -- reported beside the dense figure, which stays `value` (a sum over views needs per-splat rows)
+            el_compact = timed_steps(False, compact=True) if dist is None else None
+            r.set_profiling(True)
+            r.forward(cam, img, keep_state=True, sync=True)
+            r.backward(dL, *[views[k] for k in KEYS])
+            bwd_stages = r.stage_times()
+            r.set_profiling(False)
+            out["fwd_bwd"] = {"metric": "fwd+bwd Msplats/s", "value": round(world * P * args.steps / el / 1e6, 1),
+                              "unit": "Msplats/s", "ms_per_step": round(el * 1e3 / args.steps, 4),
+                              "grad_allreduce_bytes_per_gpu": 59 * 4 * P if world > 1 else 0,
+                              "xgmi_bytes_sent_per_gpu": mg.allreduce_bus_bytes_per_gpu(P, world),
+                              "collective": coll.name if coll is not None else None,
+                              "backward_stages_ms": {k: round(v, 4) for k, v in bwd_stages.items()}}
+            if dist is not None:
+                out["fwd_bwd"]["note"] = ("gradient collective: lcgs_grads_allreduce (RCCL, chunked behind the backward's "
+                                          "slices)" if args.collective == "rccl" else "gradient collective: torch.distributed")
+                out["fwd_bwd"]["grad_transport"] = args.grad_transport if args.collective == "rccl" else "f32"
+            if el_compact is not None:
+                out["fwd_bwd"]["compact_rows"] = {"value": round(P * args.steps / el_compact / 1e6, 1), "unit": "Msplats/s",
+                                                  "ms_per_step": round(el_compact * 1e3 / args.steps, 4)}
+            if el_local is not None:
+                out["fwd_bwd"]["without_collective"] = {"value": round(world * P * args.steps / el_local / 1e6, 1),
+                                                        "unit": "Msplats/s",
+                                                        "ms_per_step": round(el_local * 1e3 / args.steps, 4)}
+            if not args.no_moving_camera:
+                # every rank a different one of the eight C5 views at every step (view_of_rank), collective included
+                cams8 = [L.get_lookat_cam(*view_pose(k), width=W, height=H) for k in range(8)]
+                tr_mov = mg.ViewParallelTrainer(engine, coll, cams8, views, mode="allreduce" if coll is not None else "local")
+                el_mv = timed(lambda i: tr_mov.step(dL, optimise=False), args.steps, max(warm, 8))
+                out["fwd_bwd"]["moving_camera"] = {"value": round(world * P * args.steps / el_mv / 1e6, 1), "unit": "Msplats/s",
+                                                   "ms_per_step": round(el_mv * 1e3 / args.steps, 4), "views": 8}
+                r.forward(cam, img, sync=True)
+                if dist is not None:
+                    # the answer to a collective that costs several views' worth of compute: B views per GPU and step,
+                    # their gradients accumulated (lcgs_render_backward_accumulate), ONE gradient sum per step
+                    B = 4
+                    tr_acc = mg.ViewParallelTrainer(engine, coll, cams8, views, mode="allreduce", views_per_step=B)
+                    acc_steps = max(2, args.steps // B)
+                    el_acc = timed(lambda i: tr_acc.step(dL, optimise=False), acc_steps, 2)
+                    out["fwd_bwd"]["views_per_gpu_and_step_4"] = {
+                        "value": round(world * P * B * acc_steps / el_acc / 1e6, 1), "unit": "Msplats/s",
+                        "ms_per_step": round(el_acc * 1e3 / acc_steps, 4), "views_per_step": world * B,
+                        "note": "one gradient collective per step of 4 views per GPU"}
+                    r.forward(cam, img, sync=True)
+
+            # ---- full training-style step: + the optimiser (gradients -> Adam on the raw parameters -> refreshed
+            # activated arrays).  N = 1: dense, restricted to the on-screen splats, and on compact rows.
+            # N > 1: "allreduce" (lcgs_grads_allreduce + a dense lcgs_adam_step on every rank) and "sharded"
+            # (lcgs_adam_step_sharded: reduce-scatter -> Adam on the own rows -> all-gather of the activated arrays).
+            if not args.no_train_step:
+                # (on a copy of the scene: exp(log(s)) is not s to the last bit, and the parity block below compares the
+                # frame of the pristine scene)
+                act = {k: d[k].clone() for k in KEYS}
+                raw = {"pos": act["pos"], "scale": torch.log(act["scale"]), "rotq": act["rotq"].clone(), "sh": act["sh"],
+                       "opacity": torch.log(act["opacity"] / (1 - act["opacity"]))}
+                lr = {"pos": 0.0, "sh_dc": 0.0, "sh_rest": 0.0, "opacity": 0.0, "scale": 0.0, "rot": 0.0}  # scene stays put
+                eng2 = mg.HipEngine(r, raw=raw, activated=act, lr=lr)  # (binds `act` to the renderer)
+                out["train_step"] = {}
+                if dist is None:
+                    modes = ("dense", "visible_only", "visible_only_compact")
+                else:
+                    modes = ("allreduce", "sharded")
+                for mode in modes:
+                    if dist is None:
+                        def full_step(i, mode=mode):
+                            compact = mode == "visible_only_compact"
+                            r.forward(cam, img, keep_state=True, sync=False)
+                            r.backward(dL, *[views[k] for k in KEYS], compact=compact)
+                            r.adam_step(views, raw, eng2.m, eng2.v, act, i + 1, lr, visible_only=(mode != "dense"),
+                                        compact_grads=compact)
+                    else:
+                        tr = mg.ViewParallelTrainer(eng2, coll, [cam], views, mode=mode)
+
+                        def full_step(i, tr=tr):
+                            tr.step(dL, optimise=True)
+                    el2 = timed(full_step, args.steps, 2)
+                    out["train_step"][mode] = {"value": round(world * P * args.steps / el2 / 1e6, 1), "unit": "Msplats/s",
+                                               "ms_per_step": round(el2 * 1e3 / args.steps, 4)}
+                r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+                del act, raw, eng2
+    except Exception as e:  # noqa: BLE001 -- N > 1: whatever the hardware run throws belongs in the line
+        if dist is None:
+            raise
+        out.setdefault("leg_errors", {})["fwd_bwd / train_step"] = f"{type(e).__name__}: {e}"[:400]
 
     # ---- the same frames with the splats in FILE order (caller-bound arrays in the order of the file: for this stand-in
     # i.i.d., the worst case -- a view's splats are scattered over every DRAM page).  Same splats, same image.
-    if not args.no_spatial:
-        ref_img = torch.empty_like(img)
-        r.forward(cam, ref_img, sync=True)
-        df = {k: torch.from_numpy(np.ascontiguousarray(scene[k], dtype=np.float32)).to(dev) for k in KEYS}
-        r.bind_scene(*[df[k] for k in KEYS])
-        n_fo = r.forward(cam, img, sync=True)
-        fo = {"api": "lcgs_scene_bind of file-order arrays", "num_rendered_equal": bool(n_fo == n_rendered),
-              "image_equal": bool(torch.equal(img, ref_img))}
-        el_s = timed(lambda i: r.forward(cam, img, sync=False), args.steps, args.warmup)
-        fo["forward"] = {"value": round(world * args.steps / el_s, 2), "unit": "frames/s",
-                         "ms_per_step": round(el_s * 1e3 / args.steps, 4)}
-        if not args.no_backward:
-            for compact in ((False, True) if dist is None else (False,)):
-                el_b = timed_steps(False, compact=compact)  # (per-view steps; no collective in this leg)
-                fo["fwd_bwd_compact_rows" if compact else "fwd_bwd"] = {
-                    "value": round(world * P * args.steps / el_b / 1e6, 1), "unit": "Msplats/s",
-                    "ms_per_step": round(el_b * 1e3 / args.steps, 4)}
-        out["file_order"] = fo
-        r.bind_scene(*[d[k] for k in KEYS])
-        del df, ref_img
+    try:
+        if not args.no_spatial:
+            ref_img = torch.empty_like(img)
+            r.forward(cam, ref_img, sync=True)
+            df = {k: torch.from_numpy(np.ascontiguousarray(scene[k], dtype=np.float32)).to(dev) for k in KEYS}
+            r.bind_scene(*[df[k] for k in KEYS])
+            n_fo = r.forward(cam, img, sync=True)
+            fo = {"api": "lcgs_scene_bind of file-order arrays", "num_rendered_equal": bool(n_fo == n_rendered),
+                  "image_equal": bool(torch.equal(img, ref_img))}
+            el_s = timed(lambda i: r.forward(cam, img, sync=False), args.steps, args.warmup)
+            fo["forward"] = {"value": round(world * args.steps / el_s, 2), "unit": "frames/s",
+                             "ms_per_step": round(el_s * 1e3 / args.steps, 4)}
+            if not args.no_backward:
+                for compact in ((False, True) if dist is None else (False,)):
+                    el_b = timed_steps(False, compact=compact)  # (per-view steps; no collective in this leg)
+                    fo["fwd_bwd_compact_rows" if compact else "fwd_bwd"] = {
+                        "value": round(world * P * args.steps / el_b / 1e6, 1), "unit": "Msplats/s",
+                        "ms_per_step": round(el_b * 1e3 / args.steps, 4)}
+            out["file_order"] = fo
+            r.bind_scene(*[d[k] for k in KEYS])
+            del df, ref_img
+    except Exception as e:  # noqa: BLE001 -- N > 1: whatever the hardware run throws belongs in the line
+        if dist is None:
+            raise
+        out.setdefault("leg_errors", {})["file_order"] = f"{type(e).__name__}: {e}"[:400]
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference) on this box's host cores, rank 0, N = 1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -576,13 +618,14 @@ def main():
         diff = np.abs(gi - ref["img"]).max(axis=0)
         out["parity"] = {"num_rendered_equal": bool(ref["num_rendered"] == n_rendered),
                          "pixels_over_1e-4": int((diff > 1e-4).sum()), "max_abs_diff": float(diff.max())}
-    if rank == 0:
-        print(json.dumps(out))
+    emit()
     if coll is not None:
         barrier()
         coll.close()
     if dist is not None:
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 if __name__ == "__main__":

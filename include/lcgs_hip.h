@@ -299,8 +299,8 @@ LCGS_API lcgs_status lcgs_visible_rows(lcgs_context* ctx, const uint32_t** d_row
  * equal depth are still blended in ascending FILE index like the reference (a pass behind the depth sort restores that
  * order inside every run of equal depth keys of up to 4096 splats; longer runs -- thousands of splats at one depth -- keep
  * the new order and are counted in lcgs_frame_stats.equal_depth_unresolved).  Why: the splats of a view then sit in long runs
- * of consecutive rows instead of being scattered over every DRAM page (bicycle stand-in: +6 % forward frames/s,
- * +16 % forward+backward, +28 % on-screen-only training step).  Synchronises the context's stream. */
+ * of consecutive rows instead of being scattered over every DRAM page (bicycle stand-in: +4 % forward frames/s,
+ * +20 % forward+backward, +28 % on-screen-only training step).  Synchronises the context's stream. */
 LCGS_API lcgs_status lcgs_scene_reorder_spatial(lcgs_context* ctx, uint32_t* d_perm);
 
 /* Optimiser step (the reference only names training on its roadmap, doc/roadmap.md:4).

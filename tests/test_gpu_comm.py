@@ -220,3 +220,20 @@ def test_bench_runs_every_multi_gpu_code_path_on_one_rank(collective):
     assert set(out["train_step"]) == {"allreduce", "sharded"}
     assert all(v["value"] > 0 for v in out["train_step"].values())
     assert out["moving_camera"]["value"] > 0 and len(out["moving_camera"]["per_view"]) == 8
+    assert "leg_errors" not in out and "error" not in out
+
+
+def test_bench_still_prints_its_line_when_a_multi_gpu_leg_fails():
+    """N > 1 insurance: a failure in the legs behind the forward measurement is recorded in the line (`leg_errors`), the
+    forward figure is still reported and the run ends with exit code 0."""
+    env = dict(os.environ, LCGS_BENCH_FORCE_DIST="1", LCGS_BENCH_INJECT_LEG_FAILURE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29534")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--splats", "100000", "--res", "320x240", "--steps",
+                          "2", "--warmup", "1", "--no-cpu-baseline", "--no-stage-path", "--no-batch"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [x for x in res.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and "injected" in out["leg_errors"]["fwd_bwd / train_step"]
+    assert "fwd_bwd" not in out

@@ -362,7 +362,12 @@ def _frame_lists_in_file_indices(lcgs, scene, cam, order):
     r = lcgs.Renderer(lcgs.Context(0))
     r.upload_scene(scene, order=order)
     img = torch.zeros(3, cam.height, cam.width, device=DEV)
+    # a first frame that sees a sliver of the scene: the next one runs with launch sizes hinted far below its survivor
+    # count (the strided paths of the sort chain and of the equal-depth pass)
+    away = lcgs.get_lookat_cam([-5.0, 3.2, 0.5], [0.0, 9.0, 0.5], [0.0, 0.0, 1.0], width=cam.width, height=cam.height)
+    few = r.forward(away, img)
     n = r.forward(cam, img)
+    assert few * 4 < n
     st = r.frame_stats()
     lst = torch.zeros(max(st["num_pairs"], 1), dtype=torch.int32, device=DEV)
     rng_ = torch.zeros(st["num_tiles"] * 2, dtype=torch.int32, device=DEV)
