@@ -13,8 +13,6 @@
 // HBM-bound elementwise work: every array is touched once, 16-byte accesses where the layout allows.  With a row
 // list (the dense ids -> splat index map of the last forward) only the splats that reached the screen are updated
 // ("sparse Adam": their moments are the only ones that change; 2.5x fewer bytes on the bicycle stand-in).
-#include <stdlib.h>
-
 #include "launch.hpp"
 
 namespace lcgs
@@ -92,62 +90,6 @@ __global__ void __launch_bounds__(256) k_adam_sh48(int64_t rows, const uint32_t*
     }
 }
 
-// The dense case of the above (every row, no list): the index is the element, UNROLL independent 16-byte units per lane
-// with all their loads in flight before the first use; NT: streaming loads / stores (every byte is touched once).
-template <int UNROLL, bool NT>
-__global__ void __launch_bounds__(256) k_adam_sh48_dense(int64_t total16, const float4* __restrict__ grad,
-                                                         float4* __restrict__ raw, float4* __restrict__ m,
-                                                         float4* __restrict__ v, float4* act /* may alias raw */,
-                                                         float lr_dc, float lr_rest, AdamStep a)
-{
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < total16; e0 += stride * UNROLL) {
-        v4f g[UNROLL], x[UNROLL], mm[UNROLL], vv[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t e = e0 + (int64_t)u * stride;
-            if (e < total16) {
-                if (NT) {
-                    g[u]  = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(grad) + e);
-                    x[u]  = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(raw) + e);
-                    mm[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m) + e);
-                    vv[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v) + e);
-                } else {
-                    g[u]  = reinterpret_cast<const v4f*>(grad)[e];
-                    x[u]  = reinterpret_cast<const v4f*>(raw)[e];
-                    mm[u] = reinterpret_cast<const v4f*>(m)[e];
-                    vv[u] = reinterpret_cast<const v4f*>(v)[e];
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t e = e0 + (int64_t)u * stride;
-            if (e >= total16) break;
-            const float l = (e % 12) == 0 ? lr_dc : lr_rest; // floats 0..2 of a row are the dc band
-            float4 X = make_float4(x[u].x, x[u].y, x[u].z, x[u].w), M = make_float4(mm[u].x, mm[u].y, mm[u].z, mm[u].w),
-                   V = make_float4(vv[u].x, vv[u].y, vv[u].z, vv[u].w);
-            X.x -= adam_update(g[u].x, M.x, V.x, l, a);
-            X.y -= adam_update(g[u].y, M.y, V.y, l, a);
-            X.z -= adam_update(g[u].z, M.z, V.z, l, a);
-            X.w -= adam_update(g[u].w, M.w, V.w, lr_rest, a);
-            const v4f xo = { X.x, X.y, X.z, X.w }, mo = { M.x, M.y, M.z, M.w }, vo = { V.x, V.y, V.z, V.w };
-            if (NT) {
-                __builtin_nontemporal_store(xo, reinterpret_cast<v4f*>(raw) + e);
-                __builtin_nontemporal_store(mo, reinterpret_cast<v4f*>(m) + e);
-                __builtin_nontemporal_store(vo, reinterpret_cast<v4f*>(v) + e);
-                if (act != raw) __builtin_nontemporal_store(xo, reinterpret_cast<v4f*>(act) + e);
-            } else {
-                raw[e] = X;
-                m[e]   = M;
-                v[e]   = V;
-                if (act != raw) act[e] = X;
-            }
-        }
-    }
-}
-
 // quaternions: one lane per splat, 16-byte rows
 __global__ void __launch_bounds__(256) k_adam_rot(int64_t rows, const uint32_t* __restrict__ row_list,
                                                   const uint32_t* __restrict__ d_row_count,
@@ -210,22 +152,7 @@ void launch_adam_step(int64_t P, int sh_floats, const uint32_t* row_list, const 
     const bool sh_aligned = ((reinterpret_cast<uintptr_t>(grad.sh) | reinterpret_cast<uintptr_t>(raw.sh) |
                               reinterpret_cast<uintptr_t>(m.sh) | reinterpret_cast<uintptr_t>(v.sh) |
                               reinterpret_cast<uintptr_t>(act.sh)) & 15) == 0;
-    static const int variant = getenv("LCGS_ADAM_VARIANT") ? atoi(getenv("LCGS_ADAM_VARIANT")) : 0; // EXPERIMENT
-    if (sh_floats == 48 && sh_aligned && !row_list && !d_row_count && variant > 0) {
-        const int64_t total16 = rows * 12;
-        const float4 *G = reinterpret_cast<const float4*>(grad.sh);
-        float4 *R = reinterpret_cast<float4*>(raw.sh), *M = reinterpret_cast<float4*>(m.sh), *V = reinterpret_cast<float4*>(v.sh),
-               *A = reinterpret_cast<float4*>(act.sh);
-        const int blocks = variant >= 10 ? 2048 * (variant / 10) : 65536; // tens digit: bounded persistent grid
-        switch (variant % 10) {
-        case 1: hipLaunchKernelGGL((k_adam_sh48_dense<1, true>), dim3(blocks), dim3(256), 0, stream, total16, G, R, M, V, A, lr.sh_dc, lr.sh_rest, a); break;
-        case 2: hipLaunchKernelGGL((k_adam_sh48_dense<2, false>), dim3(blocks), dim3(256), 0, stream, total16, G, R, M, V, A, lr.sh_dc, lr.sh_rest, a); break;
-        case 3: hipLaunchKernelGGL((k_adam_sh48_dense<2, true>), dim3(blocks), dim3(256), 0, stream, total16, G, R, M, V, A, lr.sh_dc, lr.sh_rest, a); break;
-        case 4: hipLaunchKernelGGL((k_adam_sh48_dense<4, false>), dim3(blocks), dim3(256), 0, stream, total16, G, R, M, V, A, lr.sh_dc, lr.sh_rest, a); break;
-        case 5: hipLaunchKernelGGL((k_adam_sh48_dense<4, true>), dim3(blocks), dim3(256), 0, stream, total16, G, R, M, V, A, lr.sh_dc, lr.sh_rest, a); break;
-        default: hipLaunchKernelGGL((k_adam_sh48_dense<1, false>), dim3(blocks), dim3(256), 0, stream, total16, G, R, M, V, A, lr.sh_dc, lr.sh_rest, a); break;
-        }
-    } else if (sh_floats == 48 && sh_aligned)
+    if (sh_floats == 48 && sh_aligned)
         hipLaunchKernelGGL(k_adam_sh48, dim3(grid_for(launch_rows * 12)), dim3(256), 0, stream, rows, row_list, d_row_count,
                            reinterpret_cast<const float4*>(grad.sh), reinterpret_cast<float4*>(raw.sh),
                            reinterpret_cast<float4*>(m.sh), reinterpret_cast<float4*>(v.sh),
