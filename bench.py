@@ -527,6 +527,37 @@ def main():
                         "ms_per_step": round(el_acc * 1e3 / acc_steps, 4), "views_per_step": world * B,
                         "note": "one gradient collective per step of 4 views per GPU"}
                     r.forward(cam, img, sync=True)
+                # ---- a multi-view step on each GPU (4 views, L2 loss against a target image, gradients summed; + the
+                # collective when N > 1): the views one after the other, and through lcgs_fit_views, which lets a view's
+                # forward run beside the previous view's backward
+                B = 4
+                tgt = torch.rand(3, H, W, device=dev)
+                dLb = torch.empty(3, H, W, device=dev)
+                losses = torch.zeros(B, device=dev)
+                gl = [views[k] for k in KEYS]
+
+                def views_one_by_one(i):
+                    for j in range(B):
+                        r.forward(cams8[(i * B + j + rank) % 8], img, keep_state=True, sync=False)
+                        r.l2_loss_backward(img, tgt, dLb, losses[j:j + 1])
+                        r.backward(dLb, *gl, accumulate=j > 0)
+                    if coll is not None:
+                        coll.allreduce_grads(views)
+
+                def views_overlapped(i):
+                    r.fit_views([cams8[(i * B + j + rank) % 8] for j in range(B)], [tgt] * B, *gl, losses)
+                    if coll is not None:
+                        coll.allreduce_grads(views)
+                mv_steps = max(2, args.steps // B)
+                el_seq = timed(views_one_by_one, mv_steps, 2)
+                el_fit = timed(views_overlapped, mv_steps, 2)
+                out["fwd_bwd"]["multi_view_step_4"] = {
+                    "unit": "Msplats/s", "views_per_step": world * B,
+                    "one_by_one": {"value": round(world * P * B * mv_steps / el_seq / 1e6, 1),
+                                   "ms_per_step": round(el_seq * 1e3 / mv_steps, 4)},
+                    "lcgs_fit_views": {"value": round(world * P * B * mv_steps / el_fit / 1e6, 1),
+                                       "ms_per_step": round(el_fit * 1e3 / mv_steps, 4)}}
+                r.forward(cam, img, sync=True)
 
             # ---- full training-style step: + the optimiser (gradients -> Adam on the raw parameters -> refreshed
             # activated arrays).  N = 1: dense, restricted to the on-screen splats, and on compact rows.

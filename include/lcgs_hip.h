@@ -421,6 +421,17 @@ LCGS_API lcgs_status lcgs_image_to_rgb8_device(lcgs_context* ctx, int width, int
  * (3 H W) -- what lcgs_render_backward takes.  All device pointers; enqueued on the context's stream. */
 LCGS_API lcgs_status lcgs_l2_loss_backward(lcgs_context* ctx, int width, int height, const float* d_img_chw,
                                            const float* d_target_chw, float* d_dL_dimg, float* d_loss);
+/* The views of ONE optimiser step (a multi-view batch on this GPU): for every view lcgs_render_forward(keep_state) ->
+ * lcgs_l2_loss_backward against d_targets[j] -> lcgs_render_backward, the dense gradients summed into `grads` (the first
+ * view overwrites, the others add) and d_losses[j] = view j's loss (device, num_views floats).  Same results as those
+ * calls one view after the other (gradient sums up to float addition order), but the views alternate between the context
+ * and its sibling (the one lcgs_render_forward_batch uses), so that a view's forward runs beside the previous view's
+ * backward: +8 % views/s on the bicycle stand-in.  The last view runs on `ctx`: with a communicator attached its
+ * preprocess-backward is sliced and lcgs_grads_allreduce overlaps it as usual.  Ordered after prior work on the context's
+ * stream; the stream waits for the whole batch.  Afterwards the context holds the LAST view's frame state. */
+LCGS_API lcgs_status lcgs_fit_views(lcgs_context* ctx, int num_views, const lcgs_camera* cameras, const float bg_color[3],
+                                    float scale_modifier, const float* const* d_targets, const lcgs_grads* grads,
+                                    float* d_losses);
 /* stbi_write_png(name, w, h, 3, data, 0) (app/main.cpp:339): 8-bit RGB PNG (stored deflate blocks). */
 LCGS_API lcgs_status lcgs_write_png(const char* path, int width, int height, const uint8_t* h_rgb);
 

@@ -139,7 +139,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_sh_process", "lcgs_project_forward", "lcgs_tile_splat_forward", "lcgs_inclusive_sum_u32",
     "lcgs_sort_pairs_u64_u32", "lcgs_scene_bind", "lcgs_scene_upload", "lcgs_render_forward",
     "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists",
-    "lcgs_render_backward", "lcgs_render_backward_accumulate", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
+    "lcgs_render_backward", "lcgs_fit_views", "lcgs_render_backward_accumulate", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png", "lcgs_l2_loss_backward",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh",
@@ -549,6 +549,21 @@ class Renderer:
         fn = lib.lcgs_render_backward_compact if compact else (lib.lcgs_render_backward_accumulate if accumulate
                                                                else lib.lcgs_render_backward)
         _check(fn(self.ctx._h, _ptr(dL_dimg), C.byref(g)))
+
+    def fit_views(self, cams, targets, dpos, dscale, drotq, dsh, dopacity, losses, bg=(0.0, 0.0, 0.0),
+                  scale_modifier: float = 1.0):
+        """lcgs_fit_views: the views of one optimiser step -- forward, L2 loss against targets[j], backward -- with the
+        dense gradients summed into the five arrays and losses[j] (device tensor of len(cams) floats) = view j's loss;
+        consecutive views overlap (forward beside the previous backward)."""
+        n = len(cams)
+        if len(targets) != n:
+            raise ValueError("one target image per camera")
+        cam_arr = (Camera * n)(*cams)
+        ptrs = (C.c_void_p * n)(*[_ptr(t).value for t in targets])
+        g = _Grads(_ptr(dpos), _ptr(dscale), _ptr(drotq), _ptr(dsh), _ptr(dopacity))
+        _check(load_library().lcgs_fit_views(self.ctx._h, C.c_int(n), cam_arr, _f3(bg), C.c_float(scale_modifier), ptrs,
+                                             C.byref(g), _ptr(losses)))
+        self._generation += 1
 
     def l2_loss_backward(self, img, target, dL_dimg, loss):
         """lcgs_l2_loss_backward: loss[0] = mean((img - target)^2), dL_dimg = 2 (img - target) / numel (device tensors)"""

@@ -90,6 +90,10 @@ struct lcgs_context {
     lcgs_context* twin         = nullptr;
     hipStream_t   twin_stream  = nullptr; // owned
     hipEvent_t    ev_batch_fork = nullptr, ev_batch_join = nullptr;
+    // lcgs_fit_views: the view's image and loss gradient (per context: two views are in flight), the order of the
+    // backward passes across the two contexts
+    DeviceBuffer fit_img, fit_dL;
+    hipEvent_t   ev_fit_bwd = nullptr;
     // launch-size hints from the last synchronised frame (live counts stay on the device; larger counts are
     // still handled correctly by chunk striding)
     int64_t hint_V = 0, hint_L = 0;

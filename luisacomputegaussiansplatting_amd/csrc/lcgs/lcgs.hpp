@@ -230,6 +230,19 @@ public:
     {
         check(lcgs_render_backward(m_dev->ctx(), dL_dimg.ptr, &grads));
     }
+    // a further view of a multi-view step: its gradients are added to the arrays
+    void backward_accumulate(BufferView<float> dL_dimg, const lcgs_grads& grads)
+    {
+        check(lcgs_render_backward_accumulate(m_dev->ctx(), dL_dimg.ptr, &grads));
+    }
+    // the views of one optimiser step: forward -> L2 loss against targets[j] -> backward, gradients summed into `grads`,
+    // d_losses[j] = view j's loss; a view's forward runs beside the previous view's backward (lcgs_fit_views)
+    void fit_views(const std::vector<Camera>& cams, const std::vector<const float*>& targets, const lcgs_grads& grads,
+                   float* d_losses, const float bg[3], float scale_modifier = 1.0f)
+    {
+        if (cams.size() != targets.size()) throw Error(LCGS_ERR_INVALID_ARG, "fit_views: cams/targets size mismatch");
+        check(lcgs_fit_views(m_dev->ctx(), (int)cams.size(), cams.data(), bg, scale_modifier, targets.data(), &grads, d_losses));
+    }
     // the same gradients as compact rows (row r = the frame's r-th on-screen splat, see visible_rows): single-GPU steps
     void backward_compact(BufferView<float> dL_dimg, const lcgs_grads& grads)
     {

@@ -398,6 +398,8 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     return LCGS_OK;
 }
 
+lcgs_status prepare_twin(lcgs_context* ctx); // (the sibling context of camera / view batches, defined with them)
+
 } // namespace
 
 extern "C" {
@@ -489,6 +491,9 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
     for (hipEvent_t ev : { ctx->ev_fork, ctx->ev_join, ctx->ev_ranges, ctx->ev_aux_done, ctx->ev_render, ctx->ev_counts,
                            ctx->ev_g2d_zero })
         if (ev) (void)hipEventDestroy(ev);
+    ctx->fit_img.release();
+    ctx->fit_dL.release();
+    if (ctx->ev_fit_bwd) (void)hipEventDestroy(ctx->ev_fit_bwd);
     ctx->frame_params.release();
     ctx->slice_bounds.release();
     ctx->scene_perm.release();
@@ -1151,13 +1156,34 @@ lcgs_status lcgs_render_forward_batch(lcgs_context* ctx, int num_views, const lc
     LCGS_REQUIRE(cameras != nullptr && d_imgs != nullptr && bg_color != nullptr, "NULL argument");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     const bool two = num_views > 1 && !ctx->profiling && !ctx->use_graph && ctx->P > 0;
-    if (two && !ctx->twin) {
+    if (two) LCGS_TRY(prepare_twin(ctx));
+    for (int i = 0; i < num_views; ++i) {
+        lcgs_context* target = (two && (i & 1)) ? ctx->twin : ctx;
+        LCGS_REQUIRE(d_imgs[i] != nullptr, "NULL image pointer in the batch");
+        LCGS_TRY(lcgs_render_forward(target, &cameras[i], bg_color, scale_modifier, d_imgs[i], nullptr, 0, nullptr));
+    }
+    if (two) {
+        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_batch_join, ctx->twin_stream));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_batch_join, 0));
+    }
+    return LCGS_OK;
+}
+
+} // extern "C"
+
+namespace
+{
+// The sibling context of camera / view batches: created on first use, bound to the same scene, ordered after the work
+// already on the context's stream.
+lcgs_status prepare_twin(lcgs_context* ctx)
+{
+    if (!ctx->twin) {
         LCGS_HIP_CHECK(hipStreamCreateWithFlags(&ctx->twin_stream, hipStreamNonBlocking));
         LCGS_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_batch_fork, hipEventDisableTiming));
         LCGS_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_batch_join, hipEventDisableTiming));
         LCGS_TRY(lcgs_create(ctx->device, ctx->twin_stream, &ctx->twin));
     }
-    if (two) {
+    {
         lcgs_context* t = ctx->twin;
         if (t->pos != ctx->pos || t->P != ctx->P || t->sh != ctx->sh || t->sh_deg != ctx->sh_deg)
             LCGS_TRY(lcgs_scene_bind(t, ctx->P, ctx->sh_deg, ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity));
@@ -1179,12 +1205,44 @@ lcgs_status lcgs_render_forward_batch(lcgs_context* ctx, int num_views, const lc
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_batch_fork, ctx->stream));
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->twin_stream, ctx->ev_batch_fork, 0));
     }
-    for (int i = 0; i < num_views; ++i) {
-        lcgs_context* target = (two && (i & 1)) ? ctx->twin : ctx;
-        LCGS_REQUIRE(d_imgs[i] != nullptr, "NULL image pointer in the batch");
-        LCGS_TRY(lcgs_render_forward(target, &cameras[i], bg_color, scale_modifier, d_imgs[i], nullptr, 0, nullptr));
+    return LCGS_OK;
+}
+} // namespace
+
+extern "C" {
+
+lcgs_status lcgs_fit_views(lcgs_context* ctx, int num_views, const lcgs_camera* cameras, const float bg_color[3],
+                           float scale_modifier, const float* const* d_targets, const lcgs_grads* grads, float* d_losses)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(num_views >= 0, "num_views is negative");
+    if (num_views == 0) return LCGS_OK;
+    LCGS_REQUIRE(cameras && d_targets && grads && d_losses && bg_color, "NULL argument");
+    LCGS_REQUIRE(ctx->P > 0 && ctx->pos != nullptr, "no scene bound");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    const bool two = num_views > 1 && !ctx->profiling && !ctx->use_graph;
+    if (two) LCGS_TRY(prepare_twin(ctx));
+    lcgs_context* prev = nullptr; // the context whose backward wrote `grads` last
+    for (int j = 0; j < num_views; ++j) {
+        // alternate, ending on `ctx`: the last backward is the one a gradient all-reduce overlaps (its slices)
+        lcgs_context* c = (two && ((num_views - 1 - j) & 1)) ? ctx->twin : ctx;
+        LCGS_REQUIRE(d_targets[j] != nullptr, "NULL target image in the batch");
+        LCGS_TRY(check_camera(&cameras[j]));
+        const size_t img_bytes = (size_t)cameras[j].width * cameras[j].height * 3 * sizeof(float);
+        LCGS_TRY(c->fit_img.ensure(img_bytes));
+        LCGS_TRY(c->fit_dL.ensure(img_bytes));
+        if (!c->ev_fit_bwd) LCGS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fit_bwd, hipEventDisableTiming));
+        LCGS_TRY(lcgs_render_forward(c, &cameras[j], bg_color, scale_modifier, c->fit_img.as<float>(), nullptr, 1, nullptr));
+        LCGS_TRY(lcgs_l2_loss_backward(c, cameras[j].width, cameras[j].height, c->fit_img.as<float>(), d_targets[j],
+                                       c->fit_dL.as<float>(), d_losses + j));
+        // the gradient arrays are shared: this view's backward after the previous view's (on the other context)
+        if (prev && prev != c) LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, prev->ev_fit_bwd, 0));
+        LCGS_TRY(j == 0 ? lcgs_render_backward(c, c->fit_dL.as<float>(), grads)
+                        : lcgs_render_backward_accumulate(c, c->fit_dL.as<float>(), grads));
+        LCGS_HIP_CHECK(hipEventRecord(c->ev_fit_bwd, c->stream));
+        prev = c;
     }
-    if (two) {
+    if (two) { // (the last view ran on ctx; the one before it on the sibling, and ctx's backward already waited for it)
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_batch_join, ctx->twin_stream));
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_batch_join, 0));
     }

@@ -228,3 +228,50 @@ def test_adam_step_argument_checks(lcgs):
         r.adam_step(z, z, z, z, z, 0, LR)  # step counts from 1
     with pytest.raises(lcgs.LcgsError):
         r.adam_step(z, z, z, z, z, 1, LR, visible_only=True)  # no forward frame in this context
+
+
+def test_fit_views_equals_the_views_one_after_the_other(lcgs):
+    """lcgs_fit_views (views alternating between the context and its sibling, a forward beside the previous backward) gives
+    what forward -> L2 loss -> backward(_accumulate) per view give: the same losses and gradient sums up to the order of
+    float additions."""
+    import torch
+
+    from bench import view_pose
+    from conftest import make_scene
+    from gpu_util import DEV, upload_scene
+
+    rng = np.random.default_rng(77)
+    P, W, H = 40000, 320, 240
+    scene = make_scene(rng, P, spread=1.5, log_scale=(-3.6, 0.6))
+    d = upload_scene(scene)
+    KEYS = ("pos", "scale", "rotq", "sh", "opacity")
+    shapes = {"pos": (P, 3), "scale": (P, 3), "rotq": (P, 4), "sh": (P, 48), "opacity": (P,)}
+    for n_views in (1, 2, 3, 4):
+        cams = [lcgs.get_lookat_cam(*view_pose(k), width=W, height=H) for k in range(n_views)]
+        targets = [torch.rand(3, H, W, device=DEV) for _ in range(n_views)]
+        # reference: one view after the other on a single context
+        r = lcgs.Renderer(lcgs.Context(0))
+        r.bind_scene(*[d[k] for k in KEYS])
+        want = {k: torch.full(shapes[k], 7.0, device=DEV) for k in KEYS}
+        want_loss = torch.zeros(n_views, device=DEV)
+        img, dL = torch.zeros(3, H, W, device=DEV), torch.zeros(3, H, W, device=DEV)
+        for j, cam in enumerate(cams):
+            r.forward(cam, img, keep_state=True, sync=False)
+            r.l2_loss_backward(img, targets[j], dL, want_loss[j:j + 1])
+            r.backward(dL, *[want[k] for k in KEYS], accumulate=j > 0)
+        r.ctx.synchronize()
+        # the batch call, twice on one context (the second step starts from stale arrays and a warm sibling)
+        r2 = lcgs.Renderer(lcgs.Context(0))
+        r2.bind_scene(*[d[k] for k in KEYS])
+        for rep in range(2):
+            got = {k: torch.full(shapes[k], -3.0, device=DEV) for k in KEYS}
+            got_loss = torch.full((n_views,), -1.0, device=DEV)
+            torch.cuda.synchronize()
+            r2.fit_views(cams, targets, *[got[k] for k in KEYS], got_loss)
+            r2.ctx.synchronize()
+            assert torch.allclose(got_loss, want_loss, rtol=1e-5, atol=0.0), (n_views, rep)  # (an atomic float sum)
+            for k in KEYS:
+                num = (got[k] - want[k]).double().norm().item()
+                den = want[k].double().norm().item()
+                assert num <= 2e-4 * den + 1e-12, (n_views, rep, k, num, den)
+                assert torch.equal(got[k] == 0, want[k] == 0), (n_views, rep, k)
