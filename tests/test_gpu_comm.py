@@ -216,6 +216,7 @@ def test_bench_runs_every_multi_gpu_code_path_on_one_rank(collective):
     fb = out["fwd_bwd"]
     assert fb["value"] > 0 and fb["without_collective"]["value"] > 0 and fb["moving_camera"]["value"] > 0
     assert fb["views_per_gpu_and_step_4"]["value"] > 0 and fb["views_per_gpu_and_step_4"]["views_per_step"] == 4
+    assert fb["multi_view_step_4"]["lcgs_fit_views"]["value"] > 0 and fb["multi_view_step_4"]["one_by_one"]["value"] > 0
     assert ("rccl" in fb["collective"]) == (collective == "rccl")
     assert set(out["train_step"]) == {"allreduce", "sharded"}
     assert all(v["value"] > 0 for v in out["train_step"].values())
