@@ -61,7 +61,8 @@ void usage(const char* argv0)
     printf("  --backward               Per round of views: backward (dL/dimg = 1) + RCCL sum of the gradients over the GPUs\n");
     printf("  --fit <K>                Training without a Python binding (doc/roadmap.md:4), as a demonstration: the loaded scene's\n"
            "                           frame is the target, opacities and base colours are perturbed, K optimiser steps\n"
-           "                           (forward, L2 loss, backward, Adam) pull them back; prints the loss per step\n");
+           "                           (forward, L2 loss, backward, Adam) pull them back; prints the loss per step.  With\n"
+           "                           --cameras every step covers all views of the file (lcgs_fit_views)\n");
     printf("  --display                Not supported (headless)\n");
 }
 
@@ -332,10 +333,22 @@ int main(int argc, char** argv)
             const size_t n3 = (size_t)P * 3, n4 = (size_t)P * 4, n48 = (size_t)P * 48;
             std::vector<float> h_pos(n3), h_scale(n3), h_rotq(n4), h_sh(n48), h_op(P);
             lcgs::check(lcgs_scene_download(device.ctx(), h_pos.data(), h_scale.data(), h_rotq.data(), h_sh.data(), h_op.data()));
+            // one target per view of --cameras (the scene's own frames): an optimiser step covers all of them
+            // (lcgs_fit_views: forward -> L2 loss -> backward per view, gradients summed, consecutive views overlapping)
             lcgs::Camera cam = make_camera(views[0]);
             lcgs::Scene  scene(device);
-            lcgs::Buffer<float> d_target((size_t)W * H * 3), d_dL((size_t)W * H * 3), d_loss(1);
-            scene.render(cam, d_target, bg);
+            std::vector<lcgs::Camera>         cams;
+            std::vector<lcgs::Buffer<float>>  targets;
+            std::vector<const float*>         target_ptrs;
+            for (const auto& v : views) {
+                cams.push_back(make_camera(v));
+                targets.emplace_back((size_t)W * H * 3);
+                scene.render(cams.back(), targets.back(), bg);
+                target_ptrs.push_back(targets.back().data());
+            }
+            const int           nv = (int)cams.size();
+            lcgs::Buffer<float> d_loss((size_t)nv);
+            std::vector<float>  h_loss((size_t)nv);
             // raw 3DGS parameters (log-scale, opacity logit, un-normalised quaternion) of the PERTURBED scene
             std::vector<float> r_scale(n3), r_op(P);
             for (size_t i = 0; i < n3; ++i) r_scale[i] = std::log(h_scale[i]);
@@ -367,18 +380,19 @@ int main(int argc, char** argv)
             auto t0 = std::chrono::steady_clock::now();
             float first_loss = 0.0f, loss = 0.0f;
             for (int it = 0; it < fit_steps; ++it) {
-                scene.render(cam, d_img, bg, 1.0f, /*keep_state=*/true);
-                lcgs::check(lcgs_l2_loss_backward(device.ctx(), (int)W, (int)H, d_img.data(), d_target.data(), d_dL.data(), d_loss.data()));
-                scene.backward(d_dL, grads);
+                scene.fit_views(cams, target_ptrs, grads, d_loss.data(), bg);
                 cfg.step = it + 1;
                 lcgs::check(lcgs_adam_step(device.ctx(), P, 3, &cfg, &grads, &raw, &mm, &vv, &act));
                 device.synchronize();
-                if (hipMemcpy(&loss, d_loss.data(), sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) die("D2H copy failed");
+                if (hipMemcpy(h_loss.data(), d_loss.data(), sizeof(float) * nv, hipMemcpyDeviceToHost) != hipSuccess) die("D2H copy failed");
+                loss = 0.0f;
+                for (float l : h_loss) loss += l / (float)nv; // mean over the views
                 if (it == 0) first_loss = loss;
                 printf("step %d loss %.6e\n", it + 1, loss);
             }
             double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            printf("fit: loss %.6e -> %.6e in %d steps (%.3f ms per step)\n", first_loss, loss, fit_steps, ms / fit_steps);
+            printf("fit: loss %.6e -> %.6e in %d steps of %d view(s) (%.3f ms per step)\n", first_loss, loss, fit_steps, nv,
+                   ms / fit_steps);
             scene.render(cam, d_img, bg);
             save_view(d_img.data(), 0);
             views.clear(); // done

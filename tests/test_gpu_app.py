@@ -135,6 +135,25 @@ def test_lcgs_app_fit_trains_through_the_c_abi_only(lcgs, tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "synth0_20000_hip.png"))
 
 
+def test_lcgs_app_fit_over_several_views(lcgs, tmp_path):
+    """--fit K --cameras f: every optimiser step covers all views of the file through lcgs_fit_views (a view's forward beside
+    the previous view's backward); the mean loss over the views has to fall like the single-view one does."""
+    import re
+
+    app = os.path.join(ROOT, "luisacomputegaussiansplatting_amd", "lcgs-app")
+    cams = str(tmp_path / "cams.txt")
+    with open(cams, "w") as f:
+        for p in ([-3, -0.5, 2.3], [2.5, 1.5, 1.0], [0.2, -3.0, 0.4]):
+            f.write(" ".join(str(x) for x in p + [0, 0, 0.5] + [0, 0, 1]) + "\n")
+    res = subprocess.run([app, "--synth", "0:20000:1001", "--res=320x240", "--out", str(tmp_path), "--cameras", cams, "--fit",
+                          "30"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    assert "30 steps of 3 view(s)" in res.stdout
+    losses = [float(x) for x in re.findall(r"step \d+ loss (\S+)", res.stdout)]
+    assert len(losses) == 30 and all(np.isfinite(losses))
+    assert losses[0] > 1e-5 and losses[-1] < 0.35 * losses[0], (losses[0], losses[-1])
+
+
 def test_l2_loss_backward_matches_torch(lcgs):
     import torch
 
