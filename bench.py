@@ -99,6 +99,7 @@ def main():
     local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
+    backend = os.environ.get("LCGS_BENCH_BACKEND", "nccl")
     # (LCGS_BENCH_FORCE_DIST=1: a rehearsal hook -- one rank, but through the process group, so that every N > 1 code
     #  path of this file, collectives included, runs on a one-GPU box)
     if world > 1 or os.environ.get("LCGS_BENCH_FORCE_DIST") == "1":
@@ -108,9 +109,16 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # (LCGS_BENCH_BACKEND=gloo: a second rehearsal hook -- several ranks on ONE GPU, which RCCL refuses: the launch,
+        #  the per-rank views, the barriers and the max-over-ranks timing run as on a node; the gradient legs then fail
+        #  on every rank ("duplicate GPU") and exercise the leg-error path below)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     W, H = (int(x) for x in args.res.lower().split("x"))
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the timing reductions live
     KEYS = mg.KEYS
 
     # ---- scene (replicated on every GPU), through the library's own ingest: the context owns the device arrays and keeps
@@ -161,7 +169,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
@@ -178,7 +186,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         if dist is not None:
-            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            tt = torch.tensor([el], device=red_dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         return el
@@ -234,7 +242,7 @@ def main():
         barrier()
         el_p = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([el_p], device=dev, dtype=torch.float64)
+            t = torch.tensor([el_p], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el_p = float(t.item())
         pipelined = {"api": "lcgs_render_forward_batch", "frames_in_flight": 2, "value": round(world * args.steps / el_p, 2),

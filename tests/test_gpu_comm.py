@@ -238,3 +238,25 @@ def test_bench_still_prints_its_line_when_a_multi_gpu_leg_fails():
     out = json.loads(lines[0])
     assert out["value"] > 0 and "injected" in out["leg_errors"]["fwd_bwd / train_step"]
     assert "fwd_bwd" not in out
+
+
+def test_bench_with_two_ranks_on_one_gpu():
+    """The driver's N > 1 launch, rehearsed with two ranks on the one GPU of the box (LCGS_BENCH_BACKEND=gloo; RCCL refuses
+    two ranks on one device): torchrun, per-rank views, barriers, max-over-ranks timing, ONE line from rank 0 with the
+    whole-job rate -- and the gradient legs, which cannot build their communicator here, recorded as leg errors on every
+    rank instead of ending or hanging the run."""
+    env = dict(os.environ, LCGS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--splats",
+                          "200000", "--res", "640x480", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                          "--no-stage-path", "--no-spatial", "--leg-timeout", "120"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [x for x in res.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == "view-parallel x2"
+    assert out["camera_batch"]["value"] > 0 and out["moving_camera"]["value"] > 0
+    # the communicator of the gradient legs: refused on a shared device -> reported, or (a build that allows it) measured
+    assert ("leg_errors" in out) != ("fwd_bwd" in out and "value" in out["fwd_bwd"]), out.get("leg_errors")
