@@ -240,6 +240,27 @@ def test_bench_still_prints_its_line_when_a_multi_gpu_leg_fails():
     assert "fwd_bwd" not in out
 
 
+def test_bench_with_two_ranks_on_one_gpu_through_the_torch_collective():
+    """Same launch with --collective torch: the process group (gloo here) carries the gradients, so every N > 1 leg -- the
+    view-parallel trainer's all-reduce and sharded steps, accumulated views, lcgs_fit_views + gradient sum -- runs end to
+    end with two real ranks (rates are meaningless: gloo stages through the host)."""
+    env = dict(os.environ, LCGS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--splats",
+                          "100000", "--res", "320x240", "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-stage-path", "--no-spatial", "--leg-timeout", "300", "--collective", "torch"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [x for x in res.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and "leg_errors" not in out and "error" not in out, out.get("leg_errors")
+    fb = out["fwd_bwd"]
+    assert fb["value"] > 0 and fb["without_collective"]["value"] > fb["value"] and fb["moving_camera"]["value"] > 0
+    assert fb["views_per_gpu_and_step_4"]["views_per_step"] == 8 and fb["multi_view_step_4"]["lcgs_fit_views"]["value"] > 0
+    assert set(out["train_step"]) == {"allreduce", "sharded"} and all(v["value"] > 0 for v in out["train_step"].values())
+
+
 def test_bench_with_two_ranks_on_one_gpu():
     """The driver's N > 1 launch, rehearsed with two ranks on the one GPU of the box (LCGS_BENCH_BACKEND=gloo; RCCL refuses
     two ranks on one device): torchrun, per-rank views, barriers, max-over-ranks timing, ONE line from rank 0 with the
