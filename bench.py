@@ -455,12 +455,14 @@ def main():
         if dist is not None and os.environ.get("LCGS_BENCH_INJECT_LEG_FAILURE") == "1":  # (test hook)
             raise RuntimeError("injected failure of the gradient legs")
         if not args.no_backward:
-            gbuf = torch.zeros(59 * P, device=dev)  # pos 3 | scale 3 | rotq 4 | sh 48 | opacity 1, one flat buffer
+            # pos 3 | scale 3 | rotq 4 | sh 48 | opacity 1 in one buffer, every array starting on a 16-byte boundary
+            # (lcgs_render_backward wants that of dL/drotq; an odd P would break it otherwise)
+            gbuf = torch.zeros(59 * P + 16, device=dev)
             o0 = 0
             views = {}
             for name, width in (("pos", 3), ("scale", 3), ("rotq", 4), ("sh", 48), ("opacity", 1)):
                 views[name] = gbuf[o0:o0 + width * P].view(P, width) if width > 1 else gbuf[o0:o0 + P]
-                o0 += width * P
+                o0 = (o0 + width * P + 3) & ~3
             dL = torch.randn(3, H, W, device=dev)
             if dist is not None:
                 if args.collective == "rccl":
