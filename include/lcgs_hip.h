@@ -263,6 +263,12 @@ LCGS_API lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* o
  * ranges (proxy.h:63).  d_list: num_pairs entries; d_ranges: 2 * tiles.  Either may be NULL.  Synchronises. */
 LCGS_API lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t* d_ranges);
 
+/* Diagnostics: the compositing loop's exp (`exp(power)`, gs_tile_splatter/shader.cpp:258) evaluated on the device for n
+ * values.  The reference's exp is whatever LuisaCompute's JIT maps it to (unpinned); this library defines it as a fixed
+ * sequence of binary32 operations (csrc/kernels/gs_math.hpp::blend_exp, <= 2.73 ulp on [-6, 0]) so that a CPU restatement
+ * can reproduce the frame bit for bit.  Domain -86 <= x <= 0; outside it the result is unspecified.  Synchronises. */
+LCGS_API lcgs_status lcgs_debug_blend_exp(lcgs_context* ctx, const float* d_x, float* d_out, int64_t n);
+
 /* Backward of the last lcgs_render_forward(keep_state=1) -- no counterpart in the reference
  * (README.md:70); specified in DESIGN.md.  All outputs are device pointers, overwritten:
  * dL/dpos[3P], dL/dscale[3P] (activated scale), dL/drotq[4P] (r,x,y,z, as stored),

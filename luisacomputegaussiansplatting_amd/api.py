@@ -138,7 +138,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_get_lookat_cam", "lcgs_local_to_world_matrix", "lcgs_world_to_local_matrix", "lcgs_projection_matrix",
     "lcgs_sh_process", "lcgs_project_forward", "lcgs_tile_splat_forward", "lcgs_inclusive_sum_u32",
     "lcgs_sort_pairs_u64_u32", "lcgs_scene_bind", "lcgs_scene_upload", "lcgs_render_forward",
-    "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists",
+    "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists", "lcgs_debug_blend_exp",
     "lcgs_render_backward", "lcgs_fit_views", "lcgs_render_backward_accumulate", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png", "lcgs_l2_loss_backward",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
@@ -277,6 +277,10 @@ class Context:
 
     def set_stream(self, stream: int):
         _check(load_library().lcgs_set_stream(self._h, C.c_void_p(stream)))
+
+    def blend_exp(self, d_x, d_out, n: int):
+        """diagnostics: the compositing loop's exp (gs_math.hpp::blend_exp) over n device values"""
+        _check(load_library().lcgs_debug_blend_exp(self._h, _ptr(d_x), _ptr(d_out), C.c_int64(n)))
 
     # lcpp primitives
     def inclusive_sum(self, d_in, d_out, n: int):

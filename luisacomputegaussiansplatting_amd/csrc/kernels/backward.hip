@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256, 6) k_render_backward(CamParams cp, float 
         }
         s_a[tid]   = a;
         s_b[tid]   = b;
-        s_c[tid]   = make_float2(c, -0.5f * t);
+        s_c[tid]   = make_float2(c, fmax_(-0.5f * t, kBlendExpMin));
         s_vid[tid] = vid;
 #pragma unroll
         for (int g = 0; g < 9; ++g) s_grad[g][tid] = 0.0f;
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256, 6) k_render_backward(CamParams cp, float 
                     const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
                     const bool  cand  = (pos < last) & !(power > 0.0f) & (power >= ec.y);
                     if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
-                    const float G     = __expf(power);
+                    const float G     = blend_exp(power); // the forward's exp: the same entries pass alpha >= 1/255
                     const float oG    = eb.y * G;
                     const float alpha = __builtin_fminf(0.99f, oG);
                     const bool  valid = cand & !(alpha < 1.0f / 255.0f);
@@ -269,8 +269,9 @@ __global__ void __launch_bounds__(256, 6) k_render_backward(CamParams cp, float 
                     Bb = __builtin_fmaf(a, db, Bb);
                     T  = Tn;
                     // the 0.99 cap passes no gradient to G / opacity
-                    const float gfac = (valid & (oG < 0.99f)) ? dL_dalpha : 0.0f;
-                    v[5]           = G * gfac;    // dL/dopacity
+                    // (selected AFTER the product: on a lane that is not a candidate `power` lies outside blend_exp's
+                    //  domain and G is arbitrary bits, possibly NaN -- it must not meet a multiplication by 0)
+                    v[5] = (valid & (oG < 0.99f)) ? G * dL_dalpha : 0.0f; // dL/dopacity
                     const float h  = eb.y * v[5]; // G * dL/dG
                     const float hx = h * dx, hy = h * dy;
                     v[0] = hx;                    // the entry-uniform factors (conic, -1, -0.5) are applied once

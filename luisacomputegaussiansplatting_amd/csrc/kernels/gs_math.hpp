@@ -82,6 +82,56 @@ LCGS_HD int32_t f2i_sat(float x)
     return (int32_t)x;
 }
 
+// ---------------------------------------------------------------------------------------------
+// blend_exp -- THE exp() of the compositing loop (`exp(power)`, gs_tile_splatter/shader.cpp:258).
+//
+// The reference's exp is whatever LuisaCompute's JIT hands its backend (unpinned: CUDA expf is documented to 2 ulp,
+// its fast-math __expf to 2 + floor(|1.16 x|) ulp), and the three hard thresholds behind it (alpha < 1/255,
+// T < 1e-4, and through T every later entry of the pixel) turn a 1-ulp difference into a visibly different pixel.
+// So this library DEFINES the function, as a fixed sequence of IEEE-754 binary32 operations (fma, add, mul, one
+// integer add) that a CPU and a GPU evaluate to the same bits: the tests' CPU restatement of the reference runs the
+// same sequence in C, and the images are then equal bit for bit, not within a tolerance.
+//   t = fma(x, log2e, 1.5 * 2^23)        the low mantissa bits of t hold n = rint(x log2e)
+//   f = fma(x, log2e, -(t - 1.5 * 2^23))  x log2e - n with ONE rounding: |f| <= 1/2, no argument-scaling error
+//   2^f = E(f^2) + f O(f^2)               degree-6 minimax of 2^f on [-1/2, 1/2] with P(0) = 1 (relative error 2.6e-9),
+//                                         even and odd halves side by side (the device runs them as v_pk_fma_f32)
+//   result = 2^f with n added to the exponent field
+// Measured over EVERY binary32 in [-6, 0] (the blend's range: alpha >= 1/255 needs power >= -ln 255 = -5.54):
+// <= 2.73 ulp; over [-87, 0]: <= 20.8 ulp (the constant log2e itself is only good to 2^-26 x); exp(0) = 1 exactly.
+// Domain: kBlendExpMin = -86 <= x <= 0 (no overflow / denormal handling: the kernels gate on a power floor that is
+// clamped to it; the C version returns 0 below it -- there alpha < 1/255 for any opacity below 1e34 -- and
+// passes NaN through).
+// ---------------------------------------------------------------------------------------------
+constexpr float kExpLog2e = 0x1.715476p+0f;  // binary32 nearest to log2(e)
+constexpr float kExpMagic = 12582912.0f;     // 1.5 * 2^23
+constexpr float kBlendExpMin = -86.0f;       // below this blend_exp is not evaluated (defined as 0)
+constexpr float kExpC1 = 0x1.62e432p-1f, kExpC2 = 0x1.ebfbe2p-3f, kExpC3 = 0x1.c6ae72p-5f, kExpC4 = 0x1.3b270ep-7f,
+                kExpC5 = 0x1.5f7276p-10f, kExpC6 = 0x1.470b4ap-13f;
+
+LCGS_HD float blend_exp(float x)
+{
+    const float t  = __builtin_fmaf(x, kExpLog2e, kExpMagic);
+    const float n  = t - kExpMagic;
+    const float f  = __builtin_fmaf(x, kExpLog2e, -n);
+    const float f2 = f * f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    const v2f_ ff = { f2, f2 };
+    v2f_       eo = { __builtin_fmaf(kExpC6, f2, kExpC4), kExpC5 };
+    eo            = __builtin_elementwise_fma(eo, ff, (v2f_){ kExpC2, kExpC3 });
+    eo            = __builtin_elementwise_fma(eo, ff, (v2f_){ 1.0f, kExpC1 });
+    const float p = __builtin_fmaf(eo.y, f, eo.x);
+#else
+    float E = __builtin_fmaf(kExpC6, f2, kExpC4);
+    E       = __builtin_fmaf(E, f2, kExpC2);
+    E       = __builtin_fmaf(E, f2, 1.0f);
+    float O = __builtin_fmaf(kExpC5, f2, kExpC3);
+    O       = __builtin_fmaf(O, f2, kExpC1);
+    const float p = __builtin_fmaf(O, f, E);
+#endif
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, p) + (__builtin_bit_cast(uint32_t, t) << 23));
+}
+
 // The 16 SH basis terms and their direction gradients, signs as composed by sh_preprocessor.cpp:49-147.
 // X(k, basis, d/dx, d/dy, d/dz) with x, y, z, xx, yy, zz in scope.
 #define LCGS_SH_TERMS(X)                                                                                              \

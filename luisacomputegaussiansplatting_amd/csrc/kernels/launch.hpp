@@ -156,6 +156,7 @@ void launch_morton_keys(int64_t P, const float* pos, const float lo[3], const fl
                         uint32_t* vals, hipStream_t stream);
 void launch_gather_rows(int64_t rows, int row_floats, const uint32_t* perm, const float* src, float* dst, hipStream_t stream);
 void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream);
+void launch_blend_exp(const float* x, float* out, int64_t n, hipStream_t stream);
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,

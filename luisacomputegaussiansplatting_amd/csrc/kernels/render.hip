@@ -16,7 +16,9 @@
 //     supplies an order, else XCD-aware blocks of 8x4 tiles dealt round-robin to the 8 XCDs (tile_of_workgroup).
 //   (A one-wave64-per-tile variant was kept as a tuning hook through round 1; measured slower at every size, removed.)
 // Numerics: the per-pixel expressions keep the reference's evaluation order with no FMA contraction
-// (-ffp-contract=off); exp() is the hardware v_exp_f32 path (__expf).
+// (-ffp-contract=off); exp() is blend_exp (gs_math.hpp): a fixed sequence of IEEE operations the tests' CPU
+// restatement repeats, so the two images are equal bit for bit (v_exp_f32 differs from any CPU exp by an ulp or two, and an ulp flips the
+// hard thresholds behind it).
 #include <stdlib.h>
 
 #include <hip/hip_ext.h>
@@ -64,6 +66,9 @@ using namespace tile;
 // 64-bit mask per staging wave and strip) go to LDS; wave k then walks the set bits of "its" four masks with
 // scalar bit-scan instructions -- entries irrelevant to a strip cost that strip nothing, order is preserved.
 // ---------------------------------------------------------------------------------------------
+#ifndef LCGS_RENDER_MASKED_UPDATE
+#define LCGS_RENDER_MASKED_UPDATE 1
+#endif
 typedef float v2f __attribute__((ext_vector_type(2))); // arithmetic on it lowers to v_pk_{add,mul}_f32 (IEEE per lane)
 
 template <typename Fetch, bool KEEP>
@@ -78,7 +83,7 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                                                             uint8_t* __restrict__ strip_masks)
 {
     // one 16-byte row per entry in each of three slabs: a single address register serves all three reads
-    __shared__ float4             s_a[256]; // mean.x, mean.y, conic.x, conic.z
+    __shared__ float4             s_a[256]; // mean.x, mean.y, -conic.x / 2, -conic.z / 2
     __shared__ float4             s_b[256]; // conic.y, power floor (-t/2), -, -: with s_a, all the cull test needs
     __shared__ float4             s_c[256]; // opacity, r, g, b: read only by entries that pass it
     __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
@@ -153,8 +158,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
             if (lane == 0) s_mask[wave][k] = m;
         }
         if (kmask) {
-            s_a[tid] = make_float4(a.x, a.y, a.z, b.x);
-            *reinterpret_cast<float2*>(&s_b[tid]) = make_float2(a.w, -0.5f * t);
+            s_a[tid] = make_float4(a.x, a.y, -0.5f * a.z, -0.5f * b.x);
+            *reinterpret_cast<float2*>(&s_b[tid]) = make_float2(a.w, fmax_(-0.5f * t, kBlendExpMin));
             s_c[tid] = make_float4(b.y, b.z, b.w, c);
         }
         const uint32_t en = e + 256u;
@@ -180,19 +185,65 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     // the operations up again.  Renderer 0.227 -> 0.221 ms in same-box A/B runs, same bits.)
                     float dx = ea.x - pxy.x, dy = ea.y - pxy.y;
                     asm volatile("" : "+v"(dx), "+v"(dy));
+                    // ea.z / ea.w hold -0.5 ca / -0.5 cc (scaled by a power of two when staged: the same bits as scaling
+                    // the sum afterwards, one multiplication fewer per entry and strip)
                     float qx = (ea.z * dx) * dx, cross = eb.x * dx;
                     asm volatile("" : "+v"(qx), "+v"(cross));
                     float qy = (ea.w * dy) * dy;
                     asm volatile("" : "+v"(qy));
-                    float half = -0.5f * (qx + qy);
+                    float half = qx + qy;
                     asm volatile("" : "+v"(half));
                     const float power = half - cross * dy;
                     const bool  cand  = !(power > 0.0f) & (power >= eb.y);
-                    if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue; // scalar test of the lane mask
+                    // (lane masks from ballots of plain compares, combined with scalar ANDs: a ballot of a compound
+                    //  condition is lowered through a select and a second compare)
+                    const unsigned long long cmask =
+                        __builtin_amdgcn_ballot_w64(!(power > 0.0f)) & __builtin_amdgcn_ballot_w64(power >= eb.y);
+                    if (cmask == 0ull) continue; // scalar test of the lane mask
                     const float4 ec    = s_c[idx]; // one 16-byte read for the survivors of the test
-                    // (alpha is never NaN where cand holds, so the hardware minimum equals min(0.99, x))
-                    const float alpha  = __builtin_fminf(0.99f, ec.x * __expf(power));
+                    // (alpha is never NaN where cand holds, so the hardware minimum equals min(0.99, x); on a lane where
+                    //  it does not hold, power may lie outside blend_exp's domain and alpha is arbitrary bits -- masked)
+                    const float alpha  = __builtin_fminf(0.99f, ec.x * blend_exp(power));
                     const bool  valid  = cand & !(alpha < 1.0f / 255.0f);
+#if LCGS_RENDER_MASKED_UPDATE
+                    // Lanes that skip the entry sit the update out under the EXEC mask: what the arithmetic produces on
+                    // them is never written anywhere, and the select that used to zero their alpha is gone.  (Written as
+                    // one asm block because the compiler turns `if (valid) { ... }` back into four selects.)
+                    const unsigned long long vmask = __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f)) & cmask;
+                    const float test_T = T * (1.0f - alpha);
+                    float       wgt = T * alpha;
+                    float       nT  = test_T;
+                    // T >= 1e-4 holds for every lane (a saturating update is never applied)
+                    const unsigned long long satm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & vmask;
+                    if (KEEP) last_contrib = (valid & !(test_T < 0.0001f)) ? base - range_start + idx + 1u : last_contrib;
+                    if (satm != 0ull) { // rare: some pixel of the strip just saturated
+                        const bool sat = (satm & lane_bit) != 0ull;
+                        wgt   = sat ? 0.0f : wgt; // shader.cpp:268-272: the saturating entry is not blended
+                        nT    = sat ? T : nT;
+                        pxy.y = sat ? __builtin_nanf("") : pxy.y;
+                        if (__builtin_amdgcn_ballot_w64(pxy.y == pxy.y) == 0ull) {
+                            alive = false; // the whole strip is finished
+                            m     = 0ull;
+                        }
+                    }
+                    {
+                        float              t0, t1, t2;
+                        unsigned long long sv;
+                        asm volatile("s_and_saveexec_b64 %[sv], %[vm]\n\t"
+                                     "v_mul_f32 %[t0], %[w], %[cr]\n\t"
+                                     "v_mul_f32 %[t1], %[w], %[cg]\n\t"
+                                     "v_mul_f32 %[t2], %[w], %[cb]\n\t"
+                                     "v_add_f32 %[Cr], %[Cr], %[t0]\n\t"
+                                     "v_add_f32 %[Cg], %[Cg], %[t1]\n\t"
+                                     "v_add_f32 %[Cb], %[Cb], %[t2]\n\t"
+                                     "v_mov_b32 %[T], %[nT]\n\t"
+                                     "s_mov_b64 exec, %[sv]"
+                                     : [Cr] "+v"(Cr), [Cg] "+v"(Cgb.x), [Cb] "+v"(Cgb.y), [T] "+v"(T), [t0] "=&v"(t0),
+                                       [t1] "=&v"(t1), [t2] "=&v"(t2), [sv] "=&s"(sv)
+                                     : [w] "v"(wgt), [cr] "v"(ec.y), [cg] "v"(ec.z), [cb] "v"(ec.w), [nT] "v"(nT),
+                                       [vm] "s"(vmask));
+                    }
+#else
                     // a lane that skips the entry blends with alpha 0: T * 1 and C + 0 leave it bit-identical
                     const float a      = valid ? alpha : 0.0f;
                     float       test_T = T * (1.0f - a);
@@ -217,6 +268,7 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     Cr  = Cr + wgt * ec.y;
                     Cgb = Cgb + (v2f){wgt, wgt} * (v2f){ec.z, ec.w};
                     T   = test_T;
+#endif
                 }
             }
             if (!alive && lane == 0) atomicSub(&s_live_waves, 1u);
@@ -278,6 +330,12 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
     }
 }
 
+// diagnostics (lcgs_debug_blend_exp): the loop's exp on its own
+__global__ void __launch_bounds__(256) k_blend_exp(const float* __restrict__ x, float* __restrict__ out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = blend_exp(x[i]);
+}
+
 template <typename Fetch>
 void launch_render(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                    Fetch fetch, float* img, float* final_T, uint32_t* n_contrib, const uint32_t* d_counts,
@@ -300,6 +358,13 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
 }
 
 } // namespace
+
+void launch_blend_exp(const float* x, float* out, int64_t n, hipStream_t stream)
+{
+    if (n <= 0) return;
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_blend_exp, dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, x, out, n);
+}
 
 void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream)
 {

@@ -1297,6 +1297,17 @@ lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t*
     return LCGS_OK;
 }
 
+// Debug/parity hook: the compositing loop's exp on its own (gs_math.hpp::blend_exp).
+lcgs_status lcgs_debug_blend_exp(lcgs_context* ctx, const float* d_x, float* d_out, int64_t n)
+{
+    LCGS_REQUIRE(ctx && (n == 0 || (d_x && d_out)) && n >= 0, "null pointer / negative count");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    launch_blend_exp(d_x, d_out, n, ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return LCGS_OK;
+}
+
 namespace
 {
 lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads, bool compact,

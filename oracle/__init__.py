@@ -85,6 +85,17 @@ class Oracle:
     def set_smooth(self, on: bool) -> None:
         self.lib.orc_set_smooth(C.c_int(1 if on else 0))
 
+    def set_blend_exp(self, use_libm: bool) -> None:
+        """False (default): the build-defined blend exp the HIP kernels repeat bit for bit; True: libm's expf"""
+        self.lib.orc_set_blend_exp(C.c_int(1 if use_libm else 0))
+
+    def blend_exp(self, x):
+        """orc_blend_exp over an array of binary32 values (f32 build only)"""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        self.lib.orc_blend_exp_array(C.c_int64(x.size), _ptr(x, C.c_float), _ptr(out, C.c_float))
+        return out
+
     def set_lod_min_radius(self, px: int) -> None:
         """the product's opt-in lcgs_set_lod rule restated for orc_render (0 = off, the reference's behaviour)"""
         self.lib.orc_set_lod_min_radius(C.c_int(px))

@@ -30,12 +30,58 @@
 #define R_FABS fabs
 #else
 #define R_SQRT sqrtf
-#define R_EXP expf
+#define R_EXP orc_blend_exp_sel
 #define R_CEIL ceilf
 #define R_TAN tanf
 #define R_FABS fabsf
 #endif
 #define RC(x) ((real)(x))
+
+#ifndef ORC_IS_DOUBLE
+/* The blend's exp (`exp(power)`, gs_tile_splatter/shader.cpp:258).  The reference's own exp is whatever LuisaCompute's
+ * JIT maps it to on its backend -- unpinned (CUDA documents expf to 2 ulp and the fast-math __expf to
+ * 2 + floor(|1.16 x|) ulp) -- and the hard thresholds behind it (alpha < 1/255, T < 1e-4) turn a 1-ulp difference into
+ * a different pixel.  The build therefore DEFINES the function as a fixed sequence of IEEE-754 binary32 operations:
+ *   t = fma(x, log2e, 1.5 * 2^23);  n = t - 1.5 * 2^23 = rint(x log2e);  f = fma(x, log2e, -n)   (|f| <= 1/2)
+ *   2^f = E(f^2) + f O(f^2): degree-6 minimax of 2^f on [-1/2, 1/2] with P(0) = 1;  result = 2^f * 2^n by exponent add.
+ * Checked over EVERY binary32 in [-6, 0] (alpha >= 1/255 needs power >= -5.54): <= 2.73 ulp from the true value; exp(0)
+ * is exactly 1.  Below -86 the function is defined as 0 (true value < 5e-38), NaN passes through.  The HIP kernels run
+ * the same sequence (csrc/kernels/gs_math.hpp::blend_exp), so images are comparable bit for bit.  orc_set_blend_exp(1)
+ * switches this file back to libm's expf, which tests use to show that the definition moves no pixel by more than
+ * rounding noise unless a threshold flips.  (The f64 build, used for finite differences only, keeps libm's exp.) */
+static int g_exp_libm = 0;
+void orc_set_blend_exp(int use_libm) { g_exp_libm = use_libm; }
+
+float orc_blend_exp(float x)
+{
+    if (!(x >= -86.0f)) return x < -86.0f ? 0.0f : x;
+    const float t  = __builtin_fmaf(x, 0x1.715476p+0f, 12582912.0f);
+    const float n  = t - 12582912.0f;
+    const float f  = __builtin_fmaf(x, 0x1.715476p+0f, -n);
+    const float f2 = f * f;
+    float       E  = __builtin_fmaf(0x1.470b4ap-13f, f2, 0x1.3b270ep-7f);
+    E              = __builtin_fmaf(E, f2, 0x1.ebfbe2p-3f);
+    E              = __builtin_fmaf(E, f2, 1.0f);
+    float O        = __builtin_fmaf(0x1.5f7276p-10f, f2, 0x1.c6ae72p-5f);
+    O              = __builtin_fmaf(O, f2, 0x1.62e432p-1f);
+    const float p  = __builtin_fmaf(O, f, E);
+    uint32_t    pb, tb;
+    memcpy(&pb, &p, 4);
+    memcpy(&tb, &t, 4);
+    pb += tb << 23;
+    float r;
+    memcpy(&r, &pb, 4);
+    return r;
+}
+
+float orc_blend_exp_sel(float x) { return g_exp_libm ? expf(x) : orc_blend_exp(x); }
+void  orc_blend_exp_array(int64_t n, const float* x, float* out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = orc_blend_exp(x[i]);
+}
+#else
+void orc_set_blend_exp(int use_libm) { (void)use_libm; }
+#endif
 
 static int g_threads = 0;
 /* FD-validation aid: when non-zero the two hard blend thresholds (alpha < 1/255 skip, T < 1e-4 stop) are disabled in

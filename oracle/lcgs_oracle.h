@@ -57,6 +57,12 @@ void orc_set_threads(int n); /* 0 = all cores */
 int  orc_get_threads(void);
 /* FD-validation aid (see lcgs_oracle.c): disable the alpha < 1/255 skip and the T < 1e-4 stop */
 void orc_set_smooth(int on);
+/* The blend's exp (gs_tile_splatter/shader.cpp:258): a build-DEFINED sequence of binary32 operations, see lcgs_oracle.c.
+ * orc_set_blend_exp(1) switches the f32 build to libm's expf (comparison runs only); no-op in the f64 build. */
+void  orc_set_blend_exp(int use_libm);
+float orc_blend_exp(float x);
+float orc_blend_exp_sel(float x);
+void  orc_blend_exp_array(int64_t n, const float* x, float* out);
 
 /* camera.h:74-82, 27-51, 54-72.  Matrices are column-major m[c*4+r]. */
 void orc_get_lookat_cam(const real pos[3], const real target[3], const real world_up[3], orc_camera* cam);

@@ -25,7 +25,7 @@
 #define R_TAN tan
 #else
 #define R_SQRT sqrtf
-#define R_EXP expf
+#define R_EXP orc_blend_exp_sel /* the forward's exp (lcgs_oracle.c): the same entries pass alpha >= 1/255 */
 #define R_TAN tanf
 #endif
 #define RC(x) ((real)(x))

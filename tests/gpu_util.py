@@ -16,23 +16,29 @@ def upload_scene(scene):
     return {k: dev(scene[k]) for k in ("pos", "scale", "rotq", "sh", "opacity")}
 
 
-def assert_image_parity(gpu_img, orc, tol=1e-4, max_ambig_frac=1e-4, min_flips_allowed=2):
-    """BASELINE tolerance: per-pixel L-inf <= 1e-4.  A pixel whose oracle evaluation came within 1e-5
-    (relative) of one of the hard thresholds (alpha < 1/255, T < 1e-4, power > 0) may legitimately flip
-    with a 1-ulp difference in exp(); those pixels are exempt but counted, printed and bounded: at most 1e-4 of the
-    frame's pixels (min_flips_allowed is the floor for frames of fewer than 20 000 pixels, where one pixel is already
-    more than 1e-4 of the frame)."""
+def assert_image_parity(gpu_img, orc, **_legacy):
+    """The HIP frame must equal the oracle's BIT FOR BIT -- every pixel, no tolerance, no exempt pixels.
+
+    BASELINE's bar is 1e-4 per-pixel L-inf; until round 3 this helper held every pixel to it except those whose
+    oracle evaluation came within 1e-5 of a hard threshold (alpha < 1/255, T < 1e-4), because v_exp_f32 and libm's
+    expf differ by an ulp or two and an ulp flips a threshold.  The blend's exp is now one defined sequence of binary32
+    operations on both sides (gs_math.hpp::blend_exp = oracle/lcgs_oracle.c::orc_blend_exp), every other operation
+    already was, so the comparison is exact equality (NaN pixels, where a test feeds non-finite inputs, must be NaN
+    on both sides).  Returns (max |diff|, differing pixels) = (0.0, 0) for callers that report them."""
     ref = orc["img"]
-    diff = np.abs(gpu_img - ref).max(axis=0)
-    bad = diff > tol
-    ambig = orc["ambig"].astype(bool)
-    n_bad_clear = int((bad & ~ambig).sum())
-    assert n_bad_clear == 0, (f"{n_bad_clear} unambiguous pixels differ by more than {tol}; "
-                              f"max diff {diff[~ambig].max()}")
-    n_flipped = int((bad & ambig).sum())
-    print(f"[parity] {diff.shape[1]}x{diff.shape[0]}: threshold-ambiguous pixels {int(ambig.sum())}, "
-          f"flagged-and-different {n_flipped}, max |diff| on unflagged pixels "
-          f"{float(diff[~ambig].max()) if (~ambig).any() else 0.0:.2e}")
-    allowed = max(min_flips_allowed, int(max_ambig_frac * diff.size))
-    assert n_flipped <= allowed, f"{n_flipped} pixels flipped a threshold (allowed: {allowed} of {diff.size})"
-    return float(diff[~ambig].max()) if (~ambig).any() else 0.0, int((bad & ambig).sum())
+    assert gpu_img.shape == ref.shape and gpu_img.dtype == ref.dtype == np.float32
+    same = (gpu_img.view(np.uint32) == ref.view(np.uint32)) | ((gpu_img == ref))  # +0 / -0 compare equal
+    both_nan = np.isnan(gpu_img) & np.isnan(ref)
+    ok = same | both_nan
+    if not ok.all():
+        bad = ~ok.all(axis=0)
+        with np.errstate(invalid="ignore"):
+            diff = np.abs(gpu_img.astype(np.float64) - ref.astype(np.float64)).max(axis=0)
+        amb = orc.get("ambig")
+        n_amb = int((bad & amb.astype(bool)).sum()) if amb is not None else -1
+        ys, xs = np.nonzero(bad)
+        raise AssertionError(f"{int(bad.sum())} of {bad.size} pixels differ from the oracle (max |diff| "
+                             f"{np.nanmax(diff[bad]):.3e}; {n_amb} of them threshold-ambiguous); first at "
+                             f"(x={xs[0]}, y={ys[0]}): gpu {gpu_img[:, ys[0], xs[0]]} oracle {ref[:, ys[0], xs[0]]}")
+    print(f"[parity] {ref.shape[2]}x{ref.shape[1]}: bit-identical to the oracle")
+    return 0.0, 0

@@ -77,3 +77,33 @@ def test_sh_degrees(host_math, lcgs, oracle, deg):
     feat = (deg + 1) ** 2 * 3
     color = oracle.sh_process(np.array(cam.position, np.float32), scene["pos"], scene["sh"][:, :feat], deg=deg)
     assert np.array_equal(got["color"], color)
+
+
+def _blend_exp_inputs():
+    """Every 257th binary32 of [-6, 0] (the blend's range), a coarser sweep down to the domain's end, the edges."""
+    near = np.arange(0x80000000, np.float32(-6.0).view(np.uint32), 257, dtype=np.uint64).astype(np.uint32)
+    far = np.arange(np.float32(-6.0).view(np.uint32), np.float32(-86.0).view(np.uint32), 4099,
+                    dtype=np.uint64).astype(np.uint32)
+    edge = np.array([0.0, -0.0, -86.0, -5.5412636, -1e-30, -1e-45], np.float32).view(np.uint32)
+    return np.concatenate([near, far, edge]).view(np.float32)
+
+
+def test_blend_exp_header_matches_oracle_bitwise_and_is_an_exp(host_math, oracle):
+    """The exp of the compositing loop is a build-defined sequence of binary32 operations (gs_math.hpp::blend_exp =
+    oracle/lcgs_oracle.c::orc_blend_exp).  The header's host path and the oracle must agree bit for bit, and both must
+    be the exponential: <= 2.73 ulp on [-6, 0] (exhaustively measured bound), <= 21 ulp on [-86, 0], exp(0) == 1."""
+    x = _blend_exp_inputs()
+    got = np.empty_like(x)
+    host_math.hm_blend_exp(C.c_longlong(x.size), x.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p))
+    ref = oracle.blend_exp(x)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    true = np.exp(x.astype(np.float64))
+    ulp = np.ldexp(1.0, np.floor(np.log2(true)).astype(np.int64) - 23)
+    err = np.abs(ref.astype(np.float64) - true) / ulp
+    near = x >= np.float32(-6.0)
+    assert err[near].max() <= 2.73, err[near].max()
+    assert err.max() <= 21.0, err.max()
+    assert (ref[x == 0] == 1.0).all() and (x == 0).sum() >= 2
+    # outside the domain: 0 below -86, NaN passes through (oracle only; the kernels never evaluate it there)
+    out = oracle.blend_exp(np.array([-86.5, -1e30, -np.inf, np.nan], np.float32))
+    assert out[:3].tolist() == [0.0, 0.0, 0.0] and np.isnan(out[3])
