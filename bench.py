@@ -585,7 +585,7 @@ def main():
                 if dist is None:
                     modes = ("dense", "visible_only", "visible_only_compact")
                 else:
-                    modes = ("allreduce", "sharded")
+                    modes = ("allreduce", "sharded", "sparse")
                 for mode in modes:
                     if dist is None:
                         def full_step(i, mode=mode):
@@ -602,6 +602,17 @@ def main():
                     el2 = timed(full_step, args.steps, 2)
                     out["train_step"][mode] = {"value": round(world * P * args.steps / el2 / 1e6, 1), "unit": "Msplats/s",
                                                "ms_per_step": round(el2 * 1e3 / args.steps, 4)}
+                    if dist is not None:  # bytes one GPU sends per step: the dense modes by formula, the sparse step
+                        # from the actual message sizes of its last step (lcgs_comm_get_stats)
+                        if mode == "sparse":
+                            st = getattr(coll, "last_stats", None) or {}
+                            out["train_step"][mode].update({
+                                "xgmi_bytes_sent_per_gpu": st.get("bytes_sent"), "touched_rows": st.get("touched_rows"),
+                                "note": "reduce half = touched rows only (indices + 59 floats each, one message per owner); "
+                                        "all-gather of the activated rows as in the sharded step"})
+                        else:
+                            out["train_step"][mode]["xgmi_bytes_sent_per_gpu"] = mg.allreduce_bus_bytes_per_gpu(P, world)
+                eng2.close()
                 r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
                 del act, raw, eng2
     except Exception as e:  # noqa: BLE001 -- N > 1: whatever the hardware run throws belongs in the line

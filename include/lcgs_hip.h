@@ -372,7 +372,12 @@ LCGS_API void lcgs_comm_shard_rows(int64_t num_gaussians, int world_size, int ra
  * communicator's own stream in splat-range chunks, each behind the event of the backward slice that produced its rows, so
  * the first chunks travel while the backward's tail is still computing; the context's stream then waits for the sums
  * (enqueue lcgs_adam_step right behind it).  1.45 GB per GPU for the 6.1 M-splat scene: 2 (N-1)/N of that crosses xGMI
- * per GPU. */
+ * per GPU.
+ * Collective discipline: EVERY rank must call it once per step with the same num_gaussians / sh_degree / transport, whether
+ * or not it ran a backward (a rank without a view passes zero-filled arrays); the number and sizes of the RCCL calls
+ * issued depend on those shared values only.  Call it directly behind the backward: work the caller enqueues on the
+ * context's stream between the two must not touch the gradient arrays (the first chunks start behind their slice of the
+ * backward, only the last one behind the stream's tail). */
 LCGS_API lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* comm, int num_gaussians, int sh_degree,
                                           const lcgs_grads* grads);
 /* The whole optimiser step at N > 1 without replicated optimiser work: reduce-scatter of the gradients -> lcgs_adam_step on
@@ -383,6 +388,54 @@ LCGS_API lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* comm, in
 LCGS_API lcgs_status lcgs_adam_step_sharded(lcgs_context* ctx, lcgs_comm* comm, int num_gaussians, int sh_degree,
                                             const lcgs_adam_config* cfg, const lcgs_grads* grads, const lcgs_params* raw,
                                             const lcgs_params* m, const lcgs_params* v, const lcgs_params* activated);
+
+/* ---- Sparse gradient exchange (no counterpart in the reference: single device, app/main.cpp:162-163) -------------------
+ * A view touches only its on-screen splats (39 % of the 6.1 M-splat stand-in), so in the REDUCE half of a step a rank needs
+ * to hand a row's owner only the rows its views touched: (N-1)/N x touched x (236 + 4) bytes out per GPU instead of
+ * (N-1)/N x P x 236.  Dense rows stay the layout of every array; only the wire format is sparse.
+ *
+ * lcgs_comm_track_touched_rows(comm, 1): from now on every dense lcgs_render_backward on the communicator's context flags
+ * its frame's on-screen rows (lcgs_render_backward starts a new set, lcgs_render_backward_accumulate adds to it).  ALL
+ * ranks must enable it before the step's first backward; a rank that runs no backward in a step has an empty set (and must
+ * hold zeros in its gradient arrays).
+ *
+ * lcgs_adam_step_sparse: the whole optimiser step, same contract and same result as lcgs_adam_step_sharded up to the order
+ * of the f32 sums: touched rows -> one message per owner (ncclSend / ncclRecv, sizes agreed through one small all-gather:
+ * the step's only host synchronisation) -> the owner adds the messages to its rows in rank order -> lcgs_adam_step on the
+ * own rows (+ the < N tail rows, which are all-reduced densely) -> all-gather of the refreshed ACTIVATED arrays.
+ * cfg->visible_only must be 0 (dense Adam semantics: rows nobody touched still decay their moments).
+ *
+ * The three stages are also exported one by one, for a host that brings its own transport (multi_gpu.TorchCollective
+ * runs them over a torch.distributed process group): lcgs_sparse_touched_rows (synchronises; the set is consumed),
+ * lcgs_sparse_pack, lcgs_sparse_accumulate.  A message of `count` rows is count x (1 + 11 + (deg+1)^2 x 3) 4-byte words:
+ * [row indices, ascending][pos rows][scale rows][rotq rows][sh rows][opacity rows]. */
+#define LCGS_MAX_RANKS 64
+typedef struct lcgs_sparse_rows {
+    const uint32_t* d_rows;   /* device: the touched rows, ascending (owned by the communicator, valid until the next call) */
+    int64_t         num_rows;
+    /* rows [owner_first[o], owner_first[o + 1]) of d_rows lie in rank o's shard (o < N); [owner_first[N], num_rows) is the tail */
+    int64_t owner_first[LCGS_MAX_RANKS + 2];
+} lcgs_sparse_rows;
+/* What the last collective call of this communicator moved over the wire (per GPU; computed from the actual counts). */
+typedef struct lcgs_comm_stats {
+    int64_t bytes_sent, bytes_received; /* by this rank, all collectives of the call */
+    int64_t touched_rows;               /* sparse step: rows this rank's views touched (0 for the dense calls) */
+    int     collective_groups;          /* RCCL groups / calls issued: identical on every rank by construction */
+} lcgs_comm_stats;
+LCGS_API lcgs_status lcgs_comm_track_touched_rows(lcgs_comm* comm, int enable);
+LCGS_API lcgs_status lcgs_comm_get_stats(const lcgs_comm* comm, lcgs_comm_stats* out);
+LCGS_API lcgs_status lcgs_adam_step_sparse(lcgs_context* ctx, lcgs_comm* comm, int num_gaussians, int sh_degree,
+                                           const lcgs_adam_config* cfg, const lcgs_grads* grads, const lcgs_params* raw,
+                                           const lcgs_params* m, const lcgs_params* v, const lcgs_params* activated);
+/* world_size: the N of the exchange the rows are sharded for (the communicator's own for lcgs_adam_step_sparse; a host with
+ * its own transport passes its own -- the communicator then only serves as the context's row tracker) */
+LCGS_API lcgs_status lcgs_sparse_touched_rows(lcgs_context* ctx, lcgs_comm* comm, int num_gaussians, int world_size,
+                                              lcgs_sparse_rows* out);
+LCGS_API int64_t     lcgs_sparse_message_words(int64_t count, int sh_degree);
+LCGS_API lcgs_status lcgs_sparse_pack(lcgs_context* ctx, int sh_degree, const lcgs_grads* grads, const uint32_t* d_rows,
+                                      int64_t count, float* d_msg);
+LCGS_API lcgs_status lcgs_sparse_accumulate(lcgs_context* ctx, int sh_degree, const lcgs_grads* grads, const float* d_msg,
+                                            int64_t count);
 
 /* ------------------------------------------------------------------------------------------
  * Scene ingest / image egress (host side of `render(ply, camera) -> image`)

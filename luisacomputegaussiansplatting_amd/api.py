@@ -144,7 +144,9 @@ EXPORTED_SYMBOLS = [
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh",
     "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_set_lod", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_set_transport", "lcgs_comm_shard_rows",
-    "lcgs_grads_allreduce", "lcgs_adam_step_sharded",
+    "lcgs_grads_allreduce", "lcgs_adam_step_sharded", "lcgs_comm_track_touched_rows", "lcgs_comm_get_stats",
+    "lcgs_adam_step_sparse", "lcgs_sparse_touched_rows", "lcgs_sparse_message_words", "lcgs_sparse_pack",
+    "lcgs_sparse_accumulate",
 ]
 
 
@@ -171,7 +173,7 @@ def load_library():
         fn = getattr(lib, name)
         if name not in ("lcgs_version", "lcgs_last_error", "lcgs_get_lookat_cam", "lcgs_local_to_world_matrix",
                         "lcgs_world_to_local_matrix", "lcgs_projection_matrix", "lcgs_scene_host_free",
-                        "lcgs_image_to_rgb8", "lcgs_comm_shard_rows"):
+                        "lcgs_image_to_rgb8", "lcgs_comm_shard_rows", "lcgs_sparse_message_words"):
             fn.restype = C.c_int
     lib.lcgs_get_lookat_cam.restype = None
     lib.lcgs_local_to_world_matrix.restype = None
@@ -180,6 +182,8 @@ def load_library():
     lib.lcgs_scene_host_free.restype = None
     lib.lcgs_image_to_rgb8.restype = None
     lib.lcgs_comm_shard_rows.restype = None
+    lib.lcgs_sparse_message_words.restype = C.c_int64
+    lib.lcgs_sparse_message_words.argtypes = [C.c_int64, C.c_int]
     lib.lcgs_comm_shard_rows.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.lcgs_projection_matrix.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
     _lib = lib
@@ -696,6 +700,63 @@ class Comm:
         packs = [_Params(*[_ptr(d[k]) for k in _KEYS]) for d in (raw, m, v, activated)]
         _check(load_library().lcgs_adam_step_sharded(self.ctx._h, self._h, C.c_int(P), C.c_int(sh_degree), C.byref(cfg),
                                                      C.byref(g), *[C.byref(p) for p in packs]))
+
+
+    # ---- sparse gradient exchange (lcgs_hip.h "Sparse gradient exchange")
+    def track_touched_rows(self, enable: bool = True):
+        """lcgs_comm_track_touched_rows: dense backward passes on this context flag the rows their frame touched"""
+        _check(load_library().lcgs_comm_track_touched_rows(self._h, C.c_int(1 if enable else 0)))
+
+    def stats(self) -> dict:
+        """lcgs_comm_get_stats: what the last collective call of this communicator moved (per GPU, from actual counts)"""
+        st = _CommStats()
+        _check(load_library().lcgs_comm_get_stats(self._h, C.byref(st)))
+        return {"bytes_sent": int(st.bytes_sent), "bytes_received": int(st.bytes_received),
+                "touched_rows": int(st.touched_rows), "collective_groups": int(st.collective_groups)}
+
+    def adam_step_sparse(self, grads: dict, raw: dict, m: dict, v: dict, activated: dict, step: int, lr: dict,
+                         betas=(0.9, 0.999), eps: float = 1e-15, sh_degree: int = 3):
+        """lcgs_adam_step_sparse: touched rows -> their owners (send / recv) -> Adam on the own rows -> all-gather"""
+        P = int(raw["pos"].shape[0])
+        cfg = _adam_config(lr, betas, eps, step, 0)
+        g = _Grads(*[_ptr(grads[k]) for k in _KEYS])
+        packs = [_Params(*[_ptr(d[k]) for k in _KEYS]) for d in (raw, m, v, activated)]
+        _check(load_library().lcgs_adam_step_sparse(self.ctx._h, self._h, C.c_int(P), C.c_int(sh_degree), C.byref(cfg),
+                                                    C.byref(g), *[C.byref(p) for p in packs]))
+
+    def sparse_touched_rows(self, num_gaussians: int, world_size: Optional[int] = None):
+        """lcgs_sparse_touched_rows -> (device address of the ascending row list, owner_first[0 .. N + 1]) for an exchange
+        over `world_size` ranks (default: the communicator's own); consumes the step's touched set and synchronises"""
+        n = self.world_size if world_size is None else world_size
+        out = _SparseRows()
+        _check(load_library().lcgs_sparse_touched_rows(self.ctx._h, self._h, C.c_int(num_gaussians), C.c_int(n), C.byref(out)))
+        return int(out.d_rows or 0), [int(out.owner_first[i]) for i in range(n + 2)]
+
+    def sparse_pack(self, grads: dict, rows_addr: int, first: int, count: int, msg, sh_degree: int = 3):
+        """lcgs_sparse_pack: rows [first, first + count) of the touched list -> one message (a float32 tensor of
+        sparse_message_words(count) elements)"""
+        g = _Grads(*[_ptr(grads[k]) for k in _KEYS])
+        _check(load_library().lcgs_sparse_pack(self.ctx._h, C.c_int(sh_degree), C.byref(g), C.c_void_p(rows_addr + 4 * first),
+                                               C.c_int64(count), _ptr(msg)))
+
+    def sparse_accumulate(self, grads: dict, msg, count: int, sh_degree: int = 3):
+        """lcgs_sparse_accumulate: add a received message's rows to the dense gradient rows"""
+        g = _Grads(*[_ptr(grads[k]) for k in _KEYS])
+        _check(load_library().lcgs_sparse_accumulate(self.ctx._h, C.c_int(sh_degree), C.byref(g), _ptr(msg), C.c_int64(count)))
+
+
+def sparse_message_words(count: int, sh_degree: int = 3) -> int:
+    """4-byte words of a sparse-exchange message of `count` rows: indices + the five attribute blocks"""
+    return count * (1 + 3 + 3 + 4 + (sh_degree + 1) ** 2 * 3 + 1)
+
+
+class _SparseRows(C.Structure):
+    _fields_ = [("d_rows", C.c_void_p), ("num_rows", C.c_int64), ("owner_first", C.c_int64 * 66)]
+
+
+class _CommStats(C.Structure):
+    _fields_ = [("bytes_sent", C.c_int64), ("bytes_received", C.c_int64), ("touched_rows", C.c_int64),
+                ("collective_groups", C.c_int)]
 
 
 def render_autograd(renderer: "Renderer", cam: Camera, pos, scale, rotq, sh, opacity, bg=(0.0, 0.0, 0.0),

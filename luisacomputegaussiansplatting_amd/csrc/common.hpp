@@ -46,6 +46,7 @@ CamParams make_cam_params(const lcgs_camera& cam);
 
 // stream of an (opaque) context, for translation units that only see the forward declaration
 hipStream_t context_stream(lcgs_context* ctx);
+int         context_device(lcgs_context* ctx);
 
 // what the device ingest path needs to know about a PLY file (host/ply.cpp)
 struct PlyProbe {

@@ -13,6 +13,9 @@ constexpr int kMaxEvents    = LCGS_MAX_STAGES + 1;
 constexpr int kMaxGradSlices = 16; // splat-range slices of the dense gradient rows (chunked all-reduce)
 // (host/comm.cpp) a context that goes away before its communicator: the communicator forgets it
 void comm_forget_context(lcgs_comm* comm);
+// (host/comm.cpp) sparse exchange: a dense backward flags the rows of the frame it has just differentiated
+lcgs_status comm_mark_touched(lcgs_comm* comm, const uint32_t* vis_index, const uint32_t* d_counts, int64_t P, int64_t hint_V,
+                              bool accumulate, hipStream_t stream);
 } // namespace lcgs
 
 using lcgs::CamParams;

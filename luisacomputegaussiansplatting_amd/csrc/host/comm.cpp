@@ -47,6 +47,8 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t)            = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)                    = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)                          = nullptr;
     ncclResult_t (*GroupStart)()                                                                              = nullptr;
     ncclResult_t (*GroupEnd)()                                                                                = nullptr;
     const char* (*GetErrorString)(ncclResult_t)                                                               = nullptr;
@@ -82,6 +84,8 @@ RcclApi& rccl()
         bind(api.AllReduce, "ncclAllReduce");
         bind(api.ReduceScatter, "ncclReduceScatter");
         bind(api.AllGather, "ncclAllGather");
+        bind(api.Send, "ncclSend");
+        bind(api.Recv, "ncclRecv");
         bind(api.GroupStart, "ncclGroupStart");
         bind(api.GroupEnd, "ncclGroupEnd");
         bind(api.GetErrorString, "ncclGetErrorString");
@@ -146,6 +150,13 @@ struct lcgs_comm {
     // opt-in f16 transport (lcgs_comm_set_transport): staging for the packed gradients and the five scales
     int          transport = LCGS_TRANSPORT_F32;
     DeviceBuffer packed, scales; // 59 P halfs; 5 magnitudes | 5 scales | 5 inverses (floats)
+    int          device = 0;     // (kept beyond the context's life: lcgs_comm_destroy selects it)
+    // sparse exchange (lcgs_adam_step_sparse): touched-row flags of the current step, their compaction, the messages
+    bool         track_rows = false;
+    int64_t      flags_P    = 0;     // rows the flag array covers
+    DeviceBuffer flags, chunk_ws, rows, bounds, matrix, sendbuf, recvbuf; // bounds: [world + 2] positions + [1] total
+    uint32_t*    h_matrix = nullptr; // pinned: world x (world + 2) positions (row r = rank r's owner bounds)
+    lcgs_comm_stats stats{};
 };
 
 namespace lcgs
@@ -157,6 +168,68 @@ void comm_forget_context(lcgs_comm* c)
     c->ctx = nullptr;
 }
 } // namespace lcgs
+
+namespace
+{
+size_t row_bytes(int sh_degree) { return (size_t)(3 + 3 + 4 + (sh_degree + 1) * (sh_degree + 1) * 3 + 1) * 4; }
+
+// lcgs_adam_step on the rank's own rows [first, first + count) and on the tail rows every rank keeps (fewer than N)
+lcgs_status adam_own_rows(lcgs_context* ctx, lcgs_comm* c, int64_t P, int sh_degree, const lcgs_adam_config* cfg,
+                          const AttrRows& g, const lcgs_params* raw, const lcgs_params* m, const lcgs_params* v,
+                          const lcgs_params* activated)
+{
+    int64_t first = 0, count = 0;
+    lcgs_comm_shard_rows(P, c->world, c->rank, &first, &count);
+    const int64_t tail0 = count * c->world, tail = P - tail0;
+    auto sub = [&](const lcgs_params* p, int64_t row) {
+        const AttrRows a = attr_rows(p, sh_degree);
+        lcgs_params    o;
+        o.pos = a.ptr[0] + (size_t)row * a.width[0]; o.scale = a.ptr[1] + (size_t)row * a.width[1];
+        o.rotq = a.ptr[2] + (size_t)row * a.width[2]; o.sh = a.ptr[3] + (size_t)row * a.width[3];
+        o.opacity = a.ptr[4] + (size_t)row * a.width[4];
+        return o;
+    };
+    auto step_rows = [&](int64_t row, int64_t rows) -> lcgs_status {
+        if (rows <= 0) return LCGS_OK;
+        lcgs_grads gg = { g.ptr[0] + (size_t)row * g.width[0], g.ptr[1] + (size_t)row * g.width[1],
+                          g.ptr[2] + (size_t)row * g.width[2], g.ptr[3] + (size_t)row * g.width[3],
+                          g.ptr[4] + (size_t)row * g.width[4] };
+        const lcgs_params r_ = sub(raw, row), m_ = sub(m, row), v_ = sub(v, row), a_ = sub(activated, row);
+        return lcgs_adam_step(ctx, (int)rows, sh_degree, cfg, &gg, &r_, &m_, &v_, &a_);
+    };
+    LCGS_TRY(step_rows(first, count));
+    return step_rows(tail0, tail);
+}
+
+// all-gather of the refreshed ACTIVATED rows (what every rank's renderer reads).  Raw parameters and moments stay
+// authoritative on their owner only (plus the tail everywhere).
+lcgs_status allgather_activated(lcgs_context* ctx, lcgs_comm* c, int64_t P, int sh_degree, const AttrRows& act)
+{
+    int64_t first = 0, count = 0;
+    lcgs_comm_shard_rows(P, c->world, c->rank, &first, &count);
+    LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
+    LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    if (count > 0) {
+        LCGS_RCCL_CHECK(rccl().GroupStart());
+        for (int i = 0; i < 5; ++i) {
+            ncclResult_t r = rccl().AllGather(act.ptr[i] + (size_t)first * act.width[i], act.ptr[i],
+                                              (size_t)count * act.width[i], ncclFloat32, c->comm, c->stream);
+            if (r != ncclSuccess) {
+                (void)rccl().GroupEnd();
+                return rccl_fail(r, "ncclAllGather", __LINE__);
+            }
+        }
+        LCGS_RCCL_CHECK(rccl().GroupEnd());
+        c->stats.collective_groups += 1;
+        const int64_t b = (int64_t)((uint64_t)(c->world - 1) * (uint64_t)count * row_bytes(sh_degree));
+        c->stats.bytes_sent += b;
+        c->stats.bytes_received += b;
+    }
+    LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
+    LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
+    return LCGS_OK;
+}
+} // namespace
 
 extern "C" {
 
@@ -184,13 +257,15 @@ lcgs_status lcgs_comm_create(lcgs_context* ctx, const lcgs_comm_id* id, int rank
     LCGS_REQUIRE(ctx && id && out, "NULL argument");
     *out = nullptr;
     LCGS_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "rank / world_size out of range");
+    LCGS_REQUIRE(world_size <= LCGS_MAX_RANKS, "world_size above LCGS_MAX_RANKS");
     LCGS_REQUIRE(ctx->comm == nullptr, "the context already has a communicator attached");
     LCGS_TRY(need_rccl());
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     lcgs_comm* c = new (std::nothrow) lcgs_comm();
     if (!c) return LCGS_ERR_OUT_OF_MEMORY;
-    c->ctx   = ctx;
-    c->rank  = rank;
+    c->ctx    = ctx;
+    c->device = ctx->device;
+    c->rank   = rank;
     c->world = world_size;
     // highest dispatch priority: the collective's workgroups should get their slots as soon as a chunk is ready, not queue
     // behind the backward's remaining slices (the auxiliary stream of the context has the LOWEST, for the opposite reason)
@@ -224,8 +299,8 @@ lcgs_status lcgs_comm_create(lcgs_context* ctx, const lcgs_comm_id* id, int rank
 lcgs_status lcgs_comm_destroy(lcgs_comm* c)
 {
     if (!c) return LCGS_OK;
+    (void)hipSetDevice(c->device); // (also after the context has gone: comm_forget_context)
     if (c->ctx) {
-        (void)hipSetDevice(c->ctx->device);
         if (c->ctx->comm == c) {
             c->ctx->comm        = nullptr;
             c->ctx->grad_slices = 1;
@@ -235,6 +310,8 @@ lcgs_status lcgs_comm_destroy(lcgs_comm* c)
     if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
     c->packed.release();
     c->scales.release();
+    for (DeviceBuffer* b : { &c->flags, &c->chunk_ws, &c->rows, &c->bounds, &c->matrix, &c->sendbuf, &c->recvbuf }) b->release();
+    if (c->h_matrix) (void)hipHostFree(c->h_matrix);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_out) (void)hipEventDestroy(c->ev_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -301,15 +378,22 @@ lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* c, int num_gaussi
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
         return LCGS_OK;
     }
-    // chunks = the slices the last dense backward recorded for these very arrays; else one chunk behind the stream's tail
-    const bool chunked = ctx->slices_recorded > 1 && ctx->slices_of == (const void*)grads->d_dL_dpos && ctx->P == num_gaussians;
-    const int  K       = chunked ? ctx->slices_recorded : 1;
-    if (!chunked) {
-        LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
-        LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
-    }
+    // The NUMBER and the row ranges of the chunks come from values every rank shares (P, the slice count set when the
+    // communicator was created) -- never from what this rank happened to do before the call: a rank without a view in
+    // the last round of a batch, or with an empty frame, has run no backward and must still issue the very same
+    // sequence of collectives as its peers (RCCL: mismatched counts are undefined behaviour).  Only what a chunk WAITS
+    // for is local: the event of the backward slice that produced its rows when those events belong to these arrays,
+    // else the tail of the context's stream.
+    const int  K         = (ctx->grad_slices > 1 && P >= 4096) ? ctx->grad_slices : 1; // (render_backward's own rule)
+    const bool by_slice  = K > 1 && ctx->slices_recorded == K && ctx->slices_of == (const void*)grads->d_dL_dpos &&
+                          ctx->P == num_gaussians;
+    LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
+    if (!by_slice) LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    c->stats = lcgs_comm_stats{};
     for (int k = 0; k < K; ++k) {
-        if (chunked) LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, ctx->ev_slice[k], 0));
+        if (by_slice) LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, ctx->ev_slice[k], 0));
+        // the last chunk also waits for whatever was enqueued on the context's stream behind the backward
+        if (by_slice && k == K - 1) LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
         const int64_t r0 = (int64_t)(((uint64_t)P * (uint64_t)k) / (uint64_t)K);       // (k_slice_bounds' split)
         const int64_t r1 = (int64_t)(((uint64_t)P * (uint64_t)(k + 1)) / (uint64_t)K);
         if (r1 <= r0) continue;
@@ -323,6 +407,12 @@ lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* c, int num_gaussi
             }
         }
         LCGS_RCCL_CHECK(rccl().GroupEnd());
+        c->stats.collective_groups += 1;
+    }
+    {
+        size_t row = 0;
+        for (int i = 0; i < 5; ++i) row += a.width[i] * 4;
+        c->stats.bytes_sent = c->stats.bytes_received = (int64_t)(2 * (uint64_t)(c->world - 1) * (uint64_t)P * row / (uint64_t)c->world);
     }
     ctx->slices_recorded = 0; // consumed
     // whatever the caller enqueues next on the context's stream (the optimiser) sees the sums
@@ -371,45 +461,220 @@ lcgs_status lcgs_adam_step_sharded(lcgs_context* ctx, lcgs_comm* c, int num_gaus
     LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
     LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
 
-    // ---- 2. Adam on the own rows (and on the tail, identically on every rank): lcgs_adam_step on row sub-ranges
-    auto sub = [&](const lcgs_params* p, int64_t row) {
-        const AttrRows a = attr_rows(p, sh_degree);
-        lcgs_params    o;
-        o.pos = a.ptr[0] + (size_t)row * a.width[0]; o.scale = a.ptr[1] + (size_t)row * a.width[1];
-        o.rotq = a.ptr[2] + (size_t)row * a.width[2]; o.sh = a.ptr[3] + (size_t)row * a.width[3];
-        o.opacity = a.ptr[4] + (size_t)row * a.width[4];
-        return o;
-    };
-    auto step_rows = [&](int64_t row, int64_t rows) -> lcgs_status {
-        if (rows <= 0) return LCGS_OK;
-        lcgs_grads gg = { g.ptr[0] + (size_t)row * g.width[0], g.ptr[1] + (size_t)row * g.width[1],
-                          g.ptr[2] + (size_t)row * g.width[2], g.ptr[3] + (size_t)row * g.width[3],
-                          g.ptr[4] + (size_t)row * g.width[4] };
-        const lcgs_params r_ = sub(raw, row), m_ = sub(m, row), v_ = sub(v, row), a_ = sub(activated, row);
-        return lcgs_adam_step(ctx, (int)rows, sh_degree, cfg, &gg, &r_, &m_, &v_, &a_);
-    };
-    LCGS_TRY(step_rows(first, count));
-    LCGS_TRY(step_rows(tail0, tail));
+    c->stats                   = lcgs_comm_stats{};
+    c->stats.collective_groups = 1;
+    c->stats.bytes_sent = c->stats.bytes_received = (int64_t)((uint64_t)(N - 1) * (uint64_t)count * row_bytes(sh_degree));
 
-    // ---- 3. all-gather of the refreshed ACTIVATED rows (what every rank's renderer reads).  Raw parameters and moments
-    // stay authoritative on their owner only (plus the tail everywhere).
+    // ---- 2. Adam on the own rows (and on the tail, identically on every rank); 3. all-gather of the ACTIVATED rows
+    LCGS_TRY(adam_own_rows(ctx, c, P, sh_degree, cfg, g, raw, m, v, activated));
+    return allgather_activated(ctx, c, P, sh_degree, act);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Sparse gradient exchange (round 3).  Dense rows stay the layout; what crosses xGMI in the REDUCE half of the step is
+// only what a rank's views touched: rank r hands owner o the touched rows of o's shard (indices + 59 floats each),
+// the owner adds them to its own rows in rank order, runs Adam on its shard and the refreshed activated rows are
+// all-gathered as in the sharded step.  Exact in f32 up to the order of the sum.
+// ------------------------------------------------------------------------------------------------------------------
+lcgs_status lcgs_comm_track_touched_rows(lcgs_comm* c, int enable)
+{
+    LCGS_REQUIRE(c != nullptr, "comm is NULL");
+    c->track_rows = enable != 0;
+    c->flags_P    = 0; // the next marking backward starts from a cleared array
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_comm_get_stats(const lcgs_comm* c, lcgs_comm_stats* out)
+{
+    LCGS_REQUIRE(c && out, "NULL argument");
+    *out = c->stats;
+    return LCGS_OK;
+}
+
+int64_t lcgs_sparse_message_words(int64_t count, int sh_degree) { return sparse_message_words(count, sh_degree); }
+
+lcgs_status lcgs_sparse_pack(lcgs_context* ctx, int sh_degree, const lcgs_grads* grads, const uint32_t* d_rows, int64_t count,
+                             float* d_msg)
+{
+    LCGS_REQUIRE(ctx && grads && (count == 0 || (d_rows && d_msg)) && count >= 0 && sh_degree >= 0 && sh_degree <= 3,
+                 "bad argument");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    float* g[5] = { grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh, grads->d_dL_dopacity };
+    launch_sparse_pack(g, sh_degree, d_rows, count, d_msg, ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_sparse_accumulate(lcgs_context* ctx, int sh_degree, const lcgs_grads* grads, const float* d_msg, int64_t count)
+{
+    LCGS_REQUIRE(ctx && grads && (count == 0 || d_msg) && count >= 0 && sh_degree >= 0 && sh_degree <= 3, "bad argument");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    float* g[5] = { grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh, grads->d_dL_dopacity };
+    launch_sparse_accumulate(g, sh_degree, d_msg, count, ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    return LCGS_OK;
+}
+
+} // extern "C"
+
+namespace
+{
+// flags -> ascending rows + owner bounds, on the context's stream; the flags are consumed (cleared) behind it
+lcgs_status compact_touched(lcgs_context* ctx, lcgs_comm* c, int64_t P, int world)
+{
+    LCGS_REQUIRE(c->track_rows, "lcgs_comm_track_touched_rows(comm, 1) must be set before the step's backward passes");
+    const size_t fb = sparse_flag_bytes(P);
+    if (c->flags_P != P) { // no backward has marked anything for this scene since tracking began: an empty set
+        LCGS_TRY(c->flags.ensure(fb));
+        LCGS_HIP_CHECK(hipMemsetAsync(c->flags.ptr, 0, fb, ctx->stream));
+        c->flags_P = P;
+    }
+    LCGS_TRY(c->chunk_ws.ensure((size_t)sparse_flag_chunks(P) * 4 + 4));
+    LCGS_TRY(c->rows.ensure((size_t)P * 4 + 4));
+    LCGS_TRY(c->bounds.ensure((size_t)(LCGS_MAX_RANKS + 3) * 4));
+    uint32_t* bounds = c->bounds.as<uint32_t>();
+    uint32_t* total  = bounds + LCGS_MAX_RANKS + 2;
+    launch_compact_flags(c->flags.as<uint8_t>(), P, c->chunk_ws.as<uint32_t>(), c->rows.as<uint32_t>(), total, ctx->stream);
+    int64_t first = 0, shard = 0;
+    lcgs_comm_shard_rows(P, world, 0, &first, &shard);
+    // (P < N: shards are empty, every row is a tail row -- the bounds all sit at 0 and the tail starts there)
+    launch_owner_bounds(c->rows.as<uint32_t>(), total, shard, world, bounds, ctx->stream);
+    LCGS_HIP_CHECK(hipMemsetAsync(c->flags.ptr, 0, fb, ctx->stream)); // consumed: the next step starts empty
+    LCGS_HIP_CHECK(hipGetLastError());
+    return LCGS_OK;
+}
+} // namespace
+
+namespace lcgs
+{
+// (lcgs_abi.cpp render_backward) flag the rows of the frame a dense backward has just differentiated
+lcgs_status comm_mark_touched(lcgs_comm* c, const uint32_t* vis_index, const uint32_t* d_counts, int64_t P, int64_t hint_V,
+                              bool accumulate, hipStream_t stream)
+{
+    if (!c || !c->track_rows || P <= 0) return LCGS_OK;
+    const size_t fb = sparse_flag_bytes(P);
+    if (c->flags_P != P || !accumulate) {
+        LCGS_TRY(c->flags.ensure(fb));
+        LCGS_HIP_CHECK(hipMemsetAsync(c->flags.ptr, 0, fb, stream));
+        c->flags_P = P;
+    }
+    launch_mark_rows(vis_index, d_counts, c->flags.as<uint8_t>(), P, hint_V, stream);
+    return LCGS_OK;
+}
+} // namespace lcgs
+
+extern "C" {
+
+lcgs_status lcgs_sparse_touched_rows(lcgs_context* ctx, lcgs_comm* c, int num_gaussians, int world_size, lcgs_sparse_rows* out)
+{
+    LCGS_REQUIRE(ctx && c && out, "NULL argument");
+    LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another context");
+    LCGS_REQUIRE(num_gaussians >= 0 && world_size >= 1 && world_size <= LCGS_MAX_RANKS, "bad num_gaussians / world_size");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    memset(out, 0, sizeof(*out));
+    if (num_gaussians == 0) return LCGS_OK;
+    LCGS_TRY(compact_touched(ctx, c, num_gaussians, world_size));
+    if (!c->h_matrix) LCGS_HIP_CHECK(hipHostMalloc((void**)&c->h_matrix, (size_t)LCGS_MAX_RANKS * (LCGS_MAX_RANKS + 2) * 4, 0));
+    LCGS_HIP_CHECK(hipMemcpyAsync(c->h_matrix, c->bounds.ptr, (size_t)(world_size + 2) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    out->d_rows = c->rows.as<uint32_t>();
+    for (int o = 0; o <= world_size + 1; ++o) out->owner_first[o] = c->h_matrix[o];
+    out->num_rows = out->owner_first[world_size + 1];
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_adam_step_sparse(lcgs_context* ctx, lcgs_comm* c, int num_gaussians, int sh_degree,
+                                  const lcgs_adam_config* cfg, const lcgs_grads* grads, const lcgs_params* raw,
+                                  const lcgs_params* m, const lcgs_params* v, const lcgs_params* activated)
+{
+    LCGS_REQUIRE(ctx && c && cfg && grads && raw && m && v && activated, "NULL argument");
+    LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another context");
+    LCGS_REQUIRE(cfg->visible_only == 0, "the sparse step keeps dense-Adam semantics (every row decays): visible_only must be 0");
+    LCGS_REQUIRE(num_gaussians >= 0 && sh_degree >= 0 && sh_degree <= 3, "bad num_gaussians / sh_degree");
+    if (num_gaussians == 0) return LCGS_OK;
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t  P = num_gaussians;
+    const int      N = c->world, me = c->rank;
+    int64_t        first = 0, count = 0;
+    lcgs_comm_shard_rows(P, N, me, &first, &count);
+    const int64_t  tail0 = count * N, tail = P - tail0;
+    const AttrRows g = attr_rows(grads, sh_degree), act = attr_rows(activated, sh_degree);
+    for (int i = 0; i < 5; ++i) LCGS_REQUIRE(g.ptr[i] && act.ptr[i], "NULL device pointer");
+    ctx->slices_recorded = 0;
+    c->stats             = lcgs_comm_stats{};
+
+    // ---- 1. this rank's touched rows, ascending, and where each owner's shard begins in that list
+    LCGS_TRY(compact_touched(ctx, c, P, N));
+    const int W = N + 2; // positions per rank: N shard starts, the tail's start, the total
+    LCGS_TRY(c->matrix.ensure((size_t)N * W * 4));
+    if (!c->h_matrix) LCGS_HIP_CHECK(hipHostMalloc((void**)&c->h_matrix, (size_t)LCGS_MAX_RANKS * (LCGS_MAX_RANKS + 2) * 4, 0));
     LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
     LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
-    if (count > 0) {
-        LCGS_RCCL_CHECK(rccl().GroupStart());
-        for (int i = 0; i < 5; ++i) {
-            ncclResult_t r = rccl().AllGather(act.ptr[i] + (size_t)first * act.width[i], act.ptr[i],
-                                              (size_t)count * act.width[i], ncclFloat32, c->comm, c->stream);
-            if (r != ncclSuccess) {
-                (void)rccl().GroupEnd();
-                return rccl_fail(r, "ncclAllGather", __LINE__);
-            }
-        }
-        LCGS_RCCL_CHECK(rccl().GroupEnd());
+    // ---- 2. everybody learns everybody's counts (message sizes are host arguments of send / recv): one small
+    //         all-gather + read-back, the step's only host synchronisation
+    LCGS_RCCL_CHECK(rccl().AllGather(c->bounds.ptr, c->matrix.ptr, (size_t)W, ncclUint32, c->comm, c->stream));
+    LCGS_HIP_CHECK(hipMemcpyAsync(c->h_matrix, c->matrix.ptr, (size_t)N * W * 4, hipMemcpyDeviceToHost, c->stream));
+    LCGS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    auto rows_of = [&](int src, int owner) -> int64_t { // rows rank `src` holds for owner's shard
+        return (int64_t)c->h_matrix[src * W + owner + 1] - (int64_t)c->h_matrix[src * W + owner];
+    };
+    c->stats.touched_rows = (int64_t)c->h_matrix[me * W + N + 1];
+    int64_t send_words = 0, recv_words = 0, send_off[LCGS_MAX_RANKS], recv_off[LCGS_MAX_RANKS];
+    for (int o = 0; o < N; ++o) {
+        send_off[o] = send_words;
+        recv_off[o] = recv_words;
+        if (o == me) continue;
+        send_words += sparse_message_words(rows_of(me, o), sh_degree);
+        recv_words += sparse_message_words(rows_of(o, me), sh_degree);
     }
+    LCGS_TRY(c->sendbuf.ensure((size_t)send_words * 4 + 16));
+    LCGS_TRY(c->recvbuf.ensure((size_t)recv_words * 4 + 16));
+
+    // ---- 3. pack one message per peer (context's stream), exchange (communicator's stream); the tail rows -- fewer than
+    //         N, kept by everyone -- are all-reduced densely in the same group
+    float* gp[5] = { g.ptr[0], g.ptr[1], g.ptr[2], g.ptr[3], g.ptr[4] };
+    for (int o = 0; o < N; ++o)
+        if (o != me)
+            launch_sparse_pack(gp, sh_degree, c->rows.as<uint32_t>() + c->h_matrix[me * W + o], rows_of(me, o),
+                               c->sendbuf.as<float>() + send_off[o], ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
+    LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    LCGS_RCCL_CHECK(rccl().GroupStart());
+    {
+        ncclResult_t r = ncclSuccess;
+        for (int o = 0; o < N && r == ncclSuccess; ++o) {
+            if (o == me) continue;
+            const int64_t sw = sparse_message_words(rows_of(me, o), sh_degree), rw = sparse_message_words(rows_of(o, me), sh_degree);
+            if (sw > 0) r = rccl().Send(c->sendbuf.as<float>() + send_off[o], (size_t)sw, ncclFloat32, o, c->comm, c->stream);
+            if (r == ncclSuccess && rw > 0)
+                r = rccl().Recv(c->recvbuf.as<float>() + recv_off[o], (size_t)rw, ncclFloat32, o, c->comm, c->stream);
+        }
+        for (int i = 0; i < 5 && r == ncclSuccess && tail > 0; ++i) {
+            float* t = g.ptr[i] + (size_t)tail0 * g.width[i];
+            r        = rccl().AllReduce(t, t, (size_t)tail * g.width[i], ncclFloat32, ncclSum, c->comm, c->stream);
+        }
+        if (r != ncclSuccess) {
+            (void)rccl().GroupEnd();
+            return rccl_fail(r, "ncclSend / ncclRecv", __LINE__);
+        }
+    }
+    LCGS_RCCL_CHECK(rccl().GroupEnd());
+    c->stats.collective_groups = 2; // the counts, the messages
+    c->stats.bytes_sent        = send_words * 4 + (int64_t)(N - 1) * W * 4;
+    c->stats.bytes_received    = recv_words * 4 + (int64_t)(N - 1) * W * 4;
     LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
     LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
-    return LCGS_OK;
+
+    // ---- 4. the owner adds what it received, message by message in rank order (a fixed order: reproducible sums)
+    for (int o = 0; o < N; ++o)
+        if (o != me) launch_sparse_accumulate(gp, sh_degree, c->recvbuf.as<float>() + recv_off[o], rows_of(o, me), ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+
+    // ---- 5. Adam on the own rows (+ the tail), 6. all-gather of the refreshed ACTIVATED rows: as in the sharded step
+    LCGS_TRY(adam_own_rows(ctx, c, P, sh_degree, cfg, g, raw, m, v, activated));
+    return allgather_activated(ctx, c, P, sh_degree, act);
 }
 
 } // extern "C"

@@ -98,7 +98,9 @@ lcgs_status lcgs_l2_loss_backward(lcgs_context* ctx, int width, int height, cons
     }
     const int64_t n  = (int64_t)width * height * 3;
     hipStream_t   st = lcgs::context_stream(ctx);
-    hipError_t    e  = hipMemsetAsync(d_loss, 0, sizeof(float), st);
+    hipError_t    e  = hipSetDevice(lcgs::context_device(ctx)); // multi-GPU processes: every entry point selects its device
+    if (e != hipSuccess) return lcgs::hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
+    e = hipMemsetAsync(d_loss, 0, sizeof(float), st);
     if (e != hipSuccess) return lcgs::hip_fail(e, "hipMemsetAsync(loss)", __FILE__, __LINE__);
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;

@@ -173,6 +173,19 @@ void launch_absmax(const float* x, size_t n, uint32_t* d_out_bits, hipStream_t s
 void launch_transport_scales(const float* d_absmax5, int world, float* d_scale5, float* d_inv5, hipStream_t stream);
 void launch_pack_f16(const float* x, size_t n, const float* d_scale, uint16_t* out, hipStream_t stream);
 void launch_unpack_f16(const uint16_t* in, size_t n, const float* d_inv, float* x, hipStream_t stream);
+// comm_sparse.hip: the sparse gradient exchange (touched-row flags -> ascending row list -> per-owner messages)
+size_t   sparse_flag_bytes(int64_t P);
+uint32_t sparse_flag_chunks(int64_t P);
+void     launch_mark_rows(const uint32_t* vis_index, const uint32_t* d_counts, uint8_t* flags, int64_t P, int64_t hint_V,
+                          hipStream_t stream);
+void     launch_compact_flags(const uint8_t* flags, int64_t P, uint32_t* chunk_ws, uint32_t* rows, uint32_t* d_total,
+                              hipStream_t stream);
+void     launch_owner_bounds(const uint32_t* rows, const uint32_t* d_total, int64_t shard, int world, uint32_t* d_bounds,
+                             hipStream_t stream);
+int64_t  sparse_message_words(int64_t count, int sh_degree);
+void     launch_sparse_pack(float* const grads[5], int sh_degree, const uint32_t* rows, int64_t count, float* msg,
+                            hipStream_t stream);
+void     launch_sparse_accumulate(float* const grads[5], int sh_degree, const float* msg, int64_t count, hipStream_t stream);
 
 // ---- backward.hip ----
 size_t grads2d_bytes(int64_t V_cap);

@@ -289,6 +289,20 @@ public:
     {
         check(lcgs_adam_step_sharded(m_dev->ctx(), m_comm, num_gaussians, sh_degree, &cfg, &grads, &raw, &m, &v, &activated));
     }
+    // the same step with a sparse reduce half: only the rows this rank's views touched travel to their owners
+    // (track_touched_rows(true) on every rank before the step's backward passes)
+    void track_touched_rows(bool enable) { check(lcgs_comm_track_touched_rows(m_comm, enable ? 1 : 0)); }
+    void adam_step_sparse(int num_gaussians, const lcgs_adam_config& cfg, const lcgs_grads& grads, const lcgs_params& raw,
+                          const lcgs_params& m, const lcgs_params& v, const lcgs_params& activated, int sh_degree = 3)
+    {
+        check(lcgs_adam_step_sparse(m_dev->ctx(), m_comm, num_gaussians, sh_degree, &cfg, &grads, &raw, &m, &v, &activated));
+    }
+    lcgs_comm_stats stats() const
+    {
+        lcgs_comm_stats st;
+        check(lcgs_comm_get_stats(m_comm, &st));
+        return st;
+    }
     lcgs_comm* handle() const { return m_comm; }
 
 private:

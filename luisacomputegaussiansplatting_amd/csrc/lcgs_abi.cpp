@@ -85,6 +85,7 @@ inline int ceil_log2_u32(uint32_t v)
 namespace lcgs
 {
 hipStream_t context_stream(lcgs_context* ctx) { return ctx->stream; }
+int         context_device(lcgs_context* ctx) { return ctx->device; }
 } // namespace lcgs
 
 namespace
@@ -1415,6 +1416,10 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
     }
     ctx->slices_recorded = sliced ? slices : 0;
     ctx->slices_of       = sliced ? grads->d_dL_dpos : nullptr;
+    // sparse exchange (opt-in, lcgs_comm_track_touched_rows): the rows this frame wrote join the step's touched set
+    if (!compact && ctx->comm)
+        LCGS_TRY(lcgs::comm_mark_touched(ctx->comm, ctx->vis_index.as<uint32_t>(), ctx->counts.as<uint32_t>(), (int64_t)P,
+                                         ctx->hint_V, accumulate, st));
     LCGS_TRY(mark(ctx, "preprocess_backward"));
     LCGS_HIP_CHECK(hipGetLastError());
     if (ctx->profiling) {

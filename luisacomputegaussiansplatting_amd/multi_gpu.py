@@ -9,6 +9,12 @@ the ranks and the optimiser step is applied -- in one of two exact (f32) ways:
   mode "sharded"     lcgs_adam_step_sharded: reduce-scatter -> Adam on the rank's own rows (+ the < N tail rows) ->
                      all-gather of the refreshed activated arrays.  Same bytes on the wire, 1/N of the optimiser work.
 
+  mode "sparse"      lcgs_adam_step_sparse: like "sharded", but the REDUCE half carries only the rows this rank's views
+                     touched (a view sees 39 % of the bicycle stand-in's splats): each rank sends a row's owner the
+                     touched rows of the owner's shard -- indices + 59 floats each -- the owner adds them in rank order,
+                     runs Adam on its shard, and the refreshed activated rows are all-gathered.  Dense-Adam semantics
+                     (rows nobody touched still decay their moments), exact up to the order of the f32 sums.
+
 The reference has no counterpart (single device, app/main.cpp:162-163).
 
 Three pluggable parts keep ONE protocol for the product and for its CPU tests:
@@ -45,6 +51,17 @@ def allreduce_bus_bytes_per_gpu(num_gaussians: int, world_size: int) -> int:
     return 2 * (world_size - 1) * s // world_size
 
 
+def sparse_bus_bytes_per_gpu(num_gaussians: int, world_size: int, touched_rows: int) -> int:
+    """Expected bytes one GPU SENDS per sparse step when its views touched `touched_rows` rows spread evenly over the
+    shards: (N-1)/N of them travel to their owners as (1 + 59) words each, then the dense all-gather of the refreshed
+    activated rows ((N-1)/N S, as in the sharded step).  (The measured figure comes from lcgs_comm_get_stats.)"""
+    if world_size <= 1:
+        return 0
+    reduce_half = (world_size - 1) * touched_rows * (GRAD_FLOATS_PER_SPLAT + 1) * 4 // world_size
+    gather_half = (world_size - 1) * (num_gaussians // world_size) * GRAD_FLOATS_PER_SPLAT * 4
+    return reduce_half + gather_half
+
+
 # ------------------------------------------------------------------------------------------------ collectives
 class RcclCollective:
     """The product path: RCCL over xGMI through the C ABI (lcgs_comm_*), on the communicator's own HIP stream."""
@@ -60,6 +77,14 @@ class RcclCollective:
 
     def sharded_adam(self, engine, grads: dict, step: int):
         engine.adam_sharded(self.comm, grads, step)
+
+    def prepare(self, mode: str):
+        """collective call on trainer construction: the sparse step needs the backward passes to flag their rows"""
+        self.comm.track_touched_rows(mode == "sparse")
+
+    def sparse_adam(self, engine, grads: dict, step: int):
+        engine.adam_sparse(self.comm, grads, step)
+        self.last_stats = self.comm.stats()
 
     def close(self):
         self.comm.close()
@@ -100,6 +125,71 @@ class TorchCollective:
                 self.dist.all_gather(parts, mine)
                 for r, part in enumerate(parts):
                     act[r * count:(r + 1) * count] = part
+
+    def prepare(self, mode: str):
+        pass
+
+    def sparse_adam(self, engine, grads: dict, step: int):
+        """The protocol of lcgs_adam_step_sparse (csrc/host/comm.cpp) over a process group.  The engine supplies the
+        three device stages -- touched rows, pack, accumulate -- (HipEngine: the C ABI's lcgs_sparse_*; the CPU tests:
+        a numpy restatement); this method is the exchange: counts by all_gather, one message per peer by send / recv."""
+        import torch
+
+        dist, N, me = self.dist, self.world_size, self.rank
+        P = int(grads["pos"].shape[0])
+        first, count = api.shard_rows(P, N, me)
+        tail0 = count * N
+        handle, owner_first = engine.sparse_touched_rows(grads, N, me)  # ascending rows; positions of the shard starts
+        dev = grads["pos"].device
+        mine = torch.tensor(owner_first, dtype=torch.int64, device=dev)
+        table = [torch.empty_like(mine) for _ in range(N)]
+        dist.all_gather(table, mine)
+        table = [t.tolist() for t in table]
+        rows_of = lambda src, owner: table[src][owner + 1] - table[src][owner]
+        sends, recvs, ops = {}, {}, []
+        for o in range(N):
+            if o == me:
+                continue
+            n_out, n_in = rows_of(me, o), rows_of(o, me)
+            if n_out > 0:
+                sends[o] = torch.empty(api.sparse_message_words(n_out), dtype=torch.float32, device=dev)
+                engine.sparse_pack(grads, handle, owner_first[o], n_out, sends[o])
+            if n_in > 0:
+                recvs[o] = torch.empty(api.sparse_message_words(n_in), dtype=torch.float32, device=dev)
+        engine.flush()  # the messages are complete before the transport reads them
+        for o in range(N):
+            if o in sends:
+                ops.append(dist.P2POp(dist.isend, sends[o], o))
+            if o in recvs:
+                ops.append(dist.P2POp(dist.irecv, recvs[o], o))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if P > tail0:  # the < N tail rows every rank keeps: summed densely
+            for k in KEYS:
+                t = grads[k][tail0:].contiguous()
+                dist.all_reduce(t)
+                grads[k][tail0:] = t
+        for o in range(N):  # rank order: a fixed order of the f32 sums
+            if o in recvs:
+                engine.sparse_accumulate(grads, recvs[o], rows_of(o, me))
+        self.last_stats = {"bytes_sent": 4 * sum(int(t.numel()) for t in sends.values()),
+                           "bytes_received": 4 * sum(int(t.numel()) for t in recvs.values()),
+                           "touched_rows": owner_first[N + 1]}
+        engine.adam(grads, step, rows=(first, count))
+        engine.adam(grads, step, rows=(tail0, P - tail0))
+        if count > 0:
+            gathered = 0
+            for k in KEYS:
+                act = engine.activated[k]
+                own = act[first:first + count].contiguous()
+                parts = [torch.empty_like(own) for _ in range(N)]
+                dist.all_gather(parts, own)
+                for r, part in enumerate(parts):
+                    act[r * count:(r + 1) * count] = part
+                gathered += own.numel() * 4 * (N - 1)
+            self.last_stats["bytes_sent"] += gathered
+            self.last_stats["bytes_received"] += gathered
 
     def close(self):
         pass
@@ -147,6 +237,42 @@ class HipEngine:
     def adam_sharded(self, comm: "api.Comm", grads: dict, step: int):
         comm.adam_step_sharded(grads, self.raw, self.m, self.v, self.activated, step, self.lr, self.betas, self.eps)
 
+    def adam_sparse(self, comm: "api.Comm", grads: dict, step: int):
+        comm.adam_step_sparse(grads, self.raw, self.m, self.v, self.activated, step, self.lr, self.betas, self.eps)
+
+    # The stages of the sparse exchange one by one, for a transport that is not RCCL-behind-the-C-ABI (TorchCollective).
+    # The touched set is kept by a communicator object attached to the context: the RcclCollective's own, or -- for
+    # another transport -- a world-size-1 communicator that only serves as the context's row tracker.
+    _tracker = None
+    _own_tracker = False
+
+    def prepare(self, mode: str, collective):
+        """called by ViewParallelTrainer: make the backward passes flag their rows when (and only when) the step is sparse"""
+        if isinstance(collective, RcclCollective):
+            self._tracker = collective.comm  # (RcclCollective.prepare switches the tracking itself)
+            return
+        if mode == "sparse" and self._tracker is None:
+            self._tracker, self._own_tracker = api.Comm(self.r.ctx, 0, 1), True
+        if self._tracker is not None:
+            self._tracker.track_touched_rows(mode == "sparse")
+
+    def close(self):
+        if self._own_tracker and self._tracker is not None:
+            self._tracker.close()
+        self._tracker, self._own_tracker = None, False
+
+    def sparse_touched_rows(self, grads: dict, world_size: int, rank: int):
+        return self._tracker.sparse_touched_rows(int(grads["pos"].shape[0]), world_size)
+
+    def sparse_pack(self, grads: dict, handle, first: int, count: int, msg):
+        self._tracker.sparse_pack(grads, handle, first, count, msg)
+
+    def sparse_accumulate(self, grads: dict, msg, count: int):
+        self._tracker.sparse_accumulate(grads, msg, count)
+
+    def flush(self):
+        self.r.ctx.synchronize()
+
 
 # ------------------------------------------------------------------------------------------------ protocol
 class ViewParallelTrainer:
@@ -156,7 +282,7 @@ class ViewParallelTrainer:
                  views_per_step: int = 1):
         """views_per_step: views each rank renders (and whose gradients it accumulates) per optimiser step -- one
         collective per step, so B views per GPU amortise the gradient exchange B times."""
-        if mode not in ("allreduce", "sharded", "local"):
+        if mode not in ("allreduce", "sharded", "sparse", "local"):
             raise ValueError(mode)
         if views_per_step < 1:
             raise ValueError("views_per_step must be >= 1")
@@ -165,6 +291,10 @@ class ViewParallelTrainer:
         self.rank = collective.rank if collective is not None else 0
         self.world_size = collective.world_size if collective is not None else 1
         self.steps_done = 0
+        if collective is not None and hasattr(collective, "prepare"):
+            collective.prepare(mode)
+        if collective is not None and hasattr(engine, "prepare"):
+            engine.prepare(mode, collective)
 
     def camera_for_step(self, step: int):
         return self.cameras[view_of_rank(step, self.rank, self.world_size, len(self.cameras))]
@@ -185,5 +315,8 @@ class ViewParallelTrainer:
                 self.engine.adam(self.grads, self.steps_done)
         else:
             if not optimise:
-                raise ValueError("mode 'sharded' fuses the collective with the optimiser step")
-            self.coll.sharded_adam(self.engine, self.grads, self.steps_done)
+                raise ValueError(f"mode '{self.mode}' fuses the collective with the optimiser step")
+            if self.mode == "sparse":
+                self.coll.sparse_adam(self.engine, self.grads, self.steps_done)
+            else:
+                self.coll.sharded_adam(self.engine, self.grads, self.steps_done)

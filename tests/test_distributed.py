@@ -2,8 +2,8 @@
 (luisacomputegaussiansplatting_amd.multi_gpu: ViewParallelTrainer + TorchCollective + shard_rows / view_of_rank -- the
 very classes bench.py drives over RCCL), with a CPU stand-in for the engine only: the oracle computes a view's gradients
 and a numpy restatement of lcgs_adam_step's arithmetic applies the update (no GPU here).  Checks: the views of a step
-are disjoint and cover the batch; both collective modes ("allreduce", "sharded") leave every rank with the parameters a
-single process gets from the summed gradients; row ownership incl. the P mod N tail; max-over-ranks timing."""
+are disjoint and cover the batch; all three collective modes ("allreduce", "sharded", "sparse" -- the touched-row exchange
+of round 3) leave every rank with the parameters a single process gets from the summed gradients; row ownership incl. the P mod N tail; max-over-ranks timing."""
 import os
 import socket
 import sys
@@ -62,6 +62,7 @@ class OracleEngine:
         self.v = {k: torch.zeros_like(self.raw[k]) for k in KEYS}
         self.dL_of_view = dL_of_view
         self.views_rendered = []
+        self.touched = np.zeros(P, bool)  # rows this rank's views of the current step wrote (the HIP engine: on-screen rows)
 
     def forward_backward(self, cam, dL_dimg, grads, bg=(0.0, 0.0, 0.0), accumulate=False):
         import torch
@@ -70,12 +71,44 @@ class OracleEngine:
         self.views_rendered.append(view)
         scene = {k: self.activated[k].numpy() for k in KEYS}
         g = self.o.render_backward_full(scene, ocam, self.dL_of_view(view))
+        if not accumulate:
+            self.touched[:] = False
         for k in KEYS:
             t = torch.from_numpy(g[k].reshape(grads[k].shape).astype(np.float32))
+            self.touched |= (t.reshape(P, -1) != 0).any(1).numpy()
             if accumulate:
                 grads[k].add_(t)
             else:
                 grads[k].copy_(t)
+
+    # the three device stages of the sparse exchange (csrc/kernels/comm_sparse.hip), restated on CPU tensors
+    def sparse_touched_rows(self, grads, world, rank):
+        rows = np.flatnonzero(self.touched).astype(np.int64)
+        self.touched[:] = False  # consumed
+        c = P // world
+        bounds = [int(np.searchsorted(rows, o * c)) for o in range(world + 1)] + [len(rows)]
+        return rows, bounds
+
+    def sparse_pack(self, grads, rows, first, count, msg):
+        import torch
+
+        idx = rows[first:first + count]
+        parts = [torch.from_numpy(idx.astype(np.int32)).view(torch.float32)]
+        parts += [grads[k].reshape(P, -1)[idx].reshape(-1) for k in KEYS]
+        msg.copy_(torch.cat(parts))
+
+    def sparse_accumulate(self, grads, msg, count):
+        import torch
+
+        idx = msg[:count].view(torch.int32).to(torch.int64)
+        at = count
+        for k in KEYS:
+            w = grads[k].reshape(P, -1).shape[1]
+            grads[k].reshape(P, -1)[idx] += msg[at:at + count * w].reshape(count, w)
+            at += count * w
+
+    def flush(self):
+        pass
 
     def adam(self, grads, step, rows=None, b1=0.9, b2=0.999, eps=1e-15):
         """lcgs_adam_step (csrc/kernels/train.hip) restated: activated-space gradients -> raw-space -> Adam -> activate."""
@@ -129,13 +162,22 @@ def _worker(rank, world, port, out_dir):
     o = Oracle("f32")
     o.set_threads(2)
     cams = [(v, o.lookat(*p, width=W, height=H)) for v, p in enumerate(_poses())]
-    for mode in ("allreduce", "sharded", "allreduce_2views"):
+    stats = {}
+    for mode in ("allreduce", "sharded", "sparse", "allreduce_2views", "sparse_2views"):
         engine = OracleEngine(o, _raw_scene(), _dL)  # the scene is replicated on every rank
         grads = {k: torch.zeros_like(engine.raw[k]) for k in KEYS}
-        if mode == "allreduce_2views":  # two views per rank and optimiser step: gradients accumulate, ONE collective
-            trainer = mg.ViewParallelTrainer(engine, mg.TorchCollective(dist, rank, world), cams, grads, mode="allreduce",
-                                             views_per_step=2)
+        if mode.endswith("_2views"):  # two views per rank and optimiser step: gradients accumulate, ONE collective
+            coll = mg.TorchCollective(dist, rank, world)
+            trainer = mg.ViewParallelTrainer(engine, coll, cams, grads, mode=mode[:-len("_2views")], views_per_step=2)
             trainer.step(None)
+            if mode.startswith("sparse"):
+                stats[mode] = coll.last_stats
+        elif mode == "sparse":
+            coll = mg.TorchCollective(dist, rank, world)
+            trainer = mg.ViewParallelTrainer(engine, coll, cams, grads, mode=mode)
+            for _ in range(STEPS):
+                trainer.step(None)
+            stats[mode] = coll.last_stats
         else:
             trainer = mg.ViewParallelTrainer(engine, mg.TorchCollective(dist, rank, world), cams, grads, mode=mode)
             for _ in range(STEPS):
@@ -143,6 +185,10 @@ def _worker(rank, world, port, out_dir):
         np.savez(os.path.join(out_dir, f"{mode}_{rank}.npz"), views=np.array(engine.views_rendered),
                  **{f"act_{k}": engine.activated[k].numpy() for k in KEYS},
                  **{f"raw_{k}": engine.raw[k].numpy() for k in KEYS})
+    import json
+
+    with open(os.path.join(out_dir, f"stats_{rank}.json"), "w") as f:
+        json.dump(stats, f)
     # bench.py's timing reduction: max over ranks
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -189,8 +235,8 @@ def test_view_parallel_protocol_on_two_gloo_ranks(tmp_path, oracle):
                 total[k] += g[k]
         ref.adam(total, step + 1)
 
-    res = {(m, r): np.load(tmp_path / f"{m}_{r}.npz") for m in ("allreduce", "sharded") for r in range(world)}
-    for m in ("allreduce", "sharded"):
+    res = {(m, r): np.load(tmp_path / f"{m}_{r}.npz") for m in ("allreduce", "sharded", "sparse") for r in range(world)}
+    for m in ("allreduce", "sharded", "sparse"):
         views = np.stack([res[(m, r)]["views"] for r in range(world)], axis=1)  # [step, rank]
         assert views.tolist() == [[0, 1], [2, 3]]  # disjoint per step, the batch covered after STEPS steps
         for r in range(world):
@@ -211,11 +257,21 @@ def test_view_parallel_protocol_on_two_gloo_ranks(tmp_path, oracle):
             total[k] += g[k]
     ref2.adam(total, 1)
     for r in range(world):
-        got = np.load(tmp_path / f"allreduce_2views_{r}.npz")
-        assert got["views"].tolist() == [r, 2 + r]  # micro-step j of the step: view j * world + rank
-        for k in KEYS:
-            b = ref2.activated[k].numpy()
-            assert np.allclose(got[f"act_{k}"], b, rtol=2e-4, atol=2e-6 * np.abs(b).max()), (r, k)
+        for mode2 in ("allreduce_2views", "sparse_2views"):  # (sparse: the touched set is the UNION of the rank's two views)
+            got = np.load(tmp_path / f"{mode2}_{r}.npz")
+            assert got["views"].tolist() == [r, 2 + r]  # micro-step j of the step: view j * world + rank
+            for k in KEYS:
+                b = ref2.activated[k].numpy()
+                assert np.allclose(got[f"act_{k}"], b, rtol=2e-4, atol=2e-6 * np.abs(b).max()), (mode2, r, k)
+    # the sparse step's reduce half moved only touched rows: fewer bytes than the dense reduce-scatter's (N-1)/N S
+    import json
+
+    for r in range(world):
+        st = json.load(open(tmp_path / f"stats_{r}.json"))["sparse"]
+        dense_reduce = (world - 1) * (P // world) * 59 * 4
+        gather = (world - 1) * (P // world) * 59 * 4
+        assert 0 < st["touched_rows"] < P
+        assert st["bytes_sent"] - gather < dense_reduce, st
     # something was learnt (the update is not a no-op)
     assert not np.allclose(ref.activated["opacity"].numpy(), _activate(_raw_scene())["opacity"].astype(np.float32))
     # sharded: raw parameters are authoritative on their owner (and on the tail) only
@@ -225,11 +281,12 @@ def test_view_parallel_protocol_on_two_gloo_ranks(tmp_path, oracle):
     for r in range(world):
         first, count = L.api.shard_rows(P, world, r)
         own = np.r_[first:first + count, count * world:P]
-        for k in ("scale", "opacity", "rotq"):
-            a, b = res[("sharded", r)][f"raw_{k}"][own], ref.raw[k].numpy()[own]
-            assert np.allclose(a, b, rtol=2e-4, atol=2e-6 * np.abs(b).max()), (r, k)
-        other = np.setdiff1d(np.arange(P), own)
-        assert np.array_equal(res[("sharded", r)]["raw_scale"][other], _raw_scene()["scale"][other].astype(np.float32))
+        for m in ("sharded", "sparse"):
+            for k in ("scale", "opacity", "rotq"):
+                a, b = res[(m, r)][f"raw_{k}"][own], ref.raw[k].numpy()[own]
+                assert np.allclose(a, b, rtol=2e-4, atol=2e-6 * np.abs(b).max()), (m, r, k)
+            other = np.setdiff1d(np.arange(P), own)
+            assert np.array_equal(res[(m, r)]["raw_scale"][other], _raw_scene()["scale"][other].astype(np.float32))
 
 
 def _worker_c5(rank, world, port, out_dir):
@@ -250,7 +307,7 @@ def _worker_c5(rank, world, port, out_dir):
     o = Oracle("f32")
     o.set_threads(1)
     cams = [(v, o.lookat(*view_pose(v), width=W, height=H)) for v in range(8)]
-    for mode in ("allreduce", "sharded"):
+    for mode in ("allreduce", "sharded", "sparse"):
         engine = OracleEngine(o, _raw_scene(), _dL)
         grads = {k: torch.zeros_like(engine.raw[k]) for k in KEYS}
         trainer = mg.ViewParallelTrainer(engine, mg.TorchCollective(dist, rank, world), cams, grads, mode=mode)
@@ -282,7 +339,7 @@ def test_c5_shape_eight_ranks_eight_views_on_gloo(tmp_path, oracle):
         for k in KEYS:
             total[k] += g[k]
     ref.adam(total, 1)
-    for mode in ("allreduce", "sharded"):
+    for mode in ("allreduce", "sharded", "sparse"):
         outs = [np.load(tmp_path / f"c5_{mode}_{r}.npz") for r in range(world)]
         assert [o_["views"].tolist() for o_ in outs] == [[r] for r in range(world)]  # one view per rank, all eight covered
         for r in range(world):

@@ -165,7 +165,7 @@ def test_view_parallel_trainer_on_the_hip_engine(lcgs):
             for a in (0.0, 0.4, 0.8)]
     dL = torch.randn(3, 240, 320, device=DEV)
     outs = {}
-    for mode in ("local", "allreduce", "sharded"):
+    for mode in ("local", "allreduce", "sharded", "sparse"):
         raw, act = _raw_act(scene)
         ctx = lcgs.Context(0)
         eng = mg.HipEngine(lcgs.Renderer(ctx), raw, act, LR, eps=1e-8)
@@ -180,7 +180,7 @@ def test_view_parallel_trainer_on_the_hip_engine(lcgs):
             coll.close()
     assert not torch.equal(outs["local"]["opacity"], _raw_act(scene)[0]["opacity"])  # it trained
     lr_of = {"pos": LR["pos"], "scale": LR["scale"], "rotq": LR["rot"], "sh": LR["sh_dc"], "opacity": LR["opacity"]}
-    for mode in ("allreduce", "sharded"):
+    for mode in ("allreduce", "sharded", "sparse"):
         for k in KEYS:
             diff = (outs[mode][k] - outs["local"][k]).abs()
             assert float(diff.max()) <= 2.02 * 4 * lr_of[k], (mode, k, float(diff.max()))
@@ -218,8 +218,9 @@ def test_bench_runs_every_multi_gpu_code_path_on_one_rank(collective):
     assert fb["views_per_gpu_and_step_4"]["value"] > 0 and fb["views_per_gpu_and_step_4"]["views_per_step"] == 4
     assert fb["multi_view_step_4"]["lcgs_fit_views"]["value"] > 0 and fb["multi_view_step_4"]["one_by_one"]["value"] > 0
     assert ("rccl" in fb["collective"]) == (collective == "rccl")
-    assert set(out["train_step"]) == {"allreduce", "sharded"}
+    assert set(out["train_step"]) == {"allreduce", "sharded", "sparse"}
     assert all(v["value"] > 0 for v in out["train_step"].values())
+    assert out["train_step"]["sparse"]["touched_rows"] > 0  # (one rank: every row is its own, nothing crosses the wire)
     assert out["moving_camera"]["value"] > 0 and len(out["moving_camera"]["per_view"]) == 8
     assert "leg_errors" not in out and "error" not in out
 
@@ -258,7 +259,13 @@ def test_bench_with_two_ranks_on_one_gpu_through_the_torch_collective():
     fb = out["fwd_bwd"]
     assert fb["value"] > 0 and fb["without_collective"]["value"] > fb["value"] and fb["moving_camera"]["value"] > 0
     assert fb["views_per_gpu_and_step_4"]["views_per_step"] == 8 and fb["multi_view_step_4"]["lcgs_fit_views"]["value"] > 0
-    assert set(out["train_step"]) == {"allreduce", "sharded"} and all(v["value"] > 0 for v in out["train_step"].values())
+    assert set(out["train_step"]) == {"allreduce", "sharded", "sparse"}
+    assert all(v["value"] > 0 for v in out["train_step"].values())
+    # two real ranks: the sparse step's reduce half carried only the rows the rank's view touched
+    sp = out["train_step"]["sparse"]
+    P_ = 100000
+    assert 0 < sp["touched_rows"] < P_
+    assert sp["xgmi_bytes_sent_per_gpu"] < out["train_step"]["sharded"]["xgmi_bytes_sent_per_gpu"]
 
 
 def test_bench_with_two_ranks_on_one_gpu():
@@ -281,3 +288,179 @@ def test_bench_with_two_ranks_on_one_gpu():
     assert out["camera_batch"]["value"] > 0 and out["moving_camera"]["value"] > 0
     # the communicator of the gradient legs: refused on a shared device -> reported, or (a build that allows it) measured
     assert ("leg_errors" in out) != ("fwd_bwd" in out and "value" in out["fwd_bwd"]), out.get("leg_errors")
+
+
+def test_allreduce_issues_the_same_collectives_whether_or_not_the_rank_ran_a_backward(lcgs):
+    """Collective discipline (RCCL: mismatched counts between ranks are undefined behaviour): the number and the row
+    ranges of the chunks of lcgs_grads_allreduce depend on shared values only (P, the slice count), never on whether THIS
+    rank ran a sliced backward before the call -- a rank without a view in the last round of a batch, or with an empty
+    frame, zero-fills its arrays and must still issue what its peers issue."""
+    rng = np.random.default_rng(5)
+    scene = make_scene(rng, 9000)
+    act = upload_scene(scene)
+    ctx = lcgs.Context(0)
+    r = lcgs.Renderer(ctx)
+    r.bind_scene(*[act[k] for k in KEYS])
+    comm = lcgs.Comm(ctx, 0, 1)
+    cam = lcgs.get_lookat_cam(*POSE, width=160, height=120)
+    img = torch.zeros(3, 120, 160, device=DEV)
+    g = _grads_like(act, 0.0)
+    # a rank that rendered and differentiated its view (sliced backward, chunks behind the slice events)
+    r.forward(cam, img, keep_state=True, sync=True)
+    r.backward(torch.ones(3, 120, 160, device=DEV), *[g[k] for k in KEYS])
+    comm.allreduce_grads(g)
+    ctx.synchronize()
+    with_backward = comm.stats()
+    want = {k: g[k].clone() for k in KEYS}
+    # a rank that had no view this round: zero-filled arrays, no backward (and again with stale slice events of OTHER arrays)
+    z = _grads_like(act, 0.0)
+    comm.allreduce_grads(z)
+    ctx.synchronize()
+    without = comm.stats()
+    assert with_backward["collective_groups"] == without["collective_groups"] == 4  # LCGS_GRAD_SLICES default, P >= 4096
+    assert with_backward["bytes_sent"] == without["bytes_sent"]
+    assert all(float(z[k].abs().max()) == 0.0 for k in KEYS)
+    # work enqueued on the context's stream between the backward and the all-reduce is seen by the LAST chunk at least,
+    # and the sums are what the backward wrote (world size 1: the identity)
+    r.forward(cam, img, keep_state=True, sync=True)
+    r.backward(torch.ones(3, 120, 160, device=DEV), *[g[k] for k in KEYS])
+    comm.allreduce_grads(g)
+    ctx.synchronize()
+    for k in KEYS:
+        assert torch.allclose(g[k], want[k], rtol=1e-4, atol=1e-6 * float(want[k].abs().max()))
+    small = {k: torch.zeros(s, device=DEV) for k, s in zip(KEYS, ((8, 3), (8, 3), (8, 4), (8, 48), (8,)))}
+    comm.allreduce_grads(small)  # P < 4096: one chunk on every rank
+    assert comm.stats()["collective_groups"] == 1
+    comm.close()
+
+
+@pytest.mark.parametrize("world,P", [(4, 30001), (3, 5000), (8, 6)])
+def test_sparse_exchange_stages_with_virtual_ranks(lcgs, world, P):
+    """The device stages of the sparse gradient exchange (csrc/kernels/comm_sparse.hip: mark -> compact -> owner bounds ->
+    pack -> accumulate), with `world` VIRTUAL ranks on the one GPU: every virtual rank differentiates its own view, hands
+    each owner the touched rows of the owner's shard as one message, and the owner adds the messages to its own rows in
+    rank order.  Against the same sum formed densely by torch in the same order: bit-identical on every shard row, and the
+    touched lists are exactly the frames' on-screen rows.  (P = 6 < world: every row is a tail row, no message at all.)"""
+    rng = np.random.default_rng(world * 1000 + P)
+    scene = make_scene(rng, P, log_scale=(-3.6, 0.7))
+    act = upload_scene(scene)
+    ctx = lcgs.Context(0)
+    r = lcgs.Renderer(ctx)
+    r.bind_scene(*[act[k] for k in KEYS])
+    comm = lcgs.Comm(ctx, 0, 1)  # the context's row tracker (its own world is 1; the exchange's world is `world`)
+    comm.track_touched_rows(True)
+    W, H = 200, 152
+    img = torch.zeros(3, H, W, device=DEV)
+    shard = P // world
+    grads, msgs, touched = [], [], []
+    for rk in range(world):
+        a = 0.5 * rk
+        cam = lcgs.get_lookat_cam([-3 * np.cos(a), -0.5 + 3 * np.sin(a), 2.3], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+        g = _grads_like(act, 0.0)
+        r.forward(cam, img, keep_state=True, sync=True)
+        r.backward(torch.randn(3, H, W, device=DEV), *[g[k] for k in KEYS])
+        rows_addr, first = comm.sparse_touched_rows(P, world)
+        assert len(first) == world + 2 and first[0] == 0 and all(first[i] <= first[i + 1] for i in range(world + 1))
+        # the list is the frame's on-screen rows, ascending; its shard segments lie where the bounds say
+        vis = r.visible_rows().cpu().numpy().astype(np.int64)
+        assert first[-1] == len(vis) > 0
+        out = {}
+        for o in range(world):
+            n = first[o + 1] - first[o]
+            assert np.array_equal(np.flatnonzero((vis >= o * shard) & (vis < (o + 1) * shard)), np.arange(first[o], first[o + 1]))
+            m = torch.zeros(lcgs.api.sparse_message_words(n), device=DEV)
+            comm.sparse_pack(g, rows_addr, first[o], n, m)
+            out[o] = (m, n)
+        ctx.synchronize()
+        for o in range(world):
+            m, n = out[o]
+            assert np.array_equal(m[:n].view(torch.int32).cpu().numpy(), vis[first[o]:first[o + 1]])
+        grads.append(g)
+        msgs.append(out)
+        touched.append(vis)
+        # a second query without a backward in between: the set was consumed
+        assert comm.sparse_touched_rows(P, world)[1][-1] == 0
+    for o in range(world):
+        own = {k: grads[o][k].clone() for k in KEYS}
+        ref = {k: grads[o][k].clone() for k in KEYS}
+        for s_ in range(world):
+            if s_ == o:
+                continue
+            m, n = msgs[s_][o]
+            comm.sparse_accumulate(own, m, n)
+            for k in KEYS:
+                ref[k][o * shard:(o + 1) * shard] += grads[s_][k][o * shard:(o + 1) * shard]
+        ctx.synchronize()
+        for k in KEYS:
+            assert torch.equal(own[k][o * shard:(o + 1) * shard], ref[k][o * shard:(o + 1) * shard]), (o, k)
+            # rows outside the owner's shard were not touched by the messages
+            assert torch.equal(own[k][:o * shard], grads[o][k][:o * shard])
+            assert torch.equal(own[k][(o + 1) * shard:], grads[o][k][(o + 1) * shard:])
+    comm.close()
+
+
+def test_accumulated_views_touch_the_union_of_their_rows(lcgs):
+    """lcgs_render_backward starts a new touched set, lcgs_render_backward_accumulate adds to it: after two views of one
+    optimiser step the list is the union of both frames' on-screen rows."""
+    rng = np.random.default_rng(77)
+    P = 12000
+    scene = make_scene(rng, P, log_scale=(-3.6, 0.7))
+    act = upload_scene(scene)
+    ctx = lcgs.Context(0)
+    r = lcgs.Renderer(ctx)
+    r.bind_scene(*[act[k] for k in KEYS])
+    comm = lcgs.Comm(ctx, 0, 1)
+    comm.track_touched_rows(True)
+    W, H = 160, 120
+    img = torch.zeros(3, H, W, device=DEV)
+    g = _grads_like(act, 0.0)
+    sets = []
+    for j, a in enumerate((0.0, 1.2)):
+        cam = lcgs.get_lookat_cam([-3 * np.cos(a), -0.5 + 3 * np.sin(a), 2.3], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+        r.forward(cam, img, keep_state=True, sync=True)
+        r.backward(torch.randn(3, H, W, device=DEV), *[g[k] for k in KEYS], accumulate=j > 0)
+        sets.append(set(r.visible_rows().cpu().numpy().tolist()))
+    addr, first = comm.sparse_touched_rows(P, 2)
+    union = np.array(sorted(sets[0] | sets[1]), np.int64)
+    assert len(sets[0] ^ sets[1]) > 0 and first[-1] == len(union)
+    m = torch.zeros(lcgs.api.sparse_message_words(first[-1]), device=DEV)
+    comm.sparse_pack(g, addr, 0, first[-1], m)
+    ctx.synchronize()
+    assert np.array_equal(m[:first[-1]].view(torch.int32).cpu().numpy(), union)
+    comm.close()
+
+
+@pytest.mark.parametrize("P", [4097, 20000])
+def test_sparse_adam_step_at_world_size_one_equals_the_dense_step(lcgs, P):
+    """lcgs_adam_step_sparse through RCCL itself at world size 1 (counts all-gather, empty exchange, Adam on the own rows
+    = all rows, all-gather): bit-identical to lcgs_adam_step on the same gradients."""
+    rng = np.random.default_rng(P)
+    scene = make_scene(rng, P)
+    results = []
+    for sparse in (False, True):
+        raw, act = _raw_act(scene)
+        m = {k: torch.zeros_like(raw[k]) for k in KEYS}
+        v = {k: torch.zeros_like(raw[k]) for k in KEYS}
+        ctx = lcgs.Context(0)
+        r = lcgs.Renderer(ctx)
+        comm = lcgs.Comm(ctx, 0, 1) if sparse else None
+        if sparse:
+            with pytest.raises(lcgs.LcgsError):  # tracking is opt-in and must be on before the step
+                comm.adam_step_sparse(_grads_like(act, 0.0), raw, m, v, act, 1, LR, eps=1e-8)
+            comm.track_touched_rows(True)
+        for step in (1, 2):
+            g = {k: torch.from_numpy(np.random.default_rng(step).normal(size=tuple(raw[k].shape)).astype(np.float32)).to(DEV)
+                 for k in KEYS}
+            if sparse:
+                comm.adam_step_sparse(g, raw, m, v, act, step, LR, eps=1e-8)
+                assert comm.stats()["touched_rows"] == 0  # no backward ran: nothing was flagged (and nothing needed: N = 1)
+            else:
+                r.adam_step(g, raw, m, v, act, step, LR, eps=1e-8)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        results.append((raw, m, v, act))
+        if comm is not None:
+            comm.close()
+    for a, b in zip(*results):
+        for k in KEYS:
+            assert torch.equal(a[k], b[k]), k
