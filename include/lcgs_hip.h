@@ -252,9 +252,9 @@ typedef struct lcgs_frame_stats {
     int64_t num_rendered;
     int64_t num_pairs;
     int64_t num_tiles;
-    int64_t equal_depth_unresolved; /* re-ordered scenes only: splats in runs of more than 4096 EXACTLY equal depths, which keep
-                                     * the context's order instead of the file's (0 for any scene that is not a plane seen
-                                     * head-on; see lcgs_scene_reorder_spatial) */
+    int64_t equal_depth_unresolved; /* always 0 since round 3: runs of EXACTLY equal depths of any length are blended in file
+                                     * order in a re-ordered scene too (runs beyond 4096 members are sorted through global
+                                     * scratch; see lcgs_scene_reorder_spatial).  Kept for ABI stability. */
 } lcgs_frame_stats;
 LCGS_API lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* out);
 
@@ -303,8 +303,7 @@ LCGS_API lcgs_status lcgs_visible_rows(lcgs_context* ctx, const uint32_t** d_row
  * may be NULL); every per-splat output of later calls (radii, gradients, lcgs_visible_rows) follows the new order,
  * lcgs_scene_pointers returns the new arrays.  Images are unchanged: the blend order is by depth, and splats of exactly
  * equal depth are still blended in ascending FILE index like the reference (a pass behind the depth sort restores that
- * order inside every run of equal depth keys of up to 4096 splats; longer runs -- thousands of splats at one depth -- keep
- * the new order and are counted in lcgs_frame_stats.equal_depth_unresolved).  Why: the splats of a view then sit in long runs
+ * order inside every run of equal depth keys, of any length).  Why: the splats of a view then sit in long runs
  * of consecutive rows instead of being scattered over every DRAM page (bicycle stand-in: +4 % forward frames/s,
  * +20 % forward+backward, +28 % on-screen-only training step).  Synchronises the context's stream. */
 LCGS_API lcgs_status lcgs_scene_reorder_spatial(lcgs_context* ctx, uint32_t* d_perm);

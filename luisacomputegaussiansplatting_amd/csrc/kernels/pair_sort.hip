@@ -508,6 +508,96 @@ __global__ void __launch_bounds__(kThreads) k_scatter(const K* __restrict__ keys
 constexpr uint32_t kTieLane = 8;                   // elements per lane: the whole frame is resident at once
 constexpr uint32_t kTieSpan = kThreads * kTieLane; // elements per workgroup step
 
+// A run of MORE than kTieRunCap equal keys (a plane seen head-on: thousands of splats at exactly one depth), put into
+// file order by its first member's workgroup: a stable LSD radix sort on the members' file indices (8-bit digits, all
+// id_bits of them) through global scratch -- (scratch_k1, vals) and (scratch_k0, scratch_v) ping-pong inside the run's own
+// slot [lo, lo + m), which no other workgroup touches (only a run's first member acts, and a member's value is never
+// read by anybody else; the KEYS of the run are left alone: neighbouring workgroups compare them).  One workgroup, three
+// barriers per 256 members and pass: milliseconds for a run of 100 K -- the price of a pathological frame, paid only by
+// it; every shorter run keeps the paths above.  `s_lds` is the kTieRunCap-word LDS array of the ranked path.
+__device__ void sort_long_run_by_file_index(uint32_t* vals, uint32_t lo, uint32_t m, const TieOrder& tie, uint32_t* s_lds)
+{
+    uint32_t* s_base = s_lds;           // [256] running start of each digit
+    uint32_t* s_hist = s_lds + 256;     // [256]
+    uint32_t* s_wcnt = s_lds + 512;     // [kWaves][256] per-wave digit counts of the current block
+    uint32_t* s_scan = s_lds + 512 + kWaves * 256; // [kWaves]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t id_mask = (1u << tie.id_bits) - 1u;
+    const int      n_pass  = (int)((tie.id_bits + 7u) / 8u);
+    uint32_t*      k0 = tie.scratch_k0 + lo;
+    uint32_t*      k1 = tie.scratch_k1 + lo;
+    uint32_t*      sv = tie.scratch_v + lo;
+    uint32_t*      rv = vals + lo;
+    __syncthreads();
+    for (uint32_t j = tid; j < m; j += kThreads) k1[j] = tie.perm[tie.vis_index[rv[j] & id_mask]]; // the sort keys
+    for (int p = 0; p < n_pass; ++p) {
+        const uint32_t* src_k = (p & 1) ? k0 : k1;
+        const uint32_t* src_v = (p & 1) ? sv : rv;
+        uint32_t*       dst_k = (p & 1) ? k1 : k0;
+        uint32_t*       dst_v = (p & 1) ? rv : sv;
+        const int       shift = 8 * p;
+        s_hist[tid] = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) s_wcnt[w * 256 + tid] = 0;
+        __syncthreads(); // (also: the previous pass's stores are visible to the whole workgroup)
+        for (uint32_t j = tid; j < m; j += kThreads) atomicAdd(&s_hist[(src_k[j] >> shift) & 255u], 1u);
+        __syncthreads();
+        { // exclusive scan of the 256 digit counts: thread d owns digit d
+            const uint32_t own = s_hist[tid];
+            uint32_t       inc = own;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off, 64);
+                if (lane >= (uint32_t)off) inc += o;
+            }
+            if (lane == 63u) s_scan[wave] = inc;
+            __syncthreads();
+            uint32_t carry = 0;
+            for (uint32_t w = 0; w < wave; ++w) carry += s_scan[w];
+            s_base[tid] = carry + inc - own;
+        }
+        __syncthreads();
+        for (uint32_t base = 0; base < m; base += kThreads) { // members in order, 256 at a time: a STABLE scatter
+            const uint32_t j     = base + tid;
+            const bool     valid = j < m;
+            const uint32_t f = valid ? src_k[j] : 0u, v = valid ? src_v[j] : 0u;
+            const uint32_t d = (f >> shift) & 255u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool               bit = (d >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+            }
+            const uint32_t below = __popcll(peers & ((1ull << lane) - 1ull));
+            if (valid && below == 0u) s_wcnt[wave * 256 + d] = (uint32_t)__popcll(peers);
+            __syncthreads();
+            if (valid) {
+                uint32_t at = s_base[d] + below;
+                for (uint32_t w = 0; w < wave; ++w) at += s_wcnt[w * 256 + d];
+                dst_k[at] = f;
+                dst_v[at] = v;
+            }
+            __syncthreads();
+            { // digit tid: advance its start by what this block placed, clear the per-wave counts
+                uint32_t add = 0;
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) {
+                    add += s_wcnt[w * 256 + tid];
+                    s_wcnt[w * 256 + tid] = 0;
+                }
+                s_base[tid] += add;
+            }
+            __syncthreads();
+        }
+    }
+    if (n_pass & 1) { // the last pass landed in the scratch pair
+        __syncthreads();
+        for (uint32_t j = tid; j < m; j += kThreads) rv[j] = sv[j];
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(kThreads) k_fix_equal_depth_order(const uint32_t* __restrict__ keys, uint32_t* vals,
                                                                       uint32_t v_cap, TieOrder tie)
 {
@@ -614,7 +704,8 @@ __global__ void __launch_bounds__(kThreads) k_fix_equal_depth_order(const uint32
             }
             const uint32_t m = s_len;
             if (m > kTieRunCap) {
-                if (tid == 0) atomicAdd(&tie.d_counts[kCountTieUnresolved], m);
+                if (tie.scratch_k0 && tie.scratch_k1 && tie.scratch_v) sort_long_run_by_file_index(vals, lo, m, tie, s_f);
+                else if (tid == 0) atomicAdd(&tie.d_counts[kCountTieUnresolved], m); // (no scratch given: reported)
             } else {
                 uint32_t own[kTieRunCap / kThreads]; // the members this lane ranks (read before anything is written)
 #pragma unroll
@@ -780,8 +871,11 @@ void launch_depth_sort_from_chunks(int64_t P, int64_t v_hint, const uint4* slab,
     if (tie) {
         int64_t blocks = ((v_hint > 0 ? v_hint : P) + kTieSpan - 1) / kTieSpan; // (larger live counts are strided)
         if (blocks > 16384) blocks = 16384;
+        TieOrder t = *tie; // the other half of the ping-pong is free behind the last pass: scratch for runs beyond the cap
+        t.scratch_k0 = keys_b;
+        t.scratch_v  = vals_b;
         hipLaunchKernelGGL(k_fix_equal_depth_order, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(kThreads), 0, stream,
-                           keys_a, vals_a, (uint32_t)P, *tie);
+                           keys_a, vals_a, (uint32_t)P, t);
     }
 }
 

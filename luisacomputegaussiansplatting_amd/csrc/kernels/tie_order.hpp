@@ -12,9 +12,9 @@
 //   * one pass over the sorted keys (k_fix_equal_depth_order, pair_sort.hip) finds the runs; only the first member of a
 //     run does anything, in place: runs of two -- nearly all -- are a compare and a swap, runs of up to kTieRunShort a
 //     selection sort by one lane, runs of up to kTieRunCap members are ranked by their workgroup through LDS; longer
-//     ones stay in the context's order and are counted (lcgs_frame_stats.equal_depth_unresolved): only a scene with
-//     thousands of splats at exactly one depth -- a plane seen head-on by an axis-aligned camera -- gets there, and
-//     LCGS_ORDER_FILE is exact for those.
+//     ones -- thousands of splats at exactly one depth: a plane seen head-on by an axis-aligned camera -- are radix
+//     sorted on their file indices through global scratch by the same workgroup (round 3; until then they stayed in the
+//     context's order and were counted in lcgs_frame_stats.equal_depth_unresolved, which is now always 0).
 // Readers of the sorted order mask the values with (1 << id_bits) - 1.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -35,6 +35,9 @@ struct TieOrder { // (all device pointers)
     const uint32_t* perm      = nullptr; // that index -> file index
     uint32_t        id_bits   = 32;
     uint32_t        tag_shift = 0; // tag = file index >> tag_shift
+    // runs of more than kTieRunCap members are sorted through global scratch (three arrays of >= V words each; the depth
+    // sort supplies the free half of its ping-pong for two of them, the context a third)
+    uint32_t *scratch_k0 = nullptr, *scratch_k1 = nullptr, *scratch_v = nullptr;
 };
 
 // does the splat behind sorted value a come before the one behind b in the file?

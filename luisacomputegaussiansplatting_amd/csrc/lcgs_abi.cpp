@@ -296,6 +296,8 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
         tie.id_bits   = (uint32_t)std::max(1, ceil_log2_u32((uint32_t)P));
         tie.tag_shift = 2u * tie.id_bits > 32u ? 2u * tie.id_bits - 32u : 0u;
         id_mask       = (1u << tie.id_bits) - 1u;
+        LCGS_TRY(ctx->tie_ws.ensure((size_t)P * 4)); // scratch for runs of more than 4096 equal depths (tie_order.hpp)
+        tie.scratch_k1 = ctx->tie_ws.as<uint32_t>();
     }
     launch_depth_sort_from_chunks(P, hint_V, ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(),
                                   ctx->chunk_base.as<uint32_t>(), ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
@@ -481,7 +483,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
                              &ctx->rects, &ctx->rects_sorted, &ctx->cull_slab, &ctx->chunk_info, &ctx->chunk_base, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
                              &ctx->pairv[1], &ctx->zero_ws[0], &ctx->zero_ws[1], &ctx->zero_ws[2], &ctx->counts, &ctx->sort_ws,
                              &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order[0], &ctx->tile_order[1], &ctx->st_keys_tmp,
-                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac };
+                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac, &ctx->tie_ws };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& b : ctx->owned) b.release();
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Per-kernel mean of rocprofv3 --pmc counters (counter_collection.csv), one line per kernel."""
-import csv, glob, re, sys, collections
+import csv, glob, os, re, sys, collections
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_sources_hash
+
+print("# kernel_sources_sha256", kernel_sources_hash())
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(set)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):

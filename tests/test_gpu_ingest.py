@@ -333,28 +333,44 @@ def test_equal_depths_blend_in_file_order_after_the_spatial_reorder(lcgs, oracle
     assert (other - imgs["file"]).abs().max().item() > 1e-2
 
 
-def test_equal_depth_runs_beyond_the_cap_are_reported(lcgs, oracle):
-    """More than 4096 splats at exactly one depth: the re-ordered scene keeps its own order inside that run and says so
-    (lcgs_frame_stats.equal_depth_unresolved); the file-order scene stays exact."""
+@pytest.mark.parametrize("P", [6000, 20000])
+def test_equal_depth_runs_beyond_the_lds_cap_are_exact_too(lcgs, oracle, P):
+    """A coplanar sheet seen head-on: 6 000 / 20 000 splats at exactly ONE depth -- a single run far beyond what a
+    workgroup ranks through LDS (4096).  Until round 3 such a run kept the context's (Morton) order and was only reported
+    (lcgs_frame_stats.equal_depth_unresolved); now its workgroup radix-sorts it on the file indices through global scratch:
+    the re-ordered scene's frame is the oracle's bit for bit, its per-tile lists are the file-order scene's, and the
+    counter stays 0 (gs_tile_splatter/impl.cpp:135-143: a stable sort is exact for any run length)."""
     from gpu_util import assert_image_parity
 
-    rng = np.random.default_rng(92)
-    scene = _plane_scene(rng, 6000)
+    rng = np.random.default_rng(92 + P)
+    scene = _plane_scene(rng, P)
     W, H = 256, 192
     cam = lcgs.get_lookat_cam(*PLANE_POSE, width=W, height=H)
-    orc = oracle.render(scene, oracle.lookat(*PLANE_POSE, width=W, height=H), ambig_eps=1e-5)
-    r = lcgs.Renderer(lcgs.Context(0))
-    r.upload_scene(scene)
-    img = torch.zeros(3, H, W, device=DEV)
-    assert r.forward(cam, img) == orc["num_rendered"]
-    st = r.frame_stats()
-    assert st["equal_depth_unresolved"] == st["num_visible"] > 4096
-    rf = lcgs.Renderer(lcgs.Context(0))
-    rf.upload_scene(scene, order="file")
-    imgf = torch.zeros(3, H, W, device=DEV)
-    rf.forward(cam, imgf)
-    assert rf.frame_stats()["equal_depth_unresolved"] == 0
-    assert_image_parity(imgf.cpu().numpy(), orc)
+    orc = oracle.render(scene, oracle.lookat(*PLANE_POSE, width=W, height=H))
+    out = {}
+    for order in (None, "file"):
+        r = lcgs.Renderer(lcgs.Context(0))
+        r.upload_scene(scene, order=order)
+        img = torch.zeros(3, H, W, device=DEV)
+        assert r.forward(cam, img) == orc["num_rendered"]
+        st = r.frame_stats()
+        assert st["num_visible"] > 4096 and st["equal_depth_unresolved"] == 0
+        assert_image_parity(img.cpu().numpy(), orc)
+        lst = torch.zeros(st["num_pairs"], dtype=torch.int32, device=DEV)
+        rng_ = torch.zeros(st["num_tiles"] * 2, dtype=torch.int32, device=DEV)
+        r.last_lists(lst, rng_)
+        lst = lst.cpu().numpy().astype(np.int64)
+        if r.permutation() is not None:
+            lst = r.permutation().cpu().numpy().astype(np.int64)[lst]
+        out[order] = (lst, rng_.cpu().numpy())
+        if order is None:  # a second frame on the same context (scratch reused), and the camera-batch sibling
+            again = torch.zeros(3, H, W, device=DEV)
+            r.forward(cam, again)
+            pair = [torch.zeros(3, H, W, device=DEV) for _ in range(2)]
+            r.forward_batch([cam, cam], pair)
+            r.ctx.synchronize()
+            assert torch.equal(again, img) and torch.equal(pair[0], img) and torch.equal(pair[1], img)
+    assert np.array_equal(out[None][0], out["file"][0]) and np.array_equal(out[None][1], out["file"][1])
 
 
 def _frame_lists_in_file_indices(lcgs, scene, cam, order):
@@ -383,7 +399,7 @@ def _frame_lists_in_file_indices(lcgs, scene, cam, order):
 def test_equal_depth_runs_of_every_length_keep_the_file_order(lcgs, levels):
     """Depths quantised to `levels` planes in a 60 K-splat scene: runs of 2-3 equal depths (put right inside the last
     radix pass), of dozens (listed, ranked by a workgroup), of thousands (many of them crossing the sort's 2048-key
-    chunks) and -- 7 levels -- beyond the cap.  The re-ordered scene must yield the file-order scene's per-tile lists
+    chunks) and -- 7 levels -- beyond the LDS cap (radix-sorted through global scratch).  The re-ordered scene must yield the file-order scene's per-tile lists
     entry for entry (as file indices), and the same image bit for bit."""
     from conftest import make_scene
 
@@ -399,9 +415,7 @@ def test_equal_depth_runs_of_every_length_keep_the_file_order(lcgs, levels):
     n_s, st_s, list_s, rng_s, img_s = _frame_lists_in_file_indices(lcgs, scene, cam, None)
     assert n_f == n_s and st_f["num_pairs"] == st_s["num_pairs"] > 20000
     assert np.array_equal(rng_f, rng_s)
-    if levels == 7:  # ~8.5 K splats per depth: left in the context's order, and reported
-        assert st_s["equal_depth_unresolved"] > 4096 * 6
-        return
+    # (7 levels: ~8.5 K splats per depth, beyond the 4096 a workgroup ranks through LDS -- sorted through global scratch)
     assert st_s["equal_depth_unresolved"] == 0
     assert np.array_equal(list_f, list_s)
     assert torch.equal(img_f, img_s)
