@@ -320,8 +320,28 @@ def main():
         el_s = time.perf_counter() - t0
         stage_path = {"value": round(world * args.steps / el_s, 2), "unit": "frames/s",
                       "ms_per_step": round(el_s * 1e3 / args.steps, 4), "num_rendered": int(n_stage),
-                      "max_abs_diff_vs_fused": float((img_s - img).abs().max().item())}
-        del accel, color, means, covs, depth, radii_s, img_s
+                      "max_abs_diff_vs_fused": float((img_s - img).abs().max().item()),
+                      "mode": "LCGS_STAGES_EXACT: every operator runs at once, every buffer of the reference is produced"}
+        # the same three calls, same loop, with lcgs_set_stage_mode(LCGS_STAGES_DEFERRED): process / forward are recorded, the
+        # splatter renders the fused frame from the 3-D arrays (intermediates not written; same image, radii, num_rendered)
+        exact_img = img_s.clone()
+        ctx.set_stage_mode("deferred")
+        img_s.zero_()
+        n_def = 0
+        for _ in range(max(1, args.warmup)):
+            n_def = stage_frame()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            stage_frame()
+        barrier()
+        el_d = time.perf_counter() - t0
+        ctx.set_stage_mode("exact")
+        stage_path["deferred"] = {"value": round(world * args.steps / el_d, 2), "unit": "frames/s",
+                                  "ms_per_step": round(el_d * 1e3 / args.steps, 4), "num_rendered": int(n_def),
+                                  "image_equal_to_exact_mode": bool(torch.equal(img_s, exact_img)),
+                                  "mode": "LCGS_STAGES_DEFERRED (opt-in): same calls, the splatter renders the fused frame"}
+        del accel, color, means, covs, depth, radii_s, img_s, exact_img
 
     # ---- opt-in f16 SH coefficients for the colour pass (outside the 1e-4 bar, never `value`)
     half_sh = None

@@ -152,6 +152,20 @@ LCGS_API lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_
                                              const lcgs_tile_input* input, const lcgs_tile_output* output,
                                              int use_focal, int* num_rendered);
 
+/* How the three operators above execute (default LCGS_STAGES_EXACT: each call runs at once and leaves every buffer of
+ * the reference behind, bit for bit).  LCGS_STAGES_DEFERRED is for a caller that drives them the way app/main.cpp:266-308
+ * does -- process, forward, forward, back to back, reading only target_img / radii / num_rendered afterwards:
+ * lcgs_sh_process and lcgs_project_forward only RECORD their arguments; an lcgs_tile_splat_forward whose input proxy is
+ * exactly their outputs (same arrays, same camera, use_focal, no final_T / n_contrib request) renders the library's fused
+ * frame from the 3-D arrays instead -- the same image, radii and num_rendered (bit for bit; tests/test_gpu_stages.py), with
+ * one difference inherited from the fused frame: a splat whose covariance is NaN is invisible (exact mode reproduces the
+ * reference's zero-filled pairs for it).  The intermediate buffers (color, means_2d, covs_2d, depth and
+ * the accel proxy) are then NOT written.  A splat call that does not match, lcgs_stage_flush, lcgs_synchronize or a switch
+ * back to exact mode run whatever was recorded, so the mode never changes a result, only when it is produced. */
+typedef enum lcgs_stage_mode { LCGS_STAGES_EXACT = 0, LCGS_STAGES_DEFERRED = 1 } lcgs_stage_mode;
+LCGS_API lcgs_status lcgs_set_stage_mode(lcgs_context* ctx, int mode);
+LCGS_API lcgs_status lcgs_stage_flush(lcgs_context* ctx);
+
 /* The two external parallel primitives the splatter borrows (lcpp, absent from the reference tree):
  * DeviceScan<>::InclusiveSum (call site gs_tile_splatter/impl.cpp:104) and
  * DeviceRadixSort<>::SortPairs<ulong,uint> (call site impl.cpp:135-143).  Temp storage is owned by

@@ -136,7 +136,8 @@ class _SceneHost(C.Structure):
 EXPORTED_SYMBOLS = [
     "lcgs_version", "lcgs_last_error", "lcgs_create", "lcgs_destroy", "lcgs_set_stream", "lcgs_synchronize",
     "lcgs_get_lookat_cam", "lcgs_local_to_world_matrix", "lcgs_world_to_local_matrix", "lcgs_projection_matrix",
-    "lcgs_sh_process", "lcgs_project_forward", "lcgs_tile_splat_forward", "lcgs_inclusive_sum_u32",
+    "lcgs_sh_process", "lcgs_project_forward", "lcgs_tile_splat_forward", "lcgs_set_stage_mode", "lcgs_stage_flush",
+    "lcgs_inclusive_sum_u32",
     "lcgs_sort_pairs_u64_u32", "lcgs_scene_bind", "lcgs_scene_upload", "lcgs_render_forward",
     "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists", "lcgs_debug_blend_exp",
     "lcgs_render_backward", "lcgs_fit_views", "lcgs_render_backward_accumulate", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
@@ -281,6 +282,14 @@ class Context:
 
     def set_stream(self, stream: int):
         _check(load_library().lcgs_set_stream(self._h, C.c_void_p(stream)))
+
+    def set_stage_mode(self, mode: str):
+        """lcgs_set_stage_mode: "exact" (default: every operator runs at once and leaves the reference's buffers behind) or
+        "deferred" (process / forward are recorded, a matching splatter call renders the fused frame instead)"""
+        _check(load_library().lcgs_set_stage_mode(self._h, C.c_int({"exact": 0, "deferred": 1}[mode])))
+
+    def stage_flush(self):
+        _check(load_library().lcgs_stage_flush(self._h))
 
     def blend_exp(self, d_x, d_out, n: int):
         """diagnostics: the compositing loop's exp (gs_math.hpp::blend_exp) over n device values"""

@@ -126,6 +126,26 @@ struct lcgs_context {
     int          slices_recorded = 0;   // slices of the last dense backward whose events are valid (0: not sliced)
     const void*  slices_of = nullptr;   // the dL_dpos array those events belong to
 
+    // Stage-level operators in DEFERRED mode (lcgs_set_stage_mode): SHProcessor::process and GSProjector::forward record
+    // their arguments instead of running; a GSTileSplatter::forward whose inputs are exactly their outputs then renders
+    // the fused frame from the 3-D arrays (same image, radii, num_rendered); anything else runs the recorded calls first.
+    int stage_mode = 0; // LCGS_STAGES_EXACT
+    struct {
+        bool         pending = false;
+        int          num = 0, level = 3;
+        const float *pos = nullptr, *sh = nullptr;
+        float*       color = nullptr;
+        lcgs_camera  cam{};
+    } def_sh;
+    struct {
+        bool         pending = false;
+        int          num = 0, use_focal = 1;
+        const float *pos = nullptr, *scale = nullptr, *rotq = nullptr;
+        float        scale_modifier = 1.0f;
+        float *      means = nullptr, *covs = nullptr, *depth = nullptr;
+        lcgs_camera  cam{};
+    } def_proj;
+
     // per-stage timing
     bool             profiling = false;
     hipEvent_t       events[lcgs::kMaxEvents]{};

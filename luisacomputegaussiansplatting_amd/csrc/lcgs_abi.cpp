@@ -168,6 +168,29 @@ lcgs_status check_frame_flags(lcgs_context* ctx)
     return LCGS_OK;
 }
 
+// deferred stage mode: run a recorded SHProcessor::process / GSProjector::forward now (context.hpp def_sh / def_proj)
+lcgs_status run_deferred_sh(lcgs_context* ctx)
+{
+    if (!ctx->def_sh.pending) return LCGS_OK;
+    ctx->def_sh.pending = false;
+    CamParams cp{};
+    for (int i = 0; i < 3; ++i) cp.campos[i] = ctx->def_sh.cam.position[i];
+    launch_sh_process(ctx->def_sh.num, ctx->def_sh.level, cp, ctx->def_sh.pos, ctx->def_sh.sh, ctx->def_sh.color, ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    return LCGS_OK;
+}
+
+lcgs_status run_deferred_proj(lcgs_context* ctx)
+{
+    if (!ctx->def_proj.pending) return LCGS_OK;
+    auto& d   = ctx->def_proj;
+    d.pending = false;
+    launch_project(d.num, make_cam_params(d.cam), d.use_focal != 0, d.pos, d.scale, d.rotq, d.scale_modifier, d.means, d.depth,
+                   d.covs, ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    return LCGS_OK;
+}
+
 lcgs_status check_camera(const lcgs_camera* cam)
 {
     LCGS_REQUIRE(cam != nullptr, "camera is NULL");
@@ -525,6 +548,7 @@ lcgs_status lcgs_set_stream(lcgs_context* ctx, void* stream)
 lcgs_status lcgs_synchronize(lcgs_context* ctx)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_TRY(lcgs_stage_flush(ctx)); // deferred stage mode: whatever was recorded is produced before the caller looks
     LCGS_TRY(sync_frame(ctx));
     lcgs_status twin_status = LCGS_OK;
     if (ctx->twin) {
@@ -548,6 +572,14 @@ lcgs_status lcgs_sh_process(lcgs_context* ctx, int num_points, const float* d_po
     LCGS_REQUIRE(channel == 3, "only 3 colour channels are supported (as in the reference)");
     if (num_points == 0) return LCGS_OK;
     LCGS_REQUIRE(d_pos && d_sh && d_color, "NULL device pointer");
+    if (ctx->stage_mode == LCGS_STAGES_DEFERRED) { // recorded; run by the splatter's fused frame, or by a flush
+        if (ctx->def_sh.pending) LCGS_TRY(run_deferred_sh(ctx));
+        ctx->def_sh.pending = true;
+        ctx->def_sh.num = num_points; ctx->def_sh.level = level;
+        ctx->def_sh.pos = d_pos; ctx->def_sh.sh = d_sh; ctx->def_sh.color = d_color;
+        ctx->def_sh.cam = *camera;
+        return LCGS_OK;
+    }
     CamParams cp{};
     for (int i = 0; i < 3; ++i) cp.campos[i] = camera->position[i];
     launch_sh_process(num_points, level, cp, d_pos, d_sh, d_color, ctx->stream);
@@ -565,11 +597,39 @@ lcgs_status lcgs_project_forward(lcgs_context* ctx, int num_gaussians, const flo
     LCGS_TRY(check_camera(camera));
     if (num_gaussians == 0) return LCGS_OK;
     LCGS_REQUIRE(d_pos && d_scale && d_rotq && d_means_2d && d_covs_2d && d_depth, "NULL device pointer");
+    if (ctx->stage_mode == LCGS_STAGES_DEFERRED) {
+        if (ctx->def_proj.pending) LCGS_TRY(run_deferred_proj(ctx));
+        auto& d = ctx->def_proj;
+        d.pending = true;
+        d.num = num_gaussians; d.use_focal = use_focal;
+        d.pos = d_pos; d.scale = d_scale; d.rotq = d_rotq; d.scale_modifier = scale_modifier;
+        d.means = d_means_2d; d.covs = d_covs_2d; d.depth = d_depth;
+        d.cam = *camera;
+        return LCGS_OK;
+    }
     CamParams cp = make_cam_params(*camera);
     launch_project(num_gaussians, cp, use_focal != 0, d_pos, d_scale, d_rotq, scale_modifier, d_means_2d, d_depth,
                    d_covs_2d, ctx->stream);
     LCGS_HIP_CHECK(hipGetLastError());
     return LCGS_OK;
+}
+
+lcgs_status lcgs_set_stage_mode(lcgs_context* ctx, int mode)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(mode == LCGS_STAGES_EXACT || mode == LCGS_STAGES_DEFERRED, "unknown stage mode");
+    LCGS_TRY(lcgs_stage_flush(ctx));
+    ctx->stage_mode = mode;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_stage_flush(lcgs_context* ctx)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (!ctx->def_sh.pending && !ctx->def_proj.pending) return LCGS_OK;
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    LCGS_TRY(run_deferred_sh(ctx));
+    return run_deferred_proj(ctx);
 }
 
 lcgs_status lcgs_inclusive_sum_u32(lcgs_context* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n)
@@ -625,6 +685,39 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
     LCGS_REQUIRE(input->means_2d && input->depth_features && input->conic && input->color_features &&
                      input->opacity_features,
                  "NULL input buffer");
+    if (ctx->def_sh.pending || ctx->def_proj.pending) {
+        // Deferred mode: are this call's inputs exactly what the two recorded calls would have produced?  Then the fused
+        // frame gives the same image / radii / num_rendered from the 3-D arrays; else the recorded calls run now.
+        const auto& a = ctx->def_sh;
+        const auto& b = ctx->def_proj;
+        const bool  same_cam = memcmp(a.cam.position, b.cam.position, sizeof(float) * 3) == 0;
+        const bool  match =
+            a.pending && b.pending && a.num == P && b.num == P && a.pos == b.pos && a.color == input->color_features &&
+            b.means == input->means_2d && b.covs == input->conic && b.depth == input->depth_features && same_cam &&
+            b.use_focal != 0 && use_focal != 0 && a.level >= 0 && a.level <= 3 && b.cam.width == output->width &&
+            b.cam.height == output->height && !output->final_T && !output->n_contrib && ctx->lod_min_radius == 0 &&
+            (reinterpret_cast<uintptr_t>(b.rotq) & 15) == 0 && P < (1 << 30);
+        if (match) {
+            ctx->def_sh.pending = ctx->def_proj.pending = false;
+            // the recorded arrays stand in for the context's scene for this one frame
+            struct Saved {
+                int P, sh_deg; const float *pos, *scale, *rotq, *sh, *opacity; bool perm_valid, use_half_sh;
+            } sv = { ctx->P, ctx->sh_deg, ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity, ctx->perm_valid,
+                     ctx->use_half_sh };
+            ctx->P = P; ctx->sh_deg = a.level; ctx->pos = a.pos; ctx->scale = b.scale; ctx->rotq = b.rotq; ctx->sh = a.sh;
+            ctx->opacity = input->opacity_features; ctx->perm_valid = false; ctx->use_half_sh = false;
+            int         n  = 0;
+            lcgs_status rs = lcgs_render_forward(ctx, &b.cam, input->bg_color, b.scale_modifier, output->target_img,
+                                                 output->radii, 0, &n);
+            ctx->P = sv.P; ctx->sh_deg = sv.sh_deg; ctx->pos = sv.pos; ctx->scale = sv.scale; ctx->rotq = sv.rotq;
+            ctx->sh = sv.sh; ctx->opacity = sv.opacity; ctx->perm_valid = sv.perm_valid; ctx->use_half_sh = sv.use_half_sh;
+            ctx->last.valid = false; // (the frame state belongs to the borrowed arrays)
+            if (num_rendered) *num_rendered = n;
+            return rs;
+        }
+        LCGS_TRY(run_deferred_sh(ctx));
+        LCGS_TRY(run_deferred_proj(ctx));
+    }
     hipStream_t st = ctx->stream;
     CamParams   cp{};
     cp.width  = (uint32_t)output->width;

@@ -197,3 +197,61 @@ def test_blend_exp_on_the_device_is_the_oracles_bit_for_bit(lcgs, oracle):
     got = dout.cpu().numpy()
     ref = oracle.blend_exp(x)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), int((got.view(np.uint32) != ref.view(np.uint32)).sum())
+
+
+def test_deferred_stage_mode_gives_the_exact_modes_image_and_never_changes_a_result(lcgs, oracle, ops):
+    """lcgs_set_stage_mode(LCGS_STAGES_DEFERRED): the reference's call pattern (process, forward, forward -- back to back,
+    app/main.cpp:266-308) renders the fused frame from the 3-D arrays: same image, radii and num_rendered as the exact mode
+    bit for bit, the intermediate buffers are not written.  A splatter call that does NOT match what was recorded (here:
+    another colour buffer), a flush, or lcgs_synchronize run the recorded operators, so results never depend on the mode."""
+    ctx, sh, pr, ts = ops
+    rng = np.random.default_rng(31)
+    P, W, H = 40000, 640, 400
+    scene = make_scene(rng, P, log_scale=(-4.0, 0.8))
+    scene["pos"][:100] = rng.normal(0, 0.3, (100, 3)) + POSE[0]
+    cam = lcgs.get_lookat_cam(*POSE, width=W, height=H)
+    d = {k: dev(v) for k, v in scene.items()}
+    G = ((W + 15) // 16) * ((H + 15) // 16)
+    i64 = lambda n: torch.zeros(n, dtype=torch.int64, device=DEV)
+    i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=DEV)
+    bg = (0.1, 0.2, 0.3)
+
+    def run(mode, other_color=False):
+        ctx.set_stage_mode(mode)
+        color = torch.full((P, 3), -5.0, device=DEV)
+        means, covs, depth = (torch.full(s_, -5.0, device=DEV) for s_ in ((P, 2), (P, 3), (P,)))
+        sh.process(lcgs.GPUPointsProxy(P, 3, d["pos"]), cam, d["sh"], color, 3, 3)
+        pr.forward(lcgs.GSProjectorInputProxy(P, d["pos"], d["scale"], d["rotq"], 1.25),
+                   lcgs.GSProjectorOutputProxy(means, covs, depth), cam, True)
+        cap = 4_000_000
+        accel = lcgs.GSTileSplatterAccelProxy(i32(P), i32(P), i64(cap), i32(cap), i64(cap), i32(cap), i32(2 * G))
+        target = torch.full((3, H, W), -1.0, device=DEV)
+        radii = i32(P)
+        out = lcgs.GSSplatForwardOutputProxy(H, W, target, radii, None, None)
+        col_in = color
+        if other_color:  # the splatter is handed a colour buffer the SH operator did not write: no match
+            col_in = torch.rand(P, 3, device=DEV)
+        n = ts.forward(accel, lcgs.GSTileSplatterInputProxy(P, bg, means, depth, covs, col_in, d["opacity"]), out, True)
+        ctx.synchronize()
+        ctx.set_stage_mode("exact")
+        return n, target, radii, color, means, accel, col_in
+
+    n_e, img_e, rad_e, col_e, means_e, accel_e, _ = run("exact")
+    n_d, img_d, rad_d, col_d, means_d, accel_d, _ = run("deferred")
+    assert n_d == n_e > 100000
+    assert torch.equal(img_d, img_e) and torch.equal(rad_d, rad_e)
+    # the fused frame did not produce the intermediates ...
+    assert float(col_d.max()) == -5.0 and float(means_d.max()) == -5.0 and int(accel_d.point_list.abs().max()) == 0
+    assert float(col_e.min()) >= 0.0 and int(accel_e.point_list.abs().max()) > 0
+    # ... and a call that does not match runs the recorded operators first: the exact mode's buffers and image
+    n_m, img_m, rad_m, col_m, means_m, accel_m, col_in = run("deferred", other_color=True)
+    ctx.set_stage_mode("exact")
+    assert torch.equal(col_m, col_e) and torch.equal(means_m, means_e) and torch.equal(rad_m, rad_e) and n_m == n_e
+    assert not torch.equal(img_m, img_e)  # (it was rendered with the other colours, as asked)
+    # a flush / synchronise alone materialises what was recorded
+    ctx.set_stage_mode("deferred")
+    color = torch.full((P, 3), -5.0, device=DEV)
+    sh.process(lcgs.GPUPointsProxy(P, 3, d["pos"]), cam, d["sh"], color, 3, 3)
+    ctx.synchronize()
+    assert torch.equal(color, col_e)
+    ctx.set_stage_mode("exact")
