@@ -704,7 +704,7 @@ def main():
                 eng2 = mg.HipEngine(r, raw=raw, activated=act, lr=lr)  # (binds `act` to the renderer)
                 out["train_step"] = {}
                 if dist is None:
-                    modes = ("dense", "visible_only", "visible_only_compact")
+                    modes = ("dense", "visible_only", "visible_only_compact", "visible_only_fused")
                 else:
                     modes = ("allreduce", "sharded", "sparse")
                 for mode in modes:
@@ -712,6 +712,9 @@ def main():
                         def full_step(i, mode=mode):
                             compact = mode == "visible_only_compact"
                             r.forward(cam, img, keep_state=True, sync=False)
+                            if mode == "visible_only_fused":  # lcgs_render_backward_adam: no gradient arrays at all
+                                r.backward_adam(dL, raw, eng2.m, eng2.v, act, i + 1, lr)
+                                return
                             r.backward(dL, *[views[k] for k in KEYS], compact=compact)
                             r.adam_step(views, raw, eng2.m, eng2.v, act, i + 1, lr, visible_only=(mode != "dense"),
                                         compact_grads=compact)

@@ -350,6 +350,16 @@ LCGS_API lcgs_status lcgs_adam_step(lcgs_context* ctx, int num_gaussians, int sh
                                     const lcgs_grads* grads, const lcgs_params* raw, const lcgs_params* m,
                                     const lcgs_params* v, const lcgs_params* activated);
 
+/* Single-GPU training step without gradient arrays ("training without python binding", doc/roadmap.md:4, taken one step
+ * further): the backward of the last lcgs_render_forward(keep_state = 1) frame with the on-screen-only Adam update
+ * (lcgs_adam_step, visible_only semantics) applied in the kernel that forms the per-splat gradients.  Same result, bit for
+ * bit, as lcgs_render_backward_compact + lcgs_adam_step(visible_only = 2); no gradient row is written or read back
+ * (2 x 236 bytes per on-screen splat less).  cfg->visible_only is ignored (the step is on-screen-only by construction).
+ * The fused kernel covers sh_degree 3 with 16-byte-aligned rotq / sh rows; anything else runs the two calls internally. */
+LCGS_API lcgs_status lcgs_render_backward_adam(lcgs_context* ctx, const float* d_dL_dimg, int num_gaussians, int sh_degree,
+                                               const lcgs_adam_config* cfg, const lcgs_params* raw, const lcgs_params* m,
+                                               const lcgs_params* v, const lcgs_params* activated);
+
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU.  No counterpart in the reference, which drives one device (app/main.cpp:162-163).
  * One process per GPU; the scene is replicated; a batch of views is sharded one view per GPU (no data-path collective in

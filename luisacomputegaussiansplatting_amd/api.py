@@ -140,7 +140,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_inclusive_sum_u32",
     "lcgs_sort_pairs_u64_u32", "lcgs_scene_bind", "lcgs_scene_upload", "lcgs_render_forward",
     "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists", "lcgs_debug_blend_exp",
-    "lcgs_render_backward", "lcgs_fit_views", "lcgs_render_backward_accumulate", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
+    "lcgs_render_backward", "lcgs_render_backward_adam", "lcgs_fit_views", "lcgs_render_backward_accumulate", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png", "lcgs_l2_loss_backward",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh",
@@ -638,6 +638,20 @@ class Renderer:
         packs = [_Params(*[_ptr(d[k]) for k in keys]) for d in (raw, m, v, activated)]
         _check(load_library().lcgs_adam_step(self.ctx._h, C.c_int(P), C.c_int(sh_degree), C.byref(cfg), C.byref(g),
                                              *[C.byref(p) for p in packs]))
+
+
+    def backward_adam(self, dL_dimg, raw: dict, m: dict, v: dict, activated: dict, step: int, lr: dict,
+                      betas=(0.9, 0.999), eps: float = 1e-15, sh_degree: int = 3):
+        """lcgs_render_backward_adam: the backward of the last keep_state frame with the on-screen-only Adam update applied
+        where the per-splat gradients are formed -- no gradient arrays (= backward(compact=True) + adam_step(visible_only,
+        compact_grads), bit for bit)."""
+        keys = ("pos", "scale", "rotq", "sh", "opacity")
+        P = int(raw["pos"].shape[0])
+        cfg = _AdamConfig(lr["pos"], lr["sh_dc"], lr["sh_rest"], lr["opacity"], lr["scale"], lr["rot"], betas[0], betas[1],
+                          eps, int(step), 2)
+        packs = [_Params(*[_ptr(d[k]) for k in keys]) for d in (raw, m, v, activated)]
+        _check(load_library().lcgs_render_backward_adam(self.ctx._h, _ptr(dL_dimg), C.c_int(P), C.c_int(sh_degree),
+                                                        C.byref(cfg), *[C.byref(p) for p in packs]))
 
 
 def _adam_config(lr: dict, betas, eps: float, step: int, visible_only: int) -> _AdamConfig:

@@ -42,7 +42,7 @@ struct lcgs_context {
     // workspace of the fused frame
     DeviceBuffer cull_slab, chunk_info, chunk_base; // the cull pass's per-chunk output (fused_forward.hip k_cull_compact)
     DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws[3], counts, sort_ws,
-        expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks, shjac, tie_ws;
+        expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks, shjac, tie_ws, fused_grads;
     bool         last_has_jac = false; // the last keep_state frame stored the colour Jacobian (degree 3)
     // zero_ws holds what a frame needs zeroed: the tile ranges.  Three
     // copies rotate: while frame N runs, the auxiliary stream clears the copy of frame N + 2.  Two frames ahead, not

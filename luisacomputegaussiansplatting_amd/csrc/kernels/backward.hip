@@ -705,6 +705,150 @@ k_preprocess_backward_jac(CamParams cp, float scale_modifier, const float* __res
     }
 }
 
+// The same per-splat pass with the optimiser folded in (single-GPU training steps: lcgs_render_backward_adam).  The
+// gradients of a splat exist only in this lane's registers (geometry, opacity) and in the wave's LDS slab (the 16 + 3
+// factors of the SH outer product): the on-screen-only Adam update of train.hip -- the same adam_update, the same chain
+// rules, the same order of operations, so the result is train.hip's bit for bit -- is applied right here and NO gradient
+// row is ever written or read back (2 x 236 bytes per on-screen splat less; the separate step was 0.56 GB written by this
+// kernel + 0.56 GB read by the optimiser's on the bicycle stand-in).  Each lane owns its splat's rows in raw / m / v /
+// activated: read, updated, written by the same lane, so the in-place update of the arrays this very kernel reads
+// (the activated pos / scale / rotq are the renderer's scene arrays) needs no synchronisation.
+__global__ void __launch_bounds__(256)
+k_preprocess_backward_adam(CamParams cp, float scale_modifier, const float* pos, const float* scale, const float* rotq,
+                           const uint32_t* __restrict__ vis_index, const uint32_t* __restrict__ d_counts,
+                           const float* __restrict__ grads2d, const float4* __restrict__ shjac, AdamArrays raw, AdamArrays am,
+                           AdamArrays av, AdamArrays act, AdamRates lr, AdamStep a)
+{
+    __shared__ float s_outer[4][64 * kJacPitch];
+    const uint32_t V = d_counts[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t blk = blockIdx.x; blk * 256u < V; blk += gridDim.x) {
+        const uint32_t vid   = blk * 256u + threadIdx.x;
+        const bool     valid = vid < V;
+        const uint32_t vsafe = valid ? vid : V - 1;
+        const int      idx   = (int)vis_index[vsafe];
+        const uint32_t wave_first = blk * 256u + wave * 64u;
+        const uint32_t nvalid     = wave_first < V ? ((V - wave_first) < 64u ? (V - wave_first) : 64u) : 0u;
+        const float4* g2 = reinterpret_cast<const float4*>(grads2d + (size_t)vsafe * kG2D);
+        const float4  q0 = g2[0], q1 = g2[1];
+        const float   gcol2 = reinterpret_cast<const float*>(g2)[8];
+        const float4  j0 = shjac[(size_t)vsafe * 3 + 0], j1 = shjac[(size_t)vsafe * 3 + 1], j2 = shjac[(size_t)vsafe * 3 + 2];
+        const float   px = pos[3 * (size_t)idx + 0], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
+        const float   sc0 = scale[3 * (size_t)idx + 0], sc1 = scale[3 * (size_t)idx + 1], sc2 = scale[3 * (size_t)idx + 2];
+        const float4  q = *reinterpret_cast<const float4*>(rotq + 4 * (size_t)idx); // (r,x,y,z)
+        float*        mine = &s_outer[wave][lane * kJacPitch];
+        if (valid) {
+            const float    gmx = q0.x, gmy = q0.y, gA = q0.z, gB = q0.w, gC = q1.x, gop = q1.y;
+            const float    gcol[3] = { q1.z, q1.w, gcol2 };
+            const uint32_t mask    = __float_as_uint(j2.y);
+            float          gp[3];
+            {
+                const float dx = px - cp.campos[0], dy = py - cp.campos[1], dz = pz - cp.campos[2];
+                const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+                const float x = dx * inv, y = dy * inv, z = dz * inv;
+                const float xx = x * x, yy = y * y, zz = z * z;
+#define LCGS_BASIS(k, B, DX, DY, DZ) mine[k] = (B);
+                LCGS_SH_TERMS(LCGS_BASIS)
+#undef LCGS_BASIS
+#pragma unroll
+                for (int c = 0; c < 3; ++c) mine[16 + c] = ((mask >> c) & 1u) ? gcol[c] : 0.0f; // clamp mask
+                const float ddx = gcol[0] * j0.x + gcol[1] * j0.w + gcol[2] * j1.z;
+                const float ddy = gcol[0] * j0.y + gcol[1] * j1.x + gcol[2] * j1.w;
+                const float ddz = gcol[0] * j0.z + gcol[1] * j1.y + gcol[2] * j2.x;
+                const float dd  = x * ddx + y * ddy + z * ddz;
+                gp[0] = (ddx - x * dd) * inv;
+                gp[1] = (ddy - y * dd) * inv;
+                gp[2] = (ddz - z * dd) * inv;
+            }
+            float  gs[3];
+            float4 gq;
+            geom_backward(cp, scale_modifier, px, py, pz, sc0, sc1, sc2, q, gmx, gmy, gA, gB, gC, gp, gs, gq);
+            // ---- Adam on this splat's geometry rows (train.hip: k_adam_rows<3,0>, <3,1>, k_adam_rot, <1,2>)
+            const size_t i3 = 3 * (size_t)idx;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { // pos: raw == activated value
+                float       mm = am.pos[i3 + c], vv = av.pos[i3 + c];
+                const float x  = raw.pos[i3 + c] - adam_update(gp[c], mm, vv, lr.pos, a);
+                am.pos[i3 + c]  = mm;
+                av.pos[i3 + c]  = vv;
+                raw.pos[i3 + c] = x;
+                if (act.pos != raw.pos) act.pos[i3 + c] = x;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { // scale = exp(raw): g_raw = g * s
+                const float g  = gs[c] * act.scale[i3 + c];
+                float       mm = am.scale[i3 + c], vv = av.scale[i3 + c];
+                const float x  = raw.scale[i3 + c] - adam_update(g, mm, vv, lr.scale, a);
+                am.scale[i3 + c]  = mm;
+                av.scale[i3 + c]  = vv;
+                raw.scale[i3 + c] = x;
+                act.scale[i3 + c] = expf(x);
+            }
+            { // rotq = raw / |raw|: g_raw = (g - q (q . g)) / |raw|   (gq is (r,x,y,z), like the rows)
+                float4*      rr = reinterpret_cast<float4*>(raw.rotq) + idx;
+                float4*      rm = reinterpret_cast<float4*>(am.rotq) + idx;
+                float4*      rv = reinterpret_cast<float4*>(av.rotq) + idx;
+                float4*      ra = reinterpret_cast<float4*>(act.rotq) + idx;
+                const float4 g = gq, qa = *ra;
+                float4       x = *rr, mm = *rm, vv = *rv;
+                const float  inv_norm = 1.0f / sqrtf(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
+                const float  qg       = qa.x * g.x + qa.y * g.y + qa.z * g.z + qa.w * g.w;
+                x.x -= adam_update((g.x - qa.x * qg) * inv_norm, mm.x, vv.x, lr.rot, a);
+                x.y -= adam_update((g.y - qa.y * qg) * inv_norm, mm.y, vv.y, lr.rot, a);
+                x.z -= adam_update((g.z - qa.z * qg) * inv_norm, mm.z, vv.z, lr.rot, a);
+                x.w -= adam_update((g.w - qa.w * qg) * inv_norm, mm.w, vv.w, lr.rot, a);
+                const float n2 = 1.0f / sqrtf(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
+                *rr = x;
+                *rm = mm;
+                *rv = vv;
+                *ra = make_float4(x.x * n2, x.y * n2, x.z * n2, x.w * n2);
+            }
+            { // opacity = sigmoid(raw): g_raw = g o (1 - o)
+                const float o  = act.opacity[idx];
+                const float g  = gop * o * (1.0f - o);
+                float       mm = am.opacity[idx], vv = av.opacity[idx];
+                const float x  = raw.opacity[idx] - adam_update(g, mm, vv, lr.opacity, a);
+                am.opacity[idx]  = mm;
+                av.opacity[idx]  = vv;
+                raw.opacity[idx] = x;
+                act.opacity[idx] = 1.0f / (1.0f + expf(-x));
+            }
+        }
+        __syncthreads();
+        // ---- SH rows: 12 consecutive lanes own one splat's 192 contiguous bytes of raw / m / v (train.hip: k_adam_sh48)
+#pragma unroll 1
+        for (int i = 0; i < 12; ++i) {
+            const uint32_t cidx = (uint32_t)i * 64u + lane;
+            const uint32_t slot = cidx / 12u, part = cidx - slot * 12u;
+            const int      sidx = __shfl(idx, (int)slot, 64);
+            if (slot < nvalid) {
+                const float* o = &s_outer[wave][slot * kJacPitch];
+                float        g[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t f = part * 4u + (uint32_t)e, k = f / 3u, ch = f - 3u * k; // row[k * 3 + ch]
+                    g[e]             = o[k] * o[16u + ch];
+                }
+                const size_t r4 = (size_t)sidx * 12 + part;
+                float4*      xr = reinterpret_cast<float4*>(raw.sh) + r4;
+                float4*      xm = reinterpret_cast<float4*>(am.sh) + r4;
+                float4*      xv = reinterpret_cast<float4*>(av.sh) + r4;
+                float4       x = *xr, mm = *xm, vv = *xv;
+                const float  l = part == 0u ? lr.sh_dc : lr.sh_rest; // floats 0..2 of a row are the dc band
+                x.x -= adam_update(g[0], mm.x, vv.x, l, a);
+                x.y -= adam_update(g[1], mm.y, vv.y, l, a);
+                x.z -= adam_update(g[2], mm.z, vv.z, l, a);
+                x.w -= adam_update(g[3], mm.w, vv.w, lr.sh_rest, a);
+                *xr = x;
+                *xm = mm;
+                *xv = vv;
+                if (act.sh != raw.sh) reinterpret_cast<float4*>(act.sh)[r4] = x;
+            }
+        }
+        __syncthreads(); // the slab is reused by the next iteration
+    }
+}
+
 } // namespace
 
 size_t grads2d_bytes(int64_t V_cap) { return (size_t)V_cap * kG2D * sizeof(float); }
@@ -784,6 +928,19 @@ void launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp,
     hipLaunchKernelGGL(k_preprocess_backward, dim3((unsigned)blocks), dim3(256), 0, stream, sh_deg, cp, scale_modifier,
                        pos, scale, rotq, sh, vis_index, d_counts, grads2d, dL_dpos, dL_dscale, dL_drotq, dL_dsh,
                        dL_dopacity, mode, slice_bounds, slice);
+}
+
+void launch_preprocess_backward_adam(int64_t v_hint, const CamParams& cp, float scale_modifier, const float* pos,
+                                     const float* scale, const float* rotq, const uint32_t* vis_index, const uint32_t* d_counts,
+                                     const float* grads2d, const float4* shjac, const AdamArrays& raw, const AdamArrays& m,
+                                     const AdamArrays& v, const AdamArrays& act, const AdamRates& lr, const AdamStep& a,
+                                     hipStream_t stream)
+{
+    int64_t blocks = (v_hint + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_preprocess_backward_adam, dim3((unsigned)blocks), dim3(256), 0, stream, cp, scale_modifier, pos, scale,
+                       rotq, vis_index, d_counts, grads2d, shjac, raw, m, v, act, lr, a);
 }
 
 } // namespace lcgs

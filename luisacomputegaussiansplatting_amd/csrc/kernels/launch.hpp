@@ -135,12 +135,31 @@ struct AdamArrays {
 struct AdamRates {
     float pos, sh_dc, sh_rest, opacity, scale, rot;
 };
+// the step's scalars, and the update itself: ONE definition for train.hip's kernels and for the fused
+// preprocess-backward + Adam kernel of backward.hip (the two must agree bit for bit)
+struct AdamStep {
+    float b1, b2, eps, inv_bc1, inv_sqrt_bc2;
+};
+AdamStep make_adam_step(float beta1, float beta2, float eps, int step);
+__device__ __forceinline__ float adam_update(float g, float& m, float& v, float lr, const AdamStep& a)
+{
+    m = a.b1 * m + (1.0f - a.b1) * g;
+    v = a.b2 * v + (1.0f - a.b2) * g * g;
+    return (lr * a.inv_bc1) * m / (sqrtf(v) * a.inv_sqrt_bc2 + a.eps);
+}
 // row_list != NULL: only rows row_list[0 .. *d_row_count) are updated (launch sized for row_hint rows)
 // grad_compact (row_list only): gradient row r belongs to splat row_list[r] (lcgs_render_backward_compact's layout)
 void launch_adam_step(int64_t P, int sh_floats, const uint32_t* row_list, const uint32_t* d_row_count, int64_t row_hint,
                       const AdamArrays& grad, const AdamArrays& raw, const AdamArrays& m, const AdamArrays& v,
                       const AdamArrays& act, const AdamRates& lr, float beta1, float beta2, float eps, int step,
                       hipStream_t stream, bool grad_compact = false);
+// backward.hip: the per-splat half of the backward with the on-screen-only Adam update applied where the gradients are
+// formed (degree 3, frames that kept the colour Jacobian): no gradient rows are written at all
+void launch_preprocess_backward_adam(int64_t v_hint, const CamParams& cp, float scale_modifier, const float* pos,
+                                     const float* scale, const float* rotq, const uint32_t* vis_index, const uint32_t* d_counts,
+                                     const float* grads2d, const float4* shjac, const AdamArrays& raw, const AdamArrays& m,
+                                     const AdamArrays& v, const AdamArrays& act, const AdamRates& lr, const AdamStep& a,
+                                     hipStream_t stream);
 // byte offsets, inside one vertex record, of the 59 wanted float columns (pos3 dc3 rest45 opacity scale3 rot4)
 struct PlyColumns {
     uint32_t offset[59];

@@ -20,17 +20,6 @@ namespace lcgs
 namespace
 {
 
-struct AdamStep {
-    float b1, b2, eps, inv_bc1, inv_sqrt_bc2;
-};
-
-__device__ __forceinline__ float adam_update(float g, float& m, float& v, float lr, const AdamStep& a)
-{
-    m = a.b1 * m + (1.0f - a.b1) * g;
-    v = a.b2 * v + (1.0f - a.b2) * g * g;
-    return (lr * a.inv_bc1) * m / (sqrtf(v) * a.inv_sqrt_bc2 + a.eps);
-}
-
 // rows of ROW floats; columns below `split` use lr0, the others lr1 (SH: dc vs rest).  MODE 0 plain, 1 exp, 2 sigmoid.
 template <int ROW, int MODE>
 __global__ void __launch_bounds__(256) k_adam_rows(int64_t rows, const uint32_t* __restrict__ row_list,
@@ -126,6 +115,17 @@ unsigned grid_for(int64_t elements)
 
 } // namespace
 
+AdamStep make_adam_step(float beta1, float beta2, float eps, int step)
+{
+    AdamStep a;
+    a.b1           = beta1;
+    a.b2           = beta2;
+    a.eps          = eps;
+    a.inv_bc1      = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
+    a.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    return a;
+}
+
 void launch_adam_step(int64_t P, int sh_floats, const uint32_t* row_list, const uint32_t* d_row_count, int64_t row_hint,
                       const AdamArrays& grad, const AdamArrays& raw, const AdamArrays& m, const AdamArrays& v,
                       const AdamArrays& act, const AdamRates& lr, float beta1, float beta2, float eps, int step,
@@ -134,12 +134,7 @@ void launch_adam_step(int64_t P, int sh_floats, const uint32_t* row_list, const 
     const int64_t rows = row_list ? row_hint : P;
     const int     gc   = (grad_compact && row_list) ? 1 : 0;
     if (rows <= 0 && !d_row_count) return;
-    AdamStep a;
-    a.b1           = beta1;
-    a.b2           = beta2;
-    a.eps          = eps;
-    a.inv_bc1      = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
-    a.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    const AdamStep a = make_adam_step(beta1, beta2, eps, step);
     const int64_t launch_rows = std::max<int64_t>(rows, 1);
     hipLaunchKernelGGL((k_adam_rows<3, 0>), dim3(grid_for(launch_rows * 3)), dim3(256), 0, stream, rows, row_list, d_row_count,
                        grad.pos, raw.pos, m.pos, v.pos, act.pos, 3, lr.pos, lr.pos, a, gc);

@@ -506,7 +506,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
                              &ctx->rects, &ctx->rects_sorted, &ctx->cull_slab, &ctx->chunk_info, &ctx->chunk_base, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
                              &ctx->pairv[1], &ctx->zero_ws[0], &ctx->zero_ws[1], &ctx->zero_ws[2], &ctx->counts, &ctx->sort_ws,
                              &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order[0], &ctx->tile_order[1], &ctx->st_keys_tmp,
-                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac, &ctx->tie_ws };
+                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac, &ctx->tie_ws, &ctx->fused_grads };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& b : ctx->owned) b.release();
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
@@ -1406,8 +1406,14 @@ lcgs_status lcgs_debug_blend_exp(lcgs_context* ctx, const float* d_x, float* d_o
 
 namespace
 {
+// the optimiser folded into the per-splat pass (lcgs_render_backward_adam): no gradient arrays at all
+struct FusedAdam {
+    AdamArrays raw, m, v, act;
+    AdamRates  lr;
+    AdamStep   step;
+};
 lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads, bool compact,
-                            bool accumulate = false);
+                            bool accumulate = false, const FusedAdam* fused = nullptr);
 }
 
 lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads)
@@ -1425,6 +1431,47 @@ lcgs_status lcgs_render_backward_accumulate(lcgs_context* ctx, const float* d_dL
     return render_backward(ctx, d_dL_dimg, grads, /*compact=*/false, /*accumulate=*/true);
 }
 
+lcgs_status lcgs_render_backward_adam(lcgs_context* ctx, const float* d_dL_dimg, int num_gaussians, int sh_degree,
+                                      const lcgs_adam_config* cfg, const lcgs_params* raw, const lcgs_params* m,
+                                      const lcgs_params* v, const lcgs_params* activated)
+{
+    LCGS_REQUIRE(ctx && d_dL_dimg && cfg && raw && m && v && activated, "NULL argument");
+    LCGS_REQUIRE(num_gaussians == ctx->P && sh_degree == ctx->sh_deg, "num_gaussians / sh_degree must be the bound scene's");
+    LCGS_REQUIRE(cfg->step >= 1, "step counts from 1");
+    LCGS_REQUIRE(cfg->beta1 >= 0.0f && cfg->beta1 < 1.0f && cfg->beta2 >= 0.0f && cfg->beta2 < 1.0f, "betas must be in [0,1)");
+    const lcgs_params* packs[4] = { raw, m, v, activated };
+    for (const lcgs_params* p : packs)
+        LCGS_REQUIRE(p->pos && p->scale && p->rotq && p->sh && p->opacity, "NULL device pointer in a parameter pack");
+    auto aligned16 = [](const lcgs_params* p) {
+        return ((reinterpret_cast<uintptr_t>(p->rotq) | reinterpret_cast<uintptr_t>(p->sh)) & 15) == 0;
+    };
+    const bool fusable = ctx->sh_deg == 3 && ctx->last.valid && ctx->last.has_state && ctx->last_has_jac && aligned16(raw) &&
+                         aligned16(m) && aligned16(v) && aligned16(activated);
+    if (!fusable) {
+        // other SH degrees, frames without the kept colour Jacobian, unaligned rows: the same step as two calls on
+        // context-owned compact gradient rows (identical result; the fused kernel exists for the degree-3 training case)
+        LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t feat = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3;
+        const size_t rows = (size_t)ctx->P;
+        auto         al   = [](size_t x) { return (x + 3) & ~(size_t)3; }; // every array starts on a 16-byte boundary
+        const size_t o_scale = al(rows * 3), o_rotq = al(o_scale + rows * 3), o_sh = al(o_rotq + rows * 4),
+                     o_op = al(o_sh + rows * feat);
+        LCGS_TRY(ctx->fused_grads.ensure((o_op + rows) * 4));
+        float*     g  = ctx->fused_grads.as<float>();
+        lcgs_grads gr = { g, g + o_scale, g + o_rotq, g + o_sh, g + o_op };
+        LCGS_TRY(render_backward(ctx, d_dL_dimg, &gr, /*compact=*/true));
+        lcgs_adam_config c2 = *cfg;
+        c2.visible_only     = 2;
+        return lcgs_adam_step(ctx, num_gaussians, sh_degree, &c2, &gr, raw, m, v, activated);
+    }
+    auto      pack = [](const lcgs_params* p) { return AdamArrays{ p->pos, p->scale, p->rotq, p->sh, p->opacity }; };
+    FusedAdam fa   = { pack(raw), pack(m), pack(v), pack(activated),
+                       { cfg->lr_pos, cfg->lr_sh_dc, cfg->lr_sh_rest, cfg->lr_opacity, cfg->lr_scale, cfg->lr_rot },
+                       make_adam_step(cfg->beta1, cfg->beta2, cfg->eps, cfg->step) };
+    lcgs_grads none{};
+    return render_backward(ctx, d_dL_dimg, &none, /*compact=*/true, /*accumulate=*/false, &fa);
+}
+
 lcgs_status lcgs_visible_rows(lcgs_context* ctx, const uint32_t** d_rows, const uint32_t** d_count)
 {
     LCGS_REQUIRE(ctx && d_rows && d_count, "NULL argument");
@@ -1439,11 +1486,12 @@ lcgs_status lcgs_visible_rows(lcgs_context* ctx, const uint32_t** d_rows, const 
 namespace
 {
 lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads, bool compact,
-                            bool accumulate)
+                            bool accumulate, const FusedAdam* fused)
 {
     LCGS_REQUIRE(ctx && d_dL_dimg && grads, "NULL argument");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
-    LCGS_REQUIRE(grads->d_dL_dpos && grads->d_dL_dscale && grads->d_dL_drotq && grads->d_dL_dsh && grads->d_dL_dopacity,
+    LCGS_REQUIRE(fused || (grads->d_dL_dpos && grads->d_dL_dscale && grads->d_dL_drotq && grads->d_dL_dsh &&
+                           grads->d_dL_dopacity),
                  "NULL gradient buffer");
     if (!ctx->last.valid || !ctx->last.has_state) {
         set_last_error("lcgs_render_backward needs a preceding lcgs_render_forward(..., keep_state = 1)");
@@ -1499,7 +1547,12 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
                            ctx->counts.as<uint32_t>());
     LCGS_TRY(mark(ctx, "render_backward"));
     if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
-    const int slices = (sliced ? ctx->grad_slices : 1);
+    const int slices = fused ? 0 : (sliced ? ctx->grad_slices : 1);
+    if (fused) // (compact, unsliced: the update is applied where the gradients are formed; nothing is written out)
+        launch_preprocess_backward_adam(ctx->hint_V > 0 ? ctx->hint_V : (int64_t)P, ctx->last.cp, ctx->last.scale_modifier,
+                                        ctx->pos, ctx->scale, ctx->rotq, ctx->vis_index.as<uint32_t>(),
+                                        ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(), ctx->shjac.as<float4>(),
+                                        fused->raw, fused->m, fused->v, fused->act, fused->lr, fused->step, st);
     for (int k = 0; k < slices; ++k) {
         launch_preprocess_backward(ctx->hint_V > 0 ? ctx->hint_V : (int64_t)P, ctx->sh_deg, ctx->last.cp,
                                    ctx->last.scale_modifier, ctx->pos, ctx->scale, ctx->rotq, ctx->sh,
@@ -1512,7 +1565,7 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
     ctx->slices_recorded = sliced ? slices : 0;
     ctx->slices_of       = sliced ? grads->d_dL_dpos : nullptr;
     // sparse exchange (opt-in, lcgs_comm_track_touched_rows): the rows this frame wrote join the step's touched set
-    if (!compact && ctx->comm)
+    if (!compact && !fused && ctx->comm)
         LCGS_TRY(lcgs::comm_mark_touched(ctx->comm, ctx->vis_index.as<uint32_t>(), ctx->counts.as<uint32_t>(), (int64_t)P,
                                          ctx->hint_V, accumulate, st));
     LCGS_TRY(mark(ctx, "preprocess_backward"));
