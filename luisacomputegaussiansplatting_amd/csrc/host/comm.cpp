@@ -632,7 +632,7 @@ lcgs_status lcgs_adam_step_sparse(lcgs_context* ctx, lcgs_comm* c, int num_gauss
     LCGS_TRY(c->recvbuf.ensure((size_t)recv_words * 4 + 16));
 
     // ---- 3. pack one message per peer (context's stream), exchange (communicator's stream); the tail rows -- fewer than
-    //         N, kept by everyone -- are all-reduced densely in the same group
+    //         N, kept by everyone -- are all-reduced densely behind it
     float* gp[5] = { g.ptr[0], g.ptr[1], g.ptr[2], g.ptr[3], g.ptr[4] };
     for (int o = 0; o < N; ++o)
         if (o != me)
@@ -651,17 +651,26 @@ lcgs_status lcgs_adam_step_sparse(lcgs_context* ctx, lcgs_comm* c, int num_gauss
             if (r == ncclSuccess && rw > 0)
                 r = rccl().Recv(c->recvbuf.as<float>() + recv_off[o], (size_t)rw, ncclFloat32, o, c->comm, c->stream);
         }
-        for (int i = 0; i < 5 && r == ncclSuccess && tail > 0; ++i) {
-            float* t = g.ptr[i] + (size_t)tail0 * g.width[i];
-            r        = rccl().AllReduce(t, t, (size_t)tail * g.width[i], ncclFloat32, ncclSum, c->comm, c->stream);
-        }
         if (r != ncclSuccess) {
             (void)rccl().GroupEnd();
             return rccl_fail(r, "ncclSend / ncclRecv", __LINE__);
         }
     }
     LCGS_RCCL_CHECK(rccl().GroupEnd());
-    c->stats.collective_groups = 2; // the counts, the messages
+    if (tail > 0) { // (its own group: point-to-point and collective calls are not mixed in one)
+        LCGS_RCCL_CHECK(rccl().GroupStart());
+        ncclResult_t r = ncclSuccess;
+        for (int i = 0; i < 5 && r == ncclSuccess; ++i) {
+            float* t = g.ptr[i] + (size_t)tail0 * g.width[i];
+            r        = rccl().AllReduce(t, t, (size_t)tail * g.width[i], ncclFloat32, ncclSum, c->comm, c->stream);
+        }
+        if (r != ncclSuccess) {
+            (void)rccl().GroupEnd();
+            return rccl_fail(r, "ncclAllReduce (tail rows)", __LINE__);
+        }
+        LCGS_RCCL_CHECK(rccl().GroupEnd());
+    }
+    c->stats.collective_groups = 2 + (tail > 0 ? 1 : 0); // the counts, the messages, the tail
     c->stats.bytes_sent        = send_words * 4 + (int64_t)(N - 1) * W * 4;
     c->stats.bytes_received    = recv_words * 4 + (int64_t)(N - 1) * W * 4;
     LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
