@@ -29,7 +29,7 @@ python3 profiles/pmc_summary.py $O/sq > $O/pmc_sq.txt
 # average issue cost of one VALU instruction of the compositing loop (the loop's instruction mix -- per blended
 # entry 24 single-rate ops (mov / add / sub / mul: 2.2 cycles) + 12 full-rate ones (fma, pk_fma, cmp, min, lshl_add: 4.2),
 # per culled entry 11 + 2 -- priced with tools/microbench/issue_rates.hip, profiles/r01_issue_rates.txt); bench.py reads it
-echo "# render_avg_issue_cycles 2.85" >> $O/pmc_sq.txt
+echo "# render_avg_issue_cycles 2.8" >> $O/pmc_sq.txt
 rm -rf $O/sq
 echo "sq done"
 ls -la $O
