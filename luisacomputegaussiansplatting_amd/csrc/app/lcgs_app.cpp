@@ -1,6 +1,6 @@
 // lcgs-app -- CLI work-alike of the reference's app/main.cpp on the MI355X library.
 //   lcgs-app --ply <path> [--res WxH] [--out dir] [--world colmap|blender] [--exp_N N] [--backend hip]
-//            [--path fused|stage] [--synth kind:count:seed] [--ingest device|host] [--cameras file]
+//            [--path fused|stage|deferred] [--synth kind:count:seed] [--ingest device|host] [--cameras file]
 //            [--order file|spatial] [--pose garden|lego] [--gpus N] [--backward] [--fit K]
 // Same flags (app/main.cpp:52-124; `--key=value` and `--key value`, app/command_parser.hpp:5-79), the same
 // hard-coded look-at camera (app/main.cpp:191-207), the same frame loop (:266-308), the same output:
@@ -49,7 +49,8 @@ void usage(const char* argv0)
     printf("  --out <dir>              Set the output directory (default: out)\n");
     printf("  --world <type>           colmap or blender (default: colmap)\n");
     printf("  --exp_N <N>              Number of frames to render (default: 1)\n");
-    printf("  --path <fused|stage>     One-submission fused frame (default) or the three stage-level operators\n");
+    printf("  --path <fused|stage|deferred>  One-submission fused frame (default), the three stage-level operators, or the same\n"
+           "                           three calls in deferred mode (lcgs_set_stage_mode: the splatter renders the fused frame)\n");
     printf("  --synth <kind:count:seed> Render a synthetic stand-in scene instead of --ply (kind 0 object, 1 unbounded)\n");
     printf("  --ingest <device|host>   De-interleave/activate the PLY on the GPU (default) or on the host\n");
     printf("  --order <file|spatial>   Keep the splats in file order, or re-order them along a Morton curve at load (same image;\n"
@@ -297,8 +298,11 @@ int main(int argc, char** argv)
         lcgs::Buffer<float> d_color, d_means_2d, d_depth, d_covs_2d;
         lcgs::Buffer<uint32_t> d_tiles, d_offsets, d_lu, d_ls, d_ranges;
         lcgs::Buffer<uint64_t> d_ku, d_ks;
-        if (path == "stage") {
+        if (path != "fused" && path != "stage" && path != "deferred") die("Invalid path: " + path);
+        const bool stage_calls = path == "stage" || path == "deferred"; // app/main.cpp's own three calls
+        if (stage_calls) {
             sh_processor.create(device); projector.create(device); tile_splatter.create(device);
+            if (path == "deferred") lcgs::check(lcgs_set_stage_mode(device.ctx(), LCGS_STAGES_DEFERRED));
             d_color = lcgs::Buffer<float>((size_t)P * 3); d_means_2d = lcgs::Buffer<float>((size_t)P * 2);
             d_depth = lcgs::Buffer<float>((size_t)P); d_covs_2d = lcgs::Buffer<float>((size_t)P * 3);
             (void)hipMemset(d_means_2d.data(), 0, (size_t)P * 8); (void)hipMemset(d_depth.data(), 0, (size_t)P * 4); (void)hipMemset(d_covs_2d.data(), 0, (size_t)P * 12);
@@ -489,7 +493,7 @@ int main(int argc, char** argv)
             lcgs::Camera cam = make_camera(views[vi]);
             int  num_rendered = 0;
             auto t0           = std::chrono::steady_clock::now();
-            if (path == "stage") {
+            if (stage_calls) {
                 for (int it = 0; it < exp_N; ++it) {
                     sh_processor.process({ P, 3, d_pos }, cam, d_sh, d_color, 3, 3);
                     projector.forward({ P, d_pos, d_scale, d_rotq, 1.0f }, { d_means_2d, d_covs_2d, d_depth }, cam);

@@ -11,7 +11,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("path", ["fused", "stage"])
+@pytest.mark.parametrize("path", ["fused", "stage", "deferred"])
 def test_lcgs_app_renders_png(lcgs, oracle, tmp_path, path):
     app = os.path.join(ROOT, "luisacomputegaussiansplatting_amd", "lcgs-app")
     if not os.path.exists(app):
