@@ -83,9 +83,9 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                                                             uint8_t* __restrict__ strip_masks)
 {
     // one 16-byte row per entry in each of three slabs: a single address register serves all three reads
-    __shared__ float4             s_a[256]; // mean.x, mean.y, -conic.x / 2, -conic.z / 2
-    __shared__ float4             s_b[256]; // conic.y, power floor (-t/2), -, -: with s_a, all the cull test needs
-    __shared__ float4             s_c[256]; // opacity, r, g, b: read only by entries that pass it
+    // s_rows[0]: mean.x, mean.y, -conic.x / 2, -conic.z / 2;  [1]: conic.y, power floor (-t/2), -, - (with [0], all the cull
+    // test needs);  [2]: opacity, r, g, b (read only by entries that pass it)
+    __shared__ float4             s_rows[3][256];
     __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
     __shared__ uint32_t           s_live_waves;
 
@@ -158,9 +158,9 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
             if (lane == 0) s_mask[wave][k] = m;
         }
         if (kmask) {
-            s_a[tid] = make_float4(a.x, a.y, -0.5f * a.z, -0.5f * b.x);
-            *reinterpret_cast<float2*>(&s_b[tid]) = make_float2(a.w, fmax_(-0.5f * t, kBlendExpMin));
-            s_c[tid] = make_float4(b.y, b.z, b.w, c);
+            s_rows[0][tid] = make_float4(a.x, a.y, -0.5f * a.z, -0.5f * b.x);
+            *reinterpret_cast<float2*>(&s_rows[1][tid]) = make_float2(a.w, fmax_(-0.5f * t, kBlendExpMin));
+            s_rows[2][tid] = make_float4(b.y, b.z, b.w, c);
         }
         const uint32_t en = e + 256u;
         if (en < range_end) fetch(point_list[en], na, nb, nc);
@@ -176,8 +176,13 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     const uint32_t l   = (uint32_t)__ffsll((long long)m) - 1u;
                     asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(l)); // one scalar op instead of add/addc/and
                     const uint32_t idx = w * 64u + l;
-                    const float4   ea = s_a[idx];
-                    const float2   eb = *reinterpret_cast<const float2*>(&s_b[idx]);
+                    // ONE address register for the entry's three rows (4 KB apart: immediate offsets), pinned so that the
+                    // read behind the wave-level test does not pay for a second scalar-to-vector move
+                    uint32_t row = idx * 16u; // (byte offset: the shift stays on the scalar side)
+                    asm volatile("" : "+v"(row));
+                    const char*    rows = reinterpret_cast<const char*>(&s_rows[0][0]) + row;
+                    const float4   ea = *reinterpret_cast<const float4*>(rows);
+                    const float2   eb = *reinterpret_cast<const float2*>(rows + 4096);
                     // power = -0.5 (ca dx dx + cc dy dy) - cb dx dy, products left to right (shader.cpp:256); the
                     // x and y halves ride in one packed instruction each
                     // (plain, not packed, arithmetic: on gfx950 a packed op costs two plain ones AND drags a wait state
@@ -200,7 +205,7 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     const unsigned long long cmask =
                         __builtin_amdgcn_ballot_w64(!(power > 0.0f)) & __builtin_amdgcn_ballot_w64(power >= eb.y);
                     if (cmask == 0ull) continue; // scalar test of the lane mask
-                    const float4 ec    = s_c[idx]; // one 16-byte read for the survivors of the test
+                    const float4 ec    = *reinterpret_cast<const float4*>(rows + 8192); // one 16-byte read for the survivors
                     // (alpha is never NaN where cand holds, so the hardware minimum equals min(0.99, x); on a lane where
                     //  it does not hold, power may lie outside blend_exp's domain and alpha is arbitrary bits -- masked)
                     const float alpha  = __builtin_fminf(0.99f, ec.x * blend_exp(power));
