@@ -66,9 +66,6 @@ using namespace tile;
 // 64-bit mask per staging wave and strip) go to LDS; wave k then walks the set bits of "its" four masks with
 // scalar bit-scan instructions -- entries irrelevant to a strip cost that strip nothing, order is preserved.
 // ---------------------------------------------------------------------------------------------
-#ifndef LCGS_RENDER_MASKED_UPDATE
-#define LCGS_RENDER_MASKED_UPDATE 1
-#endif
 typedef float v2f __attribute__((ext_vector_type(2))); // arithmetic on it lowers to v_pk_{add,mul}_f32 (IEEE per lane)
 
 template <typename Fetch, bool KEEP>
@@ -183,8 +180,7 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     const char*    rows = reinterpret_cast<const char*>(&s_rows[0][0]) + row;
                     const float4   ea = *reinterpret_cast<const float4*>(rows);
                     const float2   eb = *reinterpret_cast<const float2*>(rows + 4096);
-                    // power = -0.5 (ca dx dx + cc dy dy) - cb dx dy, products left to right (shader.cpp:256); the
-                    // x and y halves ride in one packed instruction each
+                    // power = -0.5 (ca dx dx + cc dy dy) - cb dx dy, products left to right (shader.cpp:256)
                     // (plain, not packed, arithmetic: on gfx950 a packed op costs two plain ones AND drags a wait state
                     // behind it -- tools/microbench/issue_rates.hip; the empty asms stop the vectoriser from pairing
                     // the operations up again.  Renderer 0.227 -> 0.221 ms in same-box A/B runs, same bits.)
@@ -210,7 +206,6 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     //  it does not hold, power may lie outside blend_exp's domain and alpha is arbitrary bits -- masked)
                     const float alpha  = __builtin_fminf(0.99f, ec.x * blend_exp(power));
                     const bool  valid  = cand & !(alpha < 1.0f / 255.0f);
-#if LCGS_RENDER_MASKED_UPDATE
                     // Lanes that skip the entry sit the update out under the EXEC mask: what the arithmetic produces on
                     // them is never written anywhere, and the select that used to zero their alpha is gone.  (Written as
                     // one asm block because the compiler turns `if (valid) { ... }` back into four selects.)
@@ -246,34 +241,9 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                                      : [Cr] "+v"(Cr), [Cg] "+v"(Cgb.x), [Cb] "+v"(Cgb.y), [T] "+v"(T), [t0] "=&v"(t0),
                                        [t1] "=&v"(t1), [t2] "=&v"(t2), [sv] "=&s"(sv)
                                      : [w] "v"(wgt), [cr] "v"(ec.y), [cg] "v"(ec.z), [cb] "v"(ec.w), [nT] "v"(nT),
-                                       [vm] "s"(vmask));
+                                       [vm] "s"(vmask)
+                                     : "scc");
                     }
-#else
-                    // a lane that skips the entry blends with alpha 0: T * 1 and C + 0 leave it bit-identical
-                    const float a      = valid ? alpha : 0.0f;
-                    float       test_T = T * (1.0f - a);
-                    float       wgt    = T * a;
-                    // T >= 1e-4 holds for every lane (a saturating update is never applied), so a lane with
-                    // alpha 0 cannot pass this test: no "& valid" needed, the ballot stays a plain compare
-                    const unsigned long long satm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
-                    if (KEEP) {
-                        const bool upd = valid & !(test_T < 0.0001f);
-                        last_contrib   = upd ? base - range_start + idx + 1u : last_contrib;
-                    }
-                    if (satm != 0ull) { // rare: some pixel of the strip just saturated
-                        const bool sat = (satm & lane_bit) != 0ull;
-                        wgt    = sat ? 0.0f : wgt; // shader.cpp:268-272: the saturating entry is not blended
-                        test_T = sat ? T : test_T;
-                        pxy.y  = sat ? __builtin_nanf("") : pxy.y;
-                        if (__builtin_amdgcn_ballot_w64(pxy.y == pxy.y) == 0ull) {
-                            alive = false; // the whole strip is finished
-                            m     = 0ull;
-                        }
-                    }
-                    Cr  = Cr + wgt * ec.y;
-                    Cgb = Cgb + (v2f){wgt, wgt} * (v2f){ec.z, ec.w};
-                    T   = test_T;
-#endif
                 }
             }
             if (!alive && lane == 0) atomicSub(&s_live_waves, 1u);
