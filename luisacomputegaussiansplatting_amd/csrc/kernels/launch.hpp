@@ -16,8 +16,11 @@ void launch_sh_process(int P, int deg, const CamParams& cp, const float* pos, co
 void launch_project(int P, const CamParams& cp, bool use_focal, const float* pos, const float* scale,
                     const float* rotq, float scale_modifier, float* means_2d, float* depth, float* covs_2d,
                     hipStream_t stream);
+// hole_flag (optional, device word, cleared by the caller): set when a splat claims pair slots that copy_with_keys leaves
+// unwritten (radius <= 0 with tiles > 0: a NaN covariance) -- only then does the reference's zero-fill of the pair buffers matter
 void launch_allocate_tiles(int P, const CamParams& cp, bool use_focal, const float* depth, float* means_2d,
-                           float* covs_2d, uint32_t* tiles_touched, int32_t* radii, hipStream_t stream);
+                           float* covs_2d, uint32_t* tiles_touched, int32_t* radii, hipStream_t stream,
+                           uint32_t* hole_flag = nullptr);
 void launch_copy_with_keys(int P, const CamParams& cp, const float* means_2d, const uint32_t* offsets,
                            const int32_t* radii, const float* depth, uint64_t* keys, uint32_t* values,
                            hipStream_t stream);

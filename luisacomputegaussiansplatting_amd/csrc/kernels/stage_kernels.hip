@@ -97,7 +97,8 @@ __global__ void __launch_bounds__(kThreads) k_allocate_tiles(int P, CamParams cp
                                                                float* __restrict__ means_2d,
                                                                float* __restrict__ covs_2d,
                                                                uint32_t* __restrict__ tiles_touched,
-                                                               int32_t* __restrict__ radii)
+                                                               int32_t* __restrict__ radii,
+                                                               uint32_t* __restrict__ hole_flag)
 {
     const int idx = blockIdx.x * kThreads + threadIdx.x;
     if (idx >= P) return;
@@ -114,8 +115,13 @@ __global__ void __launch_bounds__(kThreads) k_allocate_tiles(int P, CamParams cp
     const float pix_x = ndc2pix(ndc_x, cp.width), pix_y = ndc2pix(ndc_y, cp.height);
     uint32_t    rmin[2], rmax[2];
     get_rect(pix_x, pix_y, radius, cp.grid_x, cp.grid_y, rmin, rmax);
+    const uint32_t tiles          = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
     radii[idx]                    = radius;
-    tiles_touched[idx]            = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
+    tiles_touched[idx]            = tiles;
+    // A splat that claims pair slots (tiles > 0) which copy_with_keys will leave unwritten (it skips radius <= 0,
+    // shader.cpp:41-42): only a NaN covariance gets here.  Its slots keep the value of the reference's BufferFiller pass
+    // (impl.cpp:117-118) -- the caller learns whether that fill is needed at all this frame.
+    if (hole_flag && radius <= 0 && tiles > 0u) *hole_flag = 1u;
     covs_2d[3 * (size_t)idx + 0]  = conic[0];
     covs_2d[3 * (size_t)idx + 1]  = conic[1];
     covs_2d[3 * (size_t)idx + 2]  = conic[2];
@@ -217,11 +223,11 @@ void launch_project(int P, const CamParams& cp, bool use_focal, const float* pos
 }
 
 void launch_allocate_tiles(int P, const CamParams& cp, bool use_focal, const float* depth, float* means_2d,
-                           float* covs_2d, uint32_t* tiles_touched, int32_t* radii, hipStream_t stream)
+                           float* covs_2d, uint32_t* tiles_touched, int32_t* radii, hipStream_t stream, uint32_t* hole_flag)
 {
     if (P <= 0) return;
     hipLaunchKernelGGL(k_allocate_tiles, dim3(blocks_for(P)), dim3(kThreads), 0, stream, P, cp, use_focal, depth,
-                       means_2d, covs_2d, tiles_touched, radii);
+                       means_2d, covs_2d, tiles_touched, radii, hole_flag);
 }
 
 void launch_copy_with_keys(int P, const CamParams& cp, const float* means_2d, const uint32_t* offsets,

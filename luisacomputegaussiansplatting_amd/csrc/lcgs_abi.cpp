@@ -725,12 +725,17 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
     cp.grid_x = div_up(cp.width, kBlockX); // impl.cpp:76-79
     cp.grid_y = div_up(cp.height, kBlockY);
 
+    LCGS_TRY(ctx->st_scalar.ensure(16));
+    uint32_t* d_hole = ctx->st_scalar.as<uint32_t>();
+    LCGS_HIP_CHECK(hipMemsetAsync(d_hole, 0, 4, st));
     launch_allocate_tiles(P, cp, use_focal != 0, input->depth_features, input->means_2d, input->conic,
-                          accel->tiles_touched, output->radii, st); // impl.cpp:87-99
+                          accel->tiles_touched, output->radii, st, d_hole); // impl.cpp:87-99
     LCGS_TRY(ctx->st_scan_temp.ensure(scan_temp_bytes(P)));
     launch_inclusive_sum_u32(accel->tiles_touched, accel->point_offsets, P, ctx->st_scan_temp.ptr, st); // impl.cpp:104
-    int32_t L = 0;
+    int32_t  L    = 0;
+    uint32_t hole = 0;
     LCGS_HIP_CHECK(hipMemcpyAsync(&L, accel->point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st)); // impl.cpp:106
+    LCGS_HIP_CHECK(hipMemcpyAsync(&hole, d_hole, 4, hipMemcpyDeviceToHost, st));
     LCGS_HIP_CHECK(hipStreamSynchronize(st));                                                        // impl.cpp:107
     if (num_rendered) *num_rendered = L;
     if (L <= 0) return LCGS_OK; // impl.cpp:109
@@ -740,8 +745,14 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
         set_last_error(buf);
         return LCGS_ERR_CAPACITY;
     }
-    LCGS_HIP_CHECK(hipMemsetAsync(accel->point_list_unsorted, 0, (size_t)L * 4, st));      // impl.cpp:117
-    LCGS_HIP_CHECK(hipMemsetAsync(accel->point_list_keys_unsorted, 0, (size_t)L * 8, st)); // impl.cpp:118
+    // The reference zero-fills both unsorted pair buffers every frame (impl.cpp:117-118) and then overwrites every slot --
+    // except those of a splat whose covariance is NaN (radius 0, tiles > 0: copy_with_keys skips it, shader.cpp:41-42), which
+    // keep the fill: key 0, splat 0.  The fill (12 bytes x num_rendered: 156 MB on the bicycle stand-in) is therefore issued
+    // only in a frame that has such a splat; the buffers' contents are the reference's either way.
+    if (hole) {
+        LCGS_HIP_CHECK(hipMemsetAsync(accel->point_list_unsorted, 0, (size_t)L * 4, st));      // impl.cpp:117
+        LCGS_HIP_CHECK(hipMemsetAsync(accel->point_list_keys_unsorted, 0, (size_t)L * 8, st)); // impl.cpp:118
+    }
     launch_copy_with_keys(P, cp, input->means_2d, accel->point_offsets, output->radii, input->depth_features,
                           accel->point_list_keys_unsorted, accel->point_list_unsorted, st); // impl.cpp:120-130
     // impl.cpp:135-143 sorts all 64 key bits; only 32 + ceil(log2 G) of them can differ

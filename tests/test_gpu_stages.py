@@ -90,7 +90,11 @@ def _tile_splat(lcgs, oracle, ops, scene, W, H, bg, use_focal=True, cap_slack=1.
     cap = max(1, int(L * cap_slack) + 7)
     i64 = lambda n: torch.zeros(n, dtype=torch.int64, device=DEV)
     i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=DEV)
-    accel = lcgs.GSTileSplatterAccelProxy(i32(P), i32(P), i64(cap), i32(cap), i64(cap), i32(cap), i32(2 * G))
+    # the unsorted pair buffers start as GARBAGE: the reference zero-fills them every frame (impl.cpp:117-118); the library
+    # only does when a slot would otherwise stay unwritten (a NaN covariance) -- either way [0, L) must be the oracle's
+    junk64 = torch.full((cap,), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64, device=DEV)
+    junk32 = torch.full((cap,), 0x5A5A5A5A, dtype=torch.int32, device=DEV)
+    accel = lcgs.GSTileSplatterAccelProxy(i32(P), i32(P), junk64, junk32, i64(cap), i32(cap), i32(2 * G))
     target = torch.full((3, H, W), -1.0, device=DEV)
     out = lcgs.GSSplatForwardOutputProxy(H, W, target, i32(P), torch.zeros(H, W, device=DEV), i32(H * W))
     inp = lcgs.GSTileSplatterInputProxy(P, tuple(bg), means, depth, covs, color, d["opacity"])
@@ -103,7 +107,7 @@ def _tile_splat(lcgs, oracle, ops, scene, W, H, bg, use_focal=True, cap_slack=1.
     assert np.array_equal(out.radii.cpu().numpy(), radii)
     vis = dd >= np.float32(0.2)
     assert np.array_equal(means.cpu().numpy()[vis], mp[vis])   # NDC -> pixel, in place
-    assert np.array_equal(covs.cpu().numpy()[vis], conic[vis])  # cov -> conic, in place
+    assert np.array_equal(covs.cpu().numpy()[vis], conic[vis], equal_nan=True)  # cov -> conic, in place
     if L > 0:
         assert np.array_equal(accel.point_list_keys_unsorted.cpu().numpy().view(np.uint64)[:L], keys)
         assert np.array_equal(u32(accel.point_list_unsorted)[:L], vals)
@@ -127,6 +131,18 @@ def test_tile_splatter_chain(lcgs, oracle, ops, res):
     scene["scale"][100:110] *= 60.0  # rects that cover the whole grid
     L = _tile_splat(lcgs, oracle, ops, scene, res[0], res[1], (0.1, 0.2, 0.3))
     assert L > 0 or res == (16, 16)
+
+
+def test_tile_splatter_nan_covariance_keeps_the_references_zero_filled_pairs(lcgs, oracle, ops):
+    """A splat whose covariance is NaN gets radius 0 but claims a tile (allocate_tiles has no such test,
+    shader.cpp:102-163); copy_with_keys skips it (radius <= 0, :41-42), so its pair slots keep the BufferFiller's zeros
+    (impl.cpp:117-118): key 0 / value 0 = splat 0 in tile 0 at depth 0.  The stage-level path reproduces that literally
+    -- the zero-fill is skipped only in frames WITHOUT such a splat -- down to the sorted lists and the image."""
+    rng = np.random.default_rng(78)
+    scene = make_scene(rng, 6000, log_scale=(-4.0, 0.7))
+    scene["scale"][[17, 2500, 5999], 1] = np.nan
+    L = _tile_splat(lcgs, oracle, ops, scene, 320, 240, (0.2, 0.1, 0.0))
+    assert L > 0
 
 
 def test_tile_splatter_nonfocal(lcgs, oracle, ops):
