@@ -102,6 +102,7 @@ struct lcgs_context {
     int64_t hint_V = 0, hint_L = 0;
     // workspace of the stage-level path / primitives
     DeviceBuffer st_keys_tmp, st_vals_tmp, st_sort_temp, st_scan_temp, st_scalar;
+    DeviceBuffer st_flags, st_u32[8], st_keys_exp, st_vals_exp; // the splatter's sort-before-duplicate (lcgs_tile_splat_forward)
     uint32_t     pair_capacity = 0;
     uint32_t*    h_counts      = nullptr; // pinned, 8 x u32
 

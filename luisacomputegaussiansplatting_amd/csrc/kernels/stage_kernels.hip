@@ -133,26 +133,31 @@ __global__ void __launch_bounds__(kThreads) k_allocate_tiles(int P, CamParams cp
 // splat's rect with one thread; here the 64 lanes of a wave first handle the small rects one per
 // lane, and rects with more than 32 tiles are expanded cooperatively by the whole wave (64
 // consecutive pairs per step, coalesced 8-byte and 4-byte stores).
+// ORDERED (the splatter's own sorted copy, see lcgs_tile_splat_forward): thread idx handles splat order[idx] and writes at
+// the offsets of THAT sequence -- the same pairs, grouped by splat in depth order instead of index order.
+template <bool ORDERED>
 __global__ void __launch_bounds__(kThreads) k_copy_with_keys(int P, CamParams cp, const float* __restrict__ means_2d,
                                                                const uint32_t* __restrict__ offsets,
                                                                const int32_t* __restrict__ radii,
                                                                const float* __restrict__ depth,
                                                                uint64_t* __restrict__ keys,
-                                                               uint32_t* __restrict__ values)
+                                                               uint32_t* __restrict__ values,
+                                                               const uint32_t* __restrict__ order)
 {
     const int idx  = blockIdx.x * kThreads + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t  rmin[2] = { 0, 0 }, rmax[2] = { 0, 0 };
-    uint32_t  off = 0, dbits = 0, w = 0, count = 0;
+    uint32_t  off = 0, dbits = 0, w = 0, count = 0, sid = 0;
     if (idx < P) {
-        const int32_t radius = radii[idx];
+        sid = ORDERED ? order[idx] : (uint32_t)idx;
+        const int32_t radius = radii[sid];
         if (radius > 0) {
             off = idx >= 1 ? offsets[idx - 1] : 0u;
-            get_rect(means_2d[2 * (size_t)idx + 0], means_2d[2 * (size_t)idx + 1], radius, cp.grid_x, cp.grid_y, rmin,
+            get_rect(means_2d[2 * (size_t)sid + 0], means_2d[2 * (size_t)sid + 1], radius, cp.grid_x, cp.grid_y, rmin,
                      rmax);
             w     = rmax[0] - rmin[0];
             count = w * (rmax[1] - rmin[1]);
-            dbits = __float_as_uint(depth[idx]);
+            dbits = __float_as_uint(depth[sid]);
         }
     }
     const bool big = count > 32u;
@@ -160,7 +165,7 @@ __global__ void __launch_bounds__(kThreads) k_copy_with_keys(int P, CamParams cp
         for (uint32_t j = rmin[1]; j < rmax[1]; ++j)
             for (uint32_t i = rmin[0]; i < rmax[0]; ++i) {
                 keys[off]   = ((uint64_t)(i + j * cp.grid_x) << 32) | (uint64_t)dbits;
-                values[off] = (uint32_t)idx;
+                values[off] = sid;
                 off         = off + 1u;
             }
     }
@@ -174,13 +179,41 @@ __global__ void __launch_bounds__(kThreads) k_copy_with_keys(int P, CamParams cp
         const uint32_t b_x0    = __shfl(rmin[0], src, 64);
         const uint32_t b_y0    = __shfl(rmin[1], src, 64);
         const uint32_t b_dbits = __shfl(dbits, src, 64);
-        const uint32_t b_idx   = (uint32_t)(idx - lane + src);
+        const uint32_t b_idx   = __shfl(sid, src, 64);
         for (uint32_t k = lane; k < b_count; k += 64) {
             const uint32_t j = b_y0 + k / b_w, i = b_x0 + k % b_w;
             keys[b_off + k]   = ((uint64_t)(i + j * cp.grid_x) << 32) | (uint64_t)b_dbits;
             values[b_off + k] = b_idx;
         }
     }
+}
+
+// ---- helpers of the splatter's sort-before-duplicate (lcgs_tile_splat_forward) ----
+// flags[i] = splat i claims pair slots; the array is padded with zeros to whole compaction chunks by the caller's memset
+__global__ void __launch_bounds__(kThreads) k_tile_flags(int P, const uint32_t* __restrict__ tiles_touched,
+                                                           uint8_t* __restrict__ flags)
+{
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx < P) flags[idx] = tiles_touched[idx] > 0u ? 1 : 0;
+}
+
+// the depth sort's input: (depth bits, splat index) of the n splats that claim slots, in index order
+__global__ void __launch_bounds__(kThreads) k_gather_depth_keys(int n, const uint32_t* __restrict__ vis,
+                                                                  const float* __restrict__ depth,
+                                                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t sid = vis[j];
+    keys[j]            = __float_as_uint(depth[sid]);
+    vals[j]            = sid;
+}
+
+__global__ void __launch_bounds__(kThreads) k_gather_u32(int n, const uint32_t* __restrict__ order,
+                                                           const uint32_t* __restrict__ src, uint32_t* __restrict__ dst)
+{
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    if (j < n) dst[j] = src[order[j]];
 }
 
 // shad_get_ranges (lcgs/src/gs_tile_splatter/shader.cpp:71-100); ranges zero-filled by the caller (impl.cpp:147)
@@ -235,8 +268,35 @@ void launch_copy_with_keys(int P, const CamParams& cp, const float* means_2d, co
                            hipStream_t stream)
 {
     if (P <= 0) return;
-    hipLaunchKernelGGL(k_copy_with_keys, dim3(blocks_for(P)), dim3(kThreads), 0, stream, P, cp, means_2d, offsets,
-                       radii, depth, keys, values);
+    hipLaunchKernelGGL(k_copy_with_keys<false>, dim3(blocks_for(P)), dim3(kThreads), 0, stream, P, cp, means_2d, offsets,
+                       radii, depth, keys, values, (const uint32_t*)nullptr);
+}
+
+void launch_copy_with_keys_ordered(int n, const CamParams& cp, const float* means_2d, const uint32_t* offsets_sorted,
+                                   const int32_t* radii, const float* depth, const uint32_t* order, uint64_t* keys,
+                                   uint32_t* values, hipStream_t stream)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_copy_with_keys<true>, dim3(blocks_for(n)), dim3(kThreads), 0, stream, n, cp, means_2d, offsets_sorted,
+                       radii, depth, keys, values, order);
+}
+
+void launch_tile_flags(int P, const uint32_t* tiles_touched, uint8_t* flags, hipStream_t stream)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_tile_flags, dim3(blocks_for(P)), dim3(kThreads), 0, stream, P, tiles_touched, flags);
+}
+
+void launch_gather_depth_keys(int n, const uint32_t* vis, const float* depth, uint32_t* keys, uint32_t* vals, hipStream_t stream)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gather_depth_keys, dim3(blocks_for(n)), dim3(kThreads), 0, stream, n, vis, depth, keys, vals);
+}
+
+void launch_gather_u32(int n, const uint32_t* order, const uint32_t* src, uint32_t* dst, hipStream_t stream)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gather_u32, dim3(blocks_for(n)), dim3(kThreads), 0, stream, n, order, src, dst);
 }
 
 void launch_get_ranges_u64(int64_t L, const uint64_t* keys, uint32_t* ranges, hipStream_t stream)

@@ -506,7 +506,8 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
                              &ctx->rects, &ctx->rects_sorted, &ctx->cull_slab, &ctx->chunk_info, &ctx->chunk_base, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
                              &ctx->pairv[1], &ctx->zero_ws[0], &ctx->zero_ws[1], &ctx->zero_ws[2], &ctx->counts, &ctx->sort_ws,
                              &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order[0], &ctx->tile_order[1], &ctx->st_keys_tmp,
-                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac, &ctx->tie_ws, &ctx->fused_grads };
+                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac, &ctx->tie_ws, &ctx->fused_grads, &ctx->st_flags, &ctx->st_keys_exp, &ctx->st_vals_exp,
+                             &ctx->st_u32[0], &ctx->st_u32[1], &ctx->st_u32[2], &ctx->st_u32[3], &ctx->st_u32[4], &ctx->st_u32[5], &ctx->st_u32[6], &ctx->st_u32[7] };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& b : ctx->owned) b.release();
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
@@ -732,10 +733,22 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
                           accel->tiles_touched, output->radii, st, d_hole); // impl.cpp:87-99
     LCGS_TRY(ctx->st_scan_temp.ensure(scan_temp_bytes(P)));
     launch_inclusive_sum_u32(accel->tiles_touched, accel->point_offsets, P, ctx->st_scan_temp.ptr, st); // impl.cpp:104
+    // (for the sort below: the splats that claim pair slots, ascending -- compacted before the one synchronisation)
+    const size_t fbytes = sparse_flag_bytes(P);
+    LCGS_TRY(ctx->st_flags.ensure(fbytes));
+    LCGS_TRY(ctx->st_u32[0].ensure((size_t)sparse_flag_chunks(P) * 4 + 4));
+    LCGS_TRY(ctx->st_u32[1].ensure((size_t)P * 4 + 4));
+    uint8_t*  d_flags = ctx->st_flags.as<uint8_t>();
+    uint32_t* d_vis   = ctx->st_u32[1].as<uint32_t>();
+    uint32_t* d_nvis  = d_hole + 1;
+    if (fbytes > (size_t)P) LCGS_HIP_CHECK(hipMemsetAsync(d_flags + P, 0, fbytes - (size_t)P, st)); // the padding
+    launch_tile_flags(P, accel->tiles_touched, d_flags, st);
+    launch_compact_flags(d_flags, P, ctx->st_u32[0].as<uint32_t>(), d_vis, d_nvis, st);
     int32_t  L    = 0;
-    uint32_t hole = 0;
+    uint32_t hole = 0, n_vis = 0;
     LCGS_HIP_CHECK(hipMemcpyAsync(&L, accel->point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st)); // impl.cpp:106
     LCGS_HIP_CHECK(hipMemcpyAsync(&hole, d_hole, 4, hipMemcpyDeviceToHost, st));
+    LCGS_HIP_CHECK(hipMemcpyAsync(&n_vis, d_nvis, 4, hipMemcpyDeviceToHost, st));
     LCGS_HIP_CHECK(hipStreamSynchronize(st));                                                        // impl.cpp:107
     if (num_rendered) *num_rendered = L;
     if (L <= 0) return LCGS_OK; // impl.cpp:109
@@ -760,9 +773,37 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
     LCGS_TRY(ctx->st_keys_tmp.ensure((size_t)L * 8));
     LCGS_TRY(ctx->st_vals_tmp.ensure((size_t)L * 4));
     LCGS_TRY(ctx->st_sort_temp.ensure(pair_sort_ws_bytes(L)));
-    launch_pair_sort_u64_preserve(accel->point_list_keys_unsorted, accel->point_list_unsorted, accel->point_list_keys,
-                                  accel->point_list, ctx->st_keys_tmp.as<uint64_t>(), ctx->st_vals_tmp.as<uint32_t>(),
-                                  L, 0, 32 + tile_bits, ctx->st_sort_temp.ptr, st);
+    if (hole || n_vis == 0 || getenv("LCGS_STAGE_LITERAL_SORT")) {
+        // the reference's sort as it stands: all live key bits of the unsorted pairs (frames with zero-filled slots, whose
+        // pairs exist nowhere but in those buffers; LCGS_STAGE_LITERAL_SORT=1 is a tuning / test hook)
+        launch_pair_sort_u64_preserve(accel->point_list_keys_unsorted, accel->point_list_unsorted, accel->point_list_keys,
+                                      accel->point_list, ctx->st_keys_tmp.as<uint64_t>(), ctx->st_vals_tmp.as<uint32_t>(),
+                                      L, 0, 32 + tile_bits, ctx->st_sort_temp.ptr, st);
+    } else {
+        // The same sorted arrays by sort-before-duplicate: a stable LSD sort on (tile << 32 | depth bits) sorts
+        // the low 32 bits first -- and all pairs of a splat share them.  So the n_vis splats that claim slots are sorted by
+        // depth bits (stable: ascending index inside equal depths, the order their pairs have in the unsorted buffers), their
+        // pairs are written out again in THAT order (k_copy_with_keys over the sorted sequence, same (y, x) order inside a
+        // splat), and only the tile bits remain to be sorted over the num_rendered pairs: 4 passes over n_vis + 2 over L
+        // instead of 6 over L, bit-identical keys / lists (tests/test_gpu_stages.py compares every entry).
+        const int n = (int)n_vis;
+        for (int i = 2; i < 8; ++i) LCGS_TRY(ctx->st_u32[i].ensure((size_t)n * 4 + 16));
+        uint32_t *ka = ctx->st_u32[2].as<uint32_t>(), *kb = ctx->st_u32[3].as<uint32_t>(), *va = ctx->st_u32[4].as<uint32_t>(),
+                 *vb = ctx->st_u32[5].as<uint32_t>(), *cnt = ctx->st_u32[6].as<uint32_t>(), *offs = ctx->st_u32[7].as<uint32_t>();
+        launch_gather_depth_keys(n, d_vis, input->depth_features, ka, va, st);
+        const int which = launch_pair_sort_u32(ka, kb, va, vb, d_nvis, n, n, 0, 32, ctx->st_sort_temp.ptr, st);
+        const uint32_t* order = which ? vb : va;
+        launch_gather_u32(n, order, accel->tiles_touched, cnt, st);
+        LCGS_TRY(ctx->st_scan_temp.ensure(scan_temp_bytes(n)));
+        launch_inclusive_sum_u32(cnt, offs, n, ctx->st_scan_temp.ptr, st);
+        LCGS_TRY(ctx->st_keys_exp.ensure((size_t)L * 8));
+        LCGS_TRY(ctx->st_vals_exp.ensure((size_t)L * 4));
+        launch_copy_with_keys_ordered(n, cp, input->means_2d, offs, output->radii, input->depth_features, order,
+                                      ctx->st_keys_exp.as<uint64_t>(), ctx->st_vals_exp.as<uint32_t>(), st);
+        launch_pair_sort_u64_preserve(ctx->st_keys_exp.as<uint64_t>(), ctx->st_vals_exp.as<uint32_t>(), accel->point_list_keys,
+                                      accel->point_list, ctx->st_keys_tmp.as<uint64_t>(), ctx->st_vals_tmp.as<uint32_t>(), L,
+                                      32, 32 + tile_bits, ctx->st_sort_temp.ptr, st);
+    }
     const size_t G = (size_t)cp.grid_x * cp.grid_y;
     LCGS_HIP_CHECK(hipMemsetAsync(accel->ranges, 0, G * 2 * 4, st)); // impl.cpp:147
     launch_get_ranges_u64(L, accel->point_list_keys, accel->ranges, st); // impl.cpp:150-156
