@@ -101,6 +101,13 @@ def main():
                          "torch.distributed's (cross-check)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries below print there too (RCCL's version banner at communicator
+    # creation, gloo's "connected to N peer ranks"): from here on file descriptor 1 points at stderr, and the line is
+    # written to the saved descriptor by emit().
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
 
     import luisacomputegaussiansplatting_amd as L
@@ -115,7 +122,7 @@ def main():
 
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"), __file__] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
+        sys.exit(subprocess.call(cmd, stdout=line_out))  # (the children's stdout is the real one)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: liblcgs_hip has no CPU path")
     # a launcher that narrows each rank's visibility to one GPU leaves fewer devices than local ranks
@@ -523,7 +530,7 @@ def main():
         if error is not None:
             out["error"] = error
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            print(json.dumps(out), file=line_out, flush=True)
 
     if dist is not None:
         def give_up():
