@@ -123,3 +123,23 @@ def test_comm_entry_points_without_a_gpu(lcgs):
     assert lib.lcgs_comm_create(None, a, C.c_int(0), C.c_int(1), C.byref(h)) == 1 and not h.value
     assert lib.lcgs_comm_destroy(None) == 0
     assert lcgs.shard_rows(10, 4, 3) == (6, 2)  # floor(10 / 4) rows each; rows 8, 9 are the tail every rank keeps
+
+
+def test_real_scene_env_hooks_switch_the_full_size_tests_to_the_file(lcgs, tmp_path, monkeypatch):
+    """conftest.baseline_scene: LCGS_<NAME>_PLY pointing at a file makes a BASELINE scene `real` (read through
+    lcgs_ply_read in the file's order), anything else the synthetic stand-in of SURVEY 8(d)."""
+    from conftest import BASELINE_SCENES, baseline_scene
+
+    assert set(BASELINE_SCENES) == {"lego", "chair", "bicycle", "garden"}
+    rng = np.random.default_rng(4)
+    P = 321
+    path = str(tmp_path / "chair.ply")
+    lcgs.write_ply_raw(path, rng.normal(0, 1, (P, 3)), rng.normal(0, 1, (P, 3)), rng.normal(0, 0.1, (P, 45)),
+                       rng.normal(0, 1, P), rng.normal(-4, 1, (P, 3)), rng.normal(0, 1, (P, 4)))
+    monkeypatch.setenv("LCGS_CHAIR_PLY", path)
+    scene, data = baseline_scene(lcgs, "chair")
+    assert data == "real" and scene["pos"].shape == (P, 3) and set(scene) == {"pos", "scale", "rotq", "sh", "opacity"}
+    monkeypatch.setenv("LCGS_CHAIR_PLY", str(tmp_path / "missing.ply"))
+    monkeypatch.setitem(BASELINE_SCENES, "chair", ("LCGS_CHAIR_PLY", 0, 1002, 500))  # (a small stand-in for this check)
+    scene, data = baseline_scene(lcgs, "chair")
+    assert data == "synthetic" and scene["pos"].shape == (500, 3)
