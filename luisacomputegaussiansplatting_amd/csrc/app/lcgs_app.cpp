@@ -64,6 +64,8 @@ void usage(const char* argv0)
            "                           frame is the target, opacities and base colours are perturbed, K optimiser steps\n"
            "                           (forward, L2 loss, backward, Adam) pull them back; prints the loss per step.  With\n"
            "                           --cameras every step covers all views of the file (lcgs_fit_views)\n");
+    printf("  --fused-adam             With --fit on one view: the optimiser is applied inside the backward's per-splat kernel\n"
+           "                           (lcgs_render_backward_adam: on-screen splats only, no gradient arrays)\n");
     printf("  --display                Not supported (headless)\n");
 }
 
@@ -82,7 +84,7 @@ int main(int argc, char** argv)
     std::string ply_path = "gsplat.ply", backend = "hip", out_dir = "out", world = "colmap", path = "fused", synth;
     std::string ingest = "device", cameras_file, order = "auto", pose = "garden";
     int         exp_N = 1, gpus = 1, fit_steps = 0;
-    bool        backward = false;
+    bool        backward = false, fused_adam = false;
     // parse_command (app/command_parser.hpp:5-79): strip leading dashes, `key=value` or `key value`
     for (int i = 1; i < argc; ++i) {
         std::string arg = argv[i];
@@ -141,6 +143,7 @@ int main(int argc, char** argv)
             fit_steps = std::stoi(value);
             if (fit_steps < 1 || fit_steps > 100000) die("--fit out of range");
         }
+        else if (key == "fused-adam" || key == "fused_adam") fused_adam = true;
         else if (key == "display") die("--display needs a GUI; this build is headless");
         else die("unknown option --" + key);
     }
@@ -383,10 +386,19 @@ int main(int argc, char** argv)
             lcgs_adam_config cfg = { 0.0f, 2.5e-2f, 0.0f, 5e-2f, 0.0f, 0.0f, 0.9f, 0.999f, 1e-15f, 1, 0 }; // opacity + dc only
             auto t0 = std::chrono::steady_clock::now();
             float first_loss = 0.0f, loss = 0.0f;
+            if (fused_adam && nv != 1) die("--fused-adam differentiates one view per step (omit --cameras)");
+            lcgs::Buffer<float> d_dL(fused_adam ? (size_t)W * H * 3 : 1);
             for (int it = 0; it < fit_steps; ++it) {
-                scene.fit_views(cams, target_ptrs, grads, d_loss.data(), bg);
                 cfg.step = it + 1;
-                lcgs::check(lcgs_adam_step(device.ctx(), P, 3, &cfg, &grads, &raw, &mm, &vv, &act));
+                if (fused_adam) { // forward (kept state) -> L2 loss and its gradient -> backward with Adam folded in
+                    scene.render(cams[0], d_img, bg, 1.0f, /*keep_state=*/true);
+                    lcgs::check(lcgs_l2_loss_backward(device.ctx(), (int)W, (int)H, d_img.data(), target_ptrs[0], d_dL.data(),
+                                                      d_loss.data()));
+                    lcgs::check(lcgs_render_backward_adam(device.ctx(), d_dL.data(), P, 3, &cfg, &raw, &mm, &vv, &act));
+                } else {
+                    scene.fit_views(cams, target_ptrs, grads, d_loss.data(), bg);
+                    lcgs::check(lcgs_adam_step(device.ctx(), P, 3, &cfg, &grads, &raw, &mm, &vv, &act));
+                }
                 device.synchronize();
                 if (hipMemcpy(h_loss.data(), d_loss.data(), sizeof(float) * nv, hipMemcpyDeviceToHost) != hipSuccess) die("D2H copy failed");
                 loss = 0.0f;

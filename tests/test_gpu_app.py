@@ -117,15 +117,17 @@ def test_lcgs_app_view_sharded_backward_with_gradient_sum(lcgs, oracle, tmp_path
         assert os.path.exists(os.path.join(out, f"synth0_{P}_hip_{k}.png"))
 
 
-def test_lcgs_app_fit_trains_through_the_c_abi_only(lcgs, tmp_path):
+@pytest.mark.parametrize("extra", [[], ["--fused-adam"]])
+def test_lcgs_app_fit_trains_through_the_c_abi_only(lcgs, tmp_path, extra):
     """--fit K: "training without python binding" (doc/roadmap.md:4) -- forward, lcgs_l2_loss_backward, lcgs_render_backward,
-    lcgs_adam_step in a C++ loop.  The target is the scene's own frame and the start a perturbed copy, so the loss has to
+    lcgs_adam_step in a C++ loop (--fused-adam: lcgs_render_backward_adam, the optimiser inside the backward's per-splat
+    kernel, no gradient arrays).  The target is the scene's own frame and the start a perturbed copy, so the loss has to
     fall, and by a lot."""
     import re
 
     app = os.path.join(ROOT, "luisacomputegaussiansplatting_amd", "lcgs-app")
     res = subprocess.run([app, "--synth", "0:20000:1001", "--res=320x240", "--out", str(tmp_path), "--world", "blender",
-                          "--pose", "lego", "--fit", "30"], capture_output=True, text=True, timeout=300)
+                          "--pose", "lego", "--fit", "30"] + extra, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
     losses = [float(x) for x in re.findall(r"step \d+ loss (\S+)", res.stdout)]
     assert len(losses) == 30 and all(np.isfinite(losses))
