@@ -18,6 +18,13 @@
  *   - projection / conic / radius / keys / blend: the reference cannot be built
  *     here (LuisaCompute + lc_parallel_primitive are external and absent), so
  *     these follow the reference source line by line but are PARITY UNPINNED.
+ *   - the blend's exp (gs_tile_splatter/shader.cpp:258): the reference's is whatever
+ *     LuisaCompute's JIT hands its backend (absent, unpinned); here a build-DEFINED
+ *     sequence of binary32 operations (orc_blend_exp, <= 2.73 ulp from the true value
+ *     on the blend's range), which the HIP kernels repeat bit for bit.  PARITY
+ *     UNPINNED against the reference below that band, like every other exp of it.
+ *   - the two reference-held output images (doc/*_cuda.png): pin the unrasterised
+ *     last tile row / column and the row flip (tests/test_reference_png.py).
  *   - scan / sort: lcpp is absent; semantics = inclusive sum / stable ascending
  *     sort.  PARITY UNPINNED.
  *   - backward: the reference has none.  Pinned by fp64 finite differences.
