@@ -123,8 +123,14 @@ def _tile_splat(lcgs, oracle, ops, scene, W, H, bg, use_focal=True, cap_slack=1.
     return L
 
 
+@pytest.mark.parametrize("sort", ["literal", "splats"])
 @pytest.mark.parametrize("res", [(800, 800), (100, 72), (333, 201), (16, 16)])
-def test_tile_splatter_chain(lcgs, oracle, ops, res):
+def test_tile_splatter_chain(lcgs, oracle, ops, res, sort, monkeypatch):
+    """Every buffer GSTileSplatter::forward leaves behind, entry for entry, through both ways the splatter produces the
+    sorted pairs: the reference's six-pass sort of the unsorted pairs ("literal", what frames below 4 M pairs take) and
+    sort-before-duplicate ("splats": the splats by depth, their pairs re-emitted in that order, two passes on the tile bits
+    -- what large frames take); LCGS_STAGE_SORT forces either."""
+    monkeypatch.setenv("LCGS_STAGE_SORT", sort)
     rng = np.random.default_rng(res[0])
     scene = make_scene(rng, 30011, log_scale=(-4.2, 0.8))
     scene["pos"][:100] = rng.normal(0, 0.3, (100, 3)) + POSE[0]
@@ -133,11 +139,13 @@ def test_tile_splatter_chain(lcgs, oracle, ops, res):
     assert L > 0 or res == (16, 16)
 
 
-def test_tile_splatter_nan_covariance_keeps_the_references_zero_filled_pairs(lcgs, oracle, ops):
+@pytest.mark.parametrize("sort", ["literal", "splats"])
+def test_tile_splatter_nan_covariance_keeps_the_references_zero_filled_pairs(lcgs, oracle, ops, sort, monkeypatch):
     """A splat whose covariance is NaN gets radius 0 but claims a tile (allocate_tiles has no such test,
     shader.cpp:102-163); copy_with_keys skips it (radius <= 0, :41-42), so its pair slots keep the BufferFiller's zeros
     (impl.cpp:117-118): key 0 / value 0 = splat 0 in tile 0 at depth 0.  The stage-level path reproduces that literally
     -- the zero-fill is skipped only in frames WITHOUT such a splat -- down to the sorted lists and the image."""
+    monkeypatch.setenv("LCGS_STAGE_SORT", sort)  # ("splats" is overridden by the zero-filled slots: they exist nowhere else)
     rng = np.random.default_rng(78)
     scene = make_scene(rng, 6000, log_scale=(-4.0, 0.7))
     scene["scale"][[17, 2500, 5999], 1] = np.nan
