@@ -820,6 +820,21 @@ def main():
                          "bit_identical": bool(np.array_equal(gi, ref["img"])),
                          "pixels_different": int((diff > 0).sum()),
                          "pixels_over_1e-4": int((diff > 1e-4).sum()), "max_abs_diff": float(diff.max())}
+        # ... and the distance to a STANDARD exp in the blend (the reference says `exp(power)`, gs_tile_splatter/shader.cpp:259;
+        # north_star's bar: 1e-4 per-pixel L-inf): the same frame against the oracle run with libm's expf.  Pixels beyond 1e-4
+        # are threshold flips (an ulp of exp moves `alpha < 1/255` or `T < 1e-4`); `all_flagged` says every one of them is
+        # marked threshold-ambiguous (within 1e-5 relative) by the libm oracle itself.
+        o.set_blend_exp(True)
+        ref_libm = o.render(scene, ocam, ambig_eps=1e-5)
+        o.set_blend_exp(False)
+        with np.errstate(invalid="ignore"):
+            dl = np.abs(gi.astype(np.float64) - ref_libm["img"].astype(np.float64)).max(axis=0)
+        amb = ref_libm["ambig"].astype(bool)
+        over = dl > 1e-4
+        out["parity"]["vs_libm_expf"] = {
+            "pixels_over_1e-4": int(over.sum()), "max_abs_diff": float(dl.max()),
+            "all_flagged": bool((~over | amb).all()), "ambiguous_pixels": int(amb.sum()),
+            "max_abs_diff_unflagged": float(dl[~amb].max()) if (~amb).any() else 0.0, "pixels": int(dl.size)}
     emit()
     if coll is not None:
         barrier()

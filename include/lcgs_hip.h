@@ -457,8 +457,11 @@ LCGS_API lcgs_status lcgs_sparse_touched_rows(lcgs_context* ctx, lcgs_comm* comm
 LCGS_API int64_t     lcgs_sparse_message_words(int64_t count, int sh_degree);
 LCGS_API lcgs_status lcgs_sparse_pack(lcgs_context* ctx, int sh_degree, const lcgs_grads* grads, const uint32_t* d_rows,
                                       int64_t count, float* d_msg);
+/* Adds the message's rows to the dense gradient rows.  The row indices come out of the (received) message: only rows in
+ * [row_first, row_first + row_count) -- the caller's shard, or [0, num_gaussians) -- are accepted, any other index is
+ * dropped without a write (a short, corrupt or mismatched-P message cannot reach memory outside the arrays). */
 LCGS_API lcgs_status lcgs_sparse_accumulate(lcgs_context* ctx, int sh_degree, const lcgs_grads* grads, const float* d_msg,
-                                            int64_t count);
+                                            int64_t count, int64_t row_first, int64_t row_count);
 
 /* ------------------------------------------------------------------------------------------
  * Scene ingest / image egress (host side of `render(ply, camera) -> image`)

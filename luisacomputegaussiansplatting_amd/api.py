@@ -762,10 +762,14 @@ class Comm:
         _check(load_library().lcgs_sparse_pack(self.ctx._h, C.c_int(sh_degree), C.byref(g), C.c_void_p(rows_addr + 4 * first),
                                                C.c_int64(count), _ptr(msg)))
 
-    def sparse_accumulate(self, grads: dict, msg, count: int, sh_degree: int = 3):
-        """lcgs_sparse_accumulate: add a received message's rows to the dense gradient rows"""
+    def sparse_accumulate(self, grads: dict, msg, count: int, sh_degree: int = 3, row_first: int = 0, row_count: int = -1):
+        """lcgs_sparse_accumulate: add a received message's rows to the dense gradient rows; only rows in
+        [row_first, row_first + row_count) are accepted (default: every row of the arrays)"""
         g = _Grads(*[_ptr(grads[k]) for k in _KEYS])
-        _check(load_library().lcgs_sparse_accumulate(self.ctx._h, C.c_int(sh_degree), C.byref(g), _ptr(msg), C.c_int64(count)))
+        if row_count < 0:
+            row_first, row_count = 0, int(grads["pos"].shape[0])
+        _check(load_library().lcgs_sparse_accumulate(self.ctx._h, C.c_int(sh_degree), C.byref(g), _ptr(msg), C.c_int64(count),
+                                                     C.c_int64(row_first), C.c_int64(row_count)))
 
 
 def sparse_message_words(count: int, sh_degree: int = 3) -> int:

@@ -42,7 +42,7 @@ struct lcgs_context {
     // workspace of the fused frame
     DeviceBuffer cull_slab, chunk_info, chunk_base; // the cull pass's per-chunk output (fused_forward.hip k_cull_compact)
     DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws[3], counts, sort_ws,
-        expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks, shjac, tie_ws, fused_grads;
+        expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks, shjac, tie_ws, fused_grads, bwd_counter;
     bool         last_has_jac = false; // the last keep_state frame stored the colour Jacobian (degree 3)
     // zero_ws holds what a frame needs zeroed: the tile ranges.  Three
     // copies rotate: while frame N runs, the auxiliary stream clears the copy of frame N + 2.  Two frames ahead, not
@@ -78,6 +78,20 @@ struct lcgs_context {
     int          order_cur = 0;  // tile_order[order_cur] is the newest complete order ...
     uint32_t     order_G   = 0;  // ... valid for this many tiles (0: none yet)
     uint32_t*    last_tile_order = nullptr; // the order the last frame rendered with (reused by the backward)
+    // Persistent renderers (render.hip / backward.hip PERSIST): a bounded grid of `k x CUs` workgroups that pull tiles from a
+    // counter, instead of one workgroup per tile.  Used while SEVERAL frames are in flight (camera batches, lcgs_fit_views):
+    // the cap leaves wave slots, registers and LDS free on every CU, so the other frame's short sort-chain kernels start at
+    // once instead of queueing behind thousands of pending tile workgroups.  0 = one workgroup per tile (in-order frames).
+    int       num_cus = 0;
+    int       persist_in_flight = 0;   // k while several frames are in flight (lcgs_render_forward_batch / lcgs_fit_views)
+    int       persist_forced = -1;     // tuning hook LCGS_RENDER_WGS_PER_CU: k for EVERY frame when >= 0
+    int       persist_bwd_in_flight = 0, persist_bwd_forced = -1; // the same for the render-backward (LCGS_BWD_WGS_PER_CU)
+    bool      frames_in_flight = false; // set around the calls of a batch
+    uint32_t* work_counters = nullptr; // [0] forward renderer, [1] render-backward: inside the frame's zeroed block
+    // CU-partitioned streams (tuning hook LCGS_CHAIN_CUS=K, measured in round 4): the sort chain on a stream masked to K
+    // CUs, record builder + renderer on the complement
+    hipStream_t chain_stream = nullptr, render_stream = nullptr;
+    hipEvent_t  ev_begin = nullptr, ev_chain = nullptr;
     bool use_graph = false; // opt-in (LCGS_GRAPH=1): measured no gain on MI355X, the short kernels are GPU-latency-bound
     // second stream: work that is independent of the sort chain (record building; gradient zero-fill) overlaps it
     hipStream_t aux_stream = nullptr;
@@ -131,6 +145,8 @@ struct lcgs_context {
     // their arguments instead of running; a GSTileSplatter::forward whose inputs are exactly their outputs then renders
     // the fused frame from the 3-D arrays (same image, radii, num_rendered); anything else runs the recorded calls first.
     int stage_mode = 0; // LCGS_STAGES_EXACT
+    int stage_sort = 0; // lcgs_tile_splat_forward's sort route: 0 = by frame size, 1 = literal six passes, 2 = sort-before-duplicate
+                        // (LCGS_STAGE_SORT=literal|splats, read once when the context is created)
     struct {
         bool         pending = false;
         int          num = 0, level = 3;

@@ -347,6 +347,7 @@ lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* c, int num_gaussi
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     const AttrRows a = attr_rows(grads, sh_degree);
     const int64_t  P = num_gaussians;
+    c->stats = lcgs_comm_stats{}; // "what the LAST collective call moved": reset on every path
     if (c->transport == LCGS_TRANSPORT_F16) {
         // Opt-in: the sum crosses the wire as f16 with one power-of-two scale per attribute, agreed by all ranks (the
         // magnitudes are max-reduced first).  One chunk behind the backward's tail: the scales need every row.
@@ -376,6 +377,9 @@ lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* c, int num_gaussi
         LCGS_HIP_CHECK(hipGetLastError());
         LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
+        c->stats.collective_groups = 2; // the magnitudes, the packed sum
+        c->stats.bytes_sent = c->stats.bytes_received =
+            (int64_t)(2 * (uint64_t)(c->world - 1) * ((uint64_t)total * 2 + 5 * 4) / (uint64_t)c->world);
         return LCGS_OK;
     }
     // The NUMBER and the row ranges of the chunks come from values every rank shares (P, the slice count set when the
@@ -389,7 +393,6 @@ lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* c, int num_gaussi
                           ctx->P == num_gaussians;
     LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
     if (!by_slice) LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
-    c->stats = lcgs_comm_stats{};
     for (int k = 0; k < K; ++k) {
         if (by_slice) LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, ctx->ev_slice[k], 0));
         // the last chunk also waits for whatever was enqueued on the context's stream behind the backward
@@ -506,12 +509,14 @@ lcgs_status lcgs_sparse_pack(lcgs_context* ctx, int sh_degree, const lcgs_grads*
     return LCGS_OK;
 }
 
-lcgs_status lcgs_sparse_accumulate(lcgs_context* ctx, int sh_degree, const lcgs_grads* grads, const float* d_msg, int64_t count)
+lcgs_status lcgs_sparse_accumulate(lcgs_context* ctx, int sh_degree, const lcgs_grads* grads, const float* d_msg, int64_t count,
+                                   int64_t row_first, int64_t row_count)
 {
     LCGS_REQUIRE(ctx && grads && (count == 0 || d_msg) && count >= 0 && sh_degree >= 0 && sh_degree <= 3, "bad argument");
+    LCGS_REQUIRE(row_first >= 0 && row_count >= 0 && row_first + row_count <= ((int64_t)1 << 30), "bad row range");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     float* g[5] = { grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh, grads->d_dL_dopacity };
-    launch_sparse_accumulate(g, sh_degree, d_msg, count, ctx->stream);
+    launch_sparse_accumulate(g, sh_degree, d_msg, count, row_first, row_count, ctx->stream);
     LCGS_HIP_CHECK(hipGetLastError());
     return LCGS_OK;
 }
@@ -678,7 +683,8 @@ lcgs_status lcgs_adam_step_sparse(lcgs_context* ctx, lcgs_comm* c, int num_gauss
 
     // ---- 4. the owner adds what it received, message by message in rank order (a fixed order: reproducible sums)
     for (int o = 0; o < N; ++o)
-        if (o != me) launch_sparse_accumulate(gp, sh_degree, c->recvbuf.as<float>() + recv_off[o], rows_of(o, me), ctx->stream);
+        if (o != me) // (only rows of the own shard are accepted, whatever the message says)
+            launch_sparse_accumulate(gp, sh_degree, c->recvbuf.as<float>() + recv_off[o], rows_of(o, me), first, count, ctx->stream);
     LCGS_HIP_CHECK(hipGetLastError());
 
     // ---- 5. Adam on the own rows (+ the tail), 6. all-gather of the refreshed ACTIVATED rows: as in the sharded step

@@ -105,7 +105,15 @@ constexpr int kG2D = 12; // floats per splat in the 2-D gradient buffer: mean(2)
 
 // (six waves per SIMD: 80 VGPRs with 8 spilled registers per lane instead of 92 and five waves -- render-backward 0.71 ->
 //  0.67 ms, +1.6 % on the whole forward+backward step in same-box A/B runs; seven waves spill 19 and lose it again)
-__global__ void __launch_bounds__(256, 6) k_render_backward(CamParams cp, float bg0, float bg1, float bg2,
+// KNOWN: the forward kept every entry's strip bits (it always does when it keeps backward state; the other instantiation
+// repeats the four strip tests and exists for callers of the launcher that pass no masks)
+// PERSIST: a bounded grid pulling tiles from *work_counter (zeroed by k_zero_grads2d), as in render.hip: while another view's
+// forward is in flight (lcgs_fit_views) the cap leaves wave slots, registers and LDS free on every CU for its sort chain.
+#ifndef LCGS_BWD_WAVES
+#define LCGS_BWD_WAVES 6
+#endif
+template <bool KNOWN, bool PERSIST>
+__global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamParams cp, float bg0, float bg1, float bg2,
                                                            const uint32_t* __restrict__ ranges,
                                                            const uint32_t* __restrict__ point_list,
                                                            const SplatRecord* __restrict__ recs,
@@ -115,7 +123,8 @@ __global__ void __launch_bounds__(256, 6) k_render_backward(CamParams cp, float 
                                                            float* __restrict__ grads2d,
                                                            const uint32_t* __restrict__ tile_order,
                                                            const uint8_t* __restrict__ strip_masks,
-                                                           const uint32_t* __restrict__ d_counts)
+                                                           const uint32_t* __restrict__ d_counts,
+                                                           uint32_t* __restrict__ work_counter)
 {
     __shared__ float4             s_a[256]; // mean.x, mean.y, conic.x, conic.y
     __shared__ float4             s_b[256]; // conic.z, opacity, r, g
@@ -124,23 +133,35 @@ __global__ void __launch_bounds__(256, 6) k_render_backward(CamParams cp, float 
     __shared__ float              s_grad[9][256];
     __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
     __shared__ uint32_t           s_max[4];
+    __shared__ uint32_t           s_slot;
 
-    uint32_t tx, ty;
-    if (tile_order) { // longest-list-first schedule of the forward (scheduling hint only)
-        if (blockIdx.x >= cp.grid_x * cp.grid_y) return;
-        const uint32_t t = tile_order[blockIdx.x];
-        tx = t % cp.grid_x;
-        ty = t / cp.grid_x;
-    } else if (!tile_of_workgroup(blockIdx.x, cp.grid_x, cp.grid_y, tx, ty)) return;
-    const uint32_t tile = ty * cp.grid_x + tx;
     // a frame that drew nothing left final_T / n_contrib untouched (the forward returns before writing them, like
     // gs_tile_splatter/impl.cpp:109): there is nothing to differentiate, and nothing valid to read
     if (d_counts && d_counts[1] == 0u) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t slots = tile_order ? cp.grid_x * cp.grid_y : render_grid_size(cp.grid_x, cp.grid_y);
+    uint32_t       slot  = blockIdx.x;
+  for (;;) { // (one pass unless PERSIST)
+    if (PERSIST) {
+        __syncthreads(); // the previous tile's last flush has read s_vid / s_grad; nobody still reads s_slot
+        if (tid == 0) s_slot = atomicAdd(work_counter, 1u);
+        __syncthreads();
+        slot = s_slot;
+    }
+    if (slot >= slots) return; // persistent grids: the exit every workgroup reaches
+    uint32_t tx, ty;
+    if (tile_order) { // longest-list-first schedule of the forward (scheduling hint only)
+        const uint32_t t = tile_order[slot];
+        tx = t % cp.grid_x;
+        ty = t / cp.grid_x;
+    } else if (!tile_of_workgroup(slot, cp.grid_x, cp.grid_y, tx, ty)) {
+        if (PERSIST) continue;
+        return;
+    }
+    const uint32_t tile = ty * cp.grid_x + tx;
     const uint32_t px = tx * kBlockX + (lane & 15u);
     const uint32_t py = ty * kBlockY + 4u * wave + (lane >> 4);
     const float    pxf = (float)px, pyf = (float)py;
-    const float    rx0 = (float)(tx * kBlockX), ry0 = (float)(ty * kBlockY), rx1 = rx0 + (float)(kBlockX - 1);
     const bool     inside = (px < cp.width) && (py < cp.height);
     const size_t   hw  = (size_t)cp.width * cp.height;
     const size_t   pix = (size_t)px + (size_t)cp.width * py;
@@ -190,16 +211,16 @@ __global__ void __launch_bounds__(256, 6) k_render_backward(CamParams cp, float 
         if (have) {
             vid = point_list[range_start + e];
             // the forward kept every entry's strip bits: entries that reach no strip are not even fetched
-            const bool known = strip_masks != nullptr;
-            if (known) kmask = strip_masks[range_start + e];
-            if (!known || kmask != 0u) {
+            if (KNOWN) kmask = strip_masks[range_start + e];
+            if (!KNOWN || kmask != 0u) {
                 const float4* p = reinterpret_cast<const float4*>(recs + vid);
                 a = p[0];                                           // mx, my, ca, cb
                 b = p[1];                                           // cc, opacity, r, g
                 c = reinterpret_cast<const float*>(recs + vid)[8];  // b
                 t = (2.0f * __logf(255.0f * b.y)) * 1.0001f + 2e-4f;
             }
-            if (!known) {
+            if (!KNOWN) {
+                const float rx0 = (float)(tx * kBlockX), ry0 = (float)(ty * kBlockY), rx1 = rx0 + (float)(kBlockX - 1);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float y0 = ry0 + 4.0f * k;
@@ -257,8 +278,15 @@ __global__ void __launch_bounds__(256, 6) k_render_backward(CamParams cp, float 
                     // leaves T alone, B + 0 * (c - B) leaves the colour behind alone, all nine terms come out 0.
                     // (No second wave-level skip: the staging floor already implies alpha >= 1/255 somewhere.)
                     const float a   = valid ? alpha : 0.0f;
-                    const float inv = __builtin_amdgcn_rcpf(1.0f - a); // gradients carry a 1e-3 tolerance
-                    const float Tn  = T * inv;                          // the forward's T in front of this splat
+                    // T in front of this splat = T / (1 - a).  v_rcp_f32 alone (1 ulp, not unbiased) is not enough HERE: T is
+                    // carried through every entry of the list, so a splat at the front of a few thousand entries saw the
+                    // rounding of every division behind it, and a screen-filling splat -- whose geometry gradients are sums
+                    // of ~1e5 cancelling per-pixel terms -- amplified that drift to a few 1e-3 (round 3's excluded "giants").
+                    // One Newton step on the quotient (two FMAs) gives T / (1 - a) to within an ulp, errors of either sign.
+                    const float oma = 1.0f - a;
+                    const float inv = __builtin_amdgcn_rcpf(oma);
+                    const float q0  = T * inv;
+                    const float Tn  = __builtin_fmaf(__builtin_fmaf(-oma, q0, T), inv, q0); // the forward's T in front of this splat
                     const float wgt = a * Tn;
                     // colour behind this splat (B) enters dL/dalpha, then absorbs the splat
                     const float dr = eb.z - Br, dg = eb.w - Bg, db = ec.x - Bb;
@@ -344,6 +372,8 @@ __global__ void __launch_bounds__(256, 6) k_render_backward(CamParams cp, float 
         }
         hi = lo;
     }
+    if (!PERSIST) return;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -855,27 +885,41 @@ size_t grads2d_bytes(int64_t V_cap) { return (size_t)V_cap * kG2D * sizeof(float
 
 namespace
 {
-__global__ void __launch_bounds__(256) k_zero_grads2d(const uint32_t* __restrict__ d_counts, float4* __restrict__ g)
+__global__ void __launch_bounds__(256) k_zero_grads2d(const uint32_t* __restrict__ d_counts, float4* __restrict__ g,
+                                                      uint32_t* __restrict__ bwd_counter)
 {
+    if (bwd_counter && blockIdx.x == 0 && threadIdx.x == 0) *bwd_counter = 0u; // the persistent render-backward's tile counter
     const size_t n = (size_t)d_counts[0] * (kG2D / 4);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         g[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 } // namespace
 
-void launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t stream)
+void launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t stream, uint32_t* bwd_counter)
 {
-    hipLaunchKernelGGL(k_zero_grads2d, dim3(2048), dim3(256), 0, stream, d_counts, reinterpret_cast<float4*>(grads2d));
+    hipLaunchKernelGGL(k_zero_grads2d, dim3(2048), dim3(256), 0, stream, d_counts, reinterpret_cast<float4*>(grads2d), bwd_counter);
 }
 
 void launch_render_backward(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                             const SplatRecord* recs, const float* final_T, const uint32_t* n_contrib,
                             const float* dL_dimg, float* grads2d, const uint32_t* tile_order, hipStream_t stream,
-                            const uint8_t* strip_masks, const uint32_t* d_counts)
+                            const uint8_t* strip_masks, const uint32_t* d_counts, uint32_t* work_counter,
+                            uint32_t persistent_wgs)
 {
     if (cp.grid_x * cp.grid_y == 0) return;
-    hipLaunchKernelGGL(k_render_backward, dim3(render_grid_size(cp.grid_x, cp.grid_y)), dim3(256), 0, stream, cp, bg[0],
-                       bg[1], bg[2], ranges, point_list, recs, final_T, n_contrib, dL_dimg, grads2d, tile_order, strip_masks, d_counts);
+    const uint32_t full = render_grid_size(cp.grid_x, cp.grid_y);
+#define LCGS_LAUNCH_BWD(KNOWN_, PERSIST_, GRID_)                                                                             \
+    hipLaunchKernelGGL((k_render_backward<KNOWN_, PERSIST_>), dim3(GRID_), dim3(256), 0, stream, cp, bg[0], bg[1], bg[2], ranges, \
+                       point_list, recs, final_T, n_contrib, dL_dimg, grads2d, tile_order, strip_masks, d_counts, work_counter)
+    if (work_counter && persistent_wgs > 0 && persistent_wgs < full) {
+        if (strip_masks) LCGS_LAUNCH_BWD(true, true, persistent_wgs);
+        else LCGS_LAUNCH_BWD(false, true, persistent_wgs);
+    } else {
+        work_counter = nullptr;
+        if (strip_masks) LCGS_LAUNCH_BWD(true, false, full);
+        else LCGS_LAUNCH_BWD(false, false, full);
+    }
+#undef LCGS_LAUNCH_BWD
 }
 
 // Splat-range slices of the survivors (for the chunked gradient all-reduce, lcgs_grads_allreduce): the dense ids are

@@ -139,7 +139,7 @@ struct AttrPtrs {
 // word w of a message of `count` rows: [0, count) indices, then the five attribute blocks
 template <bool PACK>
 __global__ void __launch_bounds__(256) k_sparse_rows(AttrPtrs a, const uint32_t* __restrict__ rows_or_null, float* __restrict__ msg,
-                                                     uint32_t count)
+                                                     uint32_t count, uint32_t row_lo, uint32_t row_hi)
 {
     const uint64_t  b1 = count, b2 = b1 + 3ull * count, b3 = b2 + 3ull * count, b4 = b3 + 4ull * count,
                    b5 = b4 + (uint64_t)a.feat * count, words = b5 + count;
@@ -159,7 +159,11 @@ __global__ void __launch_bounds__(256) k_sparse_rows(AttrPtrs a, const uint32_t*
         if (w >= b5) { base = a.p4; b0 = b5; wd = 1u; }
         const uint32_t rel = (uint32_t)(w - b0);
         const uint32_t j = rel / wd, e = rel - j * wd;
-        float*         g = base + (size_t)idx[j] * wd + e;
+        const uint32_t row = idx[j];
+        // accumulate: the indices come out of a RECEIVED message -- a row outside the caller's range (a short, corrupt or
+        // mismatched-P message) is dropped, never written through
+        if (!PACK && !(row >= row_lo && row < row_hi)) continue;
+        float* g = base + (size_t)row * wd + e;
         if (PACK) msg[w] = *g;
         else *g = *g + msg[w];
     }
@@ -218,14 +222,16 @@ void launch_sparse_pack(float* const grads[5], int sh_degree, const uint32_t* ro
 {
     if (count <= 0) return;
     hipLaunchKernelGGL((k_sparse_rows<true>), dim3(grid_words((uint64_t)sparse_message_words(count, sh_degree))), dim3(256), 0,
-                       stream, attr_ptrs(grads, sh_degree), rows, msg, (uint32_t)count);
+                       stream, attr_ptrs(grads, sh_degree), rows, msg, (uint32_t)count, 0u, 0xFFFFFFFFu);
 }
 
-void launch_sparse_accumulate(float* const grads[5], int sh_degree, const float* msg, int64_t count, hipStream_t stream)
+void launch_sparse_accumulate(float* const grads[5], int sh_degree, const float* msg, int64_t count, int64_t row_first,
+                              int64_t row_count, hipStream_t stream)
 {
-    if (count <= 0) return;
+    if (count <= 0 || row_count <= 0) return;
     hipLaunchKernelGGL((k_sparse_rows<false>), dim3(grid_words((uint64_t)sparse_message_words(count, sh_degree))), dim3(256), 0,
-                       stream, attr_ptrs(grads, sh_degree), (const uint32_t*)nullptr, const_cast<float*>(msg), (uint32_t)count);
+                       stream, attr_ptrs(grads, sh_degree), (const uint32_t*)nullptr, const_cast<float*>(msg), (uint32_t)count,
+                       (uint32_t)row_first, (uint32_t)(row_first + row_count));
 }
 
 } // namespace lcgs

@@ -191,7 +191,9 @@ void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uin
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,
                                const uint32_t* tile_order, hipStream_t stream, uint8_t* strip_masks = nullptr,
-                               hipEvent_t done = nullptr);
+                               hipEvent_t done = nullptr, uint32_t* work_counter = nullptr, uint32_t persistent_wgs = 0);
+// work_counter + persistent_wgs: a bounded grid of persistent_wgs workgroups that pull tiles from *work_counter (which
+// must be zero when the kernel starts) instead of one workgroup per tile -- caps the wave slots the renderer holds
 // strip_masks[list position] = the four per-strip reach bits of that entry (written when final_T / n_contrib are
 // kept); the backward takes them instead of repeating the tests
 bool render_forward_writes_strip_masks();
@@ -215,15 +217,18 @@ void     launch_owner_bounds(const uint32_t* rows, const uint32_t* d_total, int6
 int64_t  sparse_message_words(int64_t count, int sh_degree);
 void     launch_sparse_pack(float* const grads[5], int sh_degree, const uint32_t* rows, int64_t count, float* msg,
                             hipStream_t stream);
-void     launch_sparse_accumulate(float* const grads[5], int sh_degree, const float* msg, int64_t count, hipStream_t stream);
+void     launch_sparse_accumulate(float* const grads[5], int sh_degree, const float* msg, int64_t count, int64_t row_first,
+                                  int64_t row_count, hipStream_t stream);
 
 // ---- backward.hip ----
 size_t grads2d_bytes(int64_t V_cap);
-void   launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t stream);
+// (bwd_counter, when given, is zeroed too: the persistent render-backward's tile counter)
+void   launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t stream, uint32_t* bwd_counter = nullptr);
 void   launch_render_backward(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                               const SplatRecord* recs, const float* final_T, const uint32_t* n_contrib,
                               const float* dL_dimg, float* grads2d, const uint32_t* tile_order, hipStream_t stream,
-                              const uint8_t* strip_masks = nullptr, const uint32_t* d_counts = nullptr);
+                              const uint8_t* strip_masks = nullptr, const uint32_t* d_counts = nullptr,
+                              uint32_t* work_counter = nullptr, uint32_t persistent_wgs = 0);
 void   launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
                                   const float* scale, const float* rotq, const float* sh, const uint32_t* vis_index,
                                   const uint32_t* d_counts, const float* grads2d, float* dL_dpos, float* dL_dscale,

@@ -68,7 +68,12 @@ using namespace tile;
 // ---------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2))); // arithmetic on it lowers to v_pk_{add,mul}_f32 (IEEE per lane)
 
-template <typename Fetch, bool KEEP>
+// PERSIST: a bounded grid of workgroups that take tiles from a device counter (work_counter, zeroed with the frame's tile
+// ranges) in schedule order until it runs past the last one -- every workgroup reaches that exit.  Same image (which
+// workgroup renders which tile never mattered); what it buys is a cap on the wave slots the renderer holds per CU, so that
+// ANOTHER frame's short sort-chain kernels find free slots on every CU the moment they are dispatched instead of queueing
+// behind 8160 resident-or-pending tile workgroups (camera batches, lcgs_fit_views: DESIGN.md 9).
+template <typename Fetch, bool KEEP, bool PERSIST>
 __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg0, float bg1, float bg2,
                                                             const FrameParams* __restrict__ fpp,
                                                             const uint32_t* __restrict__ ranges,
@@ -77,7 +82,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                                                             uint32_t* __restrict__ n_contrib,
                                                             const uint32_t* __restrict__ d_counts,
                                                             const uint32_t* __restrict__ tile_order,
-                                                            uint8_t* __restrict__ strip_masks)
+                                                            uint8_t* __restrict__ strip_masks,
+                                                            uint32_t* __restrict__ work_counter)
 {
     // one 16-byte row per entry in each of three slabs: a single address register serves all three reads
     // s_rows[0]: mean.x, mean.y, -conic.x / 2, -conic.z / 2;  [1]: conic.y, power floor (-t/2), -, - (with [0], all the cull
@@ -85,6 +91,7 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
     __shared__ float4             s_rows[3][256];
     __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
     __shared__ uint32_t           s_live_waves;
+    __shared__ uint32_t           s_slot;
 
     if (fpp) { // graph replay: per-call parameters come from device memory
         cp  = fpp->cp;
@@ -92,17 +99,27 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         bg1 = fpp->bg[1];
         bg2 = fpp->bg[2];
     }
+    if (d_counts && d_counts[1] == 0u) return; // image untouched (gs_tile_splatter/impl.cpp:109)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t slots = tile_order ? cp.grid_x * cp.grid_y : render_grid_size(cp.grid_x, cp.grid_y);
+    uint32_t       slot  = blockIdx.x;
+  for (;;) { // (one pass unless PERSIST)
+    if (PERSIST) {
+        if (tid == 0) s_slot = atomicAdd(work_counter, 1u);
+        __syncthreads(); // (s_slot is not written again before every thread has passed the next barrier below)
+        slot = s_slot;
+    }
+    if (slot >= slots) return; // persistent grids: the exit every workgroup reaches
     uint32_t tx, ty;
     if (tile_order) { // scheduling hint only: which workgroup takes which tile never changes the image
-        if (blockIdx.x >= cp.grid_x * cp.grid_y) return;
-        const uint32_t t = tile_order[blockIdx.x];
+        const uint32_t t = tile_order[slot];
         tx = t % cp.grid_x;
         ty = t / cp.grid_x;
-    } else if (!tile_of_workgroup(blockIdx.x, cp.grid_x, cp.grid_y, tx, ty)) return;
+    } else if (!tile_of_workgroup(slot, cp.grid_x, cp.grid_y, tx, ty)) {
+        if (PERSIST) continue; // a padding slot of the XCD-aware map
+        return;
+    }
     const uint32_t tile = ty * cp.grid_x + tx;
-    if (d_counts && d_counts[1] == 0u) return; // image untouched (gs_tile_splatter/impl.cpp:109)
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t px = tx * kBlockX + (lane & 15u);
     const uint32_t py = ty * kBlockY + 4u * wave + (lane >> 4);
     const float rx0 = (float)(tx * kBlockX), ry0 = (float)(ty * kBlockY), rx1 = rx0 + (float)(kBlockX - 1);
@@ -263,6 +280,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
             if (n_contrib) n_contrib[pix] = last_contrib;
         }
     }
+    if (!PERSIST) return;
+  }
 }
 
 // Longest-list-first tile schedule (a scheduling hint: any order gives the same image).  Tile work is roughly
@@ -315,21 +334,26 @@ template <typename Fetch>
 void launch_render(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                    Fetch fetch, float* img, float* final_T, uint32_t* n_contrib, const uint32_t* d_counts,
                    const FrameParams* d_fp, const uint32_t* tile_order, hipStream_t stream,
-                   uint8_t* strip_masks = nullptr, hipEvent_t done = nullptr)
+                   uint8_t* strip_masks = nullptr, hipEvent_t done = nullptr, uint32_t* work_counter = nullptr,
+                   uint32_t persistent_wgs = 0)
 {
     if (cp.grid_x * cp.grid_y == 0) return;
-    {
-        const dim3 grid(render_grid_size(cp.grid_x, cp.grid_y));
-        // (`done`, when given, is carried by the dispatch packet: no separate event-record packet behind the kernel)
-        if (final_T || n_contrib)
-            hipExtLaunchKernelGGL((k_render_forward_b<Fetch, true>), grid, dim3(256), 0, stream, nullptr, done, 0, cp, bg[0],
-                                  bg[1], bg[2], d_fp, ranges, point_list, fetch, img, final_T, n_contrib, d_counts,
-                                  tile_order, strip_masks);
-        else // forward only: the last-contributor bookkeeping is compiled out
-            hipExtLaunchKernelGGL((k_render_forward_b<Fetch, false>), grid, dim3(256), 0, stream, nullptr, done, 0, cp, bg[0],
-                                  bg[1], bg[2], d_fp, ranges, point_list, fetch, img, final_T, n_contrib, d_counts,
-                                  tile_order, (uint8_t*)nullptr);
+    const uint32_t full = render_grid_size(cp.grid_x, cp.grid_y);
+    const bool     keep = final_T || n_contrib;
+    // (`done`, when given, is carried by the dispatch packet: no separate event-record packet behind the kernel)
+#define LCGS_LAUNCH_RENDER(KEEP_, PERSIST_, GRID_)                                                                          \
+    hipExtLaunchKernelGGL((k_render_forward_b<Fetch, KEEP_, PERSIST_>), dim3(GRID_), dim3(256), 0, stream, nullptr, done, 0, cp, \
+                          bg[0], bg[1], bg[2], d_fp, ranges, point_list, fetch, img, final_T, n_contrib, d_counts, tile_order, \
+                          KEEP_ ? strip_masks : (uint8_t*)nullptr, work_counter)
+    if (work_counter && persistent_wgs > 0 && persistent_wgs < full) { // a bounded grid that pulls tiles from the counter
+        if (keep) LCGS_LAUNCH_RENDER(true, true, persistent_wgs);
+        else LCGS_LAUNCH_RENDER(false, true, persistent_wgs);
+    } else {
+        work_counter = nullptr;
+        if (keep) LCGS_LAUNCH_RENDER(true, false, full);
+        else LCGS_LAUNCH_RENDER(false, false, full); // forward only: the last-contributor bookkeeping is compiled out
     }
+#undef LCGS_LAUNCH_RENDER
 }
 
 } // namespace
@@ -359,10 +383,11 @@ void launch_render_forward_aos(const CamParams& cp, const float bg[3], const uin
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,
-                               const uint32_t* tile_order, hipStream_t stream, uint8_t* strip_masks, hipEvent_t done)
+                               const uint32_t* tile_order, hipStream_t stream, uint8_t* strip_masks, hipEvent_t done,
+                               uint32_t* work_counter, uint32_t persistent_wgs)
 {
     launch_render(cp, bg, ranges, point_list, FetchRec{ recs }, img, final_T, n_contrib, d_counts, d_fp, tile_order,
-                  stream, strip_masks, done);
+                  stream, strip_masks, done, work_counter, persistent_wgs);
 }
 
 // the forward renderer fills strip_masks whenever it keeps backward state

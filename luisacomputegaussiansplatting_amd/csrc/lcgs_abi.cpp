@@ -224,6 +224,9 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
     LCGS_TRY(ctx->vis_index.ensure(P * 4));
     LCGS_TRY(ctx->rects.ensure(P * 8));
     LCGS_TRY(ctx->rects_sorted.ensure(P * 8));
+    // scratch for runs of more than 4096 equal depths of a re-ordered scene (kernels/tie_order.hpp).  Allocated HERE, with
+    // every other buffer of the frame: enqueue_forward may run inside a stream capture (LCGS_GRAPH=1), where hipMalloc fails
+    if (ctx->perm_valid) LCGS_TRY(ctx->tie_ws.ensure(P * 4));
     if (ctx->pair_capacity == 0) {
         // generous default: 288 GB of HBM makes over-provisioning the pair buffers free
         uint64_t cap       = std::max<uint64_t>((uint64_t)4 * P, (uint64_t)1 << 22);
@@ -235,7 +238,8 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
     }
     const size_t G = (size_t)cp.grid_x * cp.grid_y;
     auto         al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t b0 = 0, b1 = al(G * 2 * 4); // (b0: the chained scan's state block, gone with the scan)
+    // (b0: the chained scan's state block, gone with the scan; b1: the tile ranges + the persistent renderers' tile counters)
+    const size_t b0 = 0, b1 = al(G * 2 * 4) + 256;
     for (int i = 0; i < 3; ++i) {
         const void* before = ctx->zero_ws[i].ptr;
         LCGS_TRY(ctx->zero_ws[i].ensure(b0 + b1));
@@ -262,6 +266,7 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
         LCGS_TRY(ctx->strip_masks.ensure((size_t)ctx->pair_capacity));
         LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)P)));
         LCGS_TRY(ctx->shjac.ensure(P * 48));
+        LCGS_TRY(ctx->bwd_counter.ensure(256));
     }
     if (!ctx->h_counts) LCGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counts), 64, hipHostMallocDefault));
     return LCGS_OK;
@@ -274,7 +279,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
                             float* d_img, int32_t* d_radii, bool keep_state, const FrameParams* d_fp,
                             bool in_capture = false)
 {
-    hipStream_t  st       = ctx->stream;
+    const hipStream_t vis  = ctx->stream; // the stream whose order the caller sees
     uint32_t*    d_counts = ctx->counts.as<uint32_t>();
     const int    P        = ctx->P;
     SplatRecord* recs     = ctx->recs.as<SplatRecord>();
@@ -286,6 +291,15 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     // attributable; otherwise independent work moves to the auxiliary stream (see below).
     const bool overlap  = !ctx->profiling;
     const bool deferred = overlap && !in_capture;
+    // CU-partitioned streams (tuning hook): the sort chain on `st` = the chain stream, record builder + renderer on the
+    // render stream; the caller's stream only orders the frame (waits for what came before, is waited on by the end)
+    const bool  part = deferred && ctx->chain_stream != nullptr;
+    hipStream_t st   = part ? ctx->chain_stream : vis;
+    hipStream_t rst  = part ? ctx->render_stream : vis;
+    if (part) {
+        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_begin, vis));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_begin, 0));
+    }
     // Zeroed per frame: the tile ranges (the reference zero-fills ranges too,
     // gs_tile_splatter/impl.cpp:147).  Normally the auxiliary stream cleared this frame's copy during the last frame.
     const int zb = deferred ? ctx->zero_cur : 0;
@@ -299,6 +313,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     if (!(deferred && ctx->zero_ready[zb])) LCGS_HIP_CHECK(hipMemsetAsync(ctx->zero_ws[zb].ptr, 0, ctx->zero_bytes, st));
     ctx->zero_ready[zb]  = false;
     ctx->ranges          = reinterpret_cast<uint32_t*>(ctx->zero_ws[zb].as<char>() + ctx->zero_scan_bytes);
+    ctx->work_counters   = reinterpret_cast<uint32_t*>(ctx->zero_ws[zb].as<char>() + ctx->zero_bytes - 256);
     const DepthSortFirstPass dfirst = depth_sort_first_pass(P, ctx->sort_ws.ptr);
     launch_cull_compact(P, cp, scale_modifier, d_fp, ctx->pos, ctx->scale, ctx->rotq, ctx->opacity, d_radii,
                         ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(), dfirst, st);
@@ -319,8 +334,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
         tie.id_bits   = (uint32_t)std::max(1, ceil_log2_u32((uint32_t)P));
         tie.tag_shift = 2u * tie.id_bits > 32u ? 2u * tie.id_bits - 32u : 0u;
         id_mask       = (1u << tie.id_bits) - 1u;
-        LCGS_TRY(ctx->tie_ws.ensure((size_t)P * 4)); // scratch for runs of more than 4096 equal depths (tie_order.hpp)
-        tie.scratch_k1 = ctx->tie_ws.as<uint32_t>();
+        tie.scratch_k1 = ctx->tie_ws.as<uint32_t>(); // (sized by ensure_fused_workspace: no allocation in here)
     }
     launch_depth_sort_from_chunks(P, hint_V, ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(),
                                   ctx->chunk_base.as<uint32_t>(), ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
@@ -331,23 +345,23 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     LCGS_TRY(mark(ctx, "depth_sort"));
     // Record building (SH fetch + colour: bandwidth-bound) is independent of the rest of the sort chain (latency-bound
     // short kernels): fork it onto the auxiliary stream so the two overlap; the renderer joins.
-    hipStream_t rec_stream = overlap ? ctx->aux_stream : st;
+    hipStream_t rec_stream = part ? rst : (overlap ? ctx->aux_stream : st);
     if (overlap) {
         // (in a capture the fork is recorded here, after the whole depth sort; otherwise the first pass's scatter
         //  dispatch carries it)
         if (in_capture) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));
-        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(rec_stream, ctx->ev_fork, 0));
     }
     launch_build_records((int)std::min<int64_t>(P, hint_V), ctx->sh_deg, cp, scale_modifier, d_fp, ctx->pos, ctx->scale,
                          ctx->rotq, ctx->sh, ctx->opacity, ctx->vis_index.as<uint32_t>(), d_counts, recs, rec_stream,
                          ctx->use_half_sh ? ctx->sh_half.as<uint16_t>() : nullptr,
                          keep_state ? ctx->shjac.as<float4>() : nullptr);
     ctx->last_has_jac = keep_state && build_records_writes_jacobian(ctx->sh_deg, ctx->sh, ctx->use_half_sh);
-    if (overlap) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+    if (overlap && !part) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
     ctx->g2d_zeroed = false;
     if (deferred && keep_state) { // behind the records, beside the sort chain and the renderer
-        launch_zero_grads2d(d_counts, ctx->grads2d.as<float>(), ctx->aux_stream);
-        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_g2d_zero, ctx->aux_stream));
+        launch_zero_grads2d(d_counts, ctx->grads2d.as<float>(), rec_stream, ctx->bwd_counter.as<uint32_t>());
+        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_g2d_zero, rec_stream));
         ctx->g2d_zeroed = true;
     }
     LCGS_TRY(mark(ctx, "build_records"));
@@ -398,13 +412,23 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
         ctx->order_cur         = ob; // written before the next frame's record builder runs: its renderer waits for that
     }
 
-    if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0)); // records are ready
+    if (part) { // the records are ahead of the renderer on its own stream; it waits for the chain
+        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_chain, st));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(rst, ctx->ev_chain, 0));
+    } else if (overlap) {
+        LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0)); // records are ready
+    }
+    // several frames in flight: a bounded, persistent grid (context.hpp) -- same image, free wave slots on every CU
+    const int      k_persist = ctx->persist_forced >= 0 ? ctx->persist_forced : (ctx->frames_in_flight ? ctx->persist_in_flight : 0);
+    const uint32_t persist_wgs = (deferred && k_persist > 0) ? (uint32_t)(k_persist * std::max(ctx->num_cus, 1)) : 0u;
     launch_render_forward_rec(cp, bg, ctx->ranges, ctx->pairv[where2].as<uint32_t>(), recs, d_img,
                               keep_state ? ctx->final_T.as<float>() : nullptr,
-                              keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, d_fp, order_now, st,
-                              keep_state ? ctx->strip_masks.as<uint8_t>() : nullptr, deferred ? ctx->ev_render : nullptr);
+                              keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, d_fp, order_now, part ? rst : st,
+                              keep_state ? ctx->strip_masks.as<uint8_t>() : nullptr, deferred ? ctx->ev_render : nullptr,
+                              ctx->work_counters, persist_wgs);
     ctx->last_tile_order = order_now;
     LCGS_TRY(mark(ctx, "render"));
+    if (part) LCGS_HIP_CHECK(hipStreamWaitEvent(vis, ctx->ev_render, 0)); // the caller's stream sees the finished frame
 
     if (deferred) {
         // the counter read-back leaves through the auxiliary stream: the next frame does not queue behind it
@@ -425,6 +449,21 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
 }
 
 lcgs_status prepare_twin(lcgs_context* ctx); // (the sibling context of camera / view batches, defined with them)
+
+// marks a context and its sibling as rendering several frames at once for the duration of a batch call
+struct InFlight {
+    lcgs_context* c;
+    InFlight(lcgs_context* ctx, bool on) : c(on ? ctx : nullptr)
+    {
+        if (c) c->frames_in_flight = true;
+        if (c && c->twin) c->twin->frames_in_flight = true;
+    }
+    ~InFlight()
+    {
+        if (c) c->frames_in_flight = false;
+        if (c && c->twin) c->twin->frames_in_flight = false;
+    }
+};
 
 } // namespace
 
@@ -454,9 +493,16 @@ lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx)
     }
     lcgs_context* ctx = new (std::nothrow) lcgs_context();
     if (!ctx) return LCGS_ERR_OUT_OF_MEMORY;
-    ctx->device = device_id;
-    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    ctx->device  = device_id;
+    ctx->stream  = reinterpret_cast<hipStream_t>(stream);
+    ctx->num_cus = prop.multiProcessorCount;
+    // tuning hooks of the frames-in-flight machinery (context.hpp): workgroups per CU of the persistent renderers
+    if (const char* e = getenv("LCGS_RENDER_WGS_PER_CU")) ctx->persist_forced = atoi(e);
+    if (const char* e = getenv("LCGS_RENDER_WGS_IN_FLIGHT")) ctx->persist_in_flight = atoi(e);
+    if (const char* e = getenv("LCGS_BWD_WGS_PER_CU")) ctx->persist_bwd_forced = atoi(e);
+    if (const char* e = getenv("LCGS_BWD_WGS_IN_FLIGHT")) ctx->persist_bwd_in_flight = atoi(e);
     if (const char* e = getenv("LCGS_GRAPH")) ctx->use_graph = (e[0] == '1'); // tuning hook
+    if (const char* e = getenv("LCGS_STAGE_SORT")) ctx->stage_sort = e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0); // test hook
     // The auxiliary stream has the LOWEST dispatch priority: its bandwidth-bound workgroups fill the gaps the main
     // stream's short, latency-bound kernels leave instead of competing with them.
     hipError_t se;
@@ -471,6 +517,22 @@ lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx)
     for (hipEvent_t* ev : { &ctx->ev_fork, &ctx->ev_join, &ctx->ev_ranges, &ctx->ev_aux_done, &ctx->ev_render, &ctx->ev_counts,
                             &ctx->ev_g2d_zero })
         if (se == hipSuccess) se = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    if (const char* e = getenv("LCGS_CHAIN_CUS")) {
+        // tuning hook: the sort chain on a stream masked to K CUs, record builder + renderer on the complement.  The K
+        // units are spread evenly over the 8 XCDs whichever way the driver numbers the mask bits (XCD-interleaved or
+        // XCD-major): XCD x gets the bits 32 x + ((x + j) % 8 + 8 (j % 4)), j < K / 8.
+        const int K = atoi(e), n = ctx->num_cus;
+        if (K >= 8 && K <= 64 && K % 8 == 0 && n == 256) {
+            uint32_t chain[8] = {}, rest[8];
+            for (int x = 0; x < 8; ++x)
+                for (int j = 0; j < K / 8; ++j) chain[x] |= 1u << ((x + j) % 8 + 8 * (j % 4));
+            for (int x = 0; x < 8; ++x) rest[x] = ~chain[x];
+            if (se == hipSuccess) se = hipExtStreamCreateWithCUMask(&ctx->chain_stream, 8, chain);
+            if (se == hipSuccess) se = hipExtStreamCreateWithCUMask(&ctx->render_stream, 8, rest);
+            for (hipEvent_t* ev : { &ctx->ev_begin, &ctx->ev_chain })
+                if (se == hipSuccess) se = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+        }
+    }
     if (se != hipSuccess) {
         lcgs_status s = hip_fail(se, "aux stream / events", __FILE__, __LINE__);
         (void)lcgs_destroy(ctx); // releases whichever of the stream / events were created
@@ -484,6 +546,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
 {
     if (!ctx) return LCGS_OK;
     (void)hipSetDevice(ctx->device);
+    (void)lcgs_stage_flush(ctx); // deferred stage calls still recorded: their outputs are the caller's buffers
     if (ctx->comm) {
         comm_forget_context(ctx->comm); // (drains the communicator's stream; the caller still owns and destroys it)
         ctx->comm = nullptr;
@@ -502,11 +565,18 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
         if (ev) (void)hipEventDestroy(ev);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+    for (hipStream_t s : { ctx->chain_stream, ctx->render_stream })
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    for (hipEvent_t ev : { ctx->ev_begin, ctx->ev_chain })
+        if (ev) (void)hipEventDestroy(ev);
     DeviceBuffer* bufs[] = { &ctx->recs, &ctx->sortk[0], &ctx->sortk[1], &ctx->sortv[0], &ctx->sortv[1], &ctx->vis_index,
                              &ctx->rects, &ctx->rects_sorted, &ctx->cull_slab, &ctx->chunk_info, &ctx->chunk_base, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
                              &ctx->pairv[1], &ctx->zero_ws[0], &ctx->zero_ws[1], &ctx->zero_ws[2], &ctx->counts, &ctx->sort_ws,
                              &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order[0], &ctx->tile_order[1], &ctx->st_keys_tmp,
-                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac, &ctx->tie_ws, &ctx->fused_grads, &ctx->st_flags, &ctx->st_keys_exp, &ctx->st_vals_exp,
+                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac, &ctx->tie_ws, &ctx->fused_grads, &ctx->bwd_counter, &ctx->st_flags, &ctx->st_keys_exp, &ctx->st_vals_exp,
                              &ctx->st_u32[0], &ctx->st_u32[1], &ctx->st_u32[2], &ctx->st_u32[3], &ctx->st_u32[4], &ctx->st_u32[5], &ctx->st_u32[6], &ctx->st_u32[7] };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& b : ctx->owned) b.release();
@@ -537,6 +607,8 @@ lcgs_status lcgs_set_stream(lcgs_context* ctx, void* stream)
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
     if (ctx->stream != reinterpret_cast<hipStream_t>(stream)) {
+        // deferred stage calls were recorded against the OLD stream's order: they run there, before the switch
+        LCGS_TRY(lcgs_stage_flush(ctx));
         // frames still in flight were ordered against the old stream: drain them before switching
         LCGS_HIP_CHECK(hipSetDevice(ctx->device));
         LCGS_TRY(sync_frame(ctx));
@@ -699,7 +771,6 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
             b.cam.height == output->height && !output->final_T && !output->n_contrib && ctx->lod_min_radius == 0 &&
             (reinterpret_cast<uintptr_t>(b.rotq) & 15) == 0 && P < (1 << 30);
         if (match) {
-            ctx->def_sh.pending = ctx->def_proj.pending = false;
             // the recorded arrays stand in for the context's scene for this one frame
             struct Saved {
                 int P, sh_deg; const float *pos, *scale, *rotq, *sh, *opacity; bool perm_valid, use_half_sh;
@@ -714,6 +785,9 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
             ctx->sh = sv.sh; ctx->opacity = sv.opacity; ctx->perm_valid = sv.perm_valid; ctx->use_half_sh = sv.use_half_sh;
             ctx->last.valid = false; // (the frame state belongs to the borrowed arrays)
             if (num_rendered) *num_rendered = n;
+            // the recorded calls are consumed only by a frame that was rendered: after an error (capacity, HIP) they stay
+            // pending, and a later flush / synchronise / splatter call still produces what they promised
+            if (rs == LCGS_OK) ctx->def_sh.pending = ctx->def_proj.pending = false;
             return rs;
         }
         LCGS_TRY(run_deferred_sh(ctx));
@@ -775,8 +849,7 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
     LCGS_TRY(ctx->st_sort_temp.ensure(pair_sort_ws_bytes(L)));
     // (small frames: the six passes over few pairs beat the longer chain of short launches -- 0.36 M pairs: 4270 vs 3930
     //  frames/s, 2.0 M: equal, 13 M: 610 vs 710; LCGS_STAGE_SORT=literal|splats forces either, a tuning / test hook)
-    const char* forced  = getenv("LCGS_STAGE_SORT");
-    const bool  literal = forced ? forced[0] == 'l' : L < (4 << 20);
+    const bool literal = ctx->stage_sort ? ctx->stage_sort == 1 : L < (4 << 20); // (the hook is read once, at lcgs_create)
     if (hole || n_vis == 0 || literal) {
         // the reference's sort as it stands: all live key bits of the unsorted pairs (always for frames with zero-filled
         // slots, whose pairs exist nowhere but in those buffers)
@@ -1309,6 +1382,7 @@ lcgs_status lcgs_render_forward_batch(lcgs_context* ctx, int num_views, const lc
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     const bool two = num_views > 1 && !ctx->profiling && !ctx->use_graph && ctx->P > 0;
     if (two) LCGS_TRY(prepare_twin(ctx));
+    InFlight in_flight(ctx, two); // (the renderers keep wave slots free for the other frame's sort chain)
     for (int i = 0; i < num_views; ++i) {
         lcgs_context* target = (two && (i & 1)) ? ctx->twin : ctx;
         LCGS_REQUIRE(d_imgs[i] != nullptr, "NULL image pointer in the batch");
@@ -1374,6 +1448,7 @@ lcgs_status lcgs_fit_views(lcgs_context* ctx, int num_views, const lcgs_camera* 
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     const bool two = num_views > 1 && !ctx->profiling && !ctx->use_graph;
     if (two) LCGS_TRY(prepare_twin(ctx));
+    InFlight      in_flight(ctx, two);
     lcgs_context* prev = nullptr; // the context whose backward wrote `grads` last
     for (int j = 0; j < num_views; ++j) {
         // alternate, ending on `ctx`: the last backward is the one a gradient all-reduce overlaps (its slices)
@@ -1592,15 +1667,19 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
         ctx->g2d_zeroed = false;
     } else {
         LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)P)));
-        launch_zero_grads2d(ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(), st);
+        launch_zero_grads2d(ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(), st, ctx->bwd_counter.as<uint32_t>());
         ctx->g2d_zeroed = false;
     }
     LCGS_TRY(mark(ctx, "zero_grads"));
+    // another view's forward in flight (lcgs_fit_views): a bounded persistent grid leaves its sort chain room on every CU
+    const int      k_bwd = ctx->persist_bwd_forced >= 0 ? ctx->persist_bwd_forced
+                                                        : (ctx->frames_in_flight ? ctx->persist_bwd_in_flight : 0);
+    const uint32_t bwd_wgs = (!ctx->profiling && k_bwd > 0) ? (uint32_t)(k_bwd * std::max(ctx->num_cus, 1)) : 0u;
     launch_render_backward(ctx->last.cp, ctx->last.bg, ctx->ranges, ctx->pairv[ctx->last.list_buf].as<uint32_t>(),
                            ctx->recs.as<SplatRecord>(), ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(),
                            d_dL_dimg, ctx->grads2d.as<float>(), ctx->last_tile_order, st,
                            render_forward_writes_strip_masks() ? ctx->strip_masks.as<uint8_t>() : nullptr,
-                           ctx->counts.as<uint32_t>());
+                           ctx->counts.as<uint32_t>(), ctx->bwd_counter.as<uint32_t>(), bwd_wgs);
     LCGS_TRY(mark(ctx, "render_backward"));
     if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     const int slices = fused ? 0 : (sliced ? ctx->grad_slices : 1);

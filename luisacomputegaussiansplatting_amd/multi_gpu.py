@@ -172,7 +172,7 @@ class TorchCollective:
                 grads[k][tail0:] = t
         for o in range(N):  # rank order: a fixed order of the f32 sums
             if o in recvs:
-                engine.sparse_accumulate(grads, recvs[o], rows_of(o, me))
+                engine.sparse_accumulate(grads, recvs[o], rows_of(o, me), rows=(first, count))  # only own-shard rows are accepted
         self.last_stats = {"bytes_sent": 4 * sum(int(t.numel()) for t in sends.values()),
                            "bytes_received": 4 * sum(int(t.numel()) for t in recvs.values()),
                            "touched_rows": owner_first[N + 1]}
@@ -267,8 +267,9 @@ class HipEngine:
     def sparse_pack(self, grads: dict, handle, first: int, count: int, msg):
         self._tracker.sparse_pack(grads, handle, first, count, msg)
 
-    def sparse_accumulate(self, grads: dict, msg, count: int):
-        self._tracker.sparse_accumulate(grads, msg, count)
+    def sparse_accumulate(self, grads: dict, msg, count: int, rows=None):
+        first, n = rows if rows is not None else (0, -1)
+        self._tracker.sparse_accumulate(grads, msg, count, row_first=first, row_count=n)
 
     def flush(self):
         self.r.ctx.synchronize()

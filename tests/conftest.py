@@ -38,6 +38,18 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _side_stream_under_the_graph_hook():
+    """LCGS_GRAPH=1 (tests/test_gpu_tuning_hooks.py re-runs suites under it): the legacy NULL stream cannot be captured, and
+    a Context created without a stream takes torch's CURRENT one -- so under the hook the whole session runs on a side
+    stream; otherwise the hook would silently exercise the eager path."""
+    if os.environ.get("LCGS_GRAPH") == "1" and _has_gpu():
+        import torch
+
+        torch.cuda.set_stream(torch.cuda.Stream(device=0))
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import Oracle

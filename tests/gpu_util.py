@@ -42,3 +42,74 @@ def assert_image_parity(gpu_img, orc, **_legacy):
                              f"(x={xs[0]}, y={ys[0]}): gpu {gpu_img[:, ys[0], xs[0]]} oracle {ref[:, ys[0], xs[0]]}")
     print(f"[parity] {ref.shape[2]}x{ref.shape[1]}: bit-identical to the oracle")
     return 0.0, 0
+
+
+LIBM_AMBIG_EPS = 1e-5
+
+
+def assert_parity_vs_libm_expf(gpu_img, oracle, scene, ocam, **render_kw):
+    """The HIP frame against the oracle evaluated with a STANDARD exp (libm's expf) in the blend -- the footing the
+    reference stands on (gs_tile_splatter/shader.cpp:256-265 says `exp(power)`; BASELINE's bar is 1e-4 per-pixel L-inf).
+    The kernels' exp is a defined <= 2.73-ulp polynomial (gs_math.hpp::blend_exp), so against libm the frame moves by a few
+    1e-7 everywhere and by up to ~1e-2 where an ulp flips a hard threshold (`alpha < 1/255` skips an entry, `T < 1e-4` ends
+    the pixel).  Asserted: (i) pixels beyond 1e-4 are at most 1e-5 of the frame, (ii) EVERY one of them is flagged
+    threshold-ambiguous by the libm oracle itself (some alpha or test_T within LIBM_AMBIG_EPS relative of its threshold --
+    1e-5, not a few ulp, because T carries the relative error of every earlier (1 - alpha) factor, each amplified by up to
+    1 / (1 - 0.99)), (iii) every unflagged pixel is within 2e-6.
+    Returns {pixels_over_1e-4, max_abs_diff, all_flagged, ambiguous_pixels, max_unflagged}."""
+    oracle.set_blend_exp(True)
+    try:
+        ref = oracle.render(scene, ocam, ambig_eps=LIBM_AMBIG_EPS, **render_kw)
+    finally:
+        oracle.set_blend_exp(False)
+    st = libm_parity_stats(gpu_img, ref)
+    n = gpu_img.shape[1] * gpu_img.shape[2]
+    assert st["pixels_over_1e-4"] <= max(1, int(np.ceil(1e-5 * n))), st
+    assert st["all_flagged"], st
+    assert st["max_unflagged"] <= 2e-6, st
+    print(f"[parity vs libm expf] {gpu_img.shape[2]}x{gpu_img.shape[1]}: {st}")
+    return st
+
+
+def libm_parity_stats(gpu_img, ref):
+    with np.errstate(invalid="ignore"):
+        diff = np.abs(gpu_img.astype(np.float64) - ref["img"].astype(np.float64)).max(axis=0)
+    diff = np.where(np.isnan(gpu_img).any(axis=0) & np.isnan(ref["img"]).any(axis=0), 0.0, diff)
+    amb = ref["ambig"].astype(bool)
+    over = diff > 1e-4
+    return {"pixels_over_1e-4": int(over.sum()), "max_abs_diff": float(diff.max()),
+            "all_flagged": bool((~over | amb).all()), "ambiguous_pixels": int(amb.sum()),
+            "max_unflagged": float(diff[~amb].max()) if (~amb).any() else 0.0}
+
+
+GRAD_F32_FACTOR = 2.0   # see check_gradients
+GRAD_GIANT_BAR = 5e-3
+
+
+def check_gradients(g, ref32, ref64, P, radii, tag, report=None):
+    """The kernels' gradients against the f64 oracle -- the ONLY yardstick (the f32 oracle shares the kernels' exp and
+    threshold decisions, so agreement with it alone proves nothing about precision).  Bar per attribute, over ALL rows
+    (screen-filling giants included): BASELINE's 1e-3 relative, or -- on ill-conditioned draws (needles, near-singular 2-D
+    covariances, giants whose geometry gradients are sums of ~1e5 cancelling terms), where f32 arithmetic itself cannot
+    do better -- GRAD_F32_FACTOR x the error the f32 ORACLE makes against f64 on the same rows (the same formulas in the
+    same precision, summed in another order: its error is the measure of the conditioning, the factor covers the spread
+    between two f32 summation orders).  Rows of giants (radius > 64 px) are additionally held to GRAD_GIANT_BAR on their
+    own, so that they cannot hide inside a large norm either.
+    report: a list -> nothing is asserted, the figures are appended (soak's survey mode)."""
+    rel = lambda x, y: float(np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-30))
+    giant = radii > 64
+    for k in g:
+        a = g[k].detach().cpu().numpy().astype(np.float64).reshape(P, -1)
+        assert np.isfinite(a).all(), (tag, k)
+        b32 = ref32[k].astype(np.float64).reshape(P, -1)
+        b64 = ref64[k].astype(np.float64).reshape(P, -1)
+        e, e32 = rel(a, b64), rel(b32, b64)
+        eg = rel(a[giant], b64[giant]) if giant.any() and np.linalg.norm(b64[giant]) > 0 else 0.0
+        eg32 = rel(b32[giant], b64[giant]) if giant.any() and np.linalg.norm(b64[giant]) > 0 else 0.0
+        if report is not None:
+            report.append({"tag": tag, "k": k, "e": e, "e32": e32, "eg": eg, "eg32": eg32, "giants": int(giant.sum())})
+            continue
+        assert e <= max(1e-3, GRAD_F32_FACTOR * e32), (
+            f"{tag} {k}: {e:.2e} vs the f64 oracle (f32 oracle vs f64: {e32:.2e}; giants alone {eg:.2e} / {eg32:.2e})")
+        assert eg <= max(GRAD_GIANT_BAR, GRAD_F32_FACTOR * eg32), (
+            f"{tag} {k}: rows of the {int(giant.sum())} giants {eg:.2e} vs f64 (f32 oracle on them: {eg32:.2e})")

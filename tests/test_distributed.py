@@ -97,10 +97,12 @@ class OracleEngine:
         parts += [grads[k].reshape(P, -1)[idx].reshape(-1) for k in KEYS]
         msg.copy_(torch.cat(parts))
 
-    def sparse_accumulate(self, grads, msg, count):
+    def sparse_accumulate(self, grads, msg, count, rows=None):
         import torch
 
         idx = msg[:count].view(torch.int32).to(torch.int64)
+        if rows is not None:  # (lcgs_sparse_accumulate drops rows outside the range; the protocol never sends any)
+            assert bool(((idx >= rows[0]) & (idx < rows[0] + rows[1])).all())
         at = count
         for k in KEYS:
             w = grads[k].reshape(P, -1).shape[1]

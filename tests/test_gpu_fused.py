@@ -4,14 +4,15 @@ import pytest
 import torch
 
 from conftest import make_scene
-from gpu_util import DEV, assert_image_parity, dev, upload_scene
+from gpu_util import DEV, assert_image_parity, assert_parity_vs_libm_expf, dev, upload_scene
 
 pytestmark = pytest.mark.gpu
 
 POSE = ([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1])
 
 
-def _render_both(lcgs, oracle, scene, W, H, bg=(0.1, 0.2, 0.3), pose=POSE, scale_modifier=1.0, check_lists=True):
+def _render_both(lcgs, oracle, scene, W, H, bg=(0.1, 0.2, 0.3), pose=POSE, scale_modifier=1.0, check_lists=True,
+                 vs_libm=False):
     P = scene["pos"].shape[0]
     cam = lcgs.get_lookat_cam(*pose, width=W, height=H)
     ocam = oracle.lookat(*pose, width=W, height=H)
@@ -82,6 +83,8 @@ def _render_both(lcgs, oracle, scene, W, H, bg=(0.1, 0.2, 0.3), pose=POSE, scale
             contributes = (power <= 0) & (alpha >= np.float32(1.0 / 255.0))
             assert not contributes.any(), "a pruned (tile, splat) pair would have contributed"
     stats = assert_image_parity(img.cpu().numpy(), orc)
+    if vs_libm:  # ... and against the oracle with a standard exp (libm's expf) in the blend
+        assert_parity_vs_libm_expf(img.cpu().numpy(), oracle, scene, ocam, bg=bg, scale_modifier=scale_modifier)
     return r, orc, stats
 
 
@@ -160,7 +163,7 @@ def test_synth_stand_in_scenes(lcgs, oracle):
     from conftest import baseline_scene
 
     scene, data = baseline_scene(lcgs, "chair")
-    _, orc, stats = _render_both(lcgs, oracle, scene, 800, 800, bg=(0, 0, 0), check_lists=True)
+    _, orc, stats = _render_both(lcgs, oracle, scene, 800, 800, bg=(0, 0, 0), check_lists=True, vs_libm=True)
     assert orc["num_rendered"] > (1_000_000 if data == "synthetic" else 100_000)
 
 

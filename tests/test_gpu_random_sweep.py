@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import make_scene
-from gpu_util import DEV, assert_image_parity, dev, upload_scene
+from gpu_util import DEV, assert_image_parity, assert_parity_vs_libm_expf, check_gradients, dev, upload_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -45,6 +45,7 @@ def test_random_forward_frames(lcgs, oracle, seed):
     assert np.array_equal(radii.cpu().numpy(), ref["radii"]), f"seed {seed}"
     if n:
         assert_image_parity(img.cpu().numpy(), ref)
+        assert_parity_vs_libm_expf(img.cpu().numpy(), oracle, scene, ocam, bg=bg, scale_modifier=sm)
 
 
 @pytest.mark.parametrize("seed", range(5))
@@ -65,29 +66,8 @@ def test_random_backward_frames(lcgs, oracle, oracle64, seed):
     g = {k: torch.full_like(d[k], 3.0) for k in ("pos", "scale", "rotq", "sh", "opacity")}
     r.backward(dev(dL), g["pos"], g["scale"], g["rotq"], g["sh"], g["opacity"])
     r.ctx.synchronize()
-    # Random frames contain ill-conditioned splats (needles, near-singular 2-D covariances) on which f32 arithmetic
-    # itself is only good to ~1e-3: the yardstick is the f64 oracle, and the bar is the BASELINE tolerance or -- where
-    # f32 cannot do better -- the error of the f32 oracle (the same formulas in the same precision as the kernels).
     ref32 = oracle.render_backward_full(scene, ocam, dL, bg=bg, scale_modifier=sm)
     ref64 = oracle64.render_backward_full(scene, oracle64.lookat(*pose, width=W, height=H, fov=fov), dL, bg=bg,
                                           scale_modifier=sm)
-    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
-    # The soak's criteria (tests/test_gpu_soak.py, 375 gradient draws clean): screen-filling giants (radius > 64 px, planted
-    # next to the camera by some draws) are left out of the norms -- their geometry gradients are sums of ~1e5 cancelling
-    # terms in which the render-backward's v_rcp_f32 and float-atomic summation order (different from run to run) are
-    # amplified to a few 1e-3 -- but still have to be finite; and the bar is the BASELINE tolerance or, where f32 cannot do
-    # better, three times the f32 oracle's own error against f64.
     radii = oracle.render(scene, ocam, bg=bg, scale_modifier=sm)["radii"]
-    keep = radii <= 64
-    for k in g:
-        a = g[k].cpu().numpy().astype(np.float64)
-        assert np.isfinite(a).all(), (seed, k)
-        a = a.reshape(P, -1)[keep].ravel()
-        b32 = ref32[k].astype(np.float64).reshape(P, -1)[keep].ravel()
-        b64 = ref64[k].astype(np.float64).reshape(P, -1)[keep].ravel()
-        bar = max(1e-3, 3.0 * rel(b32, b64))
-        # (round 3: the f32 oracle and the kernels take the same threshold decisions -- one defined exp on both sides --
-        #  so a frame on which f32 arithmetic is the limit may instead be held to the f32 oracle at the BASELINE bar)
-        assert rel(a, b64) <= bar or rel(a, b32) <= 1e-3, (
-            f"seed {seed} {k}: {rel(a, b64):.2e} vs f64, {rel(a, b32):.2e} vs the f32 oracle "
-            f"(f32 oracle vs f64: {rel(b32, b64):.2e})")
+    check_gradients(g, ref32, ref64, P, radii, f"seed {seed}")  # every row, the f64 oracle: gpu_util.check_gradients

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import DEV, assert_image_parity, dev, upload_scene
+from gpu_util import DEV, assert_image_parity, check_gradients, dev, upload_scene
 from test_gpu_random_sweep import _draw
 
 pytestmark = pytest.mark.gpu
@@ -16,7 +16,8 @@ N = int(os.environ.get("LCGS_SOAK", "0"))
 
 @pytest.mark.skipif(N <= 0, reason="opt-in: set LCGS_SOAK=<number of draws>")
 def test_soak_random_frames(lcgs, oracle, oracle64):
-    flipped_total, worst_ratio = 0, 0.0
+    flipped_total = 0
+    survey = [] if os.environ.get("LCGS_SOAK_REPORT") == "1" else None
     for seed in range(1000, 1000 + N):
         rng, scene, W, H, pose, fov, bg, sm = _draw(seed)
         P = scene["pos"].shape[0]
@@ -61,28 +62,23 @@ def test_soak_random_frames(lcgs, oracle, oracle64):
             g = {k: torch.full_like(d[k], 3.0) for k in ("pos", "scale", "rotq", "sh", "opacity")}
             r.backward(dev(dL), g["pos"], g["scale"], g["rotq"], g["sh"], g["opacity"])
             r.ctx.synchronize()
-            # the yardstick of test_gpu_random_sweep.py: the f64 oracle, and the BASELINE tolerance or -- on ill-conditioned
-            # draws (needles, giants: every third seed), where f32 itself is only good to a few 1e-3 -- a small multiple of
-            # the f32 oracle's own error (3x here: the kernels use v_rcp_f32 and FMAs, and this net is cast wide for gross
-            # errors, not to characterise precision; the worst ratio is printed)
+            # the yardstick of test_gpu_random_sweep.py (gpu_util.check_gradients): the f64 oracle, every row -- screen-filling
+            # giants included since round 4 (the render-backward's T division is Newton-refined: backward.hip)
             ref32 = oracle.render_backward_full(scene, ocam, dL, bg=bg, scale_modifier=sm)
             ref64 = oracle64.render_backward_full(scene, oracle64.lookat(*pose, width=W, height=H, fov=fov), dL, bg=bg,
                                                   scale_modifier=sm)
-            rel = lambda x, y: np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-30)
-            # Screen-filling giants (radius > 64 px: every third seed plants some next to the camera) are left out of the
-            # norms: their geometry gradients are sums of ~1e5 cancelling terms in which the render-backward's v_rcp_f32 /
-            # v_exp_f32 (1e-7 per term, by design: DESIGN.md 5) are amplified to several 1e-3 where the f32 oracle's IEEE
-            # divide and libm exp stay at several 1e-4 (tests/debug/grad_outlier.py shows one such splat carrying all of
-            # the excess).  They still have to be finite.
-            keep = ref["radii"] <= 64
-            for k in g:
-                a = g[k].cpu().numpy().astype(np.float64)
-                assert np.isfinite(a).all(), (seed, k)
-                a = a.reshape(P, -1)[keep].ravel()
-                b32 = ref32[k].astype(np.float64).reshape(P, -1)[keep].ravel()
-                b64 = ref64[k].astype(np.float64).reshape(P, -1)[keep].ravel()
-                assert rel(a, b64) <= max(1e-3, 3.0 * rel(b32, b64)), (seed, k, rel(a, b64), rel(b32, b64))
-                if rel(a, b64) > 1e-3:
-                    worst_ratio = max(worst_ratio, rel(a, b64) / max(rel(b32, b64), 1e-30))
-    print(f"[soak] {N} draws, {flipped_total} threshold-flipped pixels in total; worst gradient error beyond 1e-3 = "
-          f"{worst_ratio:.2f} x the f32 oracle's own error against f64")
+            check_gradients(g, ref32, ref64, P, ref["radii"], f"seed {seed}", report=survey)
+    if survey is not None:  # LCGS_SOAK_REPORT=1: the distribution instead of assertions
+        import json
+
+        worst = sorted(survey, key=lambda r: -r["e"] / max(1e-3, r["e32"]))[:12]
+        wg = sorted(survey, key=lambda r: -r["eg"])[:12]
+        print("[soak survey] gradient checks:", len(survey))
+        for f in (1.0, 1.5, 2.0, 3.0):
+            print(f"[soak survey] beyond max(1e-3, {f} x f32-oracle error): "
+                  f"{sum(r['e'] > max(1e-3, f * r['e32']) for r in survey)}; giants alone beyond max(5e-3, {f} x): "
+                  f"{sum(r['eg'] > max(5e-3, f * r['eg32']) for r in survey)}")
+        print("[soak survey] worst by ratio:", json.dumps(worst))
+        print("[soak survey] worst giant rows:", json.dumps(wg))
+    print(f"[soak] {N} draws, {flipped_total} threshold-flipped pixels in total; gradients of every fourth draw held to the "
+          f"f64 oracle (gpu_util.check_gradients)")

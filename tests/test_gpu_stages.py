@@ -12,14 +12,18 @@ pytestmark = pytest.mark.gpu
 POSE = ([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1])
 
 
-@pytest.fixture(scope="module")
-def ops(lcgs):
+def _make_ops(lcgs):
     ctx = lcgs.Context(0)
     sh, pr, ts = lcgs.SHProcessor(), lcgs.GSProjector(), lcgs.GSTileSplatter()
     sh.create(ctx)
     pr.create(ctx)
     ts.create(ctx)
     return ctx, sh, pr, ts
+
+
+@pytest.fixture(scope="module")
+def ops(lcgs):
+    return _make_ops(lcgs)
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
@@ -131,6 +135,7 @@ def test_tile_splatter_chain(lcgs, oracle, ops, res, sort, monkeypatch):
     sort-before-duplicate ("splats": the splats by depth, their pairs re-emitted in that order, two passes on the tile bits
     -- what large frames take); LCGS_STAGE_SORT forces either."""
     monkeypatch.setenv("LCGS_STAGE_SORT", sort)
+    ops = _make_ops(lcgs)  # (the hook is read when a context is created)
     rng = np.random.default_rng(res[0])
     scene = make_scene(rng, 30011, log_scale=(-4.2, 0.8))
     scene["pos"][:100] = rng.normal(0, 0.3, (100, 3)) + POSE[0]
@@ -146,6 +151,7 @@ def test_tile_splatter_nan_covariance_keeps_the_references_zero_filled_pairs(lcg
     (impl.cpp:117-118): key 0 / value 0 = splat 0 in tile 0 at depth 0.  The stage-level path reproduces that literally
     -- the zero-fill is skipped only in frames WITHOUT such a splat -- down to the sorted lists and the image."""
     monkeypatch.setenv("LCGS_STAGE_SORT", sort)  # ("splats" is overridden by the zero-filled slots: they exist nowhere else)
+    ops = _make_ops(lcgs)  # (the hook is read when a context is created)
     rng = np.random.default_rng(78)
     scene = make_scene(rng, 6000, log_scale=(-4.0, 0.7))
     scene["scale"][[17, 2500, 5999], 1] = np.nan
@@ -278,4 +284,13 @@ def test_deferred_stage_mode_gives_the_exact_modes_image_and_never_changes_a_res
     sh.process(lcgs.GPUPointsProxy(P, 3, d["pos"]), cam, d["sh"], color, 3, 3)
     ctx.synchronize()
     assert torch.equal(color, col_e)
+    # a stream switch between record and flush: the recorded operator runs on the OLD stream, in its order, before the switch
+    color2 = torch.full((P, 3), -5.0, device=DEV)
+    sh.process(lcgs.GPUPointsProxy(P, 3, d["pos"]), cam, d["sh"], color2, 3, 3)
+    old = torch.cuda.current_stream(0).cuda_stream
+    side = torch.cuda.Stream(device=DEV)
+    ctx.set_stream(side.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(color2, col_e)
+    ctx.set_stream(old)
     ctx.set_stage_mode("exact")

@@ -12,10 +12,18 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
-FILES = ["tests/test_gpu_fused.py", "tests/test_gpu_backward.py"]
+# (the two ingest tests: a scene the context RE-ORDERED under the graph hook -- its equal-depth scratch must exist before
+#  the capture starts; round 3's advisor finding)
+FILES = ["tests/test_gpu_fused.py", "tests/test_gpu_backward.py",
+         "tests/test_gpu_ingest.py::test_upload_keeps_the_scene_in_spatial_order_by_default_too",
+         "tests/test_gpu_ingest.py::test_equal_depths_blend_in_file_order_after_the_spatial_reorder"]
 
 
-@pytest.mark.parametrize("hook", [{"LCGS_GRAPH": "1"}], ids=["hipgraph"])
+# persistent: bounded grids of tile workgroups pulling from a counter (what camera batches / lcgs_fit_views use while several
+# frames are in flight), forced for EVERY frame and for the render-backward; cu-partition: sort chain and renderer on
+# CU-masked streams (a measured-and-kept-as-hook experiment of round 4).  Same frames, bit for bit.
+@pytest.mark.parametrize("hook", [{"LCGS_GRAPH": "1"}, {"LCGS_RENDER_WGS_PER_CU": "3", "LCGS_BWD_WGS_PER_CU": "2"},
+                                  {"LCGS_CHAIN_CUS": "32"}], ids=["hipgraph", "persistent", "cu-partition"])
 def test_parity_suites_under_tuning_hook(hook):
     env = dict(os.environ, **hook)
     res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + FILES,

@@ -1,0 +1,14 @@
+# A/B of the frames-in-flight hooks (environment variables) with one library on one box:
+#   gpurun -- bash tools/gpu/ab_flight.sh "A=1 B=2" "A=3" ...       (each argument: one space-separated env setting)
+# Prints, per setting and repetition: in-order fps, camera batch fps, fwd+bwd Msplats/s, lcgs_fit_views (4 views) Msplats/s.
+cd $GRAFT_REPO_ROOT
+B="python bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-train-step --no-stage-path --no-spatial --no-moving-camera"
+for rep in 1 2; do for v in "$@"; do
+env $v timeout 300 $B 2>gpurun_out/ab_flight.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline())
+fb=d.get('fwd_bwd',{})
+print('$v | fwd', d['value'], '| batch', d.get('camera_batch',{}).get('value'), d.get('camera_batch',{}).get('images_equal'),
+      '| fwd_bwd', fb.get('value'), '| fit4', fb.get('multi_view_step_4',{}).get('lcgs_fit_views',{}).get('value'),
+      '1by1', fb.get('multi_view_step_4',{}).get('one_by_one',{}).get('value'), '| render ms', d['stages_ms'].get('render'), flush=True)" || { echo "$v FAILED"; tail -5 gpurun_out/ab_flight.err; }
+done; done
