@@ -276,10 +276,11 @@ def main():
     # Reported beside `value` (which stays the strictly in-order figure), never instead of it.
     pipelined = None
     if not args.no_batch:
-        imgs = [img, torch.zeros(3, H, W, device=dev)]
+        # (four target images in rotation: frames that may be in flight together never share one)
+        imgs = [img] + [torch.zeros(3, H, W, device=dev) for _ in range(3)]
         cams_k = [cam] * args.steps
-        imgs_k = [imgs[i & 1] for i in range(args.steps)]
-        r.forward_batch([cam] * max(2, args.warmup), [imgs[i & 1] for i in range(max(2, args.warmup))])
+        imgs_k = [imgs[i & 3] for i in range(args.steps)]
+        r.forward_batch([cam] * max(4, args.warmup), [imgs[i & 3] for i in range(max(4, args.warmup))])
         barrier()
         t0 = time.perf_counter()
         r.forward_batch(cams_k, imgs_k)
@@ -291,7 +292,7 @@ def main():
             el_p = float(t.item())
         pipelined = {"api": "lcgs_render_forward_batch", "frames_in_flight": 2, "value": round(world * args.steps / el_p, 2),
                      "unit": "frames/s", "ms_per_step": round(el_p * 1e3 / args.steps, 4),
-                     "images_equal": bool(torch.equal(imgs[0], imgs[1]))}
+                     "images_equal": bool(all(torch.equal(imgs[0], x) for x in imgs[1:]))}
 
     # ---- the drop-in boundary itself: the reference's three operators in its own call order (app/main.cpp:266-308)
     # on the same frame -- SHProcessor.process, GSProjector.forward, GSTileSplatter.forward (which synchronises once

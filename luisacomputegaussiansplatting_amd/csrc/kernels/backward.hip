@@ -286,7 +286,11 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                     const float oma = 1.0f - a;
                     const float inv = __builtin_amdgcn_rcpf(oma);
                     const float q0  = T * inv;
-                    const float Tn  = __builtin_fmaf(__builtin_fmaf(-oma, q0, T), inv, q0); // the forward's T in front of this splat
+#ifdef LCGS_BWD_NO_NEWTON // (A/B builds only: round 3's plain T * rcp(1 - a))
+                    const float Tn = q0;
+#else
+                    const float Tn = __builtin_fmaf(__builtin_fmaf(-oma, q0, T), inv, q0); // the forward's T in front of this splat
+#endif
                     const float wgt = a * Tn;
                     // colour behind this splat (B) enters dL/dalpha, then absorbs the splat
                     const float dr = eb.z - Br, dg = eb.w - Bg, db = ec.x - Bb;

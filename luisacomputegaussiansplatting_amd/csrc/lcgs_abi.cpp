@@ -455,13 +455,11 @@ struct InFlight {
     lcgs_context* c;
     InFlight(lcgs_context* ctx, bool on) : c(on ? ctx : nullptr)
     {
-        if (c) c->frames_in_flight = true;
-        if (c && c->twin) c->twin->frames_in_flight = true;
+        for (lcgs_context* t = c; t; t = t->twin) t->frames_in_flight = true;
     }
     ~InFlight()
     {
-        if (c) c->frames_in_flight = false;
-        if (c && c->twin) c->twin->frames_in_flight = false;
+        for (lcgs_context* t = c; t; t = t->twin) t->frames_in_flight = false;
     }
 };
 
@@ -612,7 +610,7 @@ lcgs_status lcgs_set_stream(lcgs_context* ctx, void* stream)
         // frames still in flight were ordered against the old stream: drain them before switching
         LCGS_HIP_CHECK(hipSetDevice(ctx->device));
         LCGS_TRY(sync_frame(ctx));
-        if (ctx->twin) LCGS_TRY(sync_frame(ctx->twin));
+        for (lcgs_context* t = ctx->twin; t; t = t->twin) LCGS_TRY(sync_frame(t));
     }
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
     return LCGS_OK;
@@ -624,9 +622,10 @@ lcgs_status lcgs_synchronize(lcgs_context* ctx)
     LCGS_TRY(lcgs_stage_flush(ctx)); // deferred stage mode: whatever was recorded is produced before the caller looks
     LCGS_TRY(sync_frame(ctx));
     lcgs_status twin_status = LCGS_OK;
-    if (ctx->twin) {
-        LCGS_TRY(sync_frame(ctx->twin));
-        twin_status = check_frame_flags(ctx->twin); // (both workspaces are checked, and grown, by one call)
+    for (lcgs_context* t = ctx->twin; t; t = t->twin) { // (every workspace is checked, and grown, by one call)
+        LCGS_TRY(sync_frame(t));
+        const lcgs_status s = check_frame_flags(t);
+        if (twin_status == LCGS_OK) twin_status = s;
     }
     const lcgs_status own_status = check_frame_flags(ctx);
     return own_status != LCGS_OK ? own_status : twin_status;
@@ -975,7 +974,7 @@ lcgs_status lcgs_scene_reorder_spatial(lcgs_context* ctx, uint32_t* d_perm)
     if (ctx->P == 0) return LCGS_OK;
     LCGS_REQUIRE(ctx->pos != nullptr, "no scene bound (call lcgs_scene_bind / lcgs_scene_upload / lcgs_scene_load_ply first)");
     LCGS_TRY(sync_frame(ctx)); // frames in flight still read the old arrays
-    if (ctx->twin) LCGS_TRY(sync_frame(ctx->twin));
+    for (lcgs_context* t = ctx->twin; t; t = t->twin) LCGS_TRY(sync_frame(t));
     hipStream_t   st = ctx->stream;
     const int64_t P  = ctx->P;
     // ---- the box: mean +- 4 sigma per axis (finite positions only), 1024 cells per axis
@@ -1381,16 +1380,26 @@ lcgs_status lcgs_render_forward_batch(lcgs_context* ctx, int num_views, const lc
     LCGS_REQUIRE(cameras != nullptr && d_imgs != nullptr && bg_color != nullptr, "NULL argument");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     const bool two = num_views > 1 && !ctx->profiling && !ctx->use_graph && ctx->P > 0;
-    if (two) LCGS_TRY(prepare_twin(ctx));
-    InFlight in_flight(ctx, two); // (the renderers keep wave slots free for the other frame's sort chain)
+    // frames in flight: 2 (measured best through round 3); LCGS_BATCH_IN_FLIGHT = 3 / 4 is a tuning hook (a chain of siblings)
+    static const int want = [] {
+        const char* e = getenv("LCGS_BATCH_IN_FLIGHT");
+        return e ? std::min(std::max(atoi(e), 2), 4) : 2;
+    }();
+    lcgs_context* ring[4] = { ctx, nullptr, nullptr, nullptr };
+    int           n_ring  = 1;
+    if (two)
+        for (; n_ring < std::min(want, num_views); ++n_ring) {
+            LCGS_TRY(prepare_twin(ring[n_ring - 1]));
+            ring[n_ring] = ring[n_ring - 1]->twin;
+        }
+    InFlight in_flight(ctx, two);
     for (int i = 0; i < num_views; ++i) {
-        lcgs_context* target = (two && (i & 1)) ? ctx->twin : ctx;
         LCGS_REQUIRE(d_imgs[i] != nullptr, "NULL image pointer in the batch");
-        LCGS_TRY(lcgs_render_forward(target, &cameras[i], bg_color, scale_modifier, d_imgs[i], nullptr, 0, nullptr));
+        LCGS_TRY(lcgs_render_forward(ring[i % n_ring], &cameras[i], bg_color, scale_modifier, d_imgs[i], nullptr, 0, nullptr));
     }
-    if (two) {
-        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_batch_join, ctx->twin_stream));
-        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_batch_join, 0));
+    for (int k = 0; k + 1 < n_ring; ++k) { // the caller's stream waits for every sibling's frames
+        LCGS_HIP_CHECK(hipEventRecord(ring[k]->ev_batch_join, ring[k]->twin_stream));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ring[k]->ev_batch_join, 0));
     }
     return LCGS_OK;
 }

@@ -82,19 +82,27 @@ def libm_parity_stats(gpu_img, ref):
             "max_unflagged": float(diff[~amb].max()) if (~amb).any() else 0.0}
 
 
-GRAD_F32_FACTOR = 2.0   # see check_gradients
+GRAD_F32_FACTOR = 6.0   # see check_gradients
 GRAD_GIANT_BAR = 5e-3
 
 
 def check_gradients(g, ref32, ref64, P, radii, tag, report=None):
     """The kernels' gradients against the f64 oracle -- the ONLY yardstick (the f32 oracle shares the kernels' exp and
     threshold decisions, so agreement with it alone proves nothing about precision).  Bar per attribute, over ALL rows
-    (screen-filling giants included): BASELINE's 1e-3 relative, or -- on ill-conditioned draws (needles, near-singular 2-D
-    covariances, giants whose geometry gradients are sums of ~1e5 cancelling terms), where f32 arithmetic itself cannot
-    do better -- GRAD_F32_FACTOR x the error the f32 ORACLE makes against f64 on the same rows (the same formulas in the
-    same precision, summed in another order: its error is the measure of the conditioning, the factor covers the spread
-    between two f32 summation orders).  Rows of giants (radius > 64 px) are additionally held to GRAD_GIANT_BAR on their
-    own, so that they cannot hide inside a large norm either.
+    (screen-filling giants included since round 4): BASELINE's 1e-3 relative, or -- on ill-conditioned draws, where f32
+    arithmetic itself cannot do better -- GRAD_F32_FACTOR x the error the f32 ORACLE makes against f64 on the same rows.
+
+    Why a multiple of the f32 oracle's error, and why 6.  Measured in round 4 (profiles/r04_gradient_error_survey.txt, 1875
+    checks of the 1500-draw soak): 237 checks are ill-conditioned (f32 oracle beyond 3e-4, up to 1.7e-1 on draws that plant
+    screen-filling splats next to the camera), and the decomposition on the CPU shows WHERE: not in the sums over pixels
+    (f64 algebra on f32-summed 2-D gradients: median 2e-4) but in the per-splat algebra of the preprocess-backward (conic ->
+    covariance -> Sigma -> scale / quaternion: products of 1e5-sized covariances and 1e-6-sized conics that cancel), which
+    no f32 evaluation of these formulas escapes.  The kernels' error there is a SECOND SAMPLE of the same rounding noise
+    (FMA contraction, another summation order): over the 237 checks the ratio kernel / f32 oracle has median 1.00,
+    geometric mean 0.94, 90th percentile 1.8, 99th 3.7, maximum 4.6 -- the heavy tail of a ratio of two independent
+    errors, not a bias.  6 covers that tail; the soak additionally asserts the DISTRIBUTION (median, 90th percentile).
+    Rows of giants (radius > 64 px) are held to max(GRAD_GIANT_BAR, 6 x the f32 oracle on those rows) on their own, so
+    that they cannot hide inside a large norm either.
     report: a list -> nothing is asserted, the figures are appended (soak's survey mode)."""
     rel = lambda x, y: float(np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-30))
     giant = radii > 64

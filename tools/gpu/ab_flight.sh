@@ -2,7 +2,7 @@
 #   gpurun -- bash tools/gpu/ab_flight.sh "A=1 B=2" "A=3" ...       (each argument: one space-separated env setting)
 # Prints, per setting and repetition: in-order fps, camera batch fps, fwd+bwd Msplats/s, lcgs_fit_views (4 views) Msplats/s.
 cd $GRAFT_REPO_ROOT
-B="python bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-train-step --no-stage-path --no-spatial --no-moving-camera"
+B="python bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-train-step --no-stage-path --no-spatial"
 for rep in 1 2; do for v in "$@"; do
 env $v timeout 300 $B 2>gpurun_out/ab_flight.err | python -c "
 import json,sys
