@@ -37,15 +37,15 @@ HBM_ATTAINABLE_GBS = 6550.0
 
 
 def kernel_sources_hash() -> str:
-    """sha256 over the device sources (csrc/kernels/*) and the ABI file that orders the launches: profile artefacts under
-    profiles/ carry the hash of the sources they were measured on, and a figure read back from them is only used while it
-    still matches -- a changed kernel must not keep reporting last round's counters."""
+    """sha256 over the device sources (csrc/kernels/*) and the ABI files that order the launches (csrc/abi_*): profile
+    artefacts under profiles/ carry the hash of the sources they were measured on, and a figure read back from them is only
+    used while it still matches -- a changed kernel must not keep reporting last round's counters."""
     import glob
     import hashlib
 
     h = hashlib.sha256()
     base = os.path.join(ROOT, "luisacomputegaussiansplatting_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(base, "kernels", "*")) + [os.path.join(base, "lcgs_abi.cpp")]):
+    for f in sorted(glob.glob(os.path.join(base, "kernels", "*")) + glob.glob(os.path.join(base, "abi_*"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

@@ -1,0 +1,59 @@
+// abi_internal.hpp -- what the translation units behind the C ABI share: the context (context.hpp), the small helpers of
+// abi_core.cpp and the frame / sibling plumbing of abi_frame.cpp.  The C ABI itself is split by subject (round 4; one
+// 1 700-line file until then), every exported symbol unchanged:
+//   abi_core.cpp      errors, device buffers, context create / destroy, stream, synchronise, profiling, stats, debug hooks
+//   abi_stages.cpp    the reference's three operators + the two lcpp primitives (stage level), deferred stage mode
+//   abi_scene.cpp     scene bind / upload / download / PLY ingest / spatial re-order / f16 SH / LOD
+//   abi_frame.cpp     the fused frame: workspace, enqueue, lcgs_render_forward, camera batches, the sibling context
+//   abi_backward.cpp  lcgs_render_backward and its variants (compact rows, accumulate, fused Adam)
+//   abi_train.cpp     lcgs_adam_step, lcgs_fit_views
+#pragma once
+
+#include "common.hpp"
+#include "context.hpp"
+#include "kernels/launch.hpp"
+
+#define LCGS_TRY(expr)                    \
+    do {                                  \
+        lcgs_status _s = (expr);          \
+        if (_s != LCGS_OK) return _s;     \
+    } while (0)
+
+namespace lcgs
+{
+namespace abi
+{
+inline int ceil_log2_u32(uint32_t v)
+{
+    int b = 0;
+    while ((1ull << b) < v) ++b;
+    return b;
+}
+
+// abi_core.cpp
+lcgs_status mark(lcgs_context* ctx, const char* name);          // per-stage timing mark (+ LCGS_DEBUG_SYNC)
+lcgs_status collect_marks(lcgs_context* ctx);
+lcgs_status sync_frame(lcgs_context* ctx);                      // the context's stream + the last frame's counter read-back
+lcgs_status check_frame_flags(lcgs_context* ctx);               // problems an asynchronous frame reported through its counters
+lcgs_status check_camera(const lcgs_camera* cam);
+// abi_stages.cpp: deferred stage mode -- run a recorded SHProcessor::process / GSProjector::forward now
+lcgs_status run_deferred_sh(lcgs_context* ctx);
+lcgs_status run_deferred_proj(lcgs_context* ctx);
+// abi_frame.cpp
+lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool keep_state);
+lcgs_status prepare_twin(lcgs_context* ctx); // the sibling context of camera / view batches: created on first use, same scene
+
+// marks a context and its siblings as rendering several frames at once for the duration of a batch call
+struct InFlight {
+    lcgs_context* c;
+    InFlight(lcgs_context* ctx, bool on) : c(on ? ctx : nullptr)
+    {
+        for (lcgs_context* t = c; t; t = t->twin) t->frames_in_flight = true;
+    }
+    ~InFlight()
+    {
+        for (lcgs_context* t = c; t; t = t->twin) t->frames_in_flight = false;
+    }
+};
+} // namespace abi
+} // namespace lcgs

@@ -1,0 +1,357 @@
+// abi_scene.cpp -- the C ABI, part 3: the scene a context renders -- bind / upload / download, PLY ingest with the
+// de-interleave and the activations on the device, the spatial (Morton) order of context-owned scenes, the opt-in f16
+// coefficients and footprint cull.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <thread>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "abi_internal.hpp"
+
+using namespace lcgs;
+using namespace lcgs::abi;
+
+extern "C" {
+
+lcgs_status lcgs_scene_bind(lcgs_context* ctx, int num_gaussians, int sh_degree, const float* d_pos,
+                            const float* d_scale, const float* d_rotq, const float* d_sh, const float* d_opacity)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(num_gaussians >= 0 && num_gaussians < (1 << 30), "num_gaussians out of range");
+    LCGS_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "sh_degree must be in [0,3]");
+    if (num_gaussians > 0) LCGS_REQUIRE(d_pos && d_scale && d_rotq && d_sh && d_opacity, "NULL device pointer");
+    LCGS_REQUIRE((reinterpret_cast<uintptr_t>(d_rotq) & 15) == 0, "rotq must be 16-byte aligned");
+    ctx->P       = num_gaussians;
+    ctx->sh_deg  = sh_degree;
+    ctx->pos     = d_pos;
+    ctx->scale   = d_scale;
+    ctx->rotq    = d_rotq;
+    ctx->sh      = d_sh;
+    ctx->opacity = d_opacity;
+    ctx->last.valid = false;
+    ctx->use_half_sh = false; // a new scene: the f16 copy (if any) is stale
+    // the caller's arrays, the caller's order -- unless these ARE the context's own re-ordered arrays (bound again after
+    // something else was): their permutation, and with it the reference's order of equal depths, still applies
+    ctx->perm_valid = ctx->perm_for_owned && num_gaussians > 0 && d_pos == ctx->owned[0].as<float>() &&
+                      d_scale == ctx->owned[1].as<float>() && d_rotq == ctx->owned[2].as<float>() &&
+                      d_sh == ctx->owned[3].as<float>() && d_opacity == ctx->owned[4].as<float>();
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_set_lod(lcgs_context* ctx, int min_radius_px)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(min_radius_px >= 0 && min_radius_px <= 4096, "min_radius_px out of range");
+    ctx->lod_min_radius = min_radius_px;
+    if (ctx->twin) ctx->twin->lod_min_radius = min_radius_px;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_set_ingest_order(lcgs_context* ctx, int order)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(order == LCGS_ORDER_FILE || order == LCGS_ORDER_SPATIAL, "order must be LCGS_ORDER_FILE or LCGS_ORDER_SPATIAL");
+    ctx->ingest_order = order;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_scene_permutation(lcgs_context* ctx, const uint32_t** d_perm)
+{
+    LCGS_REQUIRE(ctx && d_perm, "NULL argument");
+    *d_perm = ctx->perm_valid ? ctx->scene_perm.as<uint32_t>() : nullptr;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_scene_upload(lcgs_context* ctx, int num_gaussians, int sh_degree, const float* h_pos,
+                              const float* h_scale, const float* h_rotq, const float* h_sh, const float* h_opacity)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
+    LCGS_REQUIRE(num_gaussians >= 0 && num_gaussians < (1 << 30), "num_gaussians out of range");
+    LCGS_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "sh_degree must be in [0,3]");
+    if (num_gaussians > 0) LCGS_REQUIRE(h_pos && h_scale && h_rotq && h_sh && h_opacity, "NULL host pointer");
+    const size_t P        = (size_t)num_gaussians;
+    const size_t feat     = (size_t)(sh_degree + 1) * (sh_degree + 1) * 3;
+    const size_t sizes[5] = { P * 3 * 4, P * 3 * 4, P * 4 * 4, P * feat * 4, P * 4 };
+    const float* src[5]   = { h_pos, h_scale, h_rotq, h_sh, h_opacity };
+    ctx->perm_for_owned = false; // owned[] is rewritten in the given order
+    for (int i = 0; i < 5; ++i) {
+        LCGS_TRY(ctx->owned[i].ensure(std::max<size_t>(sizes[i], 16)));
+        if (sizes[i])
+            LCGS_HIP_CHECK(hipMemcpyAsync(ctx->owned[i].ptr, src[i], sizes[i], hipMemcpyHostToDevice, ctx->stream));
+    }
+    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // app/main.cpp:223
+    LCGS_TRY(lcgs_scene_bind(ctx, num_gaussians, sh_degree, ctx->owned[0].as<float>(), ctx->owned[1].as<float>(),
+                             ctx->owned[2].as<float>(), ctx->owned[3].as<float>(), ctx->owned[4].as<float>()));
+    // a scene the context owns is kept in spatial order unless the caller asked for the given one (lcgs_set_ingest_order)
+    if (ctx->ingest_order == LCGS_ORDER_SPATIAL && num_gaussians > 0) LCGS_TRY(lcgs_scene_reorder_spatial(ctx, nullptr));
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_scene_reorder_spatial(lcgs_context* ctx, uint32_t* d_perm)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->P == 0) return LCGS_OK;
+    LCGS_REQUIRE(ctx->pos != nullptr, "no scene bound (call lcgs_scene_bind / lcgs_scene_upload / lcgs_scene_load_ply first)");
+    LCGS_TRY(sync_frame(ctx)); // frames in flight still read the old arrays
+    for (lcgs_context* t = ctx->twin; t; t = t->twin) LCGS_TRY(sync_frame(t));
+    hipStream_t   st = ctx->stream;
+    const int64_t P  = ctx->P;
+    // ---- the box: mean +- 4 sigma per axis (finite positions only), 1024 cells per axis
+    DeviceBuffer partial;
+    const int    nb = pos_moment_blocks();
+    LCGS_TRY(partial.ensure((size_t)nb * 7 * sizeof(double)));
+    launch_pos_moments(P, ctx->pos, partial.as<double>(), st);
+    std::vector<double> h((size_t)nb * 7);
+    hipError_t          e = hipMemcpyAsync(h.data(), partial.ptr, h.size() * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    partial.release();
+    LCGS_HIP_CHECK(e);
+    double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    for (int b = 0; b < nb; ++b)
+        for (int k = 0; k < 7; ++k) acc[k] += h[(size_t)b * 7 + k];
+    float lo[3] = { 0, 0, 0 }, cells[3] = { 1, 1, 1 };
+    for (int a = 0; a < 3; ++a) {
+        const double n = std::max(acc[6], 1.0), mean = acc[a] / n;
+        const double sd = std::sqrt(std::max(acc[3 + a] / n - mean * mean, 0.0));
+        const double half = std::max(4.0 * sd, 1e-6);
+        lo[a]    = (float)(mean - half);
+        cells[a] = (float)(1024.0 / (2.0 * half));
+    }
+    // ---- keys, stable sort, gather
+    DeviceBuffer keys[2], vals[2], ws, fresh[5];
+    auto         drop = [&]() {
+        for (int i = 0; i < 2; ++i) {
+            keys[i].release();
+            vals[i].release();
+        }
+        ws.release();
+    };
+    lcgs_status s = LCGS_OK;
+    for (int i = 0; i < 2 && s == LCGS_OK; ++i) {
+        s = keys[i].ensure((size_t)P * 4);
+        if (s == LCGS_OK) s = vals[i].ensure((size_t)P * 4);
+    }
+    if (s == LCGS_OK) s = ws.ensure(pair_sort_ws_bytes(P));
+    const size_t feat    = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3;
+    const int    rowf[5] = { 3, 3, 4, (int)feat, 1 };
+    for (int i = 0; i < 5 && s == LCGS_OK; ++i) s = fresh[i].ensure(std::max<size_t>((size_t)P * rowf[i] * 4, 16));
+    if (s != LCGS_OK) {
+        drop();
+        for (DeviceBuffer& b : fresh) b.release();
+        return s;
+    }
+    launch_morton_keys(P, ctx->pos, lo, cells, keys[0].as<uint32_t>(), vals[0].as<uint32_t>(), st);
+    const int where = launch_pair_sort_u32(keys[0].as<uint32_t>(), keys[1].as<uint32_t>(), vals[0].as<uint32_t>(),
+                                           vals[1].as<uint32_t>(), nullptr, P, P, 0, 30, ws.ptr, st);
+    const uint32_t* perm   = vals[where].as<uint32_t>();
+    const float*    src[5] = { ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity };
+    for (int i = 0; i < 5; ++i) launch_gather_rows(P, rowf[i], perm, src[i], fresh[i].as<float>(), st);
+    e = hipGetLastError();
+    DeviceBuffer kept_perm;
+    if (e == hipSuccess && kept_perm.ensure((size_t)P * 4) != LCGS_OK) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMemcpyAsync(kept_perm.ptr, perm, (size_t)P * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && d_perm) e = hipMemcpyAsync(d_perm, perm, (size_t)P * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    drop();
+    if (e != hipSuccess) {
+        for (DeviceBuffer& b : fresh) b.release();
+        kept_perm.release();
+        LCGS_HIP_CHECK(e);
+    }
+    // ---- the context now owns (and renders from) the re-ordered copy
+    const bool half = ctx->use_half_sh, had_perm = ctx->perm_valid;
+    for (int i = 0; i < 5; ++i) {
+        ctx->owned[i].release();
+        ctx->owned[i] = fresh[i];
+    }
+    LCGS_TRY(lcgs_scene_bind(ctx, ctx->P, ctx->sh_deg, ctx->owned[0].as<float>(), ctx->owned[1].as<float>(),
+                             ctx->owned[2].as<float>(), ctx->owned[3].as<float>(), ctx->owned[4].as<float>()));
+    // the permutation stays with the context (composed with an earlier one: file index of every row)
+    if (had_perm) {
+        DeviceBuffer composed;
+        lcgs_status  cs = composed.ensure((size_t)P * 4);
+        if (cs == LCGS_OK) {
+            launch_gather_rows(P, 1, kept_perm.as<uint32_t>(), ctx->scene_perm.as<float>(), composed.as<float>(), st);
+            hipError_t ce = hipStreamSynchronize(st);
+            kept_perm.release();
+            if (ce != hipSuccess) {
+                composed.release();
+                LCGS_HIP_CHECK(ce);
+            }
+            ctx->scene_perm.release();
+            ctx->scene_perm = composed;
+        } else {
+            kept_perm.release();
+            return cs;
+        }
+    } else {
+        ctx->scene_perm.release();
+        ctx->scene_perm = kept_perm;
+    }
+    ctx->perm_valid     = true;
+    ctx->perm_for_owned = true;
+    if (half) LCGS_TRY(lcgs_scene_use_half_sh(ctx, 1)); // the f16 copy follows the new order
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_scene_pointers(lcgs_context* ctx, int* num_gaussians, int* sh_degree, const float** d_pos,
+                                const float** d_scale, const float** d_rotq, const float** d_sh, const float** d_opacity)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (num_gaussians) *num_gaussians = ctx->P;
+    if (sh_degree) *sh_degree = ctx->sh_deg;
+    if (d_pos) *d_pos = ctx->pos;
+    if (d_scale) *d_scale = ctx->scale;
+    if (d_rotq) *d_rotq = ctx->rotq;
+    if (d_sh) *d_sh = ctx->sh;
+    if (d_opacity) *d_opacity = ctx->opacity;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_scene_use_half_sh(lcgs_context* ctx, int enable)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!enable) {
+        ctx->use_half_sh = false;
+        return LCGS_OK;
+    }
+    LCGS_REQUIRE(ctx->pos != nullptr || ctx->P == 0, "no scene bound");
+    LCGS_REQUIRE(ctx->sh_deg == 3, "the f16 coefficient path exists for sh_degree 3 only");
+    const int64_t n = (int64_t)ctx->P * 48;
+    LCGS_TRY(ctx->sh_half.ensure(std::max<size_t>((size_t)n * 2, 16)));
+    launch_sh_to_half(n, ctx->sh, ctx->sh_half.as<uint16_t>(), ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    ctx->use_half_sh = true;
+    if (ctx->twin) ctx->twin->use_half_sh = false; // the sibling of a camera batch re-binds; see below
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_scene_download(lcgs_context* ctx, float* h_pos, float* h_scale, float* h_rotq, float* h_sh,
+                                float* h_opacity)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
+    const size_t P    = (size_t)ctx->P;
+    const size_t feat = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3;
+    const size_t sizes[5] = { P * 3 * 4, P * 3 * 4, P * 4 * 4, P * feat * 4, P * 4 };
+    const float* src[5]   = { ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity };
+    float*       dst[5]   = { h_pos, h_scale, h_rotq, h_sh, h_opacity };
+    for (int i = 0; i < 5; ++i)
+        if (dst[i] && sizes[i]) LCGS_HIP_CHECK(hipMemcpyAsync(dst[i], src[i], sizes[i], hipMemcpyDeviceToHost, ctx->stream));
+    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return LCGS_OK;
+}
+
+// Scene ingest with the de-interleave and the activations on the device.  The vertex records go
+// to the GPU exactly as they lie in the file -- mmap -> two pinned staging buffers filled by host threads ->
+// async copies -- and k_ply_activate turns each chunk into the five activated arrays while the next chunk is in
+// flight.  The host never touches a float: no 62 column vectors, no scalar activation loops
+// (app/gaussians.cpp:93-168), no second 1.45 GB host copy.
+lcgs_status lcgs_scene_load_ply(lcgs_context* ctx, const char* path, int* num_gaussians)
+{
+    LCGS_REQUIRE(ctx != nullptr && path != nullptr, "NULL argument");
+    if (num_gaussians) *num_gaussians = 0;
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    PlyProbe probe;
+    LCGS_TRY(ply_probe(path, &probe));
+    if (!probe.device_ok) { // ascii, or non-float columns: the general host parser
+        lcgs_scene_host h;
+        LCGS_TRY(lcgs_ply_read(path, &h));
+        lcgs_status s = lcgs_scene_upload(ctx, h.num_gaussians, h.sh_degree, h.pos, h.scale, h.rotq, h.feature, h.opacity);
+        if (num_gaussians) *num_gaussians = h.num_gaussians;
+        lcgs_scene_host_free(&h);
+        return s; // (lcgs_scene_upload applied the ingest order)
+    }
+    const int64_t N = probe.num_vertices;
+    LCGS_REQUIRE(N < (1 << 30), "too many vertices");
+    ctx->perm_for_owned = false; // owned[] is rewritten in the file's order
+    const size_t sizes[5] = { (size_t)N * 3 * 4, (size_t)N * 3 * 4, (size_t)N * 4 * 4, (size_t)N * 48 * 4, (size_t)N * 4 };
+    for (int i = 0; i < 5; ++i) LCGS_TRY(ctx->owned[i].ensure(std::max<size_t>(sizes[i], 16)));
+    if (N > 0) {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) {
+            set_last_error(std::string("cannot open ") + path);
+            return LCGS_ERR_IO;
+        }
+        const size_t map_bytes = probe.payload_offset + (size_t)N * probe.stride;
+        void*        map       = mmap(nullptr, map_bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (map == MAP_FAILED) {
+            set_last_error(std::string("cannot map ") + path);
+            return LCGS_ERR_IO;
+        }
+        (void)madvise(map, map_bytes, MADV_SEQUENTIAL);
+        const unsigned char* payload = static_cast<const unsigned char*>(map) + probe.payload_offset;
+        const int64_t        chunk   = std::max<int64_t>(1, ((int64_t)64 << 20) / (int64_t)probe.stride); // records
+        const size_t         cbytes  = (size_t)chunk * probe.stride;
+        unsigned char*       pinned[2] = { nullptr, nullptr };
+        hipEvent_t           done[2]   = { nullptr, nullptr };
+        DeviceBuffer         d_raw[2];
+        lcgs_status          st = LCGS_OK;
+        auto                 cleanup = [&]() {
+            for (int i = 0; i < 2; ++i) {
+                if (pinned[i]) (void)hipHostFree(pinned[i]);
+                if (done[i]) (void)hipEventDestroy(done[i]);
+                d_raw[i].release();
+            }
+            munmap(map, map_bytes);
+        };
+        for (int i = 0; i < 2 && st == LCGS_OK; ++i) {
+            if (hipHostMalloc(reinterpret_cast<void**>(&pinned[i]), cbytes, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess)
+                st = LCGS_ERR_OUT_OF_MEMORY;
+            else
+                st = d_raw[i].ensure(cbytes);
+        }
+        PlyColumns cols;
+        for (int w = 0; w < 59; ++w) cols.offset[w] = probe.column_offset[w];
+        int b = 0;
+        for (int64_t first = 0; first < N && st == LCGS_OK; first += chunk, b ^= 1) {
+            const int64_t count = std::min<int64_t>(chunk, N - first);
+            const size_t  bytes = (size_t)count * probe.stride;
+            if (first >= 2 * chunk && hipEventSynchronize(done[b]) != hipSuccess) st = LCGS_ERR_HIP; // buffer b is free again
+            if (st != LCGS_OK) break;
+            // page cache -> pinned memory with a few threads (one memcpy stream tops out well below PCIe rate)
+            const unsigned char* src = payload + (size_t)first * probe.stride;
+            const int            nt  = 8;
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) {
+                const size_t a = bytes * t / nt, e = bytes * (t + 1) / nt;
+                th.emplace_back([=] { memcpy(pinned[b] + a, src + a, e - a); });
+            }
+            for (auto& x : th) x.join();
+            if (hipMemcpyAsync(d_raw[b].ptr, pinned[b], bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = LCGS_ERR_HIP;
+            launch_ply_activate(d_raw[b].as<unsigned char>(), first, count, (uint32_t)probe.stride, cols,
+                                ctx->owned[0].as<float>(), ctx->owned[1].as<float>(), ctx->owned[2].as<float>(),
+                                ctx->owned[3].as<float>(), ctx->owned[4].as<float>(), ctx->stream);
+            if (hipEventRecord(done[b], ctx->stream) != hipSuccess) st = LCGS_ERR_HIP;
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == LCGS_OK) st = LCGS_ERR_HIP;
+        cleanup();
+        if (st != LCGS_OK) {
+            if (st == LCGS_ERR_HIP) set_last_error("device ingest of the PLY payload failed");
+            return st;
+        }
+    }
+    if (num_gaussians) *num_gaussians = (int)N;
+    LCGS_TRY(lcgs_scene_bind(ctx, (int)N, 3, ctx->owned[0].as<float>(), ctx->owned[1].as<float>(), ctx->owned[2].as<float>(),
+                             ctx->owned[3].as<float>(), ctx->owned[4].as<float>()));
+    // a scene the context owns is kept in spatial order unless the caller asked for the file's (lcgs_set_ingest_order)
+    if (ctx->ingest_order == LCGS_ORDER_SPATIAL && N > 0) LCGS_TRY(lcgs_scene_reorder_spatial(ctx, nullptr));
+    return LCGS_OK;
+}
+
+} // extern "C"

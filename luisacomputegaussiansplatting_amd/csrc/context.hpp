@@ -1,5 +1,5 @@
 // context.hpp -- the (opaque to callers) lcgs_context, shared by the translation units behind the C ABI
-// (lcgs_abi.cpp: frames, scene, optimiser; host/comm.cpp: the RCCL gradient collectives).
+// (abi_*.cpp: frames, scene, optimiser -- see abi_internal.hpp; host/comm.cpp: the RCCL gradient collectives).
 #pragma once
 
 #include "common.hpp"

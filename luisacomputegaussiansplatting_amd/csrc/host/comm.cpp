@@ -10,7 +10,7 @@
 // Two ways through a training step at N > 1, both exact in f32:
 //   lcgs_grads_allreduce     in-place sum of the five dense gradient arrays, issued as splat-range CHUNKS on a
 //                            dedicated stream: the dense backward runs its preprocess pass as slices and records an event
-//                            behind each (lcgs_abi.cpp render_backward), so chunk k is on the wire while slices k+1.. are
+//                            behind each (abi_backward.cpp render_backward), so chunk k is on the wire while slices k+1.. are
 //                            still being computed.  (SURVEY 8e sketched per-attribute chunks; one kernel writes all five
 //                            attributes of a splat, so the chunks are row ranges -- same idea, same bytes.)
 //   lcgs_adam_step_sharded   reduce-scatter -> Adam on the rank's own rows -> all-gather of the refreshed activated
@@ -553,7 +553,7 @@ lcgs_status compact_touched(lcgs_context* ctx, lcgs_comm* c, int64_t P, int worl
 
 namespace lcgs
 {
-// (lcgs_abi.cpp render_backward) flag the rows of the frame a dense backward has just differentiated
+// (abi_backward.cpp render_backward) flag the rows of the frame a dense backward has just differentiated
 lcgs_status comm_mark_touched(lcgs_comm* c, const uint32_t* vis_index, const uint32_t* d_counts, int64_t P, int64_t hint_V,
                               bool accumulate, hipStream_t stream)
 {

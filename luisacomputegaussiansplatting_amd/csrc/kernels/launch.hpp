@@ -24,7 +24,7 @@ void launch_allocate_tiles(int P, const CamParams& cp, bool use_focal, const flo
 void launch_copy_with_keys(int P, const CamParams& cp, const float* means_2d, const uint32_t* offsets,
                            const int32_t* radii, const float* depth, uint64_t* keys, uint32_t* values,
                            hipStream_t stream);
-// the splatter's sort-before-duplicate (lcgs_abi.cpp lcgs_tile_splat_forward): which splats claim pair slots, their depth
+// the splatter's sort-before-duplicate (abi_stages.cpp lcgs_tile_splat_forward): which splats claim pair slots, their depth
 // keys, a gather through the sorted order, and copy_with_keys over the splats IN THAT ORDER
 void launch_tile_flags(int P, const uint32_t* tiles_touched, uint8_t* flags, hipStream_t stream);
 void launch_gather_depth_keys(int n, const uint32_t* vis, const float* depth, uint32_t* keys, uint32_t* vals, hipStream_t stream);
