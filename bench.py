@@ -51,6 +51,58 @@ def kernel_sources_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def library_hash() -> str:
+    """sha256 of the liblcgs_hip.so this process loads: the profile artefacts record it too, so counters are tied to the
+    binary they were measured on, not only to the sources."""
+    import hashlib
+
+    import luisacomputegaussiansplatting_amd as L
+
+    try:
+        return hashlib.sha256(open(L.library_path(), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return "unreadable"
+
+
+def read_sq_file(path):
+    """profiles/rNN_pmc_sq*.txt (profiles/pmc_summary.py): ({kernel: {counter: per-launch mean}}, header dict)"""
+    import ast
+
+    kernels, head = {}, {}
+    for ln in open(path).read().splitlines():
+        if ln.startswith("#"):
+            parts = ln[1:].split()
+            if len(parts) >= 2:
+                head[parts[0]] = parts[-1]
+        elif "{" in ln:
+            kernels[ln.split()[0]] = ast.literal_eval(ln[ln.index("{"):])
+    return kernels, head
+
+
+def valu_issue_from_counters(c):
+    """VALU issue fraction of a kernel from SQ counters of ONE rocprofv3 pass (clock-independent: both sides are cycle
+    counts of the same launches).  SQ_ACTIVE_INST_VALU counts QUAD-cycles in which a wave had a VALU instruction in issue,
+    summed over the waves (MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles); a SIMD issues
+    one VALU instruction at a time, so 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles) is the fraction of the SIMDs'
+    cycles spent issuing VALU work.  Kernel cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs)."""
+    need = ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES")
+    if not c or any(k not in c or not c[k] for k in need):
+        return None
+    cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+    out = {"frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles), 4),
+           "source_counters": {k: c[k] for k in sorted(c) if k.startswith(("SQ_ACTIVE", "SQ_WAIT", "SQ_BUSY", "SQ_WAVE_CYCLES",
+                                                                            "GRBM", "SQ_INSTS_VALU", "SQ_INSTS_SALU"))},
+           "kernel_cycles": round(cycles)}
+    wc = c["SQ_WAVE_CYCLES"]
+    for key, name in (("SQ_ACTIVE_INST_ANY", "wave_cycles_issuing_any"), ("SQ_WAIT_INST_ANY", "wave_cycles_waiting_to_issue"),
+                      ("SQ_WAIT_ANY", "wave_cycles_parked"), ("SQ_ACTIVE_INST_VALU", "wave_cycles_issuing_valu")):
+        if key in c:
+            out[name] = round(c[key] / wc, 4)
+    if c.get("SQ_INSTS_VALU"):
+        out["issue_cycles_per_valu_instruction"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"], 3)
+    return out
+
+
 def view_pose(k: int):
     """C5 views: the lego/bicycle pose of app/main.cpp:195-197 rotated about world-up (colmap: (0,-1,0)) by k*45 deg."""
     pos = np.array([-3.0, -0.5, 2.3])
@@ -198,6 +250,20 @@ def main():
         r.forward(cam, img, sync=False)
     barrier()
     elapsed = time.perf_counter() - t0
+    # SURVEY 8d's protocol beside the contract's: the median of >= 50 frames on hipEvent pairs -- one event behind every
+    # frame on the context's stream (torch's current stream here).  Its own loop, so that `value` above is not perturbed
+    # by the event packets; reported beside `value`, never instead of it.
+    n_ev = max(50, args.steps)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev + 1)]
+    marks[0].record()
+    for i in range(n_ev):
+        r.forward(cam, img, sync=False)
+        marks[i + 1].record()
+    barrier()
+    frame_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_ev))
+    per_frame = {"frames": n_ev, "median_ms": round(frame_ms[n_ev // 2], 4), "min_ms": round(frame_ms[0], 4),
+                 "p90_ms": round(frame_ms[(n_ev * 9) // 10], 4), "frames_per_s_at_median": round(1e3 / frame_ms[n_ev // 2], 1),
+                 "how": "hipEvent pairs between consecutive frames on the context's stream (SURVEY 8d)"}
     if dist is not None:
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -426,27 +492,35 @@ def main():
     # utilisation = wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/rNN_pmc_sq.txt) x the average issue
     # cost of the compositing loop's instruction mix on this part (tools/microbench/issue_rates.hip,
     # profiles/r01_issue_rates.txt) / (1024 SIMDs x launch duration x 2.4 GHz).
-    valu = None
+    valu, sq_kernels, sq_issue_kernels = None, {}, {}
+    lib_hash = library_hash()
     try:
-        import ast
         import glob
 
-        sq_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.txt")))[-1]
-        sq_lines = open(sq_path).read().splitlines()
-        sq_hash = next((ln.split()[-1] for ln in sq_lines if ln.startswith("# kernel_sources_sha256")), None)
-        if sq_hash != src_hash:
-            profile_errors.append(f"{os.path.relpath(sq_path, ROOT)} was measured on kernel sources {sq_hash}, the library is "
-                                  f"built from {src_hash}: re-run tools/profile_round.sh (valu_issue not reported)")
-            sq_lines = []
-        cyc = next((float(ln.split()[-1]) for ln in sq_lines if ln.startswith("# render_avg_issue_cycles")), 2.96)
-        for line in sq_lines:
-            if line.startswith(stage_kernel.get(dominant, "?") + " "):
-                insts = ast.literal_eval(line[line.index("{"):])["SQ_INSTS_VALU"]
-                if same_workload and dominant == "render":
-                    valu = {"wave_instructions_per_launch": insts, "avg_issue_cycles_per_instruction": cyc,
-                            "simd_cycles_available": round(1024 * dom_ms * 1e-3 * 2.4e9),
-                            "frac": round(insts * cyc / (1024 * dom_ms * 1e-3 * 2.4e9), 4),
-                            "source": os.path.relpath(sq_path, ROOT)}
+        def newest(pattern, what):
+            paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+            if not paths:
+                return {}, None
+            kernels, head = read_sq_file(paths[-1])
+            rel = os.path.relpath(paths[-1], ROOT)
+            if head.get("kernel_sources_sha256") != src_hash:
+                profile_errors.append(f"{rel} was measured on kernel sources {head.get('kernel_sources_sha256')}, the library "
+                                      f"is built from {src_hash}: re-run tools/profile_round.sh ({what} not reported)")
+                return {}, rel
+            if head.get("library_sha256") not in (None, lib_hash):
+                profile_errors.append(f"{rel} was measured on liblcgs_hip.so {head.get('library_sha256')}, this process loaded "
+                                      f"{lib_hash} (same sources, another build): figures kept, flagged")
+            return kernels, rel
+
+        sq_kernels, sq_src = newest("r*_pmc_sq.txt", "instruction counts")
+        sq_issue_kernels, sq_issue_src = newest("r*_pmc_sq_issue.txt", "valu_issue")
+        if same_workload and dominant == "render":
+            # MEASURED issue fraction (round 4): SQ_ACTIVE_INST_VALU against the kernel's cycles, one rocprofv3 pass -- the
+            # 2.8-cycle price-list estimate of rounds 1-3 is gone
+            valu = valu_issue_from_counters(sq_issue_kernels.get("k_render_forward_b"))
+            if valu is not None:
+                valu["source"] = sq_issue_src
+                valu["wave_instructions_per_launch"] = sq_kernels.get("k_render_forward_b", {}).get("SQ_INSTS_VALU")
     except Exception as e:  # noqa: BLE001
         profile_errors.append(f"SQ counters: {type(e).__name__}: {e}")
         valu = None
@@ -458,7 +532,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "hbm_frac": round(achieved / HBM_PEAK_GBS, 4), "attainable_peak": HBM_ATTAINABLE_GBS,
                 "algorithmic_bytes_per_launch": stage_bytes.get(dominant, 0), "avg_launch_ms": round(dom_ms, 4),
-                "valu_issue": valu, "kernel_sources_sha256": src_hash,
+                "valu_issue": valu, "kernel_sources_sha256": src_hash, "library_sha256": lib_hash,
                 "note": "the dominant kernel (per-tile compositing) is VALU-issue bound, not HBM bound: `frac` is its HBM "
                         "fraction (the contract's figure), valu_issue.frac the roof it is at; see DESIGN.md 4"}
     if profile_errors:
@@ -491,6 +565,14 @@ def main():
                                   "frac_x2": round((2 * raw + wr) / sec / 1e9 / HBM_PEAK_GBS, 4),
                                   "frac_x2_of_attainable": round((2 * raw + wr) / sec / 1e9 / HBM_ATTAINABLE_GBS, 4),
                                   "source": pmc_source}
+    # north_star: ">= 1000 frames/s at >= 60 % of the HBM roofline, evidenced by rocprof HBM GB/s".  ONE answer, by the bytes
+    # the counters saw (x2-corrected fetch + write) where they are available for these sources, else by this
+    # implementation's own algorithmic bytes -- never by the survey model, which prices the reference's algorithm.
+    by = frame_views.get("pmc", {}).get("frac_x2")
+    basis = "PMC bytes (FETCH_SIZE x2 + WRITE_SIZE)" if by is not None else "own algorithmic bytes (no PMC file for these sources)"
+    by = by if by is not None else frame_views["own_algorithmic"]["frac"]
+    frame_views["target_60pct_hbm"] = (f"{'met' if by >= 0.6 else 'not met'}: {by:.2f} of 8 TB/s by {basis}; the frame's time goes to "
+                                       "VALU-issue-bound compositing and latency-bound sort launches, not to bandwidth")
 
     out = {
         "metric": "forward fps @1080p, mip360_bicycle", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
@@ -505,6 +587,7 @@ def main():
                                                      "over 1 GiB run at 6.3-6.55 TB/s on this part "
                                                      "(profiles/r02_fetch_calibration.txt); 8 TB/s is the spec figure",
                            "unit": "GB/s", **frame_views},
+        "per_frame_events": per_frame,
         "stages_ms": {k: round(v, 4) for k, v in acc.items()},
     }
     if stage_path is not None:
@@ -608,6 +691,30 @@ def main():
                               "xgmi_bytes_sent_per_gpu": mg.allreduce_bus_bytes_per_gpu(P, world),
                               "collective": coll.name if coll is not None else None,
                               "backward_stages_ms": {k: round(v, 4) for k, v in bwd_stages.items()}}
+            # ---- the metric's second half has a dominant kernel of its own: k_render_backward.  Algorithmic bytes per launch
+            # (render half of the backward): 40 L (list entry + 36-byte record re-gathered) + 20 W H (final_T,
+            # n_contrib, dL/dimg) + 40 V (2-D gradient rows, read-modify-write); time = HIP events around the kernel on the
+            # context's stream (profiling mode: alone, not beside the zero-fill); traffic and the VALU issue fraction from the
+            # committed rocprofv3 passes of this workload, refused when measured on other sources.
+            rb_ms = bwd_stages.get("render_backward", 0.0)
+            rb_bytes = 40 * Lp + 20 * W * H + 40 * V
+            if rb_ms > 0:
+                rb_gbs = rb_bytes / (rb_ms * 1e-3) / 1e9
+                rb_traffic = None
+                kk = pmc_all["kernels"].get("k_render_backward") if (pmc_all and same_workload) else None
+                if kk:
+                    rb_traffic = {"fetch_bytes_raw": kk["fetch_bytes_raw"], "fetch_bytes_x2_corrected": kk["fetch_bytes_x2"],
+                                  "write_bytes": kk["write_bytes"], "source": pmc_source}
+                rb_valu = valu_issue_from_counters(sq_issue_kernels.get("k_render_backward")) if same_workload else None
+                if rb_valu is not None:
+                    rb_valu["wave_instructions_per_launch"] = sq_kernels.get("k_render_backward", {}).get("SQ_INSTS_VALU")
+                out["fwd_bwd"]["roofline"] = {
+                    "kernel": "k_render_backward", "bound": "valu", "achieved": round(rb_gbs, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(rb_gbs / HBM_PEAK_GBS, 4), "traffic": rb_traffic,
+                    "algorithmic_bytes_per_launch": rb_bytes, "avg_launch_ms": round(rb_ms, 4), "valu_issue": rb_valu,
+                    "kernel_sources_sha256": src_hash,
+                    "note": "the step's dominant kernel: VALU-issue-bound (nine 64-lane reductions per list entry and strip); "
+                            "`frac` is its HBM fraction, valu_issue.frac the measured share of SIMD cycles issuing VALU work"}
             if dist is not None:
                 out["fwd_bwd"]["note"] = ("gradient collective: lcgs_grads_allreduce (RCCL, chunked behind the backward's "
                                           "slices)" if args.collective == "rccl" else "gradient collective: torch.distributed")

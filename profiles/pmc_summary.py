@@ -3,9 +3,10 @@
 import csv, glob, os, re, sys, collections
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import kernel_sources_hash
+from bench import kernel_sources_hash, library_hash
 
 print("# kernel_sources_sha256", kernel_sources_hash())
+print("# library_sha256", library_hash())
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(set)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):

@@ -26,10 +26,12 @@ rm -rf $O/fetch $O/write
 echo "traffic done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- python3 $CMD > $O/sq.log 2>&1 || exit 1
 python3 profiles/pmc_summary.py $O/sq > $O/pmc_sq.txt
-# average issue cost of one VALU instruction of the compositing loop (the loop's instruction mix -- per blended
-# entry 24 single-rate ops (mov / add / sub / mul: 2.2 cycles) + 12 full-rate ones (fma, pk_fma, cmp, min, lshl_add: 4.2),
-# per culled entry 11 + 2 -- priced with tools/microbench/issue_rates.hip, profiles/r01_issue_rates.txt); bench.py reads it
-echo "# render_avg_issue_cycles 2.8" >> $O/pmc_sq.txt
 rm -rf $O/sq
 echo "sq done"
+# issue-cycle counters (round 4): how busy the SIMDs' VALU issue really is -- measured, not priced from an instruction mix.
+# Quad-cycle units (MI355X_MICROARCH.md); bench.py turns them into roofline.valu_issue / fwd_bwd.roofline.valu_issue.
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/sqi -- python3 $CMD > $O/sqi.log 2>&1 || { tail -5 $O/sqi.log; exit 1; }
+python3 profiles/pmc_summary.py $O/sqi > $O/pmc_sq_issue.txt
+rm -rf $O/sqi
+echo "sq issue done"
 ls -la $O
