@@ -80,26 +80,31 @@ def read_sq_file(path):
 
 
 def valu_issue_from_counters(c):
-    """VALU issue fraction of a kernel from SQ counters of ONE rocprofv3 pass (clock-independent: both sides are cycle
-    counts of the same launches).  SQ_ACTIVE_INST_VALU counts QUAD-cycles in which a wave had a VALU instruction in issue,
-    summed over the waves (MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles); a SIMD issues
-    one VALU instruction at a time, so 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles) is the fraction of the SIMDs'
-    cycles spent issuing VALU work.  Kernel cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs)."""
+    """How busy a kernel keeps the SIMDs' vector ALUs, from SQ counters of ONE rocprofv3 pass (clock-independent: both sides
+    are cycle counts of the same launches).  Kernel cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs).
+    SQ_ACTIVE_INST_VALU counts QUAD-cycles (MI355X_MICROARCH.md) in which a wave has a VALU instruction in issue; measured
+    here it equals SQ_INSTS_VALU to 0.1 % on the forward renderer -- one quad-cycle per wave64 instruction -- while the
+    32-lane ALU is occupied 2 cycles by a full-rate instruction (v_add / v_mul / v_mov: the guide's 157 TFLOP/s f32 peak),
+    so two waves' instructions overlap and `active` can reach 2 per SIMD cycle.
+      frac = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles) / 2
+    is therefore the MEASURED share of the VALU's peak instruction rate -- a lower bound of how busy the ALU is, because
+    instructions that are not full-rate (v_fma with three register operands, v_cmp, v_cndmask, v_min / v_max: 4.1-4.4
+    cycles in tools/microbench/issue_rates.hip; transcendental and permlane 8) hold it longer than the 2 cycles assumed.
+    The wave-cycle split (issuing / ready but not issued / parked at a wait or barrier) is measured too."""
     need = ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES")
     if not c or any(k not in c or not c[k] for k in need):
         return None
     cycles = c["GRBM_GUI_ACTIVE"] / 8.0
-    out = {"frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles), 4),
-           "source_counters": {k: c[k] for k in sorted(c) if k.startswith(("SQ_ACTIVE", "SQ_WAIT", "SQ_BUSY", "SQ_WAVE_CYCLES",
-                                                                            "GRBM", "SQ_INSTS_VALU", "SQ_INSTS_SALU"))},
-           "kernel_cycles": round(cycles)}
+    active = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles)
+    out = {"frac": round(active / 2.0, 4), "valu_active_per_simd_cycle": round(active, 4), "kernel_cycles": round(cycles),
+           "basis": "measured: SQ_ACTIVE_INST_VALU (quad-cycles) over GRBM_GUI_ACTIVE, at the 2-cycle full-rate floor"}
     wc = c["SQ_WAVE_CYCLES"]
-    for key, name in (("SQ_ACTIVE_INST_ANY", "wave_cycles_issuing_any"), ("SQ_WAIT_INST_ANY", "wave_cycles_waiting_to_issue"),
-                      ("SQ_WAIT_ANY", "wave_cycles_parked"), ("SQ_ACTIVE_INST_VALU", "wave_cycles_issuing_valu")):
+    split = {}
+    for key, name in (("SQ_ACTIVE_INST_ANY", "issuing"), ("SQ_WAIT_INST_ANY", "ready_but_not_issued"), ("SQ_WAIT_ANY", "parked")):
         if key in c:
-            out[name] = round(c[key] / wc, 4)
-    if c.get("SQ_INSTS_VALU"):
-        out["issue_cycles_per_valu_instruction"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"], 3)
+            split[name] = round(c[key] / wc, 4)
+    out["wave_cycles"] = split
+    out["counters_per_launch"] = {k: c[k] for k in sorted(c)}
     return out
 
 
@@ -492,7 +497,7 @@ def main():
     # utilisation = wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/rNN_pmc_sq.txt) x the average issue
     # cost of the compositing loop's instruction mix on this part (tools/microbench/issue_rates.hip,
     # profiles/r01_issue_rates.txt) / (1024 SIMDs x launch duration x 2.4 GHz).
-    valu, sq_kernels, sq_issue_kernels = None, {}, {}
+    valu, sq_kernels, sq_issue_kernels, sq_src, sq_issue_src = None, {}, {}, None, None
     lib_hash = library_hash()
     try:
         import glob
@@ -520,7 +525,14 @@ def main():
             valu = valu_issue_from_counters(sq_issue_kernels.get("k_render_forward_b"))
             if valu is not None:
                 valu["source"] = sq_issue_src
-                valu["wave_instructions_per_launch"] = sq_kernels.get("k_render_forward_b", {}).get("SQ_INSTS_VALU")
+                # beside the measurement, the ESTIMATE of rounds 1-3 (labelled as such): the loop's instruction mix priced
+                # with the per-kind issue costs of tools/microbench/issue_rates.hip (profiles/r01_issue_rates.txt), 2.8
+                # cycles per instruction on average -- where the kernel sits if those prices hold inside the loop
+                insts = valu["counters_per_launch"].get("SQ_INSTS_VALU")
+                if insts:
+                    valu["priced_estimate"] = {"avg_issue_cycles_per_instruction": 2.8,
+                                               "frac": round(insts * 2.8 / (1024.0 * valu["kernel_cycles"]), 4),
+                                               "basis": "estimate, not a counter: instruction mix x microbenchmark prices"}
     except Exception as e:  # noqa: BLE001
         profile_errors.append(f"SQ counters: {type(e).__name__}: {e}")
         valu = None
@@ -707,7 +719,7 @@ def main():
                                   "write_bytes": kk["write_bytes"], "source": pmc_source}
                 rb_valu = valu_issue_from_counters(sq_issue_kernels.get("k_render_backward")) if same_workload else None
                 if rb_valu is not None:
-                    rb_valu["wave_instructions_per_launch"] = sq_kernels.get("k_render_backward", {}).get("SQ_INSTS_VALU")
+                    rb_valu["source"] = sq_issue_src
                 out["fwd_bwd"]["roofline"] = {
                     "kernel": "k_render_backward", "bound": "valu", "achieved": round(rb_gbs, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(rb_gbs / HBM_PEAK_GBS, 4), "traffic": rb_traffic,
