@@ -191,8 +191,83 @@ class TorchCollective:
             self.last_stats["bytes_sent"] += gathered
             self.last_stats["bytes_received"] += gathered
 
+    def owner_step(self, engine, cams, dL_dimg, grads: dict, step: int):
+        """PROTOTYPE of the splat-ownership step, verified on gloo with the oracle as the engine
+        (tests/test_distributed.py).  Rank o owns the rows owner_range(P, N, o) -- parameters, moments, gradients -- and
+        nothing is replicated or all-gathered.  Per step, with rank v rendering view v:
+          1. every owner projects ITS rows for EVERY view of the step and sends view v's rank the 2-D inputs of the rows
+             that reach the screen (row index + projected mean, depth, 2-D covariance, colour, opacity: 44 bytes a row);
+          2. rank v renders its view from the rows it received (ascending row order = the file's order of equal depths),
+             differentiates it and returns, to every owner, the 2-D gradients of that owner's rows (40 bytes a row);
+          3. every owner maps the 2-D gradients of all N views to parameter gradients of its rows, sums them in view order
+             and applies Adam to its rows.
+        What crosses the wire per GPU and step is (N-1)/N x (44 + 40) bytes x on-screen rows instead of 2 (N-1)/N x 236 bytes
+        x ALL rows.  The engine supplies the three stages (owner_records / owner_render / owner_backward)."""
+        import torch
+
+        dist, N, me = self.dist, self.world_size, self.rank
+        P = int(grads["pos"].shape[0])
+        span = owner_range(P, N, me)
+        dev = grads["pos"].device
+        # ---- 1. my rows, every view: on-screen rows + their 2-D inputs
+        mine = [engine.owner_records(cams[v], span) for v in range(N)]  # [(rows int64 [n], rec f32 [n, R])]
+        counts = torch.tensor([int(m[0].numel()) for m in mine], dtype=torch.int64, device=dev)
+        table = [torch.empty_like(counts) for _ in range(N)]
+        dist.all_gather(table, counts)
+        table = [t.tolist() for t in table]  # table[o][v]: rows owner o has on view v's screen
+        R = engine.OWNER_RECORD_FLOATS
+        got_rows = {o: torch.empty(table[o][me], dtype=torch.int64, device=dev) for o in range(N)}
+        got_rec = {o: torch.empty(table[o][me], R, dtype=torch.float32, device=dev) for o in range(N)}
+        got_rows[me], got_rec[me] = mine[me]
+        ops, sent = [], 0
+        for o in range(N):
+            if o == me:
+                continue
+            if table[me][o] > 0:  # my rows on view o's screen -> rank o
+                ops += [dist.P2POp(dist.isend, mine[o][0], o), dist.P2POp(dist.isend, mine[o][1], o)]
+                sent += table[me][o] * (4 + 4 * R)
+            if table[o][me] > 0:
+                ops += [dist.P2POp(dist.irecv, got_rows[o], o), dist.P2POp(dist.irecv, got_rec[o], o)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        # ---- 2. my view from everybody's rows (owner order = ascending row order), its 2-D gradients back to the owners
+        rows_all = torch.cat([got_rows[o] for o in range(N)])
+        rec_all = torch.cat([got_rec[o] for o in range(N)])
+        g2d_all = engine.owner_render(cams[me], rows_all, rec_all, dL_dimg)  # f32 [n, G]
+        G = engine.OWNER_GRAD_FLOATS
+        back, at = {}, 0
+        for o in range(N):
+            back[o] = g2d_all[at:at + table[o][me]].contiguous()
+            at += table[o][me]
+        g_in = {o: torch.empty(table[me][o], G, dtype=torch.float32, device=dev) for o in range(N)}
+        g_in[me] = back[me]
+        ops = []
+        for o in range(N):
+            if o == me:
+                continue
+            if table[o][me] > 0:
+                ops.append(dist.P2POp(dist.isend, back[o], o))
+                sent += table[o][me] * 4 * G
+            if table[me][o] > 0:
+                ops.append(dist.P2POp(dist.irecv, g_in[o], o))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        # ---- 3. my rows: 2-D gradients of every view -> parameter gradients (summed in view order) -> Adam
+        for v in range(N):
+            engine.owner_backward(cams[v], span, mine[v][0], g_in[v], grads, accumulate=v > 0)
+        engine.adam(grads, step, rows=span)
+        self.last_stats = {"bytes_sent": sent, "on_screen_rows_received": int(rows_all.numel())}
+
     def close(self):
         pass
+
+
+def owner_range(num_gaussians: int, world_size: int, rank: int):
+    """rows a rank OWNS in the splat-ownership step: equal contiguous shards, the P mod N tail with the last rank"""
+    c = num_gaussians // world_size
+    return (c * rank, c if rank < world_size - 1 else num_gaussians - c * rank)
 
 
 # ------------------------------------------------------------------------------------------------ engine
@@ -233,6 +308,14 @@ class HipEngine:
         sub = lambda d: {k: d[k][first:first + count] for k in KEYS}
         self.r.adam_step(sub(grads), sub(self.raw), sub(self.m), sub(self.v), sub(self.activated), step, self.lr,
                          self.betas, self.eps)
+
+    OWNER_RECORD_FLOATS, OWNER_GRAD_FLOATS = 10, 9
+
+    def owner_records(self, cam, span):
+        raise NotImplementedError("mode 'owner' is a CPU-verified prototype (DESIGN.md 7b): the HIP engine's forward half "
+                                  "exists as the stage operators, its 2-D backward has no entry point yet")
+
+    owner_render = owner_backward = owner_records
 
     def adam_sharded(self, comm: "api.Comm", grads: dict, step: int):
         comm.adam_step_sharded(grads, self.raw, self.m, self.v, self.activated, step, self.lr, self.betas, self.eps)
@@ -283,7 +366,7 @@ class ViewParallelTrainer:
                  views_per_step: int = 1):
         """views_per_step: views each rank renders (and whose gradients it accumulates) per optimiser step -- one
         collective per step, so B views per GPU amortise the gradient exchange B times."""
-        if mode not in ("allreduce", "sharded", "sparse", "local"):
+        if mode not in ("allreduce", "sharded", "sparse", "owner", "local"):
             raise ValueError(mode)
         if views_per_step < 1:
             raise ValueError("views_per_step must be >= 1")
@@ -302,6 +385,14 @@ class ViewParallelTrainer:
 
     def step(self, dL_dimg, optimise: bool = True):
         """forward + backward of this rank's view, the collective, and (optimise=True) the Adam update."""
+        if self.mode == "owner":  # splat ownership (DESIGN 7b): the exchange is part of the frame itself
+            if not optimise or self.views_per_step != 1:
+                raise ValueError("mode 'owner': one view per rank and step, optimiser included")
+            n = len(self.cameras)
+            cams = [self.cameras[view_of_rank(self.steps_done, r, self.world_size, n)] for r in range(self.world_size)]
+            self.steps_done += 1
+            self.coll.owner_step(self.engine, cams, dL_dimg, self.grads, self.steps_done)
+            return
         for j in range(self.views_per_step):  # this rank's views of the step: the first overwrites, the others add
             cam = self.camera_for_step(self.steps_done * self.views_per_step + j)
             self.engine.forward_backward(cam, dL_dimg, self.grads, accumulate=j > 0)

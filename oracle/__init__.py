@@ -303,6 +303,20 @@ class Oracle:
                                          self.rp(g["rotq"]), self.rp(g["sh"]))
         return g
 
+    def render_backward(self, width, height, bg, ranges, point_list, means_pix, conic, opacity, color, final_T, n_contrib,
+                        dL_dimg):
+        """render half of the backward on 2-D arrays (orc_render_backward): -> dL/d{pixel mean, conic, opacity, colour}"""
+        n = self.arr(opacity).shape[0]
+        rng = np.ascontiguousarray(ranges, dtype=np.uint32)
+        pl = np.ascontiguousarray(point_list, dtype=np.uint32)
+        nc = np.ascontiguousarray(n_contrib, dtype=np.uint32)
+        mp, cn, op, col, fT, dL, bga = (self.arr(x) for x in (means_pix, conic, opacity, color, final_T, dL_dimg, bg))
+        gm, gc, go, gcol = (np.zeros(s, self.dtype) for s in ((n, 2), (n, 3), (n,), (n, 3)))
+        self.lib.orc_render_backward(C.c_int(width), C.c_int(height), self.rp(bga), _ptr(rng, C.c_uint32),
+                                     _ptr(pl, C.c_uint32), self.rp(mp), self.rp(cn), self.rp(op), self.rp(col), self.rp(fT),
+                                     _ptr(nc, C.c_uint32), self.rp(dL), self.rp(gm), self.rp(gc), self.rp(go), self.rp(gcol))
+        return gm, gc, go, gcol
+
     def render_backward_full(self, scene, cam, dL_dimg, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_deg=3):
         pos = self.arr(scene["pos"], (-1, 3))
         P = pos.shape[0]

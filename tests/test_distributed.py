@@ -112,6 +112,71 @@ class OracleEngine:
     def flush(self):
         pass
 
+    # the three stages of the splat-ownership step (multi_gpu.TorchCollective.owner_step) on the oracle's
+    # stage functions: the owner's per-splat half, the view rank's 2-D half, the owner's preprocess-backward
+    OWNER_RECORD_FLOATS, OWNER_GRAD_FLOATS = 10, 9
+
+    def _shard(self, span):
+        first, count = span
+        return {k: self.activated[k][first:first + count].numpy() for k in KEYS}
+
+    def _project_shard(self, cam, span):
+        _, ocam = cam
+        s = self._shard(span)
+        m, d, c2 = self.o.project(s["pos"], s["scale"], s["rotq"], ocam)
+        _, _, tiles, rad = self.o.allocate_tiles(W, H, d, m, c2)
+        return s, m, d, c2, tiles, rad
+
+    def owner_records(self, cam, span):
+        import torch
+
+        _, ocam = cam
+        s, m, d, c2, tiles, _ = self._project_shard(cam, span)
+        color = self.o.sh_process(np.array(ocam.position[:], np.float32), s["pos"], s["sh"])
+        on = np.flatnonzero(tiles > 0)
+        rec = np.concatenate([m[on], d[on, None], c2[on], color[on], s["opacity"][on, None]], axis=1).astype(np.float32)
+        return torch.from_numpy((span[0] + on).astype(np.int64)), torch.from_numpy(np.ascontiguousarray(rec))
+
+    def owner_render(self, cam, rows, rec, dL_dimg):
+        import torch
+
+        view, _ = cam
+        self.views_rendered.append(view)
+        n = int(rows.numel())
+        if n == 0:
+            return torch.zeros(0, self.OWNER_GRAD_FLOATS)
+        assert bool((rows[1:] > rows[:-1]).all())  # ascending rows: equal depths blend in file order
+        r = rec.numpy()
+        m, d, c2, color, op = r[:, 0:2], r[:, 2], r[:, 3:6], r[:, 6:9], r[:, 9]
+        bg = (0.0, 0.0, 0.0)
+        mp, conic, tiles, rad = self.o.allocate_tiles(W, H, d, m, c2)
+        k, v = self.o.copy_with_keys(W, H, mp, self.o.inclusive_sum(tiles), rad, d)
+        ks, vs = self.o.sort_pairs(k, v)
+        rng = self.o.get_ranges(ks, ((W + 15) // 16) * ((H + 15) // 16))
+        _, fT, nc, _ = self.o.render_forward(W, H, bg, rng, vs, mp, conic, op, color)
+        gm, gc, go, gcol = self.o.render_backward(W, H, bg, rng, vs, mp, conic, op, color, fT, nc, self.dL_of_view(view))
+        return torch.from_numpy(np.concatenate([gm, gc, go[:, None], gcol], axis=1).astype(np.float32))
+
+    def owner_backward(self, cam, span, rows, g2d, grads, accumulate=False):
+        import torch
+
+        _, ocam = cam
+        first, count = span
+        s, _, _, _, _, rad = self._project_shard(cam, span)
+        at = (rows.numpy() - first).astype(np.int64)
+        gm, gc, gcol, go = np.zeros((count, 2), np.float32), np.zeros((count, 3), np.float32), np.zeros((count, 3), np.float32), \
+            np.zeros(count, np.float32)
+        g = g2d.numpy()
+        gm[at], gc[at], go[at], gcol[at] = g[:, 0:2], g[:, 2:5], g[:, 5], g[:, 6:9]
+        out = self.o.preprocess_backward(s, ocam, rad, gm, gc, gcol)
+        out["opacity"] = go
+        for k in KEYS:
+            t = torch.from_numpy(out[k].reshape(grads[k][first:first + count].shape).astype(np.float32))
+            if accumulate:
+                grads[k][first:first + count] += t
+            else:
+                grads[k][first:first + count] = t
+
     def adam(self, grads, step, rows=None, b1=0.9, b2=0.999, eps=1e-15):
         """lcgs_adam_step (csrc/kernels/train.hip) restated: activated-space gradients -> raw-space -> Adam -> activate."""
         first, count = rows if rows is not None else (0, P)
@@ -165,7 +230,7 @@ def _worker(rank, world, port, out_dir):
     o.set_threads(2)
     cams = [(v, o.lookat(*p, width=W, height=H)) for v, p in enumerate(_poses())]
     stats = {}
-    for mode in ("allreduce", "sharded", "sparse", "allreduce_2views", "sparse_2views"):
+    for mode in ("allreduce", "sharded", "sparse", "owner", "allreduce_2views", "sparse_2views"):
         engine = OracleEngine(o, _raw_scene(), _dL)  # the scene is replicated on every rank
         grads = {k: torch.zeros_like(engine.raw[k]) for k in KEYS}
         if mode.endswith("_2views"):  # two views per rank and optimiser step: gradients accumulate, ONE collective
@@ -174,7 +239,7 @@ def _worker(rank, world, port, out_dir):
             trainer.step(None)
             if mode.startswith("sparse"):
                 stats[mode] = coll.last_stats
-        elif mode == "sparse":
+        elif mode in ("sparse", "owner"):
             coll = mg.TorchCollective(dist, rank, world)
             trainer = mg.ViewParallelTrainer(engine, coll, cams, grads, mode=mode)
             for _ in range(STEPS):
@@ -250,6 +315,25 @@ def test_view_parallel_protocol_on_two_gloo_ranks(tmp_path, oracle):
         # every rank holds the same activated scene afterwards
         for k in KEYS:
             assert np.array_equal(res[(m, 0)][f"act_{k}"], res[(m, 1)][f"act_{k}"]), (m, k)
+    # splat ownership (the prototype of DESIGN.md 7b): nothing replicated -- every rank ends with ITS rows of the scene the
+    # single process gets, the other rows untouched; what it sent is 2-D records and 2-D gradients of on-screen rows only
+    import luisacomputegaussiansplatting_amd.multi_gpu as mg
+    import json as _json
+
+    for r in range(world):
+        got = np.load(tmp_path / f"owner_{r}.npz")
+        assert got["views"].tolist() == [r, 2 + r]
+        first, count = mg.owner_range(P, world, r)
+        own = np.r_[first:first + count]
+        other = np.setdiff1d(np.arange(P), own)
+        for k in KEYS:
+            for kind, refd in (("act", ref.activated), ("raw", ref.raw)):
+                a, b = got[f"{kind}_{k}"][own], refd[k].numpy()[own]
+                assert np.allclose(a, b, rtol=2e-4, atol=2e-6 * np.abs(refd[k].numpy()).max()), ("owner", r, kind, k)
+        assert np.array_equal(got["raw_scale"][other], _raw_scene()["scale"][other].astype(np.float32))
+        st = _json.load(open(tmp_path / f"stats_{r}.json"))["owner"]
+        assert 0 < st["bytes_sent"] < (world - 1) * (P // world) * 59 * 4  # below even ONE half of the dense exchange
+    assert sum(mg.owner_range(P, world, r)[1] for r in range(world)) == P
     # two views per rank and step: one step over all four views = one dense Adam step on the sum of their gradients
     ref2 = OracleEngine(oracle, _raw_scene(), _dL)
     total = {k: torch.zeros_like(ref2.raw[k]) for k in KEYS}
@@ -309,7 +393,7 @@ def _worker_c5(rank, world, port, out_dir):
     o = Oracle("f32")
     o.set_threads(1)
     cams = [(v, o.lookat(*view_pose(v), width=W, height=H)) for v in range(8)]
-    for mode in ("allreduce", "sharded", "sparse"):
+    for mode in ("allreduce", "sharded", "sparse", "owner"):
         engine = OracleEngine(o, _raw_scene(), _dL)
         grads = {k: torch.zeros_like(engine.raw[k]) for k in KEYS}
         trainer = mg.ViewParallelTrainer(engine, mg.TorchCollective(dist, rank, world), cams, grads, mode=mode)
@@ -349,3 +433,14 @@ def test_c5_shape_eight_ranks_eight_views_on_gloo(tmp_path, oracle):
                 b = ref.activated[k].numpy()
                 assert np.allclose(outs[r][f"act_{k}"], b, rtol=3e-4, atol=3e-6 * np.abs(b).max()), (mode, r, k)
                 assert np.array_equal(outs[r][f"act_{k}"], outs[0][f"act_{k}"]), (mode, r, k)  # replicas stay identical
+    # splat ownership at the node's width: every rank holds ITS 37 (the last: 42) rows of that scene
+    import luisacomputegaussiansplatting_amd.multi_gpu as mg
+
+    outs = [np.load(tmp_path / f"c5_owner_{r}.npz") for r in range(world)]
+    assert [o_["views"].tolist() for o_ in outs] == [[r] for r in range(world)]
+    for r in range(world):
+        first, count = mg.owner_range(P, world, r)
+        for k in KEYS:
+            b = ref.activated[k].numpy()
+            assert np.allclose(outs[r][f"act_{k}"][first:first + count], b[first:first + count], rtol=3e-4,
+                               atol=3e-6 * np.abs(b).max()), ("owner", r, k)
