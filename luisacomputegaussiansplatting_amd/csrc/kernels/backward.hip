@@ -383,89 +383,93 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
 // ---------------------------------------------------------------------------------------------------------------
 // 2-D gradients -> parameter gradients, one lane per surviving splat.
 // ---------------------------------------------------------------------------------------------------------------
-// dL/d{pixel mean (gmx, gmy), conic (gA, gB, gC)} -> dL/d{pos (added to gp), scale (gs), rotq (gq: r,x,y,z)} through the
-// EWA projection.  The forward quantities are recomputed (the order of gs_math.hpp is irrelevant for the derivative).
-__device__ __forceinline__ void geom_backward(const CamParams& cp, float scale_modifier, float px, float py, float pz,
-                                              float sc0, float sc1, float sc2, float4 q, float gmx, float gmy, float gA,
-                                              float gB, float gC, float gp[3], float gs[3], float4& gq)
+// dL/d{pixel mean (gmx, gmy), conic (gA, gB, gC)} -> dL/d{pos (gp), scale (gs), rotq (gq: r,x,y,z)} through the EWA
+// projection, in precision R.  The forward quantities are recomputed (the order of gs_math.hpp is irrelevant for the
+// derivative).  cov_trace = a + c of the filtered 2-D covariance (>= its larger eigenvalue: the splat's footprint).
+template <typename FP>
+__device__ __forceinline__ void geom_backward_t(const CamParams& cp, FP scale_modifier, FP px, FP py, FP pz, FP sc0, FP sc1, FP sc2,
+                                                FP qw_, FP qx_, FP qy_, FP qz_, FP gmx, FP gmy, FP gA, FP gB, FP gC, FP gp[3], FP gs[3],
+                                                FP gq[4], FP& cov_trace)
 {
     // ---- geometry: recompute the forward quantities (gs_math.hpp order is irrelevant for the derivative)
-    float v[3];
-    view_transform(cp, px, py, pz, v);
-    const float limx = 1.3f * cp.tanfovx, limy = 1.3f * cp.tanfovy;
-    const float rx = v[0] / v[2], ry = v[1] / v[2];
+    FP v[3];
+    v[0] = FP((cp.right[0])) * px + FP((cp.right[1])) * py + FP((cp.right[2])) * pz + FP(cp.tx);
+    v[1] = FP((cp.up[0])) * px + FP((cp.up[1])) * py + FP((cp.up[2])) * pz + FP(cp.ty);
+    v[2] = FP((cp.front[0])) * px + FP((cp.front[1])) * py + FP((cp.front[2])) * pz + FP(cp.tz);
+    const FP limx = FP(1.3) * FP(cp.tanfovx), limy = FP(1.3) * FP(cp.tanfovy);
+    const FP rx = v[0] / v[2], ry = v[1] / v[2];
     const int   clx = (rx < -limx) ? -1 : (rx > limx ? 1 : 0);
     const int   cly = (ry < -limy) ? -1 : (ry > limy ? 1 : 0);
-    const float tx = (clx ? (float)clx * limx : rx) * v[2];
-    const float ty = (cly ? (float)cly * limy : ry) * v[2];
-    const float tz = v[2];
-    const float sc[3] = { scale_modifier * sc0, scale_modifier * sc1, scale_modifier * sc2 };
-    const float  x = q.y, y = q.z, z = q.w, w = q.x;
-    float R[3][3];
-    R[0][0] = 1.0f - 2.0f * y * y - 2.0f * z * z; R[0][1] = 2.0f * x * y - 2.0f * z * w; R[0][2] = 2.0f * x * z + 2.0f * y * w;
-    R[1][0] = 2.0f * x * y + 2.0f * z * w; R[1][1] = 1.0f - 2.0f * x * x - 2.0f * z * z; R[1][2] = 2.0f * y * z - 2.0f * x * w;
-    R[2][0] = 2.0f * x * z - 2.0f * y * w; R[2][1] = 2.0f * y * z + 2.0f * x * w; R[2][2] = 1.0f - 2.0f * x * x - 2.0f * y * y;
-    float M[3][3], Sig[3][3];
+    const FP tx = (clx ? FP(clx) * limx : rx) * v[2];
+    const FP ty = (cly ? FP(cly) * limy : ry) * v[2];
+    const FP tz = v[2];
+    const FP sc[3] = { scale_modifier * sc0, scale_modifier * sc1, scale_modifier * sc2 };
+    const FP x = qx_, y = qy_, z = qz_, w = qw_;
+    FP Rm[3][3];
+    Rm[0][0] = FP(1.0) - FP(2.0) * y * y - FP(2.0) * z * z; Rm[0][1] = FP(2.0) * x * y - FP(2.0) * z * w; Rm[0][2] = FP(2.0) * x * z + FP(2.0) * y * w;
+    Rm[1][0] = FP(2.0) * x * y + FP(2.0) * z * w; Rm[1][1] = FP(1.0) - FP(2.0) * x * x - FP(2.0) * z * z; Rm[1][2] = FP(2.0) * y * z - FP(2.0) * x * w;
+    Rm[2][0] = FP(2.0) * x * z - FP(2.0) * y * w; Rm[2][1] = FP(2.0) * y * z + FP(2.0) * x * w; Rm[2][2] = FP(1.0) - FP(2.0) * x * x - FP(2.0) * y * y;
+    FP M[3][3], Sig[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) M[r][k] = R[r][k] * sc[k];
+        for (int k = 0; k < 3; ++k) M[r][k] = Rm[r][k] * sc[k];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int k = 0; k < 3; ++k) Sig[r][k] = M[r][0] * M[k][0] + M[r][1] * M[k][1] + M[r][2] * M[k][2];
-    const float j00 = cp.focalx / tz, j11 = cp.focaly / tz, j02 = -cp.focalx * tx / (tz * tz),
-                j12 = -cp.focaly * ty / (tz * tz);
-    float T0[3], T1[3], ST0[3], ST1[3];
+    const FP j00 = FP(cp.focalx) / tz, j11 = FP(cp.focaly) / tz, j02 = -FP(cp.focalx) * tx / (tz * tz),
+                j12 = -FP(cp.focaly) * ty / (tz * tz);
+    FP T0[3], T1[3], ST0[3], ST1[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        T0[r] = cp.right[r] * j00 + cp.front[r] * j02;
-        T1[r] = cp.up[r] * j11 + cp.front[r] * j12;
+        T0[r] = FP(cp.right[r]) * j00 + FP(cp.front[r]) * j02;
+        T1[r] = FP(cp.up[r]) * j11 + FP(cp.front[r]) * j12;
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         ST0[r] = Sig[r][0] * T0[0] + Sig[r][1] * T0[1] + Sig[r][2] * T0[2];
         ST1[r] = Sig[r][0] * T1[0] + Sig[r][1] * T1[1] + Sig[r][2] * T1[2];
     }
-    const float a = T0[0] * ST0[0] + T0[1] * ST0[1] + T0[2] * ST0[2] + 0.3f;
-    const float b = T1[0] * ST0[0] + T1[1] * ST0[1] + T1[2] * ST0[2];
-    const float c = T1[0] * ST1[0] + T1[1] * ST1[1] + T1[2] * ST1[2] + 0.3f;
-    const float D = a * c - b * b + 1e-6f;
-    const float iD2 = 1.0f / (D * D);
-    const float g00 = (-c * c * gA + b * c * gB + (D - a * c) * gC) * iD2;
-    const float g11 = ((D - a * c) * gA + a * b * gB - a * a * gC) * iD2;
-    const float g01 = (2.0f * b * c * gA - (D + 2.0f * b * b) * gB + 2.0f * a * b * gC) * iD2;
-    float Gm[3][3], dT0[3], dT1[3];
+    const FP a = T0[0] * ST0[0] + T0[1] * ST0[1] + T0[2] * ST0[2] + FP(0.3);
+    const FP b = T1[0] * ST0[0] + T1[1] * ST0[1] + T1[2] * ST0[2];
+    const FP c = T1[0] * ST1[0] + T1[1] * ST1[1] + T1[2] * ST1[2] + FP(0.3);
+    const FP D = a * c - b * b + FP(1e-6);
+    const FP iD2 = FP(1.0) / (D * D);
+    const FP g00 = (-c * c * gA + b * c * gB + (D - a * c) * gC) * iD2;
+    const FP g11 = ((D - a * c) * gA + a * b * gB - a * a * gC) * iD2;
+    const FP g01 = (FP(2.0) * b * c * gA - (D + FP(2.0) * b * b) * gB + FP(2.0) * a * b * gC) * iD2;
+    FP Gm[3][3], dT0[3], dT1[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int k = 0; k < 3; ++k) Gm[r][k] = g00 * T0[r] * T0[k] + g01 * T1[r] * T0[k] + g11 * T1[r] * T1[k];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        dT0[r] = 2.0f * g00 * ST0[r] + g01 * ST1[r];
-        dT1[r] = 2.0f * g11 * ST1[r] + g01 * ST0[r];
+        dT0[r] = FP(2.0) * g00 * ST0[r] + g01 * ST1[r];
+        dT1[r] = FP(2.0) * g11 * ST1[r] + g01 * ST0[r];
     }
-    const float dj00 = cp.right[0] * dT0[0] + cp.right[1] * dT0[1] + cp.right[2] * dT0[2];
-    const float dj02 = cp.front[0] * dT0[0] + cp.front[1] * dT0[1] + cp.front[2] * dT0[2];
-    const float dj11 = cp.up[0] * dT1[0] + cp.up[1] * dT1[1] + cp.up[2] * dT1[2];
-    const float dj12 = cp.front[0] * dT1[0] + cp.front[1] * dT1[1] + cp.front[2] * dT1[2];
-    const float itz2 = 1.0f / (tz * tz), itz3 = itz2 / tz;
-    const float dtx = dj02 * (-cp.focalx * itz2);
-    const float dty = dj12 * (-cp.focaly * itz2);
-    const float dtz = dj00 * (-cp.focalx * itz2) + dj11 * (-cp.focaly * itz2) + dj02 * (2.0f * cp.focalx * tx * itz3) +
-                      dj12 * (2.0f * cp.focaly * ty * itz3);
-    float dv[3];
-    dv[0] = clx ? 0.0f : dtx;
-    dv[1] = cly ? 0.0f : dty;
-    dv[2] = dtz + (clx ? dtx * (float)clx * limx : 0.0f) + (cly ? dty * (float)cly * limy : 0.0f);
-    const float pw = 1.0f / (v[2] + 1e-6f);
-    dv[0] += gmx * cp.focalx * pw;
-    dv[1] += gmy * cp.focaly * pw;
-    dv[2] += -(gmx * cp.focalx * v[0] + gmy * cp.focaly * v[1]) * pw * pw;
+    const FP dj00 = FP(cp.right[0]) * dT0[0] + FP(cp.right[1]) * dT0[1] + FP(cp.right[2]) * dT0[2];
+    const FP dj02 = FP(cp.front[0]) * dT0[0] + FP(cp.front[1]) * dT0[1] + FP(cp.front[2]) * dT0[2];
+    const FP dj11 = FP(cp.up[0]) * dT1[0] + FP(cp.up[1]) * dT1[1] + FP(cp.up[2]) * dT1[2];
+    const FP dj12 = FP(cp.front[0]) * dT1[0] + FP(cp.front[1]) * dT1[1] + FP(cp.front[2]) * dT1[2];
+    const FP itz2 = FP(1.0) / (tz * tz), itz3 = itz2 / tz;
+    const FP dtx = dj02 * (-FP(cp.focalx) * itz2);
+    const FP dty = dj12 * (-FP(cp.focaly) * itz2);
+    const FP dtz = dj00 * (-FP(cp.focalx) * itz2) + dj11 * (-FP(cp.focaly) * itz2) + dj02 * (FP(2.0) * FP(cp.focalx) * tx * itz3) +
+                      dj12 * (FP(2.0) * FP(cp.focaly) * ty * itz3);
+    FP dv[3];
+    dv[0] = clx ? FP(0.0) : dtx;
+    dv[1] = cly ? FP(0.0) : dty;
+    dv[2] = dtz + (clx ? dtx * FP(clx) * limx : FP(0.0)) + (cly ? dty * FP(cly) * limy : FP(0.0));
+    const FP pw = FP(1.0) / (v[2] + FP(1e-6));
+    dv[0] += gmx * FP(cp.focalx) * pw;
+    dv[1] += gmy * FP(cp.focaly) * pw;
+    dv[2] += -(gmx * FP(cp.focalx) * v[0] + gmy * FP(cp.focaly) * v[1]) * pw * pw;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) gp[i] += cp.right[i] * dv[0] + cp.up[i] * dv[1] + cp.front[i] * dv[2];
+    for (int i = 0; i < 3; ++i) gp[i] = FP(cp.right[i]) * dv[0] + FP(cp.up[i]) * dv[1] + FP(cp.front[i]) * dv[2];
 
-    float dM[3][3], dR[3][3];
+    FP dM[3][3], dRm[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -473,16 +477,51 @@ __device__ __forceinline__ void geom_backward(const CamParams& cp, float scale_m
             dM[r][k] = (Gm[r][0] + Gm[0][r]) * M[0][k] + (Gm[r][1] + Gm[1][r]) * M[1][k] + (Gm[r][2] + Gm[2][r]) * M[2][k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        gs[k] = scale_modifier * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+        gs[k] = scale_modifier * (dM[0][k] * Rm[0][k] + dM[1][k] * Rm[1][k] + dM[2][k] * Rm[2][k]);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) dR[r][k] = dM[r][k] * sc[k];
+        for (int r = 0; r < 3; ++r) dRm[r][k] = dM[r][k] * sc[k];
     }
-    const float gx_ = 2.0f * (y * (dR[0][1] + dR[1][0]) + z * (dR[0][2] + dR[2][0]) + w * (dR[2][1] - dR[1][2])) - 4.0f * x * (dR[1][1] + dR[2][2]);
-    const float gy_ = 2.0f * (x * (dR[0][1] + dR[1][0]) + z * (dR[1][2] + dR[2][1]) + w * (dR[0][2] - dR[2][0])) - 4.0f * y * (dR[0][0] + dR[2][2]);
-    const float gz_ = 2.0f * (x * (dR[0][2] + dR[2][0]) + y * (dR[1][2] + dR[2][1]) + w * (dR[1][0] - dR[0][1])) - 4.0f * z * (dR[0][0] + dR[1][1]);
-    const float gw_ = 2.0f * (z * (dR[1][0] - dR[0][1]) + y * (dR[0][2] - dR[2][0]) + x * (dR[2][1] - dR[1][2]));
+    const FP gx_ = FP(2.0) * (y * (dRm[0][1] + dRm[1][0]) + z * (dRm[0][2] + dRm[2][0]) + w * (dRm[2][1] - dRm[1][2])) - FP(4.0) * x * (dRm[1][1] + dRm[2][2]);
+    const FP gy_ = FP(2.0) * (x * (dRm[0][1] + dRm[1][0]) + z * (dRm[1][2] + dRm[2][1]) + w * (dRm[0][2] - dRm[2][0])) - FP(4.0) * y * (dRm[0][0] + dRm[2][2]);
+    const FP gz_ = FP(2.0) * (x * (dRm[0][2] + dRm[2][0]) + y * (dRm[1][2] + dRm[2][1]) + w * (dRm[1][0] - dRm[0][1])) - FP(4.0) * z * (dRm[0][0] + dRm[1][1]);
+    const FP gw_ = FP(2.0) * (z * (dRm[1][0] - dRm[0][1]) + y * (dRm[0][2] - dRm[2][0]) + x * (dRm[2][1] - dRm[1][2]));
 
-    gq = make_float4(gw_, gx_, gy_, gz_);
+    gq[0] = gw_; gq[1] = gx_; gq[2] = gy_; gq[3] = gz_; // (r, x, y, z)
+    cov_trace = a + c;
+}
+
+// A footprint beyond this (trace of the 2-D covariance, px^2: radius ~ 3 sqrt(lambda_max) > 64 px) takes the algebra in f64.
+constexpr float kGiantCovTrace = 455.0f;
+// (Both precisions are inlined: the kernels' register count doubles and their occupancy halves -- preprocess-backward
+//  0.181 -> 0.185 ms on the bicycle stand-in.  Holding them to the f32 occupancy with __launch_bounds__ spills the f64 branch
+//  to scratch and costs 0.05 ms: measured, gpurun_out/r4_ab_f64.log.)
+
+// The f32 algebra, and -- for screen-filling splats only -- the same algebra again in f64.  Their 2-D covariance is ~1e5 and
+// their conic ~1e-6: conic -> covariance -> Sigma -> scale / quaternion multiplies sums that cancel to a 1e-3..1e-5 of their
+// terms, and ANY f32 evaluation loses them (the f32 CPU restatement is off by up to 1.7e-1 on such rows; the 2-D gradients
+// feeding this step are good to ~1e-4: profiles/r04_gradient_error_survey.txt).  0.4 % of the on-screen splats of the
+// bicycle stand-in qualify; the kernels calling this are HBM-bound, the divergent f64 pass hides under their stores.
+__device__ __forceinline__ void geom_backward(const CamParams& cp, float scale_modifier, float px, float py, float pz,
+                                              float sc0, float sc1, float sc2, float4 q, float gmx, float gmy, float gA,
+                                              float gB, float gC, float gp[3], float gs[3], float4& gq)
+{
+    float dp[3], q4[4], tr;
+    geom_backward_t<float>(cp, scale_modifier, px, py, pz, sc0, sc1, sc2, q.x, q.y, q.z, q.w, gmx, gmy, gA, gB, gC, dp, gs, q4, tr);
+    if (tr > kGiantCovTrace) {
+        double dpd[3], gsd[3], q4d[4], trd;
+        geom_backward_t<double>(cp, scale_modifier, px, py, pz, sc0, sc1, sc2, q.x, q.y, q.z, q.w, gmx, gmy, gA, gB, gC, dpd, gsd,
+                                q4d, trd);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            dp[i] = (float)dpd[i];
+            gs[i] = (float)gsd[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q4[i] = (float)q4d[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gp[i] += dp[i];
+    gq = make_float4(q4[0], q4[1], q4[2], q4[3]);
 }
 
 // One lane per surviving splat (dense ids).  The splat's 48 SH coefficients arrive through the wave's LDS slab
