@@ -866,6 +866,26 @@ def main():
                                         "all-gather of the activated rows as in the sharded step"})
                         else:
                             out["train_step"][mode]["xgmi_bytes_sent_per_gpu"] = mg.allreduce_bus_bytes_per_gpu(P, world)
+                if dist is not None:
+                    # ---- splat ownership: nothing replicated, nothing all-gathered -- every rank owns P / N rows,
+                    # projects them for every view of the step and exchanges 48-byte records / 48-byte 2-D gradients of
+                    # on-screen rows with the views' renderers.  Transport: torch.distributed point-to-point on the process
+                    # group (= RCCL send / recv on a node); a leg of its own, so a failure costs nothing else.
+                    try:
+                        cams_o = [L.get_lookat_cam(*view_pose(k), width=W, height=H) for k in range(8)]
+                        tcoll = mg.TorchCollective(dist, rank, world)
+                        tr_o = mg.ViewParallelTrainer(eng2, tcoll, cams_o, views, mode="owner")
+                        el_o = timed(lambda i: tr_o.step(dL, optimise=True), args.steps, 2)
+                        st_o = getattr(tcoll, "last_stats", None) or {}
+                        out["train_step"]["owner"] = {
+                            "value": round(world * P * args.steps / el_o / 1e6, 1), "unit": "Msplats/s",
+                            "ms_per_step": round(el_o * 1e3 / args.steps, 4),
+                            "xgmi_bytes_sent_per_gpu": st_o.get("bytes_sent"),
+                            "on_screen_rows_rendered": st_o.get("on_screen_rows_received"),
+                            "note": "splat ownership: 2-D records / 2-D gradients of on-screen rows travel, Adam on the own rows only, "
+                                    "no all-gather; N host synchronisations per step (row counts) in this first form"}
+                    except Exception as e:  # noqa: BLE001
+                        out.setdefault("leg_errors", {})["train_step.owner"] = f"{type(e).__name__}: {e}"[:400]
                 eng2.close()
                 r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
                 del act, raw, eng2

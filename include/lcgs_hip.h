@@ -464,6 +464,33 @@ LCGS_API lcgs_status lcgs_sparse_accumulate(lcgs_context* ctx, int sh_degree, co
                                             int64_t count, int64_t row_first, int64_t row_count);
 
 /* ------------------------------------------------------------------------------------------
+ * Splat ownership: the frame in two halves.  No reference counterpart (one device, app/main.cpp:162-163).
+ * A GPU that OWNS the rows [row_first, row_first + row_count) of the scene runs the per-splat half of a view's frame on them
+ * (lcgs_owner_project: cull, compaction, SH colour) and gets the packed records of the rows that reach that view's screen --
+ * LCGS_OWNER_RECORD_FLOATS 4-byte words a row: pixel mean (2), conic (3), opacity, rgb (3), depth, pruned tile rect (2 x u32) --
+ * with their GLOBAL row indices, ascending.  The GPU that RENDERS the view concatenates what the owners sent in owner order
+ * (= ascending rows) and runs the rest of the frame on it (lcgs_owner_render: depth sort with the reference's order of equal
+ * depths, duplication, tile partition, compositing): the same image, bit for bit, as lcgs_render_forward of the whole scene.
+ * lcgs_owner_render_backward returns the 2-D gradients of those rows (LCGS_OWNER_GRAD_FLOATS words a row: mean (2), conic
+ * (3), opacity, rgb (3), 3 unused) and lcgs_owner_backward -- on the owner, per view slot -- turns its rows' share into
+ * parameter gradients at rows row_first ... of the full-size arrays (the first view of a step zero-fills the range, the
+ * others add).  Transport between the two halves is the caller's (multi_gpu.TorchCollective.owner_step: send / recv over
+ * a process group).  slot: the view's index inside the step, < LCGS_MAX_OWNER_VIEWS; its buffers live until re-used.
+ * ------------------------------------------------------------------------------------------ */
+#define LCGS_MAX_OWNER_VIEWS 16
+#define LCGS_OWNER_RECORD_FLOATS 12
+#define LCGS_OWNER_GRAD_FLOATS 12
+LCGS_API lcgs_status lcgs_owner_project(lcgs_context* ctx, int slot, const lcgs_camera* camera, float scale_modifier,
+                                        int row_first, int row_count, int keep_state, uint32_t* d_rows /* [row_count] */,
+                                        float* d_records /* [row_count x 12], 16-byte aligned */,
+                                        int* num_rows); /* rows written; synchronises */
+LCGS_API lcgs_status lcgs_owner_render(lcgs_context* ctx, const lcgs_camera* camera, const float bg_color[3], int num_rows,
+                                       const uint32_t* d_rows, const float* d_records, float* d_img, int keep_state);
+LCGS_API lcgs_status lcgs_owner_render_backward(lcgs_context* ctx, const float* d_dL_dimg, float* d_grads2d);
+LCGS_API lcgs_status lcgs_owner_backward(lcgs_context* ctx, int slot, const float* d_grads2d, const lcgs_grads* grads,
+                                         int accumulate);
+
+/* ------------------------------------------------------------------------------------------
  * Scene ingest / image egress (host side of `render(ply, camera) -> image`)
  * ------------------------------------------------------------------------------------------ */
 

@@ -147,7 +147,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_set_lod", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_set_transport", "lcgs_comm_shard_rows",
     "lcgs_grads_allreduce", "lcgs_adam_step_sharded", "lcgs_comm_track_touched_rows", "lcgs_comm_get_stats",
     "lcgs_adam_step_sparse", "lcgs_sparse_touched_rows", "lcgs_sparse_message_words", "lcgs_sparse_pack",
-    "lcgs_sparse_accumulate",
+    "lcgs_sparse_accumulate", "lcgs_owner_project", "lcgs_owner_render", "lcgs_owner_render_backward", "lcgs_owner_backward",
 ]
 
 
@@ -581,6 +581,42 @@ class Renderer:
         _check(load_library().lcgs_fit_views(self.ctx._h, C.c_int(n), cam_arr, _f3(bg), C.c_float(scale_modifier), ptrs,
                                              C.byref(g), _ptr(losses)))
         self._generation += 1
+
+    # ---- splat ownership: the frame in two halves
+    OWNER_RECORD_FLOATS, OWNER_GRAD_FLOATS = 12, 12
+
+    def owner_project(self, slot: int, cam: "Camera", row_first: int, row_count: int, keep_state: bool = True,
+                      scale_modifier: float = 1.0):
+        """lcgs_owner_project: the per-splat half of `cam`'s frame on the rows [row_first, row_first + row_count) of the bound
+        scene -> (global row indices int32 [n], packed records float32 [n, 12]) of the rows that reach the screen."""
+        import torch
+
+        dev = torch.device("cuda", self.ctx.device_id)
+        out_rows = torch.empty(max(row_count, 1), dtype=torch.int32, device=dev)
+        out_recs = torch.empty(max(row_count, 1), self.OWNER_RECORD_FLOATS, dtype=torch.float32, device=dev)
+        n = C.c_int(0)
+        _check(load_library().lcgs_owner_project(self.ctx._h, C.c_int(slot), C.byref(cam), C.c_float(scale_modifier),
+                                                 C.c_int(row_first), C.c_int(row_count), C.c_int(1 if keep_state else 0),
+                                                 _ptr(out_rows), _ptr(out_recs), C.byref(n)))
+        out_rows, out_recs = out_rows[:n.value], out_recs[:n.value]
+        self._generation += 1
+        return out_rows, out_recs
+
+    def owner_render(self, cam: "Camera", rows, recs, img, bg=(0.0, 0.0, 0.0), keep_state: bool = True):
+        """lcgs_owner_render: the rest of the frame from received records (ascending global rows)"""
+        _check(load_library().lcgs_owner_render(self.ctx._h, C.byref(cam), _f3(bg), C.c_int(int(rows.shape[0])), _ptr(rows),
+                                                _ptr(recs), _ptr(img), C.c_int(1 if keep_state else 0)))
+        self._generation += 1
+
+    def owner_render_backward(self, dL_dimg, grads2d):
+        """lcgs_owner_render_backward: 2-D gradients (float32 [n, 12]) of the rows the last owner_render drew"""
+        _check(load_library().lcgs_owner_render_backward(self.ctx._h, _ptr(dL_dimg), _ptr(grads2d)))
+
+    def owner_backward(self, slot: int, grads2d, dpos, dscale, drotq, dsh, dopacity, accumulate: bool):
+        """lcgs_owner_backward: the slot's rows' 2-D gradients -> parameter gradients at their rows of the full-size arrays"""
+        g = _Grads(_ptr(dpos), _ptr(dscale), _ptr(drotq), _ptr(dsh), _ptr(dopacity))
+        _check(load_library().lcgs_owner_backward(self.ctx._h, C.c_int(slot), _ptr(grads2d), C.byref(g),
+                                                  C.c_int(1 if accumulate else 0)))
 
     def l2_loss_backward(self, img, target, dL_dimg, loss):
         """lcgs_l2_loss_backward: loss[0] = mean((img - target)^2), dL_dimg = 2 (img - target) / numel (device tensors)"""

@@ -276,6 +276,8 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
                              &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac, &ctx->tie_ws, &ctx->fused_grads, &ctx->bwd_counter, &ctx->st_flags, &ctx->st_keys_exp, &ctx->st_vals_exp,
                              &ctx->st_u32[0], &ctx->st_u32[1], &ctx->st_u32[2], &ctx->st_u32[3], &ctx->st_u32[4], &ctx->st_u32[5], &ctx->st_u32[6], &ctx->st_u32[7] };
     for (DeviceBuffer* b : bufs) b->release();
+    for (auto& s : ctx->owner)
+        for (DeviceBuffer* b : { &s.vis, &s.shjac, &s.counts }) b->release();
     for (auto& b : ctx->owned) b.release();
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->aux_stream) {

@@ -1,0 +1,251 @@
+// abi_owner.cpp -- the C ABI, part 7: the frame in two halves, for the splat-ownership step of DESIGN.md 7b.  A GPU that
+// OWNS a range of rows runs the per-splat half of a view's frame on them (cull, compaction, SH colour: the packed 48-byte
+// records of the rows that reach that view's screen) and, later, the per-splat half of its backward; the GPU that RENDERS
+// the view runs everything from the depth sort on -- on records it received from the owners -- and the render-backward, and
+// hands the 2-D gradients back.  The kernels are the fused frame's own (abi_frame.cpp / abi_backward.cpp): only the seam
+// between the two halves is new.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "abi_internal.hpp"
+#include "kernels/tie_order.hpp"
+
+using namespace lcgs;
+using namespace lcgs::abi;
+
+namespace
+{
+struct RowRange {
+    const float *pos, *scale, *rotq, *sh, *opacity;
+};
+RowRange shard_of(lcgs_context* ctx, int row_first)
+{
+    const size_t feat = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3;
+    return { ctx->pos + 3 * (size_t)row_first, ctx->scale + 3 * (size_t)row_first, ctx->rotq + 4 * (size_t)row_first,
+             ctx->sh + feat * (size_t)row_first, ctx->opacity + (size_t)row_first };
+}
+} // namespace
+
+extern "C" {
+
+lcgs_status lcgs_owner_project(lcgs_context* ctx, int slot, const lcgs_camera* camera, float scale_modifier, int row_first,
+                               int row_count, int keep_state, uint32_t* d_rows, float* d_records, int* num_rows)
+{
+    LCGS_REQUIRE(ctx && num_rows, "NULL argument");
+    LCGS_REQUIRE(row_count == 0 || (d_rows && d_records), "NULL output buffer");
+    LCGS_REQUIRE((reinterpret_cast<uintptr_t>(d_records) & 15) == 0, "records must be 16-byte aligned");
+    LCGS_REQUIRE(slot >= 0 && slot < LCGS_MAX_OWNER_VIEWS, "slot out of range");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    LCGS_TRY(check_camera(camera));
+    *num_rows = 0;
+    LCGS_REQUIRE(ctx->pos != nullptr && ctx->P > 0, "no scene bound");
+    LCGS_REQUIRE(row_first >= 0 && row_count >= 0 && (int64_t)row_first + row_count <= ctx->P, "row range outside the scene");
+    auto& s = ctx->owner[slot];
+    s.valid = false;
+    s.row_first = row_first;
+    s.row_count = row_count;
+    s.num       = 0;
+    if (row_count == 0) return LCGS_OK;
+    const CamParams cp = make_cam_params(*camera);
+    LCGS_TRY(ensure_fused_workspace(ctx, cp, keep_state != 0));
+    const size_t n = (size_t)row_count;
+    LCGS_TRY(s.vis.ensure(n * 4 + 16));
+    LCGS_TRY(s.counts.ensure(64));
+    if (keep_state) LCGS_TRY(s.shjac.ensure(n * 48));
+    hipStream_t    st = ctx->stream;
+    const RowRange r  = shard_of(ctx, row_first);
+    uint32_t*      dc = s.counts.as<uint32_t>();
+    if (ctx->aux_pending) { // a pipelined frame of this context may still be using the workspace through the auxiliary stream
+        LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_aux_done, 0));
+        ctx->aux_pending = false;
+    }
+    // the fused frame's first stages on the rows of the range: cull, compaction (the depth sort's first pass only: the
+    // renderer of the view sorts what it receives), colour + packed records
+    const DepthSortFirstPass dfirst = depth_sort_first_pass(row_count, ctx->sort_ws.ptr);
+    launch_cull_compact(row_count, cp, scale_modifier, nullptr, r.pos, r.scale, r.rotq, r.opacity, nullptr,
+                        ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(), dfirst, st);
+    launch_depth_sort_from_chunks(row_count, row_count, ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(),
+                                  ctx->chunk_base.as<uint32_t>(), ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
+                                  ctx->sortv[0].as<uint32_t>(), ctx->sortv[1].as<uint32_t>(), s.vis.as<uint32_t>(),
+                                  ctx->rects.as<uint2>(), dc, ctx->sort_ws.ptr, st, nullptr, nullptr, /*first_pass_only=*/true);
+    launch_build_records(row_count, ctx->sh_deg, cp, scale_modifier, nullptr, r.pos, r.scale, r.rotq, r.sh, r.opacity,
+                         s.vis.as<uint32_t>(), dc, reinterpret_cast<SplatRecord*>(d_records), st, nullptr,
+                         keep_state ? s.shjac.as<float4>() : nullptr);
+    s.has_jac = keep_state && build_records_writes_jacobian(ctx->sh_deg, r.sh, false);
+    launch_rows_global(s.vis.as<uint32_t>(), dc, (uint32_t)row_first, d_rows, row_count, st);
+    LCGS_HIP_CHECK(hipGetLastError());
+    uint32_t h = 0;
+    LCGS_HIP_CHECK(hipMemcpyAsync(&h, dc, 4, hipMemcpyDeviceToHost, st));
+    LCGS_HIP_CHECK(hipStreamSynchronize(st));
+    s.valid          = true;
+    s.cp             = cp;
+    s.scale_modifier = scale_modifier;
+    s.num            = (int)h;
+    ctx->last.valid  = false; // (the context's own frame state was overwritten)
+    *num_rows        = (int)h;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_owner_render(lcgs_context* ctx, const lcgs_camera* camera, const float bg_color[3], int num_rows,
+                              const uint32_t* d_rows, const float* d_records, float* d_img, int keep_state)
+{
+    LCGS_REQUIRE(ctx && bg_color && d_img, "NULL argument");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    LCGS_TRY(check_camera(camera));
+    LCGS_REQUIRE(num_rows >= 0 && num_rows <= ctx->P, "num_rows out of range (the context's scene sizes the workspace)");
+    ctx->last.valid = false;
+    ctx->owner_recs = nullptr;
+    if (num_rows == 0) return LCGS_OK; // nothing on screen: image untouched, like gs_tile_splatter/impl.cpp:109
+    LCGS_REQUIRE(d_rows && d_records, "NULL device pointer");
+    LCGS_REQUIRE((reinterpret_cast<uintptr_t>(d_records) & 15) == 0, "records must be 16-byte aligned");
+    const CamParams    cp   = make_cam_params(*camera);
+    hipStream_t        st   = ctx->stream;
+    const SplatRecord* recs = reinterpret_cast<const SplatRecord*>(d_records);
+    const uint32_t     G    = cp.grid_x * cp.grid_y;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        LCGS_TRY(ensure_fused_workspace(ctx, cp, keep_state != 0));
+        uint32_t* dc = ctx->counts.as<uint32_t>();
+        if (ctx->aux_pending) { // a pipelined frame of this context may still be using the auxiliary stream's buffers
+            LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_aux_done, 0));
+            ctx->aux_pending = false;
+        }
+        for (bool& z : ctx->zero_ready) z = false;
+        LCGS_HIP_CHECK(hipMemsetAsync(ctx->zero_ws[0].ptr, 0, ctx->zero_bytes, st));
+        ctx->ranges        = reinterpret_cast<uint32_t*>(ctx->zero_ws[0].as<char>() + ctx->zero_scan_bytes);
+        ctx->work_counters = reinterpret_cast<uint32_t*>(ctx->zero_ws[0].as<char>() + ctx->zero_bytes - 256);
+        // equal depths blend in ascending FILE index (tie_order.hpp): the received rows are ascending rows of the scene as
+        // the contexts hold it -- its file order, unless the scene was re-ordered, in which case the tags restore it
+        TieOrder   tie;
+        uint32_t   id_mask = 0xFFFFFFFFu;
+        const bool tied    = ctx->perm_valid;
+        if (tied) {
+            tie.d_counts   = dc;
+            tie.vis_index  = ctx->vis_index.as<uint32_t>();
+            tie.perm       = ctx->scene_perm.as<uint32_t>();
+            tie.id_bits    = (uint32_t)std::max(1, ceil_log2_u32((uint32_t)ctx->P));
+            tie.tag_shift  = 2u * tie.id_bits > 32u ? 2u * tie.id_bits - 32u : 0u;
+            id_mask        = (1u << tie.id_bits) - 1u;
+            tie.scratch_k1 = ctx->tie_ws.as<uint32_t>();
+        }
+        launch_unpack_records(num_rows, recs, d_rows, tied ? tie.perm : nullptr, tie.id_bits, tie.tag_shift,
+                              ctx->sortk[0].as<uint32_t>(), ctx->sortv[0].as<uint32_t>(), ctx->rects.as<uint2>(),
+                              ctx->vis_index.as<uint32_t>(), dc, st);
+        const int w = launch_pair_sort_u32(ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
+                                           ctx->sortv[0].as<uint32_t>(), ctx->sortv[1].as<uint32_t>(), dc, ctx->P, num_rows, 0, 32,
+                                           ctx->sort_ws.ptr, st);
+        if (tied)
+            launch_fix_equal_depth_order(ctx->sortk[w].as<uint32_t>(), ctx->sortv[w].as<uint32_t>(),
+                                         ctx->sortk[w ^ 1].as<uint32_t>(), ctx->sortv[w ^ 1].as<uint32_t>(), ctx->P, num_rows, tie,
+                                         st);
+        const uint32_t*         order     = ctx->sortv[w].as<uint32_t>();
+        const int               tile_bits = std::max(1, ceil_log2_u32(G));
+        const int64_t           hint_L    = ctx->hint_L > 0 ? ctx->hint_L : ctx->pair_capacity;
+        const PairSortFirstPass first     = pair_sort_first_pass(ctx->pair_capacity, hint_L, 0, tile_bits, ctx->sort_ws.ptr);
+        const bool counted = launch_expand(ctx->P, num_rows, hint_L, dc, cp.grid_x, order, ctx->rects.as<uint2>(),
+                                           ctx->rects_sorted.as<uint2>(), ctx->pairk[0].as<uint32_t>(),
+                                           ctx->pairv[0].as<uint32_t>(), ctx->pair_capacity, ctx->expand_ws.as<uint32_t>(), st,
+                                           &first, id_mask);
+        const int where2 = launch_pair_sort_u32(ctx->pairk[0].as<uint32_t>(), ctx->pairk[1].as<uint32_t>(),
+                                                ctx->pairv[0].as<uint32_t>(), ctx->pairv[1].as<uint32_t>(), dc + 2,
+                                                ctx->pair_capacity, hint_L, 0, tile_bits, ctx->sort_ws.ptr, st, counted);
+        launch_get_ranges_u32(hint_L, ctx->pair_capacity, dc, ctx->pairk[where2].as<uint32_t>(), ctx->ranges, nullptr, st, nullptr);
+        uint32_t* order_now = ctx->tile_order[0].as<uint32_t>();
+        launch_tile_order(ctx->ranges, G, order_now, st);
+        ctx->order_G = 0; // (the pipelined frames' schedule buffers were used out of turn)
+        launch_render_forward_rec(cp, bg_color, ctx->ranges, ctx->pairv[where2].as<uint32_t>(), recs, d_img,
+                                  keep_state ? ctx->final_T.as<float>() : nullptr,
+                                  keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, dc, nullptr, order_now, st,
+                                  keep_state ? ctx->strip_masks.as<uint8_t>() : nullptr, nullptr);
+        LCGS_HIP_CHECK(hipGetLastError());
+        LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, dc, 40, hipMemcpyDeviceToHost, st));
+        LCGS_HIP_CHECK(hipStreamSynchronize(st));
+        ctx->counts_pending = false;
+        if ((int64_t)ctx->h_counts[4] > ctx->hint_L || (int64_t)ctx->h_counts[4] * 2 < ctx->hint_L)
+            ctx->hint_L = (int64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4 + 4096;
+        if (ctx->h_counts[3] != 0) { // the pair workspace was too small for this view: grow, redo
+            const uint64_t want = (uint64_t)ctx->h_counts[7] + ctx->h_counts[7] / 4;
+            LCGS_REQUIRE(want <= 0x7FFFFFFFull, "num_rendered exceeds 2^31 pairs");
+            ctx->pair_capacity = std::max(ctx->pair_capacity, (uint32_t)want);
+            ctx->h_counts[3] = ctx->h_counts[6] = ctx->h_counts[7] = 0;
+            LCGS_HIP_CHECK(hipMemsetAsync(dc + 6, 0, 8, st));
+            continue;
+        }
+        if (ctx->h_counts[6] != 0) { // (sticky record of this very frame's demand: nothing left to report)
+            ctx->h_counts[6] = ctx->h_counts[7] = 0;
+            LCGS_HIP_CHECK(hipMemsetAsync(dc + 6, 0, 8, st));
+        }
+        ctx->last.valid          = true;
+        ctx->last.has_state      = keep_state != 0;
+        ctx->last.cp             = cp;
+        ctx->last.scale_modifier = 1.0f;
+        ctx->last.list_buf       = where2;
+        memcpy(ctx->last.bg, bg_color, sizeof(float) * 3);
+        ctx->last_tile_order = order_now;
+        ctx->owner_recs      = recs;
+        ctx->owner_rows      = num_rows;
+        ctx->g2d_zeroed      = false;
+        return LCGS_OK;
+    }
+    set_last_error("pair buffer growth did not converge");
+    return LCGS_ERR_CAPACITY;
+}
+
+lcgs_status lcgs_owner_render_backward(lcgs_context* ctx, const float* d_dL_dimg, float* d_grads2d)
+{
+    LCGS_REQUIRE(ctx && d_dL_dimg && d_grads2d, "NULL argument");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->last.valid || !ctx->last.has_state || !ctx->owner_recs) {
+        set_last_error("lcgs_owner_render_backward needs a preceding lcgs_owner_render(..., keep_state = 1)");
+        return LCGS_ERR_STATE;
+    }
+    hipStream_t st = ctx->stream;
+    LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)ctx->P)));
+    launch_zero_grads2d(ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(), st, ctx->bwd_counter.as<uint32_t>());
+    launch_render_backward(ctx->last.cp, ctx->last.bg, ctx->ranges, ctx->pairv[ctx->last.list_buf].as<uint32_t>(), ctx->owner_recs,
+                           ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(), d_dL_dimg, ctx->grads2d.as<float>(),
+                           ctx->last_tile_order, st, ctx->strip_masks.as<uint8_t>(), ctx->counts.as<uint32_t>());
+    LCGS_HIP_CHECK(hipGetLastError());
+    LCGS_HIP_CHECK(hipMemcpyAsync(d_grads2d, ctx->grads2d.ptr, (size_t)ctx->owner_rows * LCGS_OWNER_GRAD_FLOATS * 4,
+                                  hipMemcpyDeviceToDevice, st));
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_owner_backward(lcgs_context* ctx, int slot, const float* d_grads2d, const lcgs_grads* grads, int accumulate)
+{
+    LCGS_REQUIRE(ctx && grads, "NULL argument");
+    LCGS_REQUIRE(slot >= 0 && slot < LCGS_MAX_OWNER_VIEWS, "slot out of range");
+    LCGS_REQUIRE(grads->d_dL_dpos && grads->d_dL_dscale && grads->d_dL_drotq && grads->d_dL_dsh && grads->d_dL_dopacity,
+                 "NULL gradient buffer");
+    LCGS_REQUIRE((reinterpret_cast<uintptr_t>(grads->d_dL_drotq) & 15) == 0, "dL_drotq must be 16-byte aligned");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    auto& s = ctx->owner[slot];
+    if (s.row_count == 0) return LCGS_OK; // an owner of nothing
+    if (!s.valid) {
+        set_last_error("lcgs_owner_backward needs a preceding lcgs_owner_project into this slot");
+        return LCGS_ERR_STATE;
+    }
+    hipStream_t  st   = ctx->stream;
+    const size_t feat = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3, f = (size_t)s.row_first, c = (size_t)s.row_count;
+    float *gp = grads->d_dL_dpos + 3 * f, *gs = grads->d_dL_dscale + 3 * f, *gq = grads->d_dL_drotq + 4 * f,
+          *gsh = grads->d_dL_dsh + feat * f, *go = grads->d_dL_dopacity + f;
+    if (!accumulate) { // the first view of the step: every row of the range that is not on its screen is an exact zero
+        LCGS_HIP_CHECK(hipMemsetAsync(gp, 0, c * 3 * 4, st));
+        LCGS_HIP_CHECK(hipMemsetAsync(gs, 0, c * 3 * 4, st));
+        LCGS_HIP_CHECK(hipMemsetAsync(gq, 0, c * 4 * 4, st));
+        LCGS_HIP_CHECK(hipMemsetAsync(gsh, 0, c * feat * 4, st));
+        LCGS_HIP_CHECK(hipMemsetAsync(go, 0, c * 4, st));
+    }
+    if (s.num == 0) return LCGS_OK;
+    LCGS_REQUIRE(d_grads2d != nullptr, "NULL 2-D gradients");
+    const RowRange r = shard_of(ctx, s.row_first);
+    launch_preprocess_backward(s.num, ctx->sh_deg, s.cp, s.scale_modifier, r.pos, r.scale, r.rotq, r.sh, s.vis.as<uint32_t>(),
+                               s.counts.as<uint32_t>(), d_grads2d, gp, gs, gq, gsh, go, st,
+                               s.has_jac ? s.shjac.as<float4>() : nullptr, /*compact=*/false, nullptr, 0, 1, /*accumulate=*/true);
+    LCGS_HIP_CHECK(hipGetLastError());
+    return LCGS_OK;
+}
+
+} // extern "C"

@@ -163,6 +163,18 @@ struct lcgs_context {
         lcgs_camera  cam{};
     } def_proj;
 
+    // Splat ownership (abi_owner.cpp): per view of a step, what this context computed as an OWNER of a row range
+    // (kept for that view's backward), and -- as the RENDERER of a view -- the received records the last frame was drawn from
+    struct OwnerSlot {
+        bool         valid = false, has_jac = false;
+        CamParams    cp;
+        float        scale_modifier = 1.0f;
+        int          row_first = 0, row_count = 0, num = 0;
+        DeviceBuffer vis, shjac, counts;
+    } owner[LCGS_MAX_OWNER_VIEWS];
+    const lcgs::SplatRecord* owner_recs = nullptr;
+    int                      owner_rows = 0;
+
     // per-stage timing
     bool             profiling = false;
     hipEvent_t       events[lcgs::kMaxEvents]{};

@@ -28,6 +28,7 @@
 #include <hip/hip_ext.h>
 
 #include "launch.hpp"
+#include "tie_order.hpp"
 
 namespace lcgs
 {
@@ -884,6 +885,56 @@ void launch_sh_to_half(int64_t n, const float* src, uint16_t* dst, hipStream_t s
 
 
 
+
+// ---- splat ownership
+namespace
+{
+__global__ void __launch_bounds__(256) k_rows_global(const uint32_t* __restrict__ vis, const uint32_t* __restrict__ d_count,
+                                                     uint32_t row_first, uint32_t* __restrict__ rows_out)
+{
+    const uint32_t n = *d_count;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) rows_out[i] = vis[i] + row_first;
+}
+
+__global__ void __launch_bounds__(256) k_unpack_records(uint32_t n, const SplatRecord* __restrict__ recs,
+                                                        const uint32_t* __restrict__ rows, const uint32_t* __restrict__ perm,
+                                                        uint32_t id_bits, uint32_t tag_shift, uint32_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals, uint2* __restrict__ rects,
+                                                        uint32_t* __restrict__ vis_index, uint32_t* __restrict__ d_counts)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        d_counts[0] = n;
+        d_counts[1] = n; // (non-zero iff anything can be drawn; the reference's num_rendered is not known on this side)
+        d_counts[kCountTieUnresolved] = 0u;
+    }
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const SplatRecord r = recs[i];
+        const uint32_t    row = rows[i];
+        keys[i]      = __float_as_uint(r.depth);
+        vals[i]      = perm ? (i | ((perm[row] >> tag_shift) << id_bits)) : i;
+        rects[i]     = make_uint2(r.rect_xy, r.rect_wh);
+        vis_index[i] = row;
+    }
+}
+} // namespace
+
+void launch_rows_global(const uint32_t* vis, const uint32_t* d_count, uint32_t row_first, uint32_t* rows_out, int64_t hint,
+                        hipStream_t stream)
+{
+    int64_t b = (hint + 255) / 256;
+    b         = b < 1 ? 1 : (b > 8192 ? 8192 : b);
+    hipLaunchKernelGGL(k_rows_global, dim3((unsigned)b), dim3(256), 0, stream, vis, d_count, row_first, rows_out);
+}
+
+void launch_unpack_records(int64_t n, const SplatRecord* recs, const uint32_t* rows, const uint32_t* perm, uint32_t id_bits,
+                           uint32_t tag_shift, uint32_t* keys, uint32_t* vals, uint2* rects, uint32_t* vis_index,
+                           uint32_t* d_counts, hipStream_t stream)
+{
+    int64_t b = (n + 255) / 256;
+    b         = b < 1 ? 1 : (b > 8192 ? 8192 : b);
+    hipLaunchKernelGGL(k_unpack_records, dim3((unsigned)b), dim3(256), 0, stream, (uint32_t)n, recs, rows, perm, id_bits,
+                       tag_shift, keys, vals, rects, vis_index, d_counts);
+}
 
 size_t expand_ws_bytes(int P_cap) { return (size_t)((P_cap + kExpandChunk - 1) / kExpandChunk + 8) * sizeof(uint32_t); }
 

@@ -89,7 +89,20 @@ void launch_depth_sort_from_chunks(int64_t P, int64_t v_hint, const uint4* slab,
                                    hipStream_t stream, hipEvent_t fork = nullptr,
                                    // re-ordered scenes: equal depths come out in FILE order (tie_order.hpp); the sorted
                                    // values then carry a file-index tag above their id_bits -- readers mask it off
-                                   const TieOrder* tie = nullptr);
+                                   const TieOrder* tie = nullptr,
+                                   // first_pass_only: stop behind the compaction (vis_index, rects, V, num_rendered)
+                                   bool first_pass_only = false);
+void launch_fix_equal_depth_order(uint32_t* keys, uint32_t* vals, uint32_t* scratch_k, uint32_t* scratch_v, int64_t n_cap,
+                                  int64_t v_hint, const TieOrder& tie, hipStream_t stream);
+// ---- splat ownership: a frame from RECEIVED records instead of the context's own cull pass
+// rows_out[i] = vis[i] + row_first for i < *d_count
+void launch_rows_global(const uint32_t* vis, const uint32_t* d_count, uint32_t row_first, uint32_t* rows_out, int64_t hint,
+                        hipStream_t stream);
+// n records (ascending global row order) -> the depth sort's input (keys = depth bits, vals = position [| file-index tag]),
+// rects, vis_index = rows; d_counts[0] = n, [1] = the sum of the pruned rects' tiles (non-zero iff anything is drawn)
+void launch_unpack_records(int64_t n, const SplatRecord* recs, const uint32_t* rows, const uint32_t* perm, uint32_t id_bits,
+                           uint32_t tag_shift, uint32_t* keys, uint32_t* vals, uint2* rects, uint32_t* vis_index,
+                           uint32_t* d_counts, hipStream_t stream);
 struct PairSortFirstPass;
 size_t expand_ws_bytes(int P_cap);
 // v_hint: expected survivor count (bounds the launch; larger live counts are handled by chunk striding)

@@ -849,7 +849,7 @@ int launch_pair_sort_u32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
 void launch_depth_sort_from_chunks(int64_t P, int64_t v_hint, const uint4* slab, const uint2* chunk_info,
                                    uint32_t* chunk_base, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
                                    uint32_t* vals_b, uint32_t* vis_index, uint2* rects, uint32_t* d_counts, void* ws_,
-                                   hipStream_t stream, hipEvent_t fork, const TieOrder* tie)
+                                   hipStream_t stream, hipEvent_t fork, const TieOrder* tie, bool first_pass_only)
 {
     if (P <= 0) return;
     constexpr int  kItems = 8;
@@ -863,6 +863,7 @@ void launch_depth_sort_from_chunks(int64_t P, int64_t v_hint, const uint4* slab,
     hipExtLaunchKernelGGL(k_scatter_first<kItems>, dim3(nb), dim3(kThreads), 0, stream, nullptr, fork, 0, slab, chunk_info,
                           chunk_base, keys_b, vals_b, vis_index, rects, 0xFFu, 8, counts, totals, stride,
                           tie ? tie->perm : nullptr, tie ? tie->id_bits : 32u, tie ? tie->tag_shift : 0u);
+    if (first_pass_only) return; // (the compaction: dense vis_index / rects, V and num_rendered -- splat-ownership owners)
     const uint32_t* sk[3] = { keys_b, keys_a, keys_b };
     const uint32_t* sv[3] = { vals_b, vals_a, vals_b };
     uint32_t*       dk[3] = { keys_a, keys_b, keys_a };
@@ -877,6 +878,21 @@ void launch_depth_sort_from_chunks(int64_t P, int64_t v_hint, const uint4* slab,
         hipLaunchKernelGGL(k_fix_equal_depth_order, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(kThreads), 0, stream,
                            keys_a, vals_a, (uint32_t)P, t);
     }
+}
+
+// The equal-depth pass on its own (a depth sort that did not come through launch_depth_sort_from_chunks): (keys, vals) sorted,
+// (scratch_k, scratch_v) the free half of the sort's ping-pong.
+void launch_fix_equal_depth_order(uint32_t* keys, uint32_t* vals, uint32_t* scratch_k, uint32_t* scratch_v, int64_t n_cap,
+                                  int64_t v_hint, const TieOrder& tie, hipStream_t stream)
+{
+    if (n_cap <= 0) return;
+    int64_t blocks = ((v_hint > 0 ? v_hint : n_cap) + kTieSpan - 1) / kTieSpan;
+    if (blocks > 16384) blocks = 16384;
+    TieOrder t   = tie;
+    t.scratch_k0 = scratch_k;
+    t.scratch_v  = scratch_v;
+    hipLaunchKernelGGL(k_fix_equal_depth_order, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(kThreads), 0, stream, keys, vals,
+                       (uint32_t)n_cap, t);
 }
 
 // The stage-level sort (lcpp DeviceRadixSort::SortPairs<ulong, uint>, call site gs_tile_splatter/impl.cpp:135-143):

@@ -192,8 +192,8 @@ class TorchCollective:
             self.last_stats["bytes_received"] += gathered
 
     def owner_step(self, engine, cams, dL_dimg, grads: dict, step: int):
-        """PROTOTYPE of the splat-ownership step, verified on gloo with the oracle as the engine
-        (tests/test_distributed.py).  Rank o owns the rows owner_range(P, N, o) -- parameters, moments, gradients -- and
+        """PROTOTYPE of the splat-ownership step, verified on gloo with a CPU restatement as the engine
+        (tests/test_distributed.py) and on the device through HipEngine's two-halves frame (csrc/abi_owner.cpp).  Rank o owns the rows owner_range(P, N, o) -- parameters, moments, gradients -- and
         nothing is replicated or all-gathered.  Per step, with rank v rendering view v:
           1. every owner projects ITS rows for EVERY view of the step and sends view v's rank the 2-D inputs of the rows
              that reach the screen (row index + projected mean, depth, 2-D covariance, colour, opacity: 44 bytes a row);
@@ -309,13 +309,37 @@ class HipEngine:
         self.r.adam_step(sub(grads), sub(self.raw), sub(self.m), sub(self.v), sub(self.activated), step, self.lr,
                          self.betas, self.eps)
 
-    OWNER_RECORD_FLOATS, OWNER_GRAD_FLOATS = 10, 9
+    # ---- splat ownership on the device: the frame in two halves (csrc/abi_owner.cpp)
+    OWNER_RECORD_FLOATS, OWNER_GRAD_FLOATS = 12, 12
+
+    def _owner_slot(self, cam):
+        """the step's views get one slot each, in the order the protocol projects them (reset by the first backward)"""
+        key = id(cam)
+        if key not in self._slots:
+            self._slots[key] = len(self._slots)
+        return self._slots[key]
 
     def owner_records(self, cam, span):
-        raise NotImplementedError("mode 'owner' is a CPU-verified prototype (DESIGN.md 7b): the HIP engine's forward half "
-                                  "exists as the stage operators, its 2-D backward has no entry point yet")
+        if getattr(self, "_slots_done", True):
+            self._slots, self._slots_done = {}, False
+        rows, recs = self.r.owner_project(self._owner_slot(cam), cam, span[0], span[1], keep_state=True)
+        return rows.to(dtype=__import__("torch").int64), recs
 
-    owner_render = owner_backward = owner_records
+    def owner_render(self, cam, rows, recs, dL_dimg, bg=(0.0, 0.0, 0.0)):
+        import torch
+
+        if self._img is None or tuple(self._img.shape) != (3, cam.height, cam.width):
+            self._img = torch.empty(3, cam.height, cam.width, device=recs.device, dtype=torch.float32)
+        g2d = torch.zeros(int(rows.shape[0]), self.OWNER_GRAD_FLOATS, device=recs.device, dtype=torch.float32)
+        if rows.numel() == 0:
+            return g2d
+        self.r.owner_render(cam, rows.to(torch.int32).contiguous(), recs.contiguous(), self._img, bg=bg, keep_state=True)
+        self.r.owner_render_backward(dL_dimg, g2d)
+        return g2d
+
+    def owner_backward(self, cam, span, rows, g2d, grads: dict, accumulate: bool = False):
+        self._slots_done = True  # (the next owner_records starts a new step)
+        self.r.owner_backward(self._slots[id(cam)], g2d.contiguous(), *[grads[k] for k in KEYS], accumulate=accumulate)
 
     def adam_sharded(self, comm: "api.Comm", grads: dict, step: int):
         comm.adam_step_sharded(grads, self.raw, self.m, self.v, self.activated, step, self.lr, self.betas, self.eps)

@@ -218,7 +218,7 @@ def test_bench_runs_every_multi_gpu_code_path_on_one_rank(collective):
     assert fb["views_per_gpu_and_step_4"]["value"] > 0 and fb["views_per_gpu_and_step_4"]["views_per_step"] == 4
     assert fb["multi_view_step_4"]["lcgs_fit_views"]["value"] > 0 and fb["multi_view_step_4"]["one_by_one"]["value"] > 0
     assert ("rccl" in fb["collective"]) == (collective == "rccl")
-    assert set(out["train_step"]) == {"allreduce", "sharded", "sparse"}
+    assert set(out["train_step"]) == {"allreduce", "sharded", "sparse", "owner"}, out.get("leg_errors")
     assert all(v["value"] > 0 for v in out["train_step"].values())
     assert out["train_step"]["sparse"]["touched_rows"] > 0  # (one rank: every row is its own, nothing crosses the wire)
     assert out["moving_camera"]["value"] > 0 and len(out["moving_camera"]["per_view"]) == 8
@@ -259,7 +259,7 @@ def test_bench_with_two_ranks_on_one_gpu_through_the_torch_collective():
     fb = out["fwd_bwd"]
     assert fb["value"] > 0 and fb["without_collective"]["value"] > fb["value"] and fb["moving_camera"]["value"] > 0
     assert fb["views_per_gpu_and_step_4"]["views_per_step"] == 8 and fb["multi_view_step_4"]["lcgs_fit_views"]["value"] > 0
-    assert set(out["train_step"]) == {"allreduce", "sharded", "sparse"}
+    assert set(out["train_step"]) == {"allreduce", "sharded", "sparse", "owner"}, out.get("leg_errors")
     assert all(v["value"] > 0 for v in out["train_step"].values())
     # two real ranks: the sparse step's reduce half carried only the rows the rank's view touched
     sp = out["train_step"]["sparse"]

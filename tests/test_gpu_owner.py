@@ -1,0 +1,179 @@
+"""`-m gpu`: the frame in two halves (csrc/abi_owner.cpp; DESIGN.md 7b, splat ownership).  With VIRTUAL ranks on the one GPU:
+every owner projects its row range for a view, the view's renderer draws the concatenated records, and the owners turn their
+share of the 2-D gradients into parameter gradients -- the image must be the fused frame's (and the oracle's) bit for bit, the
+gradients the ordinary backward's."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_scene
+from gpu_util import DEV, assert_image_parity, upload_scene
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("pos", "scale", "rotq", "sh", "opacity")
+POSE = ([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1])
+W, H = 320, 240
+
+
+def _ranges(P, world):
+    import luisacomputegaussiansplatting_amd.multi_gpu as mg
+
+    return [mg.owner_range(P, world, r) for r in range(world)]
+
+
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def _two_halves(lcgs, r, cam, spans, dL, grads, accumulate=False, bg=(0.1, 0.2, 0.3)):
+    """one view through the two halves on renderer r: returns the image"""
+    parts = [r.owner_project(o, cam, first, count) for o, (first, count) in enumerate(spans)]
+    rows = torch.cat([p[0] for p in parts])
+    recs = torch.cat([p[1] for p in parts])
+    assert bool((rows[1:] > rows[:-1]).all())
+    img = torch.full((3, H, W), -1.0, device=DEV)
+    r.owner_render(cam, rows, recs, img, bg=bg, keep_state=True)
+    g2d = torch.zeros(rows.shape[0], r.OWNER_GRAD_FLOATS, device=DEV)
+    r.owner_render_backward(dL, g2d)
+    at = 0
+    for o, p in enumerate(parts):
+        n = int(p[0].shape[0])
+        r.owner_backward(o, g2d[at:at + n].contiguous(), *[grads[k] for k in KEYS], accumulate=accumulate)
+        at += n
+    r.ctx.synchronize()
+    return img, int(rows.shape[0])
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("reordered", [False, True])
+def test_two_halves_equal_the_fused_frame_and_its_backward(lcgs, oracle, world, reordered):
+    rng = np.random.default_rng(40 + world)
+    P = 30001
+    scene = make_scene(rng, P, log_scale=(-4.0, 0.8))
+    scene["pos"][100:200] = scene["pos"][300:400]  # exactly equal depths across what will be different owners' rows
+    scene["pos"][P - 150:P - 50] = scene["pos"][300:400]
+    cam = lcgs.get_lookat_cam(*POSE, width=W, height=H)
+    bg = (0.1, 0.2, 0.3)
+    # the ordinary path: one context, the whole scene
+    ref = lcgs.Renderer(lcgs.Context(0))
+    if reordered:
+        ref.upload_scene(scene)  # context-owned: spatial order, equal depths restored to file order by the tie pass
+        act = ref.scene_tensors()
+    else:
+        act = upload_scene(scene)
+        ref.bind_scene(*[act[k] for k in KEYS])
+    img_ref = torch.full((3, H, W), -1.0, device=DEV)
+    n_ref = ref.forward(cam, img_ref, bg=bg, keep_state=True, sync=True)
+    dL = torch.from_numpy(rng.normal(size=(3, H, W)).astype(np.float32)).to(DEV)
+    g_ref = {k: torch.full_like(act[k], 7.0) for k in KEYS}
+    ref.backward(dL, *[g_ref[k] for k in KEYS])
+    ref.ctx.synchronize()
+    orc = oracle.render(scene, oracle.lookat(*POSE, width=W, height=H), bg=bg)
+    assert n_ref == orc["num_rendered"] > 0
+    assert_image_parity(img_ref.cpu().numpy(), orc)
+    # the two halves, with `world` virtual owners, on another context holding the same arrays (same order, same permutation)
+    r = lcgs.Renderer(lcgs.Context(0))
+    if reordered:
+        r.upload_scene(scene)
+        act2 = r.scene_tensors()
+        assert all(torch.equal(act2[k], act[k]) for k in KEYS)
+    else:
+        r.bind_scene(*[act[k] for k in KEYS])
+        act2 = act
+    g = {k: torch.full_like(act2[k], 5.0) for k in KEYS}
+    img, n_rows = _two_halves(lcgs, r, cam, _ranges(P, world), dL, g, bg=bg)
+    assert n_rows == ref.frame_stats()["num_visible"]
+    assert torch.equal(img, img_ref), f"{int((img != img_ref).any(0).sum())} pixels differ from the fused frame"
+    for k in KEYS:
+        zero_ref = (g_ref[k].reshape(P, -1) == 0).all(1)
+        assert torch.equal((g[k].reshape(P, -1) == 0).all(1), zero_ref), k  # the same rows are exact zeros
+        assert _rel(g[k], g_ref[k]) <= 1e-4, (k, _rel(g[k], g_ref[k]))  # (float-atomic order of the 2-D sums: two runs of ONE path differ by ~2e-5)
+
+
+def test_views_accumulate_and_empty_ranges_are_harmless(lcgs):
+    rng = np.random.default_rng(9)
+    P = 12000
+    scene = make_scene(rng, P, log_scale=(-4.0, 0.8))
+    scene["pos"][:4000] += np.array([0.0, 0.0, 50.0], np.float32)  # the first owner's rows are nowhere near the screen
+    act = upload_scene(scene)
+    cams = [lcgs.get_lookat_cam([-3 * np.cos(a), -0.5 + 3 * np.sin(a), 2.3], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+            for a in (0.0, 0.7)]
+    dLs = [torch.randn(3, H, W, device=DEV) for _ in cams]
+    ref = lcgs.Renderer(lcgs.Context(0))
+    ref.bind_scene(*[act[k] for k in KEYS])
+    img = torch.zeros(3, H, W, device=DEV)
+    g_ref = {k: torch.zeros_like(act[k]) for k in KEYS}
+    for j, (cam, dL) in enumerate(zip(cams, dLs)):
+        ref.forward(cam, img, keep_state=True, sync=True)
+        ref.backward(dL, *[g_ref[k] for k in KEYS], accumulate=j > 0)
+    ref.ctx.synchronize()
+    # two owners ((0, 4000): off screen; the rest), two views; each (owner, view) pair its own slot
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.bind_scene(*[act[k] for k in KEYS])
+    spans = [(0, 4000), (4000, P - 4000)]
+    g = {k: torch.full_like(act[k], 3.0) for k in KEYS}
+    for j, (cam, dL) in enumerate(zip(cams, dLs)):
+        parts = [r.owner_project(2 * j + o, cam, f, c) for o, (f, c) in enumerate(spans)]
+        assert parts[0][0].numel() == 0  # nothing of the first range reaches the screen
+        rows, recs = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+        r.owner_render(cam, rows, recs, img, keep_state=True)
+        g2d = torch.zeros(rows.shape[0], r.OWNER_GRAD_FLOATS, device=DEV)
+        r.owner_render_backward(dL, g2d)
+        r.owner_backward(2 * j + 0, g2d[:0], *[g[k] for k in KEYS], accumulate=j > 0)
+        r.owner_backward(2 * j + 1, g2d, *[g[k] for k in KEYS], accumulate=j > 0)
+    r.ctx.synchronize()
+    for k in KEYS:
+        assert float(g[k][:4000].abs().max()) == 0.0  # zero-filled by the first view, never touched again
+        assert _rel(g[k], g_ref[k]) <= 1e-4, (k, _rel(g[k], g_ref[k]))
+
+
+def test_owner_step_of_the_package_on_the_hip_engine(lcgs):
+    """multi_gpu.ViewParallelTrainer(mode="owner") with HipEngine at world size 1 (a single-rank process group on gloo): the
+    protocol's local path -- every message stays on the rank -- must give the parameters of an ordinary step."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    import luisacomputegaussiansplatting_amd.multi_gpu as mg
+
+    rng = np.random.default_rng(3)
+    P = 20000
+    scene = make_scene(rng, P, log_scale=(-4.0, 0.8))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        lr = {"pos": 1.6e-3, "sh_dc": 2.5e-2, "sh_rest": 1.25e-3, "opacity": 5e-2, "scale": 5e-3, "rot": 1e-2}
+        cams = [lcgs.get_lookat_cam(*POSE, width=W, height=H)]
+        dL = torch.randn(3, H, W, device=DEV)
+        results = {}
+        for mode in ("local", "owner"):
+            act = upload_scene(scene)
+            raw = {"pos": act["pos"], "scale": torch.log(act["scale"]), "rotq": act["rotq"].clone(), "sh": act["sh"],
+                   "opacity": torch.log(act["opacity"] / (1 - act["opacity"]))}
+            r = lcgs.Renderer(lcgs.Context(0))
+            eng = mg.HipEngine(r, raw=raw, activated=act, lr=lr)
+            grads = {k: torch.zeros_like(act[k]) for k in KEYS}
+            coll = mg.TorchCollective(dist, 0, 1) if mode == "owner" else None
+            tr = mg.ViewParallelTrainer(eng, coll, cams, grads, mode=mode)
+            for _ in range(2):
+                tr.step(dL)
+            r.ctx.synchronize()
+            results[mode] = {k: raw[k].clone() for k in KEYS}
+            if mode == "owner":
+                assert coll.last_stats["bytes_sent"] == 0 and coll.last_stats["on_screen_rows_received"] > 0
+        for k in KEYS:
+            a, b = results["owner"][k], results["local"][k]
+            # Adam's first steps move every touched parameter by ~lr whatever the gradient's size: a last-bit difference in a
+            # gradient near zero can flip a sign -- compare in units of the learning rate
+            unit = max(lr.get({"rotq": "rot"}.get(k, k), lr["sh_dc"]), 1e-12)
+            d = (a - b).abs() / unit
+            assert float((d > 0.05).float().mean()) < 0.01, (k, float(d.max()))
+    finally:
+        dist.destroy_process_group()
