@@ -216,7 +216,8 @@ class TorchCollective:
         dist.all_gather(table, counts)
         table = [t.tolist() for t in table]  # table[o][v]: rows owner o has on view v's screen
         R = engine.OWNER_RECORD_FLOATS
-        got_rows = {o: torch.empty(table[o][me], dtype=torch.int64, device=dev) for o in range(N)}
+        row_dtype = mine[me][0].dtype  # (the engine's: int32 on the device)
+        got_rows = {o: torch.empty(table[o][me], dtype=row_dtype, device=dev) for o in range(N)}
         got_rec = {o: torch.empty(table[o][me], R, dtype=torch.float32, device=dev) for o in range(N)}
         got_rows[me], got_rec[me] = mine[me]
         ops, sent = [], 0
@@ -225,7 +226,7 @@ class TorchCollective:
                 continue
             if table[me][o] > 0:  # my rows on view o's screen -> rank o
                 ops += [dist.P2POp(dist.isend, mine[o][0], o), dist.P2POp(dist.isend, mine[o][1], o)]
-                sent += table[me][o] * (4 + 4 * R)
+                sent += table[me][o] * (mine[o][0].element_size() + 4 * R)
             if table[o][me] > 0:
                 ops += [dist.P2POp(dist.irecv, got_rows[o], o), dist.P2POp(dist.irecv, got_rec[o], o)]
         if ops:
@@ -323,7 +324,7 @@ class HipEngine:
         if getattr(self, "_slots_done", True):
             self._slots, self._slots_done = {}, False
         rows, recs = self.r.owner_project(self._owner_slot(cam), cam, span[0], span[1], keep_state=True)
-        return rows.to(dtype=__import__("torch").int64), recs
+        return rows, recs
 
     def owner_render(self, cam, rows, recs, dL_dimg, bg=(0.0, 0.0, 0.0)):
         import torch
@@ -333,7 +334,7 @@ class HipEngine:
         g2d = torch.zeros(int(rows.shape[0]), self.OWNER_GRAD_FLOATS, device=recs.device, dtype=torch.float32)
         if rows.numel() == 0:
             return g2d
-        self.r.owner_render(cam, rows.to(torch.int32).contiguous(), recs.contiguous(), self._img, bg=bg, keep_state=True)
+        self.r.owner_render(cam, rows.contiguous(), recs.contiguous(), self._img, bg=bg, keep_state=True)
         self.r.owner_render_backward(dL_dimg, g2d)
         return g2d
 
