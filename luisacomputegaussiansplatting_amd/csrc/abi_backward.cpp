@@ -110,6 +110,10 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
         set_last_error("lcgs_render_backward needs a preceding lcgs_render_forward(..., keep_state = 1)");
         return LCGS_ERR_STATE;
     }
+    if (ctx->owner_recs) { // the last frame was lcgs_owner_render's: its records are not this context's own
+        set_last_error("the last frame was drawn from received records (lcgs_owner_render): use lcgs_owner_render_backward");
+        return LCGS_ERR_STATE;
+    }
     LCGS_REQUIRE((reinterpret_cast<uintptr_t>(grads->d_dL_drotq) & 15) == 0, "dL_drotq must be 16-byte aligned");
     hipStream_t  st   = ctx->stream;
     const size_t P    = (size_t)ctx->P;

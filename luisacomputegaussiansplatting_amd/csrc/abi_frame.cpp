@@ -283,6 +283,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
     LCGS_REQUIRE(ctx->pos != nullptr, "no scene bound (call lcgs_scene_bind / lcgs_scene_upload first)");
     CamParams cp      = make_cam_params(*camera);
     cp.lod_min_radius = ctx->lod_min_radius;
+    ctx->owner_recs   = nullptr; // (an ordinary frame: its backward is lcgs_render_backward again)
     uint32_t        earlier_truncated = 0; // asynchronous frames before this one that overflowed the pair workspace
     for (int attempt = 0; attempt < 4; ++attempt) {
         LCGS_TRY(ensure_fused_workspace(ctx, cp, keep_state != 0));

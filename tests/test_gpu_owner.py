@@ -177,3 +177,31 @@ def test_owner_step_of_the_package_on_the_hip_engine(lcgs):
             assert float((d > 0.05).float().mean()) < 0.01, (k, float(d.max()))
     finally:
         dist.destroy_process_group()
+
+
+def test_the_two_backward_entry_points_do_not_mix(lcgs):
+    rng = np.random.default_rng(1)
+    scene = make_scene(rng, 5000)
+    act = upload_scene(scene)
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.bind_scene(*[act[k] for k in KEYS])
+    cam = lcgs.get_lookat_cam(*POSE, width=W, height=H)
+    img = torch.zeros(3, H, W, device=DEV)
+    dL = torch.ones(3, H, W, device=DEV)
+    g = {k: torch.zeros_like(act[k]) for k in KEYS}
+    g2d = torch.zeros(5000, r.OWNER_GRAD_FLOATS, device=DEV)
+    with pytest.raises(lcgs.LcgsError) as e:  # no owner frame yet
+        r.owner_render_backward(dL, g2d)
+    assert e.value.status == 8  # LCGS_ERR_STATE
+    rows, recs = r.owner_project(0, cam, 0, 5000)
+    r.owner_render(cam, rows, recs, img, keep_state=True)
+    with pytest.raises(lcgs.LcgsError):  # a frame drawn from received records is not differentiated by the ordinary call
+        r.backward(dL, *[g[k] for k in KEYS])
+    r.owner_render_backward(dL, g2d[:rows.shape[0]])
+    r.forward(cam, img, keep_state=True, sync=True)  # an ordinary frame again: the ordinary backward again
+    r.backward(dL, *[g[k] for k in KEYS])
+    with pytest.raises(lcgs.LcgsError):
+        r.owner_render_backward(dL, g2d)
+    with pytest.raises(lcgs.LcgsError):  # rows outside the scene
+        r.owner_project(1, cam, 4000, 2000)
+    r.ctx.synchronize()
