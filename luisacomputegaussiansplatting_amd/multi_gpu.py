@@ -210,7 +210,7 @@ class TorchCollective:
         span = owner_range(P, N, me)
         dev = grads["pos"].device
         # ---- 1. my rows, every view: on-screen rows + their 2-D inputs
-        mine = [engine.owner_records(cams[v], span) for v in range(N)]  # [(rows int64 [n], rec f32 [n, R])]
+        mine = [engine.owner_records(cams[v], span, slot=v) for v in range(N)]  # [(rows [n], rec f32 [n, R])]
         counts = torch.tensor([int(m[0].numel()) for m in mine], dtype=torch.int64, device=dev)
         table = [torch.empty_like(counts) for _ in range(N)]
         dist.all_gather(table, counts)
@@ -257,7 +257,7 @@ class TorchCollective:
                 w.wait()
         # ---- 3. my rows: 2-D gradients of every view -> parameter gradients (summed in view order) -> Adam
         for v in range(N):
-            engine.owner_backward(cams[v], span, mine[v][0], g_in[v], grads, accumulate=v > 0)
+            engine.owner_backward(cams[v], span, mine[v][0], g_in[v], grads, accumulate=v > 0, slot=v)
         engine.adam(grads, step, rows=span)
         self.last_stats = {"bytes_sent": sent, "on_screen_rows_received": int(rows_all.numel())}
 
@@ -313,18 +313,9 @@ class HipEngine:
     # ---- splat ownership on the device: the frame in two halves (csrc/abi_owner.cpp)
     OWNER_RECORD_FLOATS, OWNER_GRAD_FLOATS = 12, 12
 
-    def _owner_slot(self, cam):
-        """the step's views get one slot each, in the order the protocol projects them (reset by the first backward)"""
-        key = id(cam)
-        if key not in self._slots:
-            self._slots[key] = len(self._slots)
-        return self._slots[key]
-
-    def owner_records(self, cam, span):
-        if getattr(self, "_slots_done", True):
-            self._slots, self._slots_done = {}, False
-        rows, recs = self.r.owner_project(self._owner_slot(cam), cam, span[0], span[1], keep_state=True)
-        return rows, recs
+    def owner_records(self, cam, span, slot: int = 0):
+        """slot: the view's index inside the step (its state is kept there until owner_backward(slot=...))"""
+        return self.r.owner_project(slot, cam, span[0], span[1], keep_state=True)
 
     def owner_render(self, cam, rows, recs, dL_dimg, bg=(0.0, 0.0, 0.0)):
         import torch
@@ -338,9 +329,8 @@ class HipEngine:
         self.r.owner_render_backward(dL_dimg, g2d)
         return g2d
 
-    def owner_backward(self, cam, span, rows, g2d, grads: dict, accumulate: bool = False):
-        self._slots_done = True  # (the next owner_records starts a new step)
-        self.r.owner_backward(self._slots[id(cam)], g2d.contiguous(), *[grads[k] for k in KEYS], accumulate=accumulate)
+    def owner_backward(self, cam, span, rows, g2d, grads: dict, accumulate: bool = False, slot: int = 0):
+        self.r.owner_backward(slot, g2d.contiguous(), *[grads[k] for k in KEYS], accumulate=accumulate)
 
     def adam_sharded(self, comm: "api.Comm", grads: dict, step: int):
         comm.adam_step_sharded(grads, self.raw, self.m, self.v, self.activated, step, self.lr, self.betas, self.eps)

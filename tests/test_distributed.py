@@ -127,7 +127,7 @@ class OracleEngine:
         _, _, tiles, rad = self.o.allocate_tiles(W, H, d, m, c2)
         return s, m, d, c2, tiles, rad
 
-    def owner_records(self, cam, span):
+    def owner_records(self, cam, span, slot=0):
         import torch
 
         _, ocam = cam
@@ -157,7 +157,7 @@ class OracleEngine:
         gm, gc, go, gcol = self.o.render_backward(W, H, bg, rng, vs, mp, conic, op, color, fT, nc, self.dL_of_view(view))
         return torch.from_numpy(np.concatenate([gm, gc, go[:, None], gcol], axis=1).astype(np.float32))
 
-    def owner_backward(self, cam, span, rows, g2d, grads, accumulate=False):
+    def owner_backward(self, cam, span, rows, g2d, grads, accumulate=False, slot=0):
         import torch
 
         _, ocam = cam
