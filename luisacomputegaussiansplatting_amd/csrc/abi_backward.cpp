@@ -148,8 +148,7 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
         LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dopacity, 0, P * 4, zs));
     }
     if (overlap) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
-    if (ctx->g2d_zeroed && !ctx->profiling) { // cleared during the forward (first backward of this frame only)
-        LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_g2d_zero, 0));
+    if (ctx->g2d_zeroed && !ctx->profiling) { // cleared by the forward's renderer (first backward of this frame only)
         ctx->g2d_zeroed = false;
     } else {
         LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)P)));

@@ -176,12 +176,10 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
                          keep_state ? ctx->shjac.as<float4>() : nullptr);
     ctx->last_has_jac = keep_state && build_records_writes_jacobian(ctx->sh_deg, ctx->sh, ctx->use_half_sh);
     if (overlap && !part) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+    // keep_state frames: the 2-D gradient rows the backward adds to are cleared by the RENDERER as a side job (render.hip):
+    // no launch on the auxiliary stream, no cross-stream wait in front of the render-backward
     ctx->g2d_zeroed = false;
-    if (deferred && keep_state) { // behind the records, beside the sort chain and the renderer
-        launch_zero_grads2d(d_counts, ctx->grads2d.as<float>(), rec_stream, ctx->bwd_counter.as<uint32_t>());
-        LCGS_HIP_CHECK(hipEventRecord(ctx->ev_g2d_zero, rec_stream));
-        ctx->g2d_zeroed = true;
-    }
+    const bool g2d_in_render = deferred && keep_state;
     LCGS_TRY(mark(ctx, "build_records"));
 
     // stable partition by tile id: only ceil(log2 G) key bits are live.  The kernel that writes the pairs also leaves
@@ -243,7 +241,9 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
                               keep_state ? ctx->final_T.as<float>() : nullptr,
                               keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, d_fp, order_now, part ? rst : st,
                               keep_state ? ctx->strip_masks.as<uint8_t>() : nullptr, deferred ? ctx->ev_render : nullptr,
-                              ctx->work_counters, persist_wgs);
+                              ctx->work_counters, persist_wgs, g2d_in_render ? ctx->grads2d.as<float>() : nullptr,
+                              g2d_in_render ? ctx->bwd_counter.as<uint32_t>() : nullptr);
+    ctx->g2d_zeroed = g2d_in_render; // (consumed by the first backward of this frame; same stream: no event)
     ctx->last_tile_order = order_now;
     LCGS_TRY(mark(ctx, "render"));
     if (part) LCGS_HIP_CHECK(hipStreamWaitEvent(vis, ctx->ev_render, 0)); // the caller's stream sees the finished frame

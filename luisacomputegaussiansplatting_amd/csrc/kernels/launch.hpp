@@ -204,7 +204,10 @@ void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uin
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,
                                const uint32_t* tile_order, hipStream_t stream, uint8_t* strip_masks = nullptr,
-                               hipEvent_t done = nullptr, uint32_t* work_counter = nullptr, uint32_t persistent_wgs = 0);
+                               hipEvent_t done = nullptr, uint32_t* work_counter = nullptr, uint32_t persistent_wgs = 0,
+                               // frames that keep backward state: the renderer also clears the 2-D gradient rows
+                               // (12 floats x d_counts[0]) and the backward's counter block as a side job
+                               float* g2d_zero = nullptr, uint32_t* bwd_counters = nullptr);
 // work_counter + persistent_wgs: a bounded grid of persistent_wgs workgroups that pull tiles from *work_counter (which
 // must be zero when the kernel starts) instead of one workgroup per tile -- caps the wave slots the renderer holds
 // strip_masks[list position] = the four per-strip reach bits of that entry (written when final_T / n_contrib are

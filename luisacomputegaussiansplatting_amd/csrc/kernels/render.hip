@@ -83,7 +83,9 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                                                             const uint32_t* __restrict__ d_counts,
                                                             const uint32_t* __restrict__ tile_order,
                                                             uint8_t* __restrict__ strip_masks,
-                                                            uint32_t* __restrict__ work_counter)
+                                                            uint32_t* __restrict__ work_counter,
+                                                            float4* __restrict__ g2d_zero,
+                                                            uint32_t* __restrict__ bwd_counters)
 {
     // one 16-byte row per entry in each of three slabs: a single address register serves all three reads
     // s_rows[0]: mean.x, mean.y, -conic.x / 2, -conic.z / 2;  [1]: conic.y, power floor (-t/2), -, - (with [0], all the cull
@@ -110,6 +112,16 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         slot = s_slot;
     }
     if (slot >= slots) return; // persistent grids: the exit every workgroup reaches
+    if (KEEP && g2d_zero) {
+        // A side job of frames that keep backward state: slot s clears its share of the 2-D gradient rows the render-backward
+        // will add to (12 floats per on-screen splat) -- stores into a memory system this VALU-bound kernel leaves idle,
+        // instead of a separate launch on the auxiliary stream and a cross-stream wait (~10 us) in front of the backward.
+        const uint32_t n4  = d_counts[0] * 3u; // float4s
+        const uint32_t per = (n4 + slots - 1u) / slots;
+        const uint32_t beg = slot * per, end = beg + per < n4 ? beg + per : n4;
+        for (uint32_t i = beg + tid; i < end; i += 256u) g2d_zero[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (slot == 0u && tid < 32u && bwd_counters) bwd_counters[tid] = 0u; // (see k_zero_grads2d)
+    }
     uint32_t tx, ty;
     if (tile_order) { // scheduling hint only: which workgroup takes which tile never changes the image
         const uint32_t t = tile_order[slot];
@@ -335,7 +347,7 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
                    Fetch fetch, float* img, float* final_T, uint32_t* n_contrib, const uint32_t* d_counts,
                    const FrameParams* d_fp, const uint32_t* tile_order, hipStream_t stream,
                    uint8_t* strip_masks = nullptr, hipEvent_t done = nullptr, uint32_t* work_counter = nullptr,
-                   uint32_t persistent_wgs = 0)
+                   uint32_t persistent_wgs = 0, float* g2d_zero = nullptr, uint32_t* bwd_counters = nullptr)
 {
     if (cp.grid_x * cp.grid_y == 0) return;
     const uint32_t full = render_grid_size(cp.grid_x, cp.grid_y);
@@ -344,7 +356,7 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
 #define LCGS_LAUNCH_RENDER(KEEP_, PERSIST_, GRID_)                                                                          \
     hipExtLaunchKernelGGL((k_render_forward_b<Fetch, KEEP_, PERSIST_>), dim3(GRID_), dim3(256), 0, stream, nullptr, done, 0, cp, \
                           bg[0], bg[1], bg[2], d_fp, ranges, point_list, fetch, img, final_T, n_contrib, d_counts, tile_order, \
-                          KEEP_ ? strip_masks : (uint8_t*)nullptr, work_counter)
+                          KEEP_ ? strip_masks : (uint8_t*)nullptr, work_counter, reinterpret_cast<float4*>(g2d_zero), bwd_counters)
     if (work_counter && persistent_wgs > 0 && persistent_wgs < full) { // a bounded grid that pulls tiles from the counter
         if (keep) LCGS_LAUNCH_RENDER(true, true, persistent_wgs);
         else LCGS_LAUNCH_RENDER(false, true, persistent_wgs);
@@ -384,10 +396,10 @@ void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uin
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,
                                const uint32_t* tile_order, hipStream_t stream, uint8_t* strip_masks, hipEvent_t done,
-                               uint32_t* work_counter, uint32_t persistent_wgs)
+                               uint32_t* work_counter, uint32_t persistent_wgs, float* g2d_zero, uint32_t* bwd_counters)
 {
     launch_render(cp, bg, ranges, point_list, FetchRec{ recs }, img, final_T, n_contrib, d_counts, d_fp, tile_order,
-                  stream, strip_masks, done, work_counter, persistent_wgs);
+                  stream, strip_masks, done, work_counter, persistent_wgs, g2d_zero, bwd_counters);
 }
 
 // the forward renderer fills strip_masks whenever it keeps backward state
