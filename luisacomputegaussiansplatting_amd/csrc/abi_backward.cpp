@@ -124,8 +124,35 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
     // is pure HBM writes and independent of the render-backward: it runs on the auxiliary stream beside it.
     // (Compact rows: every row that exists is written by the preprocess-backward, nothing to clear.)
     // accumulate: the arrays hold the sum of earlier views of the batch -- no fill, the rows are added to
-    const bool  overlap = !ctx->profiling && !compact && !accumulate;
+    // Round 4: the fill is a SIDE JOB of the render-backward kernel (backward.hip, DenseFill) -- its workgroups clear their
+    // share of the five arrays with fire-and-forget stores before they turn to their tile -- instead of 0.33 ms of memset
+    // kernels on the auxiliary stream, which cost the VALU-bound kernel beside them 0.13 ms of wave slots.
+    // (LCGS_BWD_FILL=aux keeps the memsets: the A/B hook; per-stage profiling keeps them too, in order, as "zero_grads".)
+    static const bool fill_on_aux = [] { const char* e = getenv("LCGS_BWD_FILL"); return e && e[0] == 'a'; }();
+    const bool  dense_fill = !compact && !accumulate;
+    const bool  fill_in_kernel = dense_fill && !ctx->profiling && !fill_on_aux;
+    const bool  overlap = !ctx->profiling && dense_fill && !fill_in_kernel;
     hipStream_t zs      = overlap ? ctx->aux_stream : st;
+    DenseFill   fill;
+    if (fill_in_kernel) {
+        // the 16-byte-aligned interior of every array goes to the kernel; an unaligned head / tail (never with torch's or
+        // hipMalloc's allocations) is cleared here
+        float*       base[5]  = { grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh, grads->d_dL_dopacity };
+        const size_t bytes[5] = { P * 3 * 4, P * 3 * 4, P * 4 * 4, P * feat * 4, P * 4 };
+        float4**     dst[5]   = { &fill.p0, &fill.p1, &fill.p2, &fill.p3, &fill.p4 };
+        for (int a = 0; a < 5; ++a) {
+            const uintptr_t b0 = reinterpret_cast<uintptr_t>(base[a]), b1 = b0 + bytes[a];
+            const uintptr_t a0 = std::min((b0 + 15) & ~(uintptr_t)15, b1), a1 = std::max(b1 & ~(uintptr_t)15, a0);
+            if (a0 > b0) LCGS_HIP_CHECK(hipMemsetAsync(base[a], 0, a0 - b0, st));
+            if (b1 > a1) LCGS_HIP_CHECK(hipMemsetAsync(reinterpret_cast<void*>(a1), 0, b1 - a1, st));
+            *dst[a]    = reinterpret_cast<float4*>(a0);
+            fill.n4[a] = (uint32_t)((a1 - a0) / 16);
+        }
+        if (fill.n4[3] == 0) { // (a scene too small to have an aligned interior in the SH array: plain memsets)
+            for (int a = 0; a < 5; ++a) LCGS_HIP_CHECK(hipMemsetAsync(base[a], 0, bytes[a], st));
+            fill = DenseFill{};
+        }
+    }
     if (overlap) {
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
@@ -140,7 +167,7 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
         launch_slice_bounds(ctx->vis_index.as<uint32_t>(), ctx->counts.as<uint32_t>(), (int64_t)P, ctx->grad_slices,
                             ctx->slice_bounds.as<uint32_t>(), zs); // (before the fill: ev_join / stream order covers it)
     }
-    if (!compact && !accumulate) {
+    if (dense_fill && !fill_in_kernel) {
         LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dpos, 0, P * 3 * 4, zs));
         LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_dscale, 0, P * 3 * 4, zs));
         LCGS_HIP_CHECK(hipMemsetAsync(grads->d_dL_drotq, 0, P * 4 * 4, zs));
@@ -164,7 +191,7 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
                            ctx->recs.as<SplatRecord>(), ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(),
                            d_dL_dimg, ctx->grads2d.as<float>(), ctx->last_tile_order, st,
                            render_forward_writes_strip_masks() ? ctx->strip_masks.as<uint8_t>() : nullptr,
-                           ctx->counts.as<uint32_t>(), ctx->bwd_counter.as<uint32_t>(), bwd_wgs);
+                           ctx->counts.as<uint32_t>(), ctx->bwd_counter.as<uint32_t>(), bwd_wgs, fill_in_kernel ? &fill : nullptr);
     LCGS_TRY(mark(ctx, "render_backward"));
     if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     const int slices = fused ? 0 : (sliced ? ctx->grad_slices : 1);

@@ -240,11 +240,19 @@ void     launch_sparse_accumulate(float* const grads[5], int sh_degree, const fl
 size_t grads2d_bytes(int64_t V_cap);
 // (bwd_counter, when given, is zeroed too: the persistent render-backward's tile counter)
 void   launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t stream, uint32_t* bwd_counter = nullptr);
+// The dense gradient arrays' zero-fill as a side job of the render-backward: the 16-byte-aligned interiors of the five arrays
+// (pos, scale, rotq, sh, opacity) as float4 counts; n4[3] == 0: no fill.  (Plain members, not arrays: a dynamically indexed
+// kernel argument would live in scratch memory.)
+struct DenseFill {
+    float4 *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr;
+    uint32_t n4[5] = { 0, 0, 0, 0, 0 };
+};
 void   launch_render_backward(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                               const SplatRecord* recs, const float* final_T, const uint32_t* n_contrib,
                               const float* dL_dimg, float* grads2d, const uint32_t* tile_order, hipStream_t stream,
                               const uint8_t* strip_masks = nullptr, const uint32_t* d_counts = nullptr,
-                              uint32_t* work_counter = nullptr, uint32_t persistent_wgs = 0);
+                              uint32_t* work_counter = nullptr, uint32_t persistent_wgs = 0,
+                              const DenseFill* fill = nullptr);
 void   launch_preprocess_backward(int64_t v_hint, int sh_deg, const CamParams& cp, float scale_modifier, const float* pos,
                                   const float* scale, const float* rotq, const float* sh, const uint32_t* vis_index,
                                   const uint32_t* d_counts, const float* grads2d, float* dL_dpos, float* dL_dscale,
