@@ -126,32 +126,20 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
     // accumulate: the arrays hold the sum of earlier views of the batch -- no fill, the rows are added to
     // Round 4: the fill is a SIDE JOB of the render-backward kernel (backward.hip, DenseFill) -- its workgroups clear their
     // share of the five arrays with fire-and-forget stores before they turn to their tile -- instead of 0.33 ms of memset
-    // kernels on the auxiliary stream, which cost the VALU-bound kernel beside them 0.13 ms of wave slots.
+    // kernels on the auxiliary stream, a fork and a join: 1.741 -> 1.724 ms per step (most of what the fill costs the
+    // VALU-bound kernel is the memory system's either way).
     // (LCGS_BWD_FILL=aux keeps the memsets: the A/B hook; per-stage profiling keeps them too, in order, as "zero_grads".)
     static const bool fill_on_aux = [] { const char* e = getenv("LCGS_BWD_FILL"); return e && e[0] == 'a'; }();
     const bool  dense_fill = !compact && !accumulate;
-    const bool  fill_in_kernel = dense_fill && !ctx->profiling && !fill_on_aux;
+    const bool  fill_in_kernel = dense_fill && !ctx->profiling && !fill_on_aux && P * feat < ((size_t)1 << 32); // (u32 lengths)
     const bool  overlap = !ctx->profiling && dense_fill && !fill_in_kernel;
     hipStream_t zs      = overlap ? ctx->aux_stream : st;
     DenseFill   fill;
     if (fill_in_kernel) {
-        // the 16-byte-aligned interior of every array goes to the kernel; an unaligned head / tail (never with torch's or
-        // hipMalloc's allocations) is cleared here
-        float*       base[5]  = { grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh, grads->d_dL_dopacity };
-        const size_t bytes[5] = { P * 3 * 4, P * 3 * 4, P * 4 * 4, P * feat * 4, P * 4 };
-        float4**     dst[5]   = { &fill.p0, &fill.p1, &fill.p2, &fill.p3, &fill.p4 };
-        for (int a = 0; a < 5; ++a) {
-            const uintptr_t b0 = reinterpret_cast<uintptr_t>(base[a]), b1 = b0 + bytes[a];
-            const uintptr_t a0 = std::min((b0 + 15) & ~(uintptr_t)15, b1), a1 = std::max(b1 & ~(uintptr_t)15, a0);
-            if (a0 > b0) LCGS_HIP_CHECK(hipMemsetAsync(base[a], 0, a0 - b0, st));
-            if (b1 > a1) LCGS_HIP_CHECK(hipMemsetAsync(reinterpret_cast<void*>(a1), 0, b1 - a1, st));
-            *dst[a]    = reinterpret_cast<float4*>(a0);
-            fill.n4[a] = (uint32_t)((a1 - a0) / 16);
-        }
-        if (fill.n4[3] == 0) { // (a scene too small to have an aligned interior in the SH array: plain memsets)
-            for (int a = 0; a < 5; ++a) LCGS_HIP_CHECK(hipMemsetAsync(base[a], 0, bytes[a], st));
-            fill = DenseFill{};
-        }
+        fill.b0 = grads->d_dL_dpos; fill.b1 = grads->d_dL_dscale; fill.b2 = grads->d_dL_drotq; fill.b3 = grads->d_dL_dsh;
+        fill.b4 = grads->d_dL_dopacity;
+        const size_t n[5] = { P * 3, P * 3, P * 4, P * feat, P };
+        for (int a = 0; a < 5; ++a) fill.n[a] = (uint32_t)n[a];
     }
     if (overlap) {
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));

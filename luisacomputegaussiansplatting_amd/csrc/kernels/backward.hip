@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
     // a frame that drew nothing left final_T / n_contrib untouched (the forward returns before writing them, like
     // gs_tile_splatter/impl.cpp:109): there is nothing to differentiate, and nothing valid to read
     const bool     nothing_drawn = d_counts && d_counts[1] == 0u;
-    if (nothing_drawn && fill.n4[3] == 0u) return;
+    if (nothing_drawn && fill.n[3] == 0u) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t slots = tile_order ? cp.grid_x * cp.grid_y : render_grid_size(cp.grid_x, cp.grid_y);
     uint32_t       slot  = blockIdx.x;
@@ -153,13 +153,25 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         slot = s_slot;
     }
     if (slot >= slots) return; // persistent grids: the exit every workgroup reaches
-    if (fill.n4[3] != 0u) { // (wave-uniform) the dense rows' zero-fill: this slot's share of each array
+    if (fill.n[3] != 0u) { // (wave-uniform) the dense rows' zero-fill: this slot's share of each array
         const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#define LCGS_FILL(A)                                                                          \
-    {                                                                                         \
-        const uint32_t n4 = fill.n4[A], per = (n4 + slots - 1u) / slots, beg = slot * per;    \
-        const uint32_t end = beg + per < n4 ? beg + per : n4;                                 \
-        for (uint32_t i = beg + tid; i < end; i += 256u) fill.p##A[i] = z;                    \
+        // per array: up to 3 floats in front of the first 16-byte boundary and behind the last one go to slot 0, the aligned
+        // interior is shared out as float4 stores
+#define LCGS_FILL(A)                                                                                     \
+    {                                                                                                    \
+        float*         base = fill.b##A;                                                                 \
+        const uint32_t n    = fill.n[A];                                                                 \
+        uint32_t       head = (uint32_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(base) & 15u)) & 15u) >> 2; \
+        head                = head < n ? head : n;                                                       \
+        const uint32_t n4 = (n - head) >> 2, tail = n - head - 4u * n4;                                   \
+        float4*        mid = reinterpret_cast<float4*>(base + head);                                     \
+        const uint32_t per = (n4 + slots - 1u) / slots, beg = slot * per;                                \
+        const uint32_t end = beg + per < n4 ? beg + per : n4;                                            \
+        for (uint32_t i = beg + tid; i < end; i += 256u) mid[i] = z;                                     \
+        if (slot == 0u) {                                                                                \
+            if (tid < head) base[tid] = 0.0f;                                                            \
+            if (tid < tail) base[head + 4u * n4 + tid] = 0.0f;                                           \
+        }                                                                                                \
     }
         LCGS_FILL(0) LCGS_FILL(1) LCGS_FILL(2) LCGS_FILL(3) LCGS_FILL(4)
 #undef LCGS_FILL

@@ -240,12 +240,12 @@ void     launch_sparse_accumulate(float* const grads[5], int sh_degree, const fl
 size_t grads2d_bytes(int64_t V_cap);
 // (bwd_counter, when given, is zeroed too: the persistent render-backward's tile counter)
 void   launch_zero_grads2d(const uint32_t* d_counts, float* grads2d, hipStream_t stream, uint32_t* bwd_counter = nullptr);
-// The dense gradient arrays' zero-fill as a side job of the render-backward: the 16-byte-aligned interiors of the five arrays
-// (pos, scale, rotq, sh, opacity) as float4 counts; n4[3] == 0: no fill.  (Plain members, not arrays: a dynamically indexed
-// kernel argument would live in scratch memory.)
+// The dense gradient arrays' zero-fill as a side job of the render-backward: the five arrays (pos, scale, rotq, sh, opacity)
+// and their lengths in floats; n[3] == 0: no fill.  (Plain pointer members: a dynamically indexed kernel argument would live in
+// scratch memory.)
 struct DenseFill {
-    float4 *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr;
-    uint32_t n4[5] = { 0, 0, 0, 0, 0 };
+    float *b0 = nullptr, *b1 = nullptr, *b2 = nullptr, *b3 = nullptr, *b4 = nullptr;
+    uint32_t n[5] = { 0, 0, 0, 0, 0 };
 };
 void   launch_render_backward(const CamParams& cp, const float bg[3], const uint32_t* ranges, const uint32_t* point_list,
                               const SplatRecord* recs, const float* final_T, const uint32_t* n_contrib,
