@@ -165,9 +165,7 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         head                = head < n ? head : n;                                                       \
         const uint32_t n4 = (n - head) >> 2, tail = n - head - 4u * n4;                                   \
         float4*        mid = reinterpret_cast<float4*>(base + head);                                     \
-        const uint32_t per = (n4 + slots - 1u) / slots, beg = slot * per;                                \
-        const uint32_t end = beg + per < n4 ? beg + per : n4;                                            \
-        for (uint32_t i = beg + tid; i < end; i += 256u) mid[i] = z;                                     \
+        for (uint32_t i = slot * 256u + tid; i < n4; i += slots * 256u) mid[i] = z; /* 4 KB per slot and step */ \
         if (slot == 0u) {                                                                                \
             if (tid < head) base[tid] = 0.0f;                                                            \
             if (tid < tail) base[head + 4u * n4 + tid] = 0.0f;                                           \

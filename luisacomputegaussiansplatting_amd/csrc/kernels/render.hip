@@ -116,10 +116,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         // A side job of frames that keep backward state: slot s clears its share of the 2-D gradient rows the render-backward
         // will add to (12 floats per on-screen splat) -- stores into a memory system this VALU-bound kernel leaves idle,
         // instead of a separate launch on the auxiliary stream and a cross-stream wait (~10 us) in front of the backward.
-        const uint32_t n4  = d_counts[0] * 3u; // float4s
-        const uint32_t per = (n4 + slots - 1u) / slots;
-        const uint32_t beg = slot * per, end = beg + per < n4 ? beg + per : n4;
-        for (uint32_t i = beg + tid; i < end; i += 256u) g2d_zero[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const uint32_t n4 = d_counts[0] * 3u; // float4s; the slots stride over them, 4 KB per slot and step
+        for (uint32_t i = slot * 256u + tid; i < n4; i += slots * 256u) g2d_zero[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (slot == 0u && tid < 32u && bwd_counters) bwd_counters[tid] = 0u; // (see k_zero_grads2d)
     }
     uint32_t tx, ty;
