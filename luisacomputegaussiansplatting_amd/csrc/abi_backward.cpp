@@ -77,6 +77,7 @@ lcgs_status lcgs_render_backward_adam(lcgs_context* ctx, const float* d_dL_dimg,
         c2.visible_only     = 2;
         return lcgs_adam_step(ctx, num_gaussians, sh_degree, &c2, &gr, raw, m, v, activated);
     }
+    scene_arrays_written(ctx, activated->pos, activated->scale, activated->rotq); // (a context-owned scene trained in place)
     auto      pack = [](const lcgs_params* p) { return AdamArrays{ p->pos, p->scale, p->rotq, p->sh, p->opacity }; };
     FusedAdam fa   = { pack(raw), pack(m), pack(v), pack(activated),
                        { cfg->lr_pos, cfg->lr_sh_dc, cfg->lr_sh_rest, cfg->lr_opacity, cfg->lr_scale, cfg->lr_rot },

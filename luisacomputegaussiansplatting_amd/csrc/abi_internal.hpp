@@ -39,6 +39,11 @@ lcgs_status check_camera(const lcgs_camera* cam);
 // abi_stages.cpp: deferred stage mode -- run a recorded SHProcessor::process / GSProjector::forward now
 lcgs_status run_deferred_sh(lcgs_context* ctx);
 lcgs_status run_deferred_proj(lcgs_context* ctx);
+// abi_scene.cpp: the cull pass's {position, extent bound} rows of a context-owned scene (context.hpp cull_bound)
+lcgs_status refresh_cull_bound(lcgs_context* ctx);
+// ... dropped when the library itself writes activated arrays that ARE the context's scene (optimiser steps): the frames
+// fall back to reading position + scale + rotation until the arrays are bound again
+void scene_arrays_written(lcgs_context* ctx, const float* pos, const float* scale, const float* rotq);
 // abi_frame.cpp
 lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool keep_state);
 lcgs_status prepare_twin(lcgs_context* ctx); // the sibling context of camera / view batches: created on first use, same scene

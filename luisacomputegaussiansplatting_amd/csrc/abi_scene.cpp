@@ -21,6 +21,43 @@
 using namespace lcgs;
 using namespace lcgs::abi;
 
+namespace lcgs
+{
+namespace abi
+{
+// The bound arrays are the context's own (lcgs_scene_upload / lcgs_scene_load_ply / lcgs_scene_reorder_spatial, or those
+// arrays bound again): (re)build the 16-byte {position, extent bound} rows the cull pass's phase 1 reads.  Caller-owned
+// arrays get none -- the library cannot know when they change.  LCGS_CULL_BOUND=0 switches it off (A/B hook).
+lcgs_status refresh_cull_bound(lcgs_context* ctx)
+{
+    static const bool enabled = [] {
+        const char* e = getenv("LCGS_CULL_BOUND");
+        return !(e && e[0] == '0');
+    }();
+    ctx->cull_bound = nullptr;
+    const bool own = ctx->P > 0 && ctx->pos == ctx->owned[0].as<float>() && ctx->scale == ctx->owned[1].as<float>() &&
+                     ctx->rotq == ctx->owned[2].as<float>();
+    if (!own || !enabled) return LCGS_OK;
+    LCGS_TRY(ctx->cull_bound_buf.ensure((size_t)ctx->P * sizeof(float4)));
+    launch_cull_bound(ctx->P, ctx->pos, ctx->scale, ctx->rotq, ctx->cull_bound_buf.as<float4>(), ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    ctx->cull_bound = ctx->cull_bound_buf.as<float4>();
+    return LCGS_OK;
+}
+
+void scene_arrays_written(lcgs_context* ctx, const float* pos, const float* scale, const float* rotq)
+{
+    for (lcgs_context* c = ctx; c; c = c->twin) {
+        if (!c->cull_bound || c->P <= 0) continue;
+        auto inside = [&](const float* p, const float* base, size_t floats) {
+            return p != nullptr && base != nullptr && p >= base && p < base + floats * (size_t)c->P;
+        };
+        if (inside(pos, c->pos, 3) || inside(scale, c->scale, 3) || inside(rotq, c->rotq, 4)) c->cull_bound = nullptr;
+    }
+}
+} // namespace abi
+} // namespace lcgs
+
 extern "C" {
 
 lcgs_status lcgs_scene_bind(lcgs_context* ctx, int num_gaussians, int sh_degree, const float* d_pos,
@@ -45,7 +82,7 @@ lcgs_status lcgs_scene_bind(lcgs_context* ctx, int num_gaussians, int sh_degree,
     ctx->perm_valid = ctx->perm_for_owned && num_gaussians > 0 && d_pos == ctx->owned[0].as<float>() &&
                       d_scale == ctx->owned[1].as<float>() && d_rotq == ctx->owned[2].as<float>() &&
                       d_sh == ctx->owned[3].as<float>() && d_opacity == ctx->owned[4].as<float>();
-    return LCGS_OK;
+    return refresh_cull_bound(ctx); // (the context's own arrays only; ordered on ctx->stream like the frames that read it)
 }
 
 lcgs_status lcgs_set_lod(lcgs_context* ctx, int min_radius_px)

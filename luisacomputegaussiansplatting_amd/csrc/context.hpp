@@ -38,6 +38,12 @@ struct lcgs_context {
     bool         perm_for_owned = false;  // scene_perm describes the current contents of owned[] (bound or not)
     DeviceBuffer sh_half;            // opt-in f16 copy of sh for the fused forward's colour pass (lcgs_scene_use_half_sh)
     bool         use_half_sh = false;
+    // {position, extent bound} rows of a scene the context OWNS (abi_scene.cpp refresh_cull_bound): the cull pass's phase 1
+    // reads these 16 bytes instead of 40 bytes of position + scale + rotation.  cull_bound is what frames use -- the
+    // context's own buffer, a sibling's borrowed pointer, or NULL (caller-bound arrays, or owned arrays the library has
+    // written since: lcgs_adam_step & co. drop it; binding the owned arrays again rebuilds it)
+    DeviceBuffer          cull_bound_buf;
+    const float4*         cull_bound = nullptr;
 
     // workspace of the fused frame
     DeviceBuffer cull_slab, chunk_info, chunk_base; // the cull pass's per-chunk output (fused_forward.hip k_cull_compact)
@@ -58,7 +64,7 @@ struct lcgs_context {
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey {
         const void *pos = nullptr, *scale = nullptr, *rotq = nullptr, *sh = nullptr, *opacity = nullptr, *sh_half = nullptr,
-                   *img = nullptr, *radii = nullptr;
+                   *img = nullptr, *radii = nullptr, *cull_bound = nullptr;
         int         P = -1, sh_deg = -1, width = 0, height = 0, keep_state = -1;
         int64_t     hint_V = -1, hint_L = -1;
         uint32_t    capacity = 0;
@@ -66,7 +72,7 @@ struct lcgs_context {
         bool        operator==(const GraphKey& o) const
         {
             return pos == o.pos && scale == o.scale && rotq == o.rotq && sh == o.sh && opacity == o.opacity &&
-                   sh_half == o.sh_half && img == o.img && radii == o.radii && P == o.P && sh_deg == o.sh_deg && width == o.width &&
+                   sh_half == o.sh_half && img == o.img && radii == o.radii && cull_bound == o.cull_bound && P == o.P && sh_deg == o.sh_deg && width == o.width &&
                    height == o.height && keep_state == o.keep_state && hint_V == o.hint_V && hint_L == o.hint_L &&
                    capacity == o.capacity && stream == o.stream;
         }

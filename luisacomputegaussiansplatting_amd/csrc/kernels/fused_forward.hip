@@ -23,6 +23,8 @@
 //   k_get_ranges_u32     per-tile [start,end) (gs_tile_splatter/shader.cpp:71-100).
 //
 // Element counts (V, L) never leave the device: kernels read them from d_counts.
+#include <algorithm>
+
 #include <hip/hip_fp16.h>
 
 #include <hip/hip_ext.h>
@@ -169,11 +171,12 @@ __device__ __forceinline__ ScreenBound make_screen_bound(const CamParams& cp)
     return b;
 }
 
-__device__ __forceinline__ bool may_reach_screen(const CamParams& cp, const ScreenBound& sb, float scale_modifier,
-                                                 const SplatIn& in)
+// (px, py, pz): the splat's position; g: an upper bound of sqrt(lambda_max(Sigma)) -- see splat_extent_bound
+__device__ __forceinline__ bool may_reach_screen(const CamParams& cp, const ScreenBound& sb, float px_, float py_, float pz_,
+                                                 float g)
 {
     float v[3], ndc[2];
-    view_transform(cp, in.px, in.py, in.pz, v);
+    view_transform(cp, px_, py_, pz_, v);
     if (v[2] < 0.2f) return false; // gs_projector/shader.cpp:121 (same expression as project_splat)
     ndc_from_view(cp, v, ndc);
     const float px = ndc2pix(ndc[0], cp.width), py = ndc2pix(ndc[1], cp.height); // bit-identical to phase 2
@@ -183,12 +186,7 @@ __device__ __forceinline__ bool may_reach_screen(const CamParams& cp, const Scre
     const float a = cp.focalx * iz, b = cp.focaly * iz;                   // |j00|, |j11|; |j02| = a cx, |j12| = b cy
     const float t0 = a * a * (sb.lr2 + cx * (cx * sb.lf2 + 2.0f * sb.drf)); // >= |T0|^2
     const float t1 = b * b * (sb.lu2 + cy * (cy * sb.lf2 + 2.0f * sb.duf)); // >= |T1|^2
-    // lambda_max(Sigma) = |R diag(s)|^2 <= (|R| s_max)^2, and R(q) = I + |q|^2 (R(q/|q|) - I): |R| <= |1 - n| + n
-    const float4 q  = in.q;
-    const float  n  = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
-    const float  sm = fabsf(scale_modifier) * fmaxf(fmaxf(fabsf(in.sx), fabsf(in.sy)), fabsf(in.sz));
-    const float  g  = (fabsf(1.0f - n) + n) * sm;
-    const float  tr = (t0 + t1) * (g * g) * 1.01f; // >= cov2d.xx + cov2d.yy, 1 % slack for the rounding of either side
+    const float tr = (t0 + t1) * (g * g) * 1.01f; // >= cov2d.xx + cov2d.yy, 1 % slack for the rounding of either side
     // filtered: mid = tr/2 + 0.3, det >= 0  =>  lambda1 = mid + sqrt(max(0.1, mid^2 - det)) <= 2 mid + 0.05
     const float rb = 3.0f * __builtin_amdgcn_sqrtf(tr + 0.65f) * 1.001f + 2.0f; // >= ceil(3 sqrt(lambda1)), + 1 px slack
     // get_rect: the rect is empty iff px + r < 1 or px - r >= 16 (grid_x - 1), likewise in y
@@ -199,21 +197,51 @@ __device__ __forceinline__ bool may_reach_screen(const CamParams& cp, const Scre
     return true;
 }
 
-template <bool RADII>
+// The camera-independent factor of the bound: lambda_max(Sigma) = |R diag(s)|^2 <= (|R| s_max)^2 with
+// R(q) = I + |q|^2 (R(q/|q|) - I), i.e. |R| <= |1 - n| + n for the stored, un-normalised quaternion (n = |q|^2).
+// Times |scale_modifier| it is the g of may_reach_screen.  A context-owned scene keeps it beside the position
+// (lcgs_context::cull_bound, 16 bytes a splat) so that phase 1 of the cull pass reads 16 instead of 40 bytes per splat.
+__device__ __forceinline__ float splat_extent_bound(float sx, float sy, float sz, const float4& q)
+{
+    const float n = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    return (fabsf(1.0f - n) + n) * fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz));
+}
+
+__device__ __forceinline__ bool may_reach_screen(const CamParams& cp, const ScreenBound& sb, float scale_modifier,
+                                                 const SplatIn& in)
+{
+    return may_reach_screen(cp, sb, in.px, in.py, in.pz, fabsf(scale_modifier) * splat_extent_bound(in.sx, in.sy, in.sz, in.q));
+}
+
+__global__ void __launch_bounds__(256) k_cull_bound(int64_t P, const float* __restrict__ pos, const float* __restrict__ scale,
+                                                      const float* __restrict__ rotq, float4* __restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
+        const SplatIn in = load_splat(i, pos, scale, rotq);
+        out[i]           = make_float4(in.px, in.py, in.pz, splat_extent_bound(in.sx, in.sy, in.sz, in.q));
+    }
+}
+
+// BOUND (context-owned scenes, lcgs_context::cull_bound): phase 1 reads ONE 16-byte {position, extent bound} row per splat
+// instead of the 40 bytes of position + scale + rotation in 28 loads per lane -- the pass was bound by that load pipeline,
+// not by arithmetic or bytes (REJECTED.md, "The frame's cull pass") -- and phase 2 fetches scale / rotation / opacity of
+// the candidates only (40 % of the stand-in's splats, in runs of consecutive rows); no LDS staging of inputs.
+template <bool RADII, bool BOUND>
 __global__ void __launch_bounds__(kCullThreads)
 k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __restrict__ fpp,
                const float* __restrict__ pos,
                const float* __restrict__ scale, const float* __restrict__ rotq, const float* __restrict__ opacity,
                int32_t* __restrict__ radii, uint4* __restrict__ slab, uint2* __restrict__ chunk_info,
-               uint32_t* __restrict__ counts0, uint32_t stride0, uint32_t mask0)
+               uint32_t* __restrict__ counts0, uint32_t stride0, uint32_t mask0, const float4* __restrict__ bound4)
 {
+    static_assert(!(RADII && BOUND), "the radii of off-screen splats need phase 2 on everything");
     __shared__ uint32_t s_wave_vis[kCullItems][kCullWaves];
     __shared__ uint32_t s_wave_tiles[kCullWaves];
     __shared__ uint32_t s_hist[256];
     __shared__ uint16_t s_cand[kCullChunk]; // chunk-local indices of the phase-1 survivors, in index order
     // the first kCullStaged candidates' inputs (10 floats each, one array per component: conflict-free) so that
     // phase 2 does not fetch them a second time; later candidates (rare: a chunk averages 820) are read again
-    __shared__ float s_in[RADII ? 1 : 10][RADII ? 1 : kCullStaged];
+    __shared__ float s_in[(RADII || BOUND) ? 1 : 10][(RADII || BOUND) ? 1 : kCullStaged];
 
     if (fpp) { // graph replay: per-call parameters come from device memory
         cp             = fpp->cp;
@@ -235,15 +263,19 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
         const ScreenBound sb = make_screen_bound(cp);
         uint32_t          rank[kCullItems], cmask = 0;
         SplatIn           in[kCullItems]; // all 28 loads of the lane's four splats are issued before the first test
+        float4            pb[kCullItems]; // BOUND: four loads
 #pragma unroll
         for (int k = 0; k < kCullItems; ++k) {
             const int64_t idx = base + (int64_t)k * kCullThreads + tid;
-            in[k]             = load_splat(idx < P ? idx : (int64_t)P - 1, pos, scale, rotq);
+            if (BOUND) pb[k] = bound4[idx < P ? idx : (int64_t)P - 1];
+            else in[k] = load_splat(idx < P ? idx : (int64_t)P - 1, pos, scale, rotq);
         }
+        const float am = fabsf(scale_modifier);
 #pragma unroll
         for (int k = 0; k < kCullItems; ++k) {
             const int64_t idx = base + (int64_t)k * kCullThreads + tid;
-            const bool    c   = idx < P && may_reach_screen(cp, sb, scale_modifier, in[k]);
+            const bool    c   = idx < P && (BOUND ? may_reach_screen(cp, sb, pb[k].x, pb[k].y, pb[k].z, am * pb[k].w)
+                                                  : may_reach_screen(cp, sb, scale_modifier, in[k]));
             const unsigned long long m = __ballot(c);
             rank[k] = __popcll(m & ((1ull << lane) - 1ull));
             if (c) cmask |= 1u << k;
@@ -258,7 +290,7 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
                 if (w == wave && ((cmask >> k) & 1u)) {
                     const uint32_t slot = run + rank[k];
                     s_cand[slot]        = (uint16_t)(k * kCullThreads + tid);
-                    if (slot < (uint32_t)kCullStaged) {
+                    if (!BOUND && slot < (uint32_t)kCullStaged) {
                         s_in[0][slot] = in[k].px; s_in[1][slot] = in[k].py; s_in[2][slot] = in[k].pz;
                         s_in[3][slot] = in[k].sx; s_in[4][slot] = in[k].sy; s_in[5][slot] = in[k].sz;
                         s_in[6][slot] = in[k].q.x; s_in[7][slot] = in[k].q.y; s_in[8][slot] = in[k].q.z;
@@ -292,7 +324,12 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
                 const int64_t idx = base + (int64_t)s_cand[c];
                 gidx[k]           = (uint32_t)idx;
                 SplatIn in;
-                if (!RADII && k * kCullThreads < kCullStaged) { // (static per round: rounds 0 and 1 come from LDS)
+                if (BOUND) { // position from the bound row (the same bits), the rest from the scene's arrays
+                    const float4 p4 = bound4[idx];
+                    in.px = p4.x; in.py = p4.y; in.pz = p4.z;
+                    in.sx = scale[3 * (size_t)idx + 0]; in.sy = scale[3 * (size_t)idx + 1]; in.sz = scale[3 * (size_t)idx + 2];
+                    in.q  = *reinterpret_cast<const float4*>(rotq + 4 * (size_t)idx);
+                } else if (!RADII && k * kCullThreads < kCullStaged) { // (static per round: rounds 0 and 1 come from LDS)
                     in.px = s_in[0][c]; in.py = s_in[1][c]; in.pz = s_in[2][c];
                     in.sx = s_in[3][c]; in.sy = s_in[4][c]; in.sz = s_in[5][c];
                     in.q  = make_float4(s_in[6][c], s_in[7][c], s_in[8][c], s_in[9][c]);
@@ -828,18 +865,30 @@ void launch_set_frame_params(const FrameParams& fp, FrameParams* d_fp, hipStream
     hipLaunchKernelGGL(k_set_frame_params, dim3(1), dim3(1), 0, stream, fp, d_fp);
 }
 
+void launch_cull_bound(int64_t P, const float* pos, const float* scale, const float* rotq, float4* out, hipStream_t stream)
+{
+    if (P <= 0) return;
+    const int64_t blocks = (P + 255) / 256;
+    hipLaunchKernelGGL(k_cull_bound, dim3((unsigned)std::min<int64_t>(blocks, 16384)), dim3(256), 0, stream, P, pos, scale, rotq,
+                       out);
+}
+
 void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const FrameParams* d_fp, const float* pos,
                          const float* scale, const float* rotq, const float* opacity, int32_t* radii, uint4* slab,
-                         uint2* chunk_info, const DepthSortFirstPass& first, hipStream_t stream)
+                         uint2* chunk_info, const DepthSortFirstPass& first, hipStream_t stream, const float4* bound4)
 {
     if (radii)
-        hipLaunchKernelGGL(k_cull_compact<true>, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, P, cp, scale_modifier,
-                           d_fp, pos, scale, rotq, opacity, radii, slab, chunk_info, first.counts, first.row_stride,
-                           first.mask);
+        hipLaunchKernelGGL((k_cull_compact<true, false>), dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, P, cp,
+                           scale_modifier, d_fp, pos, scale, rotq, opacity, radii, slab, chunk_info, first.counts,
+                           first.row_stride, first.mask, nullptr);
+    else if (bound4)
+        hipLaunchKernelGGL((k_cull_compact<false, true>), dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, P, cp,
+                           scale_modifier, d_fp, pos, scale, rotq, opacity, radii, slab, chunk_info, first.counts,
+                           first.row_stride, first.mask, bound4);
     else
-        hipLaunchKernelGGL(k_cull_compact<false>, dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, P, cp, scale_modifier,
-                           d_fp, pos, scale, rotq, opacity, radii, slab, chunk_info, first.counts, first.row_stride,
-                           first.mask);
+        hipLaunchKernelGGL((k_cull_compact<false, false>), dim3(chunks_for(P)), dim3(kCullThreads), 0, stream, P, cp,
+                           scale_modifier, d_fp, pos, scale, rotq, opacity, radii, slab, chunk_info, first.counts,
+                           first.row_stride, first.mask, nullptr);
 }
 
 void launch_build_records(int P_cap, int sh_deg, const CamParams& cp, float scale_modifier, const FrameParams* d_fp,

@@ -95,3 +95,116 @@ def test_screen_bound_with_extreme_values(lcgs):
     assert a[0] == b[0] and a[1]["num_pairs"] == b[1]["num_pairs"] and a[1]["num_visible"] == b[1]["num_visible"]
     assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
     assert torch.equal(a[2].nan_to_num(7.0), b[2].nan_to_num(7.0))
+
+
+# ---- round 4: a scene the CONTEXT owns keeps {position, extent bound} rows (16 bytes a splat) and phase 1 reads those
+# instead of position + scale + rotation; arrays bound by the caller take the full-input path.  Same frame, bit for bit.
+def _owned_and_bound(lcgs, scene):
+    own = lcgs.Renderer(lcgs.Context(0))
+    own.upload_scene(scene, order="file")  # context-owned, the given order: rows line up with the caller-bound renderer's
+    d = upload_scene(scene)
+    ref = lcgs.Renderer(lcgs.Context(0))
+    ref.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    ref.P = own.P
+    return own, ref, d
+
+
+@pytest.mark.parametrize("seed,res,scale_modifier,skew", [(11, (640, 360), 1.0, False), (12, (333, 517), 2.5, False),
+                                                         (13, (1920, 1080), 0.4, True), (14, (97, 61), -6.0, True)])
+def test_bound_rows_equal_full_inputs(lcgs, seed, res, scale_modifier, skew):
+    rng = np.random.default_rng(seed)
+    P = 120_000 + seed  # (a ragged last chunk)
+    scene = _edge_scene(rng, P)
+    own, ref, _ = _owned_and_bound(lcgs, scene)
+    W, H = res
+    for ang in (0.0, 1.1, 2.7):
+        cam = lcgs.get_lookat_cam([-4.0 * np.cos(ang), 4.0 * np.sin(ang), 1.0], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+        if skew:
+            cam = _skewed(lcgs, cam)
+        a = _lists(lcgs, own, cam, W, H, False, scale_modifier)   # bound rows
+        b = _lists(lcgs, ref, cam, W, H, False, scale_modifier)   # position + scale + rotation
+        c = _lists(lcgs, own, cam, W, H, True, scale_modifier)    # radii asked for: phase 2 on everything
+        for x in (b, c):
+            assert a[0] == x[0] and a[1]["num_pairs"] == x[1]["num_pairs"] and a[1]["num_visible"] == x[1]["num_visible"]
+            assert torch.equal(a[3], x[3]) and torch.equal(a[4], x[4]) and torch.equal(a[2], x[2])
+        assert a[0] > 0 and a[1]["num_visible"] < P
+
+
+def test_bound_rows_with_extreme_values_and_in_a_batch(lcgs):
+    rng = np.random.default_rng(19)
+    P = 20_000
+    scene = _edge_scene(rng, P)
+    scene["scale"][0:50] = 1e18
+    scene["scale"][50:100] = 1e-30
+    scene["pos"][100:150] *= 1e6
+    scene["rotq"][150:200] *= 1e10
+    scene["rotq"][200:220] = 0.0
+    scene["pos"][220:230] = np.nan
+    scene["scale"][230:240] = np.inf
+    scene["rotq"][240:250] = np.nan
+    scene["scale"][250:260, 1] = np.nan
+    own, ref, _ = _owned_and_bound(lcgs, scene)
+    W, H = 512, 288
+    cam = lcgs.get_lookat_cam([-4.0, 0.0, 1.0], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+    for sm in (1.0, 0.0, 3.0):
+        a = _lists(lcgs, own, cam, W, H, False, sm)
+        b = _lists(lcgs, ref, cam, W, H, False, sm)
+        assert a[0] == b[0] and a[1]["num_pairs"] == b[1]["num_pairs"] and a[1]["num_visible"] == b[1]["num_visible"]
+        assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+        assert torch.equal(a[2].nan_to_num(7.0), b[2].nan_to_num(7.0))
+    # the camera-batch sibling borrows the rows
+    cam2 = lcgs.get_lookat_cam([0.0, -4.0, 1.5], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+    pair = [torch.zeros(3, H, W, device=DEV) for _ in range(4)]
+    own.forward_batch([cam, cam2, cam, cam2], pair)
+    own.ctx.synchronize()
+    for cam_k, img_k in zip([cam, cam2], pair[:2]):
+        one = torch.zeros(3, H, W, device=DEV)
+        ref.forward(cam_k, one, sync=True)
+        assert torch.equal(one.nan_to_num(7.0), img_k.nan_to_num(7.0))
+    assert torch.equal(pair[0].nan_to_num(7.0), pair[2].nan_to_num(7.0)) and torch.equal(pair[1].nan_to_num(7.0), pair[3].nan_to_num(7.0))
+
+
+def test_bound_rows_follow_the_scene(lcgs):
+    """The rows are derived data: an optimiser step on the context's own arrays drops them (frames read the arrays again),
+    binding the arrays again rebuilds them, a spatial re-order rebuilds them in the new order."""
+    rng = np.random.default_rng(21)
+    P = 60_000
+    scene = make_scene(rng, P, spread=2.0)
+    W, H = 400, 300
+    cam = lcgs.get_lookat_cam([-4.0, 0.5, 1.0], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+    own, ref, d = _owned_and_bound(lcgs, scene)
+    keys = ("pos", "scale", "rotq", "sh", "opacity")
+    act = own.scene_tensors()
+
+    def same_frame():
+        a, b = torch.zeros(3, H, W, device=DEV), torch.zeros(3, H, W, device=DEV)
+        na, nb = own.forward(cam, a, sync=True), ref.forward(cam, b, sync=True)
+        assert na == nb > 0 and torch.equal(a, b)
+        return a
+
+    first = same_frame()
+    # 1. Adam in place on the context's arrays (and the same step on the caller-bound copy): positions and scales move
+    grads = {k: torch.from_numpy(rng.normal(size=tuple(act[k].shape)).astype(np.float32)).to(DEV) for k in keys}
+    lr = {"pos": 0.05, "sh_dc": 0.0, "sh_rest": 0.0, "opacity": 0.0, "scale": 0.2, "rot": 0.05}
+    for r_, arr in ((own, act), (ref, d)):
+        raw = {"pos": arr["pos"], "scale": torch.log(arr["scale"]), "rotq": arr["rotq"].clone(), "sh": arr["sh"],
+               "opacity": torch.log(arr["opacity"] / (1 - arr["opacity"]))}
+        m = {k: torch.zeros_like(raw[k]) for k in keys}
+        v = {k: torch.zeros_like(raw[k]) for k in keys}
+        r_.adam_step(grads, raw, m, v, arr, 1, lr)
+    moved = same_frame()
+    assert not torch.equal(moved, first)
+    # 2. the arrays bound again: rows rebuilt from the moved scene
+    own.bind_scene(*[act[k] for k in keys])
+    assert torch.equal(same_frame(), moved)
+    # 3. written behind the library's back, then bound again (the documented way to say "the scene changed")
+    act["pos"][: P // 2] += 0.3
+    d["pos"][: P // 2] += 0.3
+    own.bind_scene(*[act[k] for k in keys])
+    assert not torch.equal(same_frame(), moved)
+    # 4. a spatial re-order: new arrays, new rows; the image does not change
+    before = same_frame()
+    own.reorder_scene_spatial()
+    after = torch.zeros(3, H, W, device=DEV)
+    own.forward(cam, after, sync=True)
+    assert torch.equal(after, before)
