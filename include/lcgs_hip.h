@@ -207,7 +207,12 @@ LCGS_API lcgs_status lcgs_set_ingest_order(lcgs_context* ctx, int order);
 /* *d_perm: context-owned device array, (*d_perm)[r] = file index of splat r; NULL while the scene is in file / caller order.
  * Valid until the next call that binds, loads or re-orders a scene. */
 LCGS_API lcgs_status lcgs_scene_permutation(lcgs_context* ctx, const uint32_t** d_perm);
-/* Device pointers of the bound scene (any of the outputs may be NULL). */
+/* Device pointers of the bound scene (any of the outputs may be NULL).  The arrays of a scene the CONTEXT owns are read-only
+ * through these pointers: the context keeps data derived from them (the permutation; 16-byte {position, extent bound} rows
+ * that let the frame's cull pass read 16 instead of 40 bytes per splat).  The library's own writers (lcgs_adam_step & co.
+ * with these arrays as `activated`) drop the derived rows by themselves; after changing the arrays any other way, bind them
+ * again (lcgs_scene_bind with the same pointers), which rebuilds the rows.  Caller-owned arrays (lcgs_scene_bind of anything
+ * else) carry no derived data and may change between frames freely. */
 LCGS_API lcgs_status lcgs_scene_pointers(lcgs_context* ctx, int* num_gaussians, int* sh_degree, const float** d_pos,
                                          const float** d_scale, const float** d_rotq, const float** d_sh,
                                          const float** d_opacity);

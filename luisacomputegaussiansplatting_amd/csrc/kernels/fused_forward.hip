@@ -225,7 +225,9 @@ __global__ void __launch_bounds__(256) k_cull_bound(int64_t P, const float* __re
 // BOUND (context-owned scenes, lcgs_context::cull_bound): phase 1 reads ONE 16-byte {position, extent bound} row per splat
 // instead of the 40 bytes of position + scale + rotation in 28 loads per lane -- the pass was bound by that load pipeline,
 // not by arithmetic or bytes (REJECTED.md, "The frame's cull pass") -- and phase 2 fetches scale / rotation / opacity of
-// the candidates only (40 % of the stand-in's splats, in runs of consecutive rows); no LDS staging of inputs.
+// the candidates only (40 % of the stand-in's splats, in runs of consecutive rows); only positions are staged in LDS.
+// (A bounded grid of workgroups striding over the chunks with the next chunk's rows requested ahead -- the "persistent,
+// software-pipelined cull" of earlier rounds' to-do lists -- was built on this form and measured SLOWER: REJECTED.md.)
 template <bool RADII, bool BOUND>
 __global__ void __launch_bounds__(kCullThreads)
 k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __restrict__ fpp,
@@ -242,6 +244,7 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
     // the first kCullStaged candidates' inputs (10 floats each, one array per component: conflict-free) so that
     // phase 2 does not fetch them a second time; later candidates (rare: a chunk averages 820) are read again
     __shared__ float s_in[(RADII || BOUND) ? 1 : 10][(RADII || BOUND) ? 1 : kCullStaged];
+    __shared__ float s_pos[BOUND ? 3 : 1][BOUND ? kCullStaged : 1]; // BOUND: only the positions travel through LDS
 
     if (fpp) { // graph replay: per-call parameters come from device memory
         cp             = fpp->cp;
@@ -290,6 +293,9 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
                 if (w == wave && ((cmask >> k) & 1u)) {
                     const uint32_t slot = run + rank[k];
                     s_cand[slot]        = (uint16_t)(k * kCullThreads + tid);
+                    if (BOUND && slot < (uint32_t)kCullStaged) {
+                        s_pos[0][slot] = pb[k].x; s_pos[1][slot] = pb[k].y; s_pos[2][slot] = pb[k].z;
+                    }
                     if (!BOUND && slot < (uint32_t)kCullStaged) {
                         s_in[0][slot] = in[k].px; s_in[1][slot] = in[k].py; s_in[2][slot] = in[k].pz;
                         s_in[3][slot] = in[k].sx; s_in[4][slot] = in[k].sy; s_in[5][slot] = in[k].sz;
@@ -324,9 +330,13 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
                 const int64_t idx = base + (int64_t)s_cand[c];
                 gidx[k]           = (uint32_t)idx;
                 SplatIn in;
-                if (BOUND) { // position from the bound row (the same bits), the rest from the scene's arrays
-                    const float4 p4 = bound4[idx];
-                    in.px = p4.x; in.py = p4.y; in.pz = p4.z;
+                if (BOUND) { // position from phase 1, the rest from the scene's arrays
+                    if (k * kCullThreads < kCullStaged) { // (static per round)
+                        in.px = s_pos[0][c]; in.py = s_pos[1][c]; in.pz = s_pos[2][c];
+                    } else { // (rare: a chunk averages 820 candidates) the same bits from the row
+                        const float4 p4 = bound4[idx];
+                        in.px = p4.x; in.py = p4.y; in.pz = p4.z;
+                    }
                     in.sx = scale[3 * (size_t)idx + 0]; in.sy = scale[3 * (size_t)idx + 1]; in.sz = scale[3 * (size_t)idx + 2];
                     in.q  = *reinterpret_cast<const float4*>(rotq + 4 * (size_t)idx);
                 } else if (!RADII && k * kCullThreads < kCullStaged) { // (static per round: rounds 0 and 1 come from LDS)
