@@ -459,7 +459,9 @@ def main():
     V, Lref, Lp, G = stats["num_visible"], stats["num_rendered"], stats["num_pairs"], stats["num_tiles"]
     # Algorithmic bytes per launch of each stage = per-unit figure x units
     stage_bytes = {
-        "cull_compact": 40 * P + 4 * V + 16 * V,  # pos/scale/rotq of every splat, opacity of the candidates (~V), slab slots
+        # a context-owned scene (this one): one 16-byte {position, extent bound} row per splat, then scale / rotation / opacity
+        # of the candidates (~V), slab slots; caller-bound arrays (LCGS_CULL_BOUND=0: the A/B hook): pos/scale/rotq of every splat
+        "cull_compact": (16 * P + 32 * V + 16 * V) if os.environ.get("LCGS_CULL_BOUND", "1") != "0" else (40 * P + 4 * V + 16 * V),
         "build_records": (4 + 44 + 192) * V + 48 * V,
         # first pass from the 16-byte slab slots (+ dense index / rect writes), three 20-byte passes, and -- re-ordered
         # scenes -- the equal-depth pass (keys, about a third of the values)
