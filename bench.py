@@ -885,7 +885,7 @@ def main():
                             "xgmi_bytes_sent_per_gpu": st_o.get("bytes_sent"),
                             "on_screen_rows_rendered": st_o.get("on_screen_rows_received"),
                             "note": "splat ownership: 2-D records / 2-D gradients of on-screen rows travel, Adam on the own rows only, "
-                                    "no all-gather; N host synchronisations per step (row counts) in this first form"}
+                                    "no all-gather; one host synchronisation per step for the N row counts (lcgs_owner_counts) + one inside the view's frame"}
                     except Exception as e:  # noqa: BLE001
                         out.setdefault("leg_errors", {})["train_step.owner"] = f"{type(e).__name__}: {e}"[:400]
                 eng2.close()

@@ -488,7 +488,11 @@ LCGS_API lcgs_status lcgs_sparse_accumulate(lcgs_context* ctx, int sh_degree, co
 LCGS_API lcgs_status lcgs_owner_project(lcgs_context* ctx, int slot, const lcgs_camera* camera, float scale_modifier,
                                         int row_first, int row_count, int keep_state, uint32_t* d_rows /* [row_count] */,
                                         float* d_records /* [row_count x 12], 16-byte aligned */,
-                                        int* num_rows); /* rows written; synchronises */
+                                        int* num_rows); /* rows written; synchronises.  NULL: the call only enqueues --
+                                                         * the count stays on the device until lcgs_owner_counts */
+/* The row counts of slots [first_slot, first_slot + num_slots) with ONE synchronisation: an owner projects its rows for every
+ * view of a step (N asynchronous lcgs_owner_project calls, num_rows = NULL) and reads the N message sizes at once. */
+LCGS_API lcgs_status lcgs_owner_counts(lcgs_context* ctx, int first_slot, int num_slots, int* num_rows /* [num_slots] */);
 LCGS_API lcgs_status lcgs_owner_render(lcgs_context* ctx, const lcgs_camera* camera, const float bg_color[3], int num_rows,
                                        const uint32_t* d_rows, const float* d_records, float* d_img, int keep_state);
 LCGS_API lcgs_status lcgs_owner_render_backward(lcgs_context* ctx, const float* d_dL_dimg, float* d_grads2d);

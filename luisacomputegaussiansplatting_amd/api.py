@@ -147,7 +147,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_set_lod", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_set_transport", "lcgs_comm_shard_rows",
     "lcgs_grads_allreduce", "lcgs_adam_step_sharded", "lcgs_comm_track_touched_rows", "lcgs_comm_get_stats",
     "lcgs_adam_step_sparse", "lcgs_sparse_touched_rows", "lcgs_sparse_message_words", "lcgs_sparse_pack",
-    "lcgs_sparse_accumulate", "lcgs_owner_project", "lcgs_owner_render", "lcgs_owner_render_backward", "lcgs_owner_backward",
+    "lcgs_sparse_accumulate", "lcgs_owner_project", "lcgs_owner_counts", "lcgs_owner_render", "lcgs_owner_render_backward", "lcgs_owner_backward",
 ]
 
 
@@ -601,6 +601,25 @@ class Renderer:
         out_rows, out_recs = out_rows[:n.value], out_recs[:n.value]
         self._generation += 1
         return out_rows, out_recs
+
+    def owner_project_all(self, cams, row_first: int, row_count: int, keep_state: bool = True, scale_modifier: float = 1.0):
+        """The same for every view of a step -- view v into slot v -- with ONE synchronisation: N asynchronous
+        lcgs_owner_project calls (num_rows = NULL), then lcgs_owner_counts.  -> [(rows, records)] per view."""
+        import torch
+
+        dev = torch.device("cuda", self.ctx.device_id)
+        lib, outs = load_library(), []
+        for v, cam in enumerate(cams):
+            out_rows = torch.empty(max(row_count, 1), dtype=torch.int32, device=dev)
+            out_recs = torch.empty(max(row_count, 1), self.OWNER_RECORD_FLOATS, dtype=torch.float32, device=dev)
+            _check(lib.lcgs_owner_project(self.ctx._h, C.c_int(v), C.byref(cam), C.c_float(scale_modifier), C.c_int(row_first),
+                                          C.c_int(row_count), C.c_int(1 if keep_state else 0), _ptr(out_rows), _ptr(out_recs),
+                                          None))
+            outs.append((out_rows, out_recs))
+        counts = (C.c_int * len(outs))()
+        _check(lib.lcgs_owner_counts(self.ctx._h, C.c_int(0), C.c_int(len(outs)), counts))
+        self._generation += 1
+        return [(r[:counts[v]], q[:counts[v]]) for v, (r, q) in enumerate(outs)]
 
     def owner_render(self, cam: "Camera", rows, recs, img, bg=(0.0, 0.0, 0.0), keep_state: bool = True):
         """lcgs_owner_render: the rest of the frame from received records (ascending global rows)"""

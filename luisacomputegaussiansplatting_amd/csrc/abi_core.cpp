@@ -296,6 +296,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
     for (hipEvent_t ev : ctx->ev_slice)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    if (ctx->h_owner_counts) (void)hipHostFree(ctx->h_owner_counts);
     if (ctx->events_created)
         for (auto& ev : ctx->events) (void)hipEventDestroy(ev);
     delete ctx;

@@ -34,13 +34,13 @@ extern "C" {
 lcgs_status lcgs_owner_project(lcgs_context* ctx, int slot, const lcgs_camera* camera, float scale_modifier, int row_first,
                                int row_count, int keep_state, uint32_t* d_rows, float* d_records, int* num_rows)
 {
-    LCGS_REQUIRE(ctx && num_rows, "NULL argument");
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
     LCGS_REQUIRE(row_count == 0 || (d_rows && d_records), "NULL output buffer");
     LCGS_REQUIRE((reinterpret_cast<uintptr_t>(d_records) & 15) == 0, "records must be 16-byte aligned");
     LCGS_REQUIRE(slot >= 0 && slot < LCGS_MAX_OWNER_VIEWS, "slot out of range");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     LCGS_TRY(check_camera(camera));
-    *num_rows = 0;
+    if (num_rows) *num_rows = 0;
     LCGS_REQUIRE(ctx->pos != nullptr && ctx->P > 0, "no scene bound");
     LCGS_REQUIRE(row_first >= 0 && row_count >= 0 && (int64_t)row_first + row_count <= ctx->P, "row range outside the scene");
     auto& s = ctx->owner[slot];
@@ -78,15 +78,37 @@ lcgs_status lcgs_owner_project(lcgs_context* ctx, int slot, const lcgs_camera* c
     s.has_jac = keep_state && build_records_writes_jacobian(ctx->sh_deg, r.sh, false);
     launch_rows_global(s.vis.as<uint32_t>(), dc, (uint32_t)row_first, d_rows, row_count, st);
     LCGS_HIP_CHECK(hipGetLastError());
-    uint32_t h = 0;
-    LCGS_HIP_CHECK(hipMemcpyAsync(&h, dc, 4, hipMemcpyDeviceToHost, st));
-    LCGS_HIP_CHECK(hipStreamSynchronize(st));
     s.valid          = true;
     s.cp             = cp;
     s.scale_modifier = scale_modifier;
-    s.num            = (int)h;
+    s.num            = -1; // (on the device until read back)
     ctx->last.valid  = false; // (the context's own frame state was overwritten)
-    *num_rows        = (int)h;
+    if (!num_rows) return LCGS_OK; // asynchronous: lcgs_owner_counts reads the count (with the other views' counts)
+    return lcgs_owner_counts(ctx, slot, 1, num_rows);
+}
+
+lcgs_status lcgs_owner_counts(lcgs_context* ctx, int first_slot, int num_slots, int* num_rows)
+{
+    LCGS_REQUIRE(ctx && num_rows, "NULL argument");
+    LCGS_REQUIRE(first_slot >= 0 && num_slots >= 0 && first_slot + num_slots <= LCGS_MAX_OWNER_VIEWS, "slots out of range");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->h_owner_counts)
+        LCGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_owner_counts), LCGS_MAX_OWNER_VIEWS * 4, hipHostMallocDefault));
+    bool pending = false;
+    for (int k = 0; k < num_slots; ++k) {
+        auto& s = ctx->owner[first_slot + k];
+        ctx->h_owner_counts[first_slot + k] = 0;
+        if (s.valid && s.row_count > 0 && s.num < 0) {
+            LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_owner_counts + first_slot + k, s.counts.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
+            pending = true;
+        }
+    }
+    if (pending) LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < num_slots; ++k) {
+        auto& s = ctx->owner[first_slot + k];
+        if (s.valid && s.row_count > 0 && s.num < 0) s.num = (int)ctx->h_owner_counts[first_slot + k];
+        num_rows[k] = (s.valid && s.row_count > 0) ? s.num : 0;
+    }
     return LCGS_OK;
 }
 
@@ -238,6 +260,10 @@ lcgs_status lcgs_owner_backward(lcgs_context* ctx, int slot, const float* d_grad
         LCGS_HIP_CHECK(hipMemsetAsync(gq, 0, c * 4 * 4, st));
         LCGS_HIP_CHECK(hipMemsetAsync(gsh, 0, c * feat * 4, st));
         LCGS_HIP_CHECK(hipMemsetAsync(go, 0, c * 4, st));
+    }
+    if (s.num < 0) {
+        set_last_error("the slot's row count is still on the device: call lcgs_owner_counts after an asynchronous lcgs_owner_project");
+        return LCGS_ERR_STATE;
     }
     if (s.num == 0) return LCGS_OK;
     LCGS_REQUIRE(d_grads2d != nullptr, "NULL 2-D gradients");

@@ -178,6 +178,7 @@ struct lcgs_context {
         int          row_first = 0, row_count = 0, num = 0;
         DeviceBuffer vis, shjac, counts;
     } owner[LCGS_MAX_OWNER_VIEWS];
+    uint32_t*                h_owner_counts = nullptr; // pinned, LCGS_MAX_OWNER_VIEWS words (lcgs_owner_counts)
     const lcgs::SplatRecord* owner_recs = nullptr;
     int                      owner_rows = 0;
 

@@ -210,7 +210,10 @@ class TorchCollective:
         span = owner_range(P, N, me)
         dev = grads["pos"].device
         # ---- 1. my rows, every view: on-screen rows + their 2-D inputs
-        mine = [engine.owner_records(cams[v], span, slot=v) for v in range(N)]  # [(rows [n], rec f32 [n, R])]
+        if hasattr(engine, "owner_records_all"):  # (the device engine: N asynchronous projections, one read-back of the counts)
+            mine = engine.owner_records_all(cams, span)
+        else:
+            mine = [engine.owner_records(cams[v], span, slot=v) for v in range(N)]  # [(rows [n], rec f32 [n, R])]
         counts = torch.tensor([int(m[0].numel()) for m in mine], dtype=torch.int64, device=dev)
         table = [torch.empty_like(counts) for _ in range(N)]
         dist.all_gather(table, counts)
@@ -316,6 +319,10 @@ class HipEngine:
     def owner_records(self, cam, span, slot: int = 0):
         """slot: the view's index inside the step (its state is kept there until owner_backward(slot=...))"""
         return self.r.owner_project(slot, cam, span[0], span[1], keep_state=True)
+
+    def owner_records_all(self, cams, span):
+        """every view of the step (view v -> slot v) with one host synchronisation (lcgs_owner_counts)"""
+        return self.r.owner_project_all(cams, span[0], span[1], keep_state=True)
 
     def owner_render(self, cam, rows, recs, dL_dimg, bg=(0.0, 0.0, 0.0)):
         import torch

@@ -205,3 +205,41 @@ def test_the_two_backward_entry_points_do_not_mix(lcgs):
     with pytest.raises(lcgs.LcgsError):  # rows outside the scene
         r.owner_project(1, cam, 4000, 2000)
     r.ctx.synchronize()
+
+
+def test_every_view_of_a_step_with_one_read_back(lcgs):
+    """owner_project_all: N asynchronous projections (view v -> slot v) + lcgs_owner_counts = the N synchronous calls; a slot
+    whose count is still on the device refuses the backward."""
+    rng = np.random.default_rng(77)
+    P = 30_000
+    scene = make_scene(rng, P, spread=2.0)
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.upload_scene(scene)  # context-owned: the cull pass of the range reads the bound rows
+    poses = [([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1]), ([0.5, -3.2, 1.5], [0, 0, 0.5], [0, 0, 1]),
+             ([60.0, 0.0, 1.0], [80.0, 0.0, 1.0], [0, 0, 1])]  # (the third looks away: nothing on screen)
+    cams = [lcgs.get_lookat_cam(*p, width=W, height=H) for p in poses]
+    first, count = 5_000, 20_000
+    one_by_one = [r.owner_project(v, cam, first, count) for v, cam in enumerate(cams)]
+    together = r.owner_project_all(cams, first, count)
+    assert len(together) == len(cams)
+    for (ra, qa), (rb, qb) in zip(one_by_one, together):
+        assert ra.shape == rb.shape and torch.equal(ra, rb) and torch.equal(qa, qb)
+    assert together[0][0].numel() > 0 and together[2][0].numel() == 0
+    # the backward of a slot needs its count on the host
+    import ctypes as C
+
+    import luisacomputegaussiansplatting_amd.api as api
+
+    lib = api.load_library()
+    rows = torch.empty(count, dtype=torch.int32, device=DEV)
+    recs = torch.empty(count, 12, dtype=torch.float32, device=DEV)
+    assert lib.lcgs_owner_project(r.ctx._h, C.c_int(0), C.byref(cams[0]), C.c_float(1.0), C.c_int(first), C.c_int(count),
+                                  C.c_int(1), api._ptr(rows), api._ptr(recs), None) == 0
+    g = {k: torch.zeros(P, *s, device=DEV) for k, s in (("pos", (3,)), ("scale", (3,)), ("rotq", (4,)), ("sh", (48,)), ("opacity", ()))}
+    g2d = torch.zeros(count, 12, device=DEV)
+    with pytest.raises(api.LcgsError):
+        r.owner_backward(0, g2d, *[g[k] for k in KEYS], accumulate=False)
+    n = (C.c_int * 1)()
+    assert lib.lcgs_owner_counts(r.ctx._h, C.c_int(0), C.c_int(1), n) == 0 and n[0] == together[0][0].numel()
+    r.owner_backward(0, g2d[:n[0]].contiguous(), *[g[k] for k in KEYS], accumulate=False)
+    r.ctx.synchronize()
