@@ -297,6 +297,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->h_owner_counts) (void)hipHostFree(ctx->h_owner_counts);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->events_created)
         for (auto& ev : ctx->events) (void)hipEventDestroy(ev);
     delete ctx;

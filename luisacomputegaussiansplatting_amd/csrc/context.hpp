@@ -125,6 +125,7 @@ struct lcgs_context {
     DeviceBuffer st_flags, st_u32[8], st_keys_exp, st_vals_exp; // the splatter's sort-before-duplicate (lcgs_tile_splat_forward)
     uint32_t     pair_capacity = 0;
     uint32_t*    h_counts      = nullptr; // pinned, 8 x u32
+    uint32_t*    h_stage       = nullptr; // pinned, 4 x u32: the stage-level splatter's one read-back (num_rendered & co.)
 
     // state of the last forward (for backward and stats)
     struct {
