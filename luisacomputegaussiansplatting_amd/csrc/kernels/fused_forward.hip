@@ -244,7 +244,7 @@ k_cull_compact(int P, CamParams cp, float scale_modifier, const FrameParams* __r
     // the first kCullStaged candidates' inputs (10 floats each, one array per component: conflict-free) so that
     // phase 2 does not fetch them a second time; later candidates (rare: a chunk averages 820) are read again
     __shared__ float s_in[(RADII || BOUND) ? 1 : 10][(RADII || BOUND) ? 1 : kCullStaged];
-    __shared__ float s_pos[BOUND ? 3 : 1][BOUND ? kCullStaged : 1]; // BOUND: only the positions travel through LDS
+    __shared__ float s_pos[3][BOUND ? kCullStaged : 1]; // BOUND: only the positions travel through LDS
 
     if (fpp) { // graph replay: per-call parameters come from device memory
         cp             = fpp->cp;
@@ -459,7 +459,11 @@ k_build_records(int sh_deg, CamParams cp, float scale_modifier, const FrameParam
             const uint32_t slot = c / 12u, part = c - slot * 12u;
             const int      sidx = __shfl(idx, (int)slot, 64);
             q[i]                = make_float4(0, 0, 0, 0);
-            if (slot < nvalid) q[i] = reinterpret_cast<const float4*>(sh + (size_t)sidx * 48)[part];
+            if (slot < nvalid) { // read once per frame: a streaming load (builder alone 0.133 -> 0.124 ms; the frame beside it unchanged)
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sh + (size_t)sidx * 48) + part);
+                q[i]        = make_float4(t.x, t.y, t.z, t.w);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
