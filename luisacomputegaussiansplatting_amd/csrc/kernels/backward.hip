@@ -154,7 +154,11 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
     }
     if (slot >= slots) return; // persistent grids: the exit every workgroup reaches
     if (fill.n[3] != 0u) { // (wave-uniform) the dense rows' zero-fill: this slot's share of each array
-        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        // (streaming stores: 1.45 GB that nothing reads before the preprocess pass overwrites 39 % of it -- together with
+        //  that pass's streaming row stores +2.2 % forward+backward in same-box A/B, profiles/r04_nt_accesses_ab.txt)
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f z = { 0.0f, 0.0f, 0.0f, 0.0f };
+#define LCGS_FILL_STORE(P) __builtin_nontemporal_store(z, reinterpret_cast<v4f*>(P))
         // per array: up to 3 floats in front of the first 16-byte boundary and behind the last one go to slot 0, the aligned
         // interior is shared out as float4 stores
 #define LCGS_FILL(A)                                                                                     \
@@ -165,7 +169,7 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         head                = head < n ? head : n;                                                       \
         const uint32_t n4 = (n - head) >> 2, tail = n - head - 4u * n4;                                   \
         float4*        mid = reinterpret_cast<float4*>(base + head);                                     \
-        for (uint32_t i = slot * 256u + tid; i < n4; i += slots * 256u) mid[i] = z; /* 4 KB per slot and step */ \
+        for (uint32_t i = slot * 256u + tid; i < n4; i += slots * 256u) LCGS_FILL_STORE(mid + i); /* 4 KB per slot and step */ \
         if (slot == 0u) {                                                                                \
             if (tid < head) base[tid] = 0.0f;                                                            \
             if (tid < tail) base[head + 4u * n4 + tid] = 0.0f;                                           \
@@ -173,6 +177,7 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
     }
         LCGS_FILL(0) LCGS_FILL(1) LCGS_FILL(2) LCGS_FILL(3) LCGS_FILL(4)
 #undef LCGS_FILL
+#undef LCGS_FILL_STORE
     }
     if (nothing_drawn) {
         if (PERSIST) continue;
@@ -800,7 +805,11 @@ k_preprocess_backward_jac(CamParams cp, float scale_modifier, const float* __res
                     const float4 o = *dst;
                     v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
                 }
-                *dst = make_float4(v[0], v[1], v[2], v[3]);
+                { // written once, read by the optimiser / the all-reduce a kernel later: a streaming store
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    v4f t = { v[0], v[1], v[2], v[3] };
+                    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(dst));
+                }
             }
         }
         __syncthreads(); // the slab is reused by the next iteration
