@@ -30,6 +30,7 @@
 #include <hip/hip_ext.h>
 
 #include "launch.hpp"
+#include "stream_access.hpp"
 #include "tie_order.hpp"
 
 namespace lcgs
@@ -459,11 +460,8 @@ k_build_records(int sh_deg, CamParams cp, float scale_modifier, const FrameParam
             const uint32_t slot = c / 12u, part = c - slot * 12u;
             const int      sidx = __shfl(idx, (int)slot, 64);
             q[i]                = make_float4(0, 0, 0, 0);
-            if (slot < nvalid) { // read once per frame: a streaming load (builder alone 0.133 -> 0.124 ms; the frame beside it unchanged)
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sh + (size_t)sidx * 48) + part);
-                q[i]        = make_float4(t.x, t.y, t.z, t.w);
-            }
+            // (read once per frame: a streaming load -- builder alone 0.133 -> 0.124 ms; the frame beside it unchanged)
+            if (slot < nvalid) q[i] = ld_stream(reinterpret_cast<const float4*>(sh + (size_t)sidx * 48) + part);
         }
 #pragma unroll
         for (int i = 0; i < 12; ++i) {

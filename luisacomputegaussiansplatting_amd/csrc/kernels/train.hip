@@ -14,6 +14,7 @@
 // list (the dense ids -> splat index map of the last forward) only the splats that reached the screen are updated
 // ("sparse Adam": their moments are the only ones that change; 2.5x fewer bytes on the bicycle stand-in).
 #include "launch.hpp"
+#include "stream_access.hpp"
 
 namespace lcgs
 {
@@ -22,20 +23,6 @@ namespace
 
 // Gradients and moments are touched once per step and are far larger than the caches: streaming (non-temporal) accesses
 // (dense step 1.95 -> 1.87 ms, 5.18 -> 5.42 TB/s in same-box A/B, profiles/r04_nt_accesses_ab.txt).
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld_stream(const float4* p)
-{
-    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
-    return make_float4(t.x, t.y, t.z, t.w);
-}
-__device__ __forceinline__ void st_stream(float4* p, const float4& x)
-{
-    v4f t = { x.x, x.y, x.z, x.w };
-    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
-}
-__device__ __forceinline__ float ld_stream(const float* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void  st_stream(float* p, float x) { __builtin_nontemporal_store(x, p); }
-
 // rows of ROW floats; columns below `split` use lr0, the others lr1 (SH: dc vs rest).  MODE 0 plain, 1 exp, 2 sigmoid.
 template <int ROW, int MODE>
 __global__ void __launch_bounds__(256) k_adam_rows(int64_t rows, const uint32_t* __restrict__ row_list,
