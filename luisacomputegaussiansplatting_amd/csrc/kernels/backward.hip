@@ -17,6 +17,7 @@
 // Thresholds are constants for the derivative: near cull, alpha < 1/255 skip, T < 1e-4 stop and power > 0 gate the
 // sums; the 0.99 alpha cap, the colour clamp and a saturated cam_clamp axis pass no gradient.
 #include "launch.hpp"
+#include "stream_access.hpp"
 #include "tile_common.hpp"
 
 namespace lcgs
@@ -805,11 +806,8 @@ k_preprocess_backward_jac(CamParams cp, float scale_modifier, const float* __res
                     const float4 o = *dst;
                     v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
                 }
-                { // written once, read by the optimiser / the all-reduce a kernel later: a streaming store
-                    typedef float v4f __attribute__((ext_vector_type(4)));
-                    v4f t = { v[0], v[1], v[2], v[3] };
-                    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(dst));
-                }
+                // written once, read by the optimiser / the all-reduce a kernel later: a streaming store
+                st_stream(dst, make_float4(v[0], v[1], v[2], v[3]));
             }
         }
         __syncthreads(); // the slab is reused by the next iteration
