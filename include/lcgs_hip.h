@@ -217,6 +217,17 @@ LCGS_API lcgs_status lcgs_scene_pointers(lcgs_context* ctx, int* num_gaussians, 
                                          const float** d_scale, const float** d_rotq, const float** d_sh,
                                          const float** d_opacity);
 
+/* Caller-owned arrays that do not change from frame to frame (a trained scene being viewed: the reference's own use,
+ * app/main.cpp:180-223 uploads once) can have the same derived rows as a context-owned scene: the three arrays are declared
+ * static, the context builds the 16-byte {position, extent bound} rows once (on its stream), and every fused frame whose
+ * position / scale / rotation arrays are EXACTLY these pointers (lcgs_render_forward after lcgs_scene_bind) and that asks for
+ * no radii culls from them (forward +2 %; a frame that returns the reference's radii array -- the stage operators in deferred
+ * mode do -- projects every splat anyway).  The declaration lasts until it is repeated (same
+ * pointers: "the contents changed"), withdrawn (num_gaussians = 0 or d_pos = NULL), or the library itself writes the arrays
+ * (lcgs_adam_step & co.).  Changing the arrays behind a standing declaration gives wrong frames. */
+LCGS_API lcgs_status lcgs_scene_declare_static(lcgs_context* ctx, int num_gaussians, const float* d_pos, const float* d_scale,
+                                               const float* d_rotq);
+
 /* Opt-in reduced-precision SH for the fused forward.  enable != 0 converts the bound degree-3
  * coefficients to an f16 copy owned by the context (on the device; call again after the coefficients change, and
  * after every lcgs_scene_bind); the per-frame colour pass then reads 96 instead of 192 bytes per on-screen splat.

@@ -147,7 +147,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_set_lod", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_set_transport", "lcgs_comm_shard_rows",
     "lcgs_grads_allreduce", "lcgs_adam_step_sharded", "lcgs_comm_track_touched_rows", "lcgs_comm_get_stats",
     "lcgs_adam_step_sparse", "lcgs_sparse_touched_rows", "lcgs_sparse_message_words", "lcgs_sparse_pack",
-    "lcgs_sparse_accumulate", "lcgs_owner_project", "lcgs_owner_counts", "lcgs_owner_render", "lcgs_owner_render_backward", "lcgs_owner_backward",
+    "lcgs_sparse_accumulate", "lcgs_scene_declare_static", "lcgs_owner_project", "lcgs_owner_counts", "lcgs_owner_render", "lcgs_owner_render_backward", "lcgs_owner_backward",
 ]
 
 
@@ -459,6 +459,16 @@ class Renderer:
         self._generation += 1
         _check(load_library().lcgs_scene_bind(self.ctx._h, C.c_int(P), C.c_int(sh_degree), _ptr(pos), _ptr(scale),
                                               _ptr(rotq), _ptr(sh), _ptr(opacity)))
+
+    def declare_static(self, pos=None, scale=None, rotq=None):
+        """lcgs_scene_declare_static: caller-owned arrays that do not change between frames get the cull pass's 16-byte
+        {position, extent bound} rows (what a context-owned scene has by itself).  No arguments: withdraw."""
+        if pos is None:
+            _check(load_library().lcgs_scene_declare_static(self.ctx._h, C.c_int(0), None, None, None))
+            return
+        self._static = [pos, scale, rotq]
+        _check(load_library().lcgs_scene_declare_static(self.ctx._h, C.c_int(int(pos.shape[0])), _ptr(pos), _ptr(scale),
+                                                        _ptr(rotq)))
 
     def reorder_scene_spatial(self):
         """lcgs_scene_reorder_spatial: the context re-orders its scene along a Morton curve and renders from its own

@@ -134,7 +134,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     ctx->work_counters   = reinterpret_cast<uint32_t*>(ctx->zero_ws[zb].as<char>() + ctx->zero_bytes - 256);
     const DepthSortFirstPass dfirst = depth_sort_first_pass(P, ctx->sort_ws.ptr);
     launch_cull_compact(P, cp, scale_modifier, d_fp, ctx->pos, ctx->scale, ctx->rotq, ctx->opacity, d_radii,
-                        ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(), dfirst, st, ctx->cull_bound);
+                        ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(), dfirst, st, ctx->cull_rows());
     LCGS_TRY(mark(ctx, "cull_compact"));
     const int64_t hint_V = ctx->hint_V > 0 ? ctx->hint_V : P;
     const int64_t hint_L = ctx->hint_L > 0 ? ctx->hint_L : ctx->pair_capacity;
@@ -298,7 +298,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
             lcgs_context::GraphKey key;
             key.pos = ctx->pos; key.scale = ctx->scale; key.rotq = ctx->rotq; key.sh = ctx->sh; key.opacity = ctx->opacity;
             key.sh_half = ctx->use_half_sh ? ctx->sh_half.ptr : nullptr; // (selects the kernel and its coefficient rows)
-            key.cull_bound = ctx->cull_bound; // (selects the cull kernel)
+            key.cull_bound = ctx->cull_rows(); // (selects the cull kernel)
             key.img = d_img; key.radii = d_radii; key.P = ctx->P; key.sh_deg = ctx->sh_deg;
             key.width = camera->width; key.height = camera->height; key.keep_state = keep_state != 0;
             key.hint_V = ctx->hint_V; key.hint_L = ctx->hint_L; key.capacity = ctx->pair_capacity; key.stream = ctx->stream;
@@ -439,6 +439,7 @@ lcgs_status prepare_twin(lcgs_context* ctx)
         t->use_half_sh    = false;
         t->lod_min_radius = ctx->lod_min_radius;
         t->cull_bound     = ctx->cull_bound; // (borrowed, like the permutation: built on ctx->stream before the fork below)
+        t->cull_key       = ctx->cull_key;
         // the sibling renders the same (possibly re-ordered) arrays: it borrows their permutation for the order of equal depths
         t->scene_perm.ptr   = ctx->scene_perm.ptr;
         t->scene_perm.bytes = 0;

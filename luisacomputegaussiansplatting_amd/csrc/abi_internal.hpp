@@ -41,6 +41,7 @@ lcgs_status run_deferred_sh(lcgs_context* ctx);
 lcgs_status run_deferred_proj(lcgs_context* ctx);
 // abi_scene.cpp: the cull pass's {position, extent bound} rows of a context-owned scene (context.hpp cull_bound)
 lcgs_status refresh_cull_bound(lcgs_context* ctx);
+lcgs_status build_cull_bound(lcgs_context* ctx, int P, const float* pos, const float* scale, const float* rotq);
 // ... dropped when the library itself writes activated arrays that ARE the context's scene (optimiser steps): the frames
 // fall back to reading position + scale + rotation until the arrays are bound again
 void scene_arrays_written(lcgs_context* ctx, const float* pos, const float* scale, const float* rotq);

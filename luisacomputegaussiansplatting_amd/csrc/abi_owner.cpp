@@ -67,7 +67,7 @@ lcgs_status lcgs_owner_project(lcgs_context* ctx, int slot, const lcgs_camera* c
     const DepthSortFirstPass dfirst = depth_sort_first_pass(row_count, ctx->sort_ws.ptr);
     launch_cull_compact(row_count, cp, scale_modifier, nullptr, r.pos, r.scale, r.rotq, r.opacity, nullptr,
                         ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(), dfirst, st,
-                        ctx->cull_bound ? ctx->cull_bound + row_first : nullptr); // (a context-owned scene's bound rows)
+                        ctx->cull_rows() ? ctx->cull_rows() + row_first : nullptr); // (the scene's bound rows, if it has them)
     launch_depth_sort_from_chunks(row_count, row_count, ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(),
                                   ctx->chunk_base.as<uint32_t>(), ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
                                   ctx->sortv[0].as<uint32_t>(), ctx->sortv[1].as<uint32_t>(), s.vis.as<uint32_t>(),

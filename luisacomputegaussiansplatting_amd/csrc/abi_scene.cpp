@@ -30,29 +30,41 @@ namespace abi
 // arrays get none -- the library cannot know when they change.  LCGS_CULL_BOUND=0 switches it off (A/B hook).
 lcgs_status refresh_cull_bound(lcgs_context* ctx)
 {
+    const bool own = ctx->P > 0 && ctx->pos == ctx->owned[0].as<float>() && ctx->scale == ctx->owned[1].as<float>() &&
+                     ctx->rotq == ctx->owned[2].as<float>();
+    if (!own) return LCGS_OK; // (rows of other arrays -- declared static -- stay: a frame uses them only for THOSE arrays)
+    return build_cull_bound(ctx, ctx->P, ctx->pos, ctx->scale, ctx->rotq);
+}
+
+// rows for the given arrays (on ctx->stream, like the frames that read them); LCGS_CULL_BOUND=0 switches them off (A/B hook)
+lcgs_status build_cull_bound(lcgs_context* ctx, int P, const float* pos, const float* scale, const float* rotq)
+{
     static const bool enabled = [] {
         const char* e = getenv("LCGS_CULL_BOUND");
         return !(e && e[0] == '0');
     }();
     ctx->cull_bound = nullptr;
-    const bool own = ctx->P > 0 && ctx->pos == ctx->owned[0].as<float>() && ctx->scale == ctx->owned[1].as<float>() &&
-                     ctx->rotq == ctx->owned[2].as<float>();
-    if (!own || !enabled) return LCGS_OK;
-    LCGS_TRY(ctx->cull_bound_buf.ensure((size_t)ctx->P * sizeof(float4)));
-    launch_cull_bound(ctx->P, ctx->pos, ctx->scale, ctx->rotq, ctx->cull_bound_buf.as<float4>(), ctx->stream);
+    ctx->cull_key   = {};
+    if (!enabled || P <= 0 || !pos || !scale || !rotq) return LCGS_OK;
+    LCGS_TRY(ctx->cull_bound_buf.ensure((size_t)P * sizeof(float4)));
+    launch_cull_bound(P, pos, scale, rotq, ctx->cull_bound_buf.as<float4>(), ctx->stream);
     LCGS_HIP_CHECK(hipGetLastError());
     ctx->cull_bound = ctx->cull_bound_buf.as<float4>();
+    ctx->cull_key   = { pos, scale, rotq, P };
     return LCGS_OK;
 }
 
 void scene_arrays_written(lcgs_context* ctx, const float* pos, const float* scale, const float* rotq)
 {
     for (lcgs_context* c = ctx; c; c = c->twin) {
-        if (!c->cull_bound || c->P <= 0) continue;
+        if (!c->cull_bound || c->cull_key.P <= 0) continue;
         auto inside = [&](const float* p, const float* base, size_t floats) {
-            return p != nullptr && base != nullptr && p >= base && p < base + floats * (size_t)c->P;
+            return p != nullptr && base != nullptr && p >= base && p < base + floats * (size_t)c->cull_key.P;
         };
-        if (inside(pos, c->pos, 3) || inside(scale, c->scale, 3) || inside(rotq, c->rotq, 4)) c->cull_bound = nullptr;
+        if (inside(pos, c->cull_key.pos, 3) || inside(scale, c->cull_key.scale, 3) || inside(rotq, c->cull_key.rotq, 4)) {
+            c->cull_bound = nullptr;
+            c->cull_key   = {};
+        }
     }
 }
 } // namespace abi
@@ -83,6 +95,22 @@ lcgs_status lcgs_scene_bind(lcgs_context* ctx, int num_gaussians, int sh_degree,
                       d_scale == ctx->owned[1].as<float>() && d_rotq == ctx->owned[2].as<float>() &&
                       d_sh == ctx->owned[3].as<float>() && d_opacity == ctx->owned[4].as<float>();
     return refresh_cull_bound(ctx); // (the context's own arrays only; ordered on ctx->stream like the frames that read it)
+}
+
+lcgs_status lcgs_scene_declare_static(lcgs_context* ctx, int num_gaussians, const float* d_pos, const float* d_scale,
+                                      const float* d_rotq)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(num_gaussians >= 0 && num_gaussians < (1 << 30), "num_gaussians out of range");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (num_gaussians == 0 || !d_pos) { // withdraw the declaration
+        ctx->cull_bound = nullptr;
+        ctx->cull_key   = {};
+        return refresh_cull_bound(ctx); // (a context-owned scene that is bound keeps its own rows)
+    }
+    LCGS_REQUIRE(d_scale && d_rotq, "NULL device pointer");
+    LCGS_REQUIRE((reinterpret_cast<uintptr_t>(d_rotq) & 15) == 0, "rotq must be 16-byte aligned");
+    return build_cull_bound(ctx, num_gaussians, d_pos, d_scale, d_rotq);
 }
 
 lcgs_status lcgs_set_lod(lcgs_context* ctx, int min_radius_px)

@@ -44,6 +44,18 @@ struct lcgs_context {
     // written since: lcgs_adam_step & co. drop it; binding the owned arrays again rebuilds it)
     DeviceBuffer          cull_bound_buf;
     const float4*         cull_bound = nullptr;
+    // ... valid for exactly these arrays (the context's own, or caller arrays declared static: lcgs_scene_declare_static);
+    // a frame uses the rows only when its position / scale / rotation arrays are these (cull_rows())
+    struct {
+        const float *pos = nullptr, *scale = nullptr, *rotq = nullptr;
+        int          P = 0;
+    } cull_key;
+    const float4* cull_rows() const
+    {
+        return (cull_bound && pos == cull_key.pos && scale == cull_key.scale && rotq == cull_key.rotq && P == cull_key.P)
+                   ? cull_bound
+                   : nullptr;
+    }
 
     // workspace of the fused frame
     DeviceBuffer cull_slab, chunk_info, chunk_base; // the cull pass's per-chunk output (fused_forward.hip k_cull_compact)

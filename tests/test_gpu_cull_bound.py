@@ -208,3 +208,64 @@ def test_bound_rows_follow_the_scene(lcgs):
     after = torch.zeros(3, H, W, device=DEV)
     own.forward(cam, after, sync=True)
     assert torch.equal(after, before)
+
+
+def test_declared_static_arrays_of_the_caller(lcgs):
+    """lcgs_scene_declare_static: caller-bound arrays get the rows on request; the frames (fused; the three stage operators in
+    deferred mode beside a standing declaration) stay the full-input frames bit for bit; the declaration is keyed to the pointers, repeated after a change,
+    and dropped by the library's own writers."""
+    rng = np.random.default_rng(31)
+    P = 90_001
+    scene = _edge_scene(rng, P)
+    d = upload_scene(scene)
+    W, H = 640, 360
+    cam = lcgs.get_lookat_cam([-4.0, 0.3, 1.0], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+    plain = lcgs.Renderer(lcgs.Context(0))
+    plain.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    plain.P = P
+    ref = _lists(lcgs, plain, cam, W, H, False, 1.0)
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    r.P = P
+    r.declare_static(d["pos"], d["scale"], d["rotq"])
+    a = _lists(lcgs, r, cam, W, H, False, 1.0)
+    assert a[0] == ref[0] > 0 and torch.equal(a[3], ref[3]) and torch.equal(a[4], ref[4]) and torch.equal(a[2], ref[2])
+    # other arrays bound: the rows belong to the declared ones and are not used
+    d2 = upload_scene({k: (v + (0.25 if k == "pos" else 0.0)).astype(np.float32) for k, v in scene.items()})
+    r.bind_scene(d2["pos"], d2["scale"], d2["rotq"], d2["sh"], d2["opacity"])
+    plain.bind_scene(d2["pos"], d2["scale"], d2["rotq"], d2["sh"], d2["opacity"])
+    b, refb = _lists(lcgs, r, cam, W, H, False, 1.0), _lists(lcgs, plain, cam, W, H, False, 1.0)
+    assert b[0] == refb[0] and torch.equal(b[2], refb[2]) and not torch.equal(b[2], a[2])
+    # back to the declared arrays, changed in place: the declaration is repeated
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    plain.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    d["pos"][: P // 3] -= 0.4
+    d["scale"][P // 2:] *= 1.5
+    r.declare_static(d["pos"], d["scale"], d["rotq"])
+    c, refc = _lists(lcgs, r, cam, W, H, False, 1.0), _lists(lcgs, plain, cam, W, H, False, 1.0)
+    assert c[0] == refc[0] and torch.equal(c[3], refc[3]) and torch.equal(c[2], refc[2]) and not torch.equal(c[2], a[2])
+    # the stage operators in deferred mode render the fused frame from the caller's arrays (with radii: every splat is projected)
+    shp, prj, spl = lcgs.SHProcessor(), lcgs.GSProjector(), lcgs.GSTileSplatter()
+    for op in (shp, prj, spl):
+        op.create(r.ctx)
+    z = lambda *s_, dt=torch.float32: torch.zeros(*s_, dtype=dt, device=DEV)
+    G = ((W + 15) // 16) * ((H + 15) // 16)
+    color, means, covs, depth = z(P, 3), z(P, 2), z(P, 3), z(P)
+    Lcap = 4_000_000
+    accel = lcgs.GSTileSplatterAccelProxy(z(P, dt=torch.int32), z(P, dt=torch.int32), z(Lcap, dt=torch.int64), z(Lcap, dt=torch.int32),
+                                          z(Lcap, dt=torch.int64), z(Lcap, dt=torch.int32), z(2 * G, dt=torch.int32))
+    radii_s, img_s = z(P, dt=torch.int32), z(3, H, W)
+    r.ctx.set_stage_mode("deferred")
+    shp.process(lcgs.GPUPointsProxy(P, 3, d["pos"]), cam, d["sh"], color, 3, 3)
+    prj.forward(lcgs.GSProjectorInputProxy(P, d["pos"], d["scale"], d["rotq"], 1.0), lcgs.GSProjectorOutputProxy(means, covs, depth), cam)
+    n = spl.forward(accel, lcgs.GSTileSplatterInputProxy(P, (0.0, 0.0, 0.0), means, depth, covs, color, d["opacity"]),
+                    lcgs.GSSplatForwardOutputProxy(H, W, img_s, radii_s))
+    r.ctx.set_stage_mode("exact")
+    assert n == refc[0]
+    fused = torch.zeros(3, H, W, device=DEV)
+    plain.forward(cam, fused, sync=True)
+    assert torch.equal(img_s, fused)
+    # withdrawn: frames as before
+    r.declare_static()
+    e = _lists(lcgs, r, cam, W, H, False, 1.0)
+    assert e[0] == refc[0] and torch.equal(e[2], refc[2])
