@@ -224,7 +224,9 @@ LCGS_API lcgs_status lcgs_scene_pointers(lcgs_context* ctx, int* num_gaussians, 
  * no radii culls from them (forward +2 %; a frame that returns the reference's radii array -- the stage operators in deferred
  * mode do -- projects every splat anyway).  The declaration lasts until it is repeated (same
  * pointers: "the contents changed"), withdrawn (num_gaussians = 0 or d_pos = NULL), or the library itself writes the arrays
- * (lcgs_adam_step & co.).  Changing the arrays behind a standing declaration gives wrong frames. */
+ * (lcgs_adam_step & co.), or the context builds rows for a scene of its own (lcgs_scene_upload / lcgs_scene_load_ply /
+ * lcgs_scene_reorder_spatial: one set of rows per context).  Changing the arrays behind a standing declaration gives wrong
+ * frames. */
 LCGS_API lcgs_status lcgs_scene_declare_static(lcgs_context* ctx, int num_gaussians, const float* d_pos, const float* d_scale,
                                                const float* d_rotq);
 
