@@ -216,6 +216,15 @@ LCGS_API lcgs_status lcgs_scene_permutation(lcgs_context* ctx, const uint32_t** 
 LCGS_API lcgs_status lcgs_scene_pointers(lcgs_context* ctx, int* num_gaussians, int* sh_degree, const float** d_pos,
                                          const float** d_scale, const float** d_rotq, const float** d_sh,
                                          const float** d_opacity);
+/* "I changed the bound arrays behind the library's back" (a write through a const-cast of the pointers above, a tensor that
+ * aliases them, another process): everything any live context of the process derived from them is dropped -- the cull rows
+ * (rebuilt at once for a context-owned scene, on ctx's stream), the f16 coefficient copy, the kept state of the last frame.
+ * Order it behind the writes.  Not needed after the library's own writers (lcgs_adam_step & co., the sharded steps'
+ * all-gather), which do the same by themselves, whichever context they are issued through. */
+LCGS_API lcgs_status lcgs_scene_modified(lcgs_context* ctx);
+/* Diagnostics: how many of the derived rows in use for the bound arrays are NOT what the arrays say now (0 = consistent, or
+ * nothing derived in use).  A test-mode guard against a forgotten lcgs_scene_modified.  Synchronises. */
+LCGS_API lcgs_status lcgs_debug_verify_derived(lcgs_context* ctx, int64_t* stale_rows);
 
 /* Caller-owned arrays that do not change from frame to frame (a trained scene being viewed: the reference's own use,
  * app/main.cpp:180-223 uploads once) can have the same derived rows as a context-owned scene: the three arrays are declared

@@ -143,7 +143,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_render_backward", "lcgs_render_backward_adam", "lcgs_fit_views", "lcgs_render_backward_accumulate", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png", "lcgs_l2_loss_backward",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
-    "lcgs_render_forward_batch", "lcgs_scene_use_half_sh",
+    "lcgs_render_forward_batch", "lcgs_scene_use_half_sh", "lcgs_scene_modified", "lcgs_debug_verify_derived",
     "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_set_lod", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_set_transport", "lcgs_comm_shard_rows",
     "lcgs_grads_allreduce", "lcgs_adam_step_sharded", "lcgs_comm_track_touched_rows", "lcgs_comm_get_stats",
     "lcgs_adam_step_sparse", "lcgs_sparse_touched_rows", "lcgs_sparse_message_words", "lcgs_sparse_pack",
@@ -513,13 +513,26 @@ class Renderer:
         return torch.as_tensor(_View(), device=f"cuda:{self.ctx.device_id}")
 
     def scene_tensors(self) -> dict:
-        """lcgs_scene_pointers as torch tensors aliasing the bound arrays (the context's own after load_ply / a re-order)."""
+        """lcgs_scene_pointers as torch tensors aliasing the bound arrays (the context's own after load_ply / a re-order).
+        The C ABI hands these out as const: the context keeps data derived from them (include/lcgs_hip.h).  torch has no
+        read-only tensors, so the views are writable -- after writing them in place by anything but the library's own
+        optimiser steps, call scene_modified(), or frames cull from stale rows (verify_derived() is the test-mode guard)."""
         ptrs = [C.c_void_p() for _ in range(5)]
         n, deg = C.c_int(0), C.c_int(0)
         _check(load_library().lcgs_scene_pointers(self.ctx._h, C.byref(n), C.byref(deg), *[C.byref(p) for p in ptrs]))
         P, feat = n.value, (deg.value + 1) ** 2 * 3
         shapes = {"pos": (P, 3), "scale": (P, 3), "rotq": (P, 4), "sh": (P, feat), "opacity": (P,)}
         return {k: self._device_view(p.value, shapes[k], "<f4") for k, p in zip(("pos", "scale", "rotq", "sh", "opacity"), ptrs)}
+
+    def scene_modified(self):
+        """lcgs_scene_modified: the bound arrays were written behind the library's back; derived data is dropped / rebuilt."""
+        _check(load_library().lcgs_scene_modified(self.ctx._h))
+
+    def verify_derived(self) -> int:
+        """lcgs_debug_verify_derived: derived rows in use that no longer match the bound arrays (0 = consistent)."""
+        n = C.c_int64(0)
+        _check(load_library().lcgs_debug_verify_derived(self.ctx._h, C.byref(n)))
+        return int(n.value)
 
     def permutation(self):
         """lcgs_scene_permutation: int32 device tensor, [r] = file index of splat r; None while in file / caller order."""

@@ -235,6 +235,7 @@ lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx)
         (void)lcgs_destroy(ctx); // releases whichever of the stream / events were created
         return s;
     }
+    abi::registry_add(ctx);
     *out_ctx    = ctx;
     return LCGS_OK;
 }
@@ -242,6 +243,7 @@ lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx)
 lcgs_status lcgs_destroy(lcgs_context* ctx)
 {
     if (!ctx) return LCGS_OK;
+    abi::registry_remove(ctx);
     (void)hipSetDevice(ctx->device);
     (void)lcgs_stage_flush(ctx); // deferred stage calls still recorded: their outputs are the caller's buffers
     if (ctx->comm) {
@@ -274,7 +276,8 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
                              &ctx->pairv[1], &ctx->zero_ws[0], &ctx->zero_ws[1], &ctx->zero_ws[2], &ctx->counts, &ctx->sort_ws,
                              &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order[0], &ctx->tile_order[1], &ctx->st_keys_tmp,
                              &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac, &ctx->tie_ws, &ctx->fused_grads, &ctx->bwd_counter, &ctx->st_flags, &ctx->st_keys_exp, &ctx->st_vals_exp,
-                             &ctx->st_u32[0], &ctx->st_u32[1], &ctx->st_u32[2], &ctx->st_u32[3], &ctx->st_u32[4], &ctx->st_u32[5], &ctx->st_u32[6], &ctx->st_u32[7] };
+                             &ctx->st_u32[0], &ctx->st_u32[1], &ctx->st_u32[2], &ctx->st_u32[3], &ctx->st_u32[4], &ctx->st_u32[5], &ctx->st_u32[6], &ctx->st_u32[7],
+                             &ctx->cull_bound_buf, &ctx->verify_ws };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& s : ctx->owner)
         for (DeviceBuffer* b : { &s.vis, &s.shjac, &s.counts }) b->release();

@@ -79,7 +79,10 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
         LCGS_TRY(ctx->strip_masks.ensure((size_t)ctx->pair_capacity));
         LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)P)));
         LCGS_TRY(ctx->shjac.ensure(P * 48));
-        LCGS_TRY(ctx->bwd_counter.ensure(256));
+        if (!ctx->bwd_counter.ptr) { // (allocated once; starts at zero whatever runs first)
+            LCGS_TRY(ctx->bwd_counter.ensure(256));
+            LCGS_HIP_CHECK(hipMemsetAsync(ctx->bwd_counter.ptr, 0, 256, ctx->stream));
+        }
     }
     if (!ctx->h_counts) LCGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counts), 64, hipHostMallocDefault));
     return LCGS_OK;

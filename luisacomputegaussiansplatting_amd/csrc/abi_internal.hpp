@@ -44,7 +44,11 @@ lcgs_status refresh_cull_bound(lcgs_context* ctx);
 lcgs_status build_cull_bound(lcgs_context* ctx, int P, const float* pos, const float* scale, const float* rotq);
 // ... dropped when the library itself writes activated arrays that ARE the context's scene (optimiser steps): the frames
 // fall back to reading position + scale + rotation until the arrays are bound again
+// (EVERY live context of the process is looked at -- a second context that renders the same arrays keeps rows of its own)
 void scene_arrays_written(lcgs_context* ctx, const float* pos, const float* scale, const float* rotq);
+// the process's live contexts (lcgs_create / lcgs_destroy), for scene_arrays_written
+void registry_add(lcgs_context* ctx);
+void registry_remove(lcgs_context* ctx);
 // abi_frame.cpp
 lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool keep_state);
 lcgs_status prepare_twin(lcgs_context* ctx); // the sibling context of camera / view batches: created on first use, same scene

@@ -155,7 +155,7 @@ lcgs_status lcgs_owner_render(lcgs_context* ctx, const lcgs_camera* camera, cons
         }
         launch_unpack_records(num_rows, recs, d_rows, tied ? tie.perm : nullptr, tie.id_bits, tie.tag_shift,
                               ctx->sortk[0].as<uint32_t>(), ctx->sortv[0].as<uint32_t>(), ctx->rects.as<uint2>(),
-                              ctx->vis_index.as<uint32_t>(), dc, st);
+                              ctx->vis_index.as<uint32_t>(), dc, (uint32_t)ctx->P, cp.grid_x, cp.grid_y, st);
         const int w = launch_pair_sort_u32(ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
                                            ctx->sortv[0].as<uint32_t>(), ctx->sortv[1].as<uint32_t>(), dc, ctx->P, num_rows, 0, 32,
                                            ctx->sort_ws.ptr, st);
@@ -219,6 +219,7 @@ lcgs_status lcgs_owner_render(lcgs_context* ctx, const lcgs_camera* camera, cons
 lcgs_status lcgs_owner_render_backward(lcgs_context* ctx, const float* d_dL_dimg, float* d_grads2d)
 {
     LCGS_REQUIRE(ctx && d_dL_dimg && d_grads2d, "NULL argument");
+    LCGS_REQUIRE((reinterpret_cast<uintptr_t>(d_grads2d) & 15) == 0, "d_grads2d must be 16-byte aligned (rows are float4 x 3)");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     if (!ctx->last.valid || !ctx->last.has_state || !ctx->owner_recs) {
         set_last_error("lcgs_owner_render_backward needs a preceding lcgs_owner_render(..., keep_state = 1)");
@@ -243,6 +244,7 @@ lcgs_status lcgs_owner_backward(lcgs_context* ctx, int slot, const float* d_grad
     LCGS_REQUIRE(grads->d_dL_dpos && grads->d_dL_dscale && grads->d_dL_drotq && grads->d_dL_dsh && grads->d_dL_dopacity,
                  "NULL gradient buffer");
     LCGS_REQUIRE((reinterpret_cast<uintptr_t>(grads->d_dL_drotq) & 15) == 0, "dL_drotq must be 16-byte aligned");
+    LCGS_REQUIRE((reinterpret_cast<uintptr_t>(d_grads2d) & 15) == 0, "d_grads2d must be 16-byte aligned (rows are float4 x 3)");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     auto& s = ctx->owner[slot];
     if (s.row_count == 0) return LCGS_OK; // an owner of nothing

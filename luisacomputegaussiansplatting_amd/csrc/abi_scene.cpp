@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -54,9 +55,30 @@ lcgs_status build_cull_bound(lcgs_context* ctx, int P, const float* pos, const f
     return LCGS_OK;
 }
 
-void scene_arrays_written(lcgs_context* ctx, const float* pos, const float* scale, const float* rotq)
+namespace
 {
-    for (lcgs_context* c = ctx; c; c = c->twin) {
+std::mutex                 g_registry_mutex;
+std::vector<lcgs_context*> g_registry;
+} // namespace
+void registry_add(lcgs_context* ctx)
+{
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    g_registry.push_back(ctx);
+}
+void registry_remove(lcgs_context* ctx)
+{
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    g_registry.erase(std::remove(g_registry.begin(), g_registry.end(), ctx), g_registry.end());
+}
+
+// The library is about to write (or has let someone write) position / scale / rotation rows inside the given arrays: every
+// context whose derived rows were built from arrays that overlap them drops the rows -- this context, its batch siblings AND
+// any other context of the process that renders the same arrays (an optimiser step issued through context A on arrays
+// context B owns).  Frames fall back to reading the arrays themselves until the rows are rebuilt (bind / lcgs_scene_modified).
+void scene_arrays_written(lcgs_context* /*ctx*/, const float* pos, const float* scale, const float* rotq)
+{
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    for (lcgs_context* c : g_registry) {
         if (!c->cull_bound || c->cull_key.P <= 0) continue;
         auto inside = [&](const float* p, const float* base, size_t floats) {
             return p != nullptr && base != nullptr && p >= base && p < base + floats * (size_t)c->cull_key.P;
@@ -111,6 +133,37 @@ lcgs_status lcgs_scene_declare_static(lcgs_context* ctx, int num_gaussians, cons
     LCGS_REQUIRE(d_scale && d_rotq, "NULL device pointer");
     LCGS_REQUIRE((reinterpret_cast<uintptr_t>(d_rotq) & 15) == 0, "rotq must be 16-byte aligned");
     return build_cull_bound(ctx, num_gaussians, d_pos, d_scale, d_rotq);
+}
+
+lcgs_status lcgs_scene_modified(lcgs_context* ctx)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    // whoever keeps rows derived from the bound arrays (this context, its siblings, another context on the same arrays)
+    // drops them; this context builds its own again (context-owned arrays only, ordered on its stream behind the
+    // caller's writes as far as the caller ordered those before this call)
+    scene_arrays_written(ctx, ctx->pos, ctx->scale, ctx->rotq);
+    ctx->use_half_sh = false; // the f16 copy of the coefficients (if any) is stale as well
+    ctx->last.valid  = false; // ... and so is the kept state of the last frame
+    return refresh_cull_bound(ctx);
+}
+
+lcgs_status lcgs_debug_verify_derived(lcgs_context* ctx, int64_t* stale_rows)
+{
+    LCGS_REQUIRE(ctx && stale_rows, "NULL argument");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    *stale_rows = 0;
+    const float4* rows = ctx->cull_rows();
+    if (!rows || ctx->P <= 0) return LCGS_OK; // nothing derived is in use for the bound arrays
+    LCGS_TRY(ctx->verify_ws.ensure(8));
+    LCGS_HIP_CHECK(hipMemsetAsync(ctx->verify_ws.ptr, 0, 8, ctx->stream));
+    launch_cull_bound_verify(ctx->P, ctx->pos, ctx->scale, ctx->rotq, rows, ctx->verify_ws.as<unsigned long long>(), ctx->stream);
+    LCGS_HIP_CHECK(hipGetLastError());
+    unsigned long long n = 0;
+    LCGS_HIP_CHECK(hipMemcpyAsync(&n, ctx->verify_ws.ptr, 8, hipMemcpyDeviceToHost, ctx->stream));
+    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *stale_rows = (int64_t)n;
+    return LCGS_OK;
 }
 
 lcgs_status lcgs_set_lod(lcgs_context* ctx, int min_radius_px)

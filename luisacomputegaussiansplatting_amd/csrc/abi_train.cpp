@@ -26,6 +26,8 @@ lcgs_status lcgs_adam_step(lcgs_context* ctx, int num_gaussians, int sh_degree, 
     LCGS_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "sh_degree must be in [0,3]");
     LCGS_REQUIRE(cfg->step >= 1, "step counts from 1");
     LCGS_REQUIRE(cfg->beta1 >= 0.0f && cfg->beta1 < 1.0f && cfg->beta2 >= 0.0f && cfg->beta2 < 1.0f, "betas must be in [0,1)");
+    // (before the empty-range return: a rank whose shard is empty still belongs to a step that rewrites the arrays)
+    scene_arrays_written(ctx, activated->pos, activated->scale, activated->rotq); // (a context-owned scene trained in place)
     if (num_gaussians == 0) return LCGS_OK;
     const lcgs_params* packs[4] = { raw, m, v, activated };
     for (const lcgs_params* p : packs)
@@ -43,7 +45,6 @@ lcgs_status lcgs_adam_step(lcgs_context* ctx, int num_gaussians, int sh_degree, 
         d_rows   = ctx->counts.as<uint32_t>(); // [0] = survivors of the last frame
         hint     = ctx->hint_V > 0 ? std::min<int64_t>(ctx->hint_V, num_gaussians) : num_gaussians;
     }
-    scene_arrays_written(ctx, activated->pos, activated->scale, activated->rotq); // (a context-owned scene trained in place)
     auto pack = [](const lcgs_params* p) { return AdamArrays{ p->pos, p->scale, p->rotq, p->sh, p->opacity }; };
     const AdamArrays g = { grads->d_dL_dpos, grads->d_dL_dscale, grads->d_dL_drotq, grads->d_dL_dsh, grads->d_dL_dopacity };
     const AdamRates  lr = { cfg->lr_pos, cfg->lr_sh_dc, cfg->lr_sh_rest, cfg->lr_opacity, cfg->lr_scale, cfg->lr_rot };

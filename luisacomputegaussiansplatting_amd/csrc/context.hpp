@@ -16,6 +16,12 @@ void comm_forget_context(lcgs_comm* comm);
 // (host/comm.cpp) sparse exchange: a dense backward flags the rows of the frame it has just differentiated
 lcgs_status comm_mark_touched(lcgs_comm* comm, const uint32_t* vis_index, const uint32_t* d_counts, int64_t P, int64_t hint_V,
                               bool accumulate, hipStream_t stream);
+namespace abi
+{
+// (abi_scene.cpp) position / scale / rotation rows inside these arrays are being written: every live context drops the rows
+// it derived from them (the cull pass's {position, extent bound} rows)
+void scene_arrays_written(lcgs_context* ctx, const float* pos, const float* scale, const float* rotq);
+} // namespace abi
 } // namespace lcgs
 
 using lcgs::CamParams;
@@ -43,6 +49,7 @@ struct lcgs_context {
     // context's own buffer, a sibling's borrowed pointer, or NULL (caller-bound arrays, or owned arrays the library has
     // written since: lcgs_adam_step & co. drop it; binding the owned arrays again rebuilds it)
     DeviceBuffer          cull_bound_buf;
+    DeviceBuffer          verify_ws; // lcgs_debug_verify_derived: one counter
     const float4*         cull_bound = nullptr;
     // ... valid for exactly these arrays (the context's own, or caller arrays declared static: lcgs_scene_declare_static);
     // a frame uses the rows only when its position / scale / rotation arrays are these (cull_rows())

@@ -207,6 +207,9 @@ lcgs_status allgather_activated(lcgs_context* ctx, lcgs_comm* c, int64_t P, int 
 {
     int64_t first = 0, count = 0;
     lcgs_comm_shard_rows(P, c->world, c->rank, &first, &count);
+    // the other ranks' rows land in these arrays: whatever a context derived from them (the cull pass's 16-byte rows) is
+    // stale from here on -- also on a rank whose own shard is empty and whose lcgs_adam_step therefore wrote nothing
+    abi::scene_arrays_written(ctx, act.ptr[0], act.ptr[1], act.ptr[2]);
     LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
     LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
     if (count > 0) {

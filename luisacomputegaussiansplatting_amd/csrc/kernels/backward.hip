@@ -104,6 +104,16 @@ __device__ __forceinline__ void reduce_quad_and_add(float pair[9], float quad[9]
 
 constexpr int kG2D = 12; // floats per splat in the 2-D gradient buffer: mean(2) conic(3) opacity(1) rgb(3) pad(3)
 
+#ifdef LCGS_BWD_STATS // (measuring builds only, tools/gpu/bwd_stats.py: what the render-backward's waves actually walk)
+// [0] (entry, strip) pairs walked  [1] ... that pass the wave-level candidate test  [2] lanes that blend, summed
+// [3] strips with at least one walked entry  [4] staging rounds  [5] tiles  [6] list entries staged  [7] entries fetched
+// [8 + b] strips whose walked count n satisfies 2^(b-1) < n <= 2^b (b = 0: n <= 1 incl. 0 ... b = 15)
+__device__ unsigned long long g_bwd_stats[32];
+#define LCGS_STAT(i, n) (st_[(i)] += (n))
+#else
+#define LCGS_STAT(i, n)
+#endif
+
 // (six waves per SIMD: 80 VGPRs with 8 spilled registers per lane instead of 92 and five waves -- render-backward 0.71 ->
 //  0.67 ms, +1.6 % on the whole forward+backward step in same-box A/B runs; seven waves spill 19 and lose it again)
 // KNOWN: the forward kept every entry's strip bits (it always does when it keeps backward state; the other instantiation
@@ -146,6 +156,10 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t slots = tile_order ? cp.grid_x * cp.grid_y : render_grid_size(cp.grid_x, cp.grid_y);
     uint32_t       slot  = blockIdx.x;
+#ifdef LCGS_BWD_STATS
+    unsigned long long st_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    uint32_t           sub_[13];
+#endif
   for (;;) { // (one pass unless PERSIST)
     if (PERSIST) {
         __syncthreads(); // the previous tile's last flush has read s_vid / s_grad; nobody still reads s_slot
@@ -184,6 +198,9 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         if (PERSIST) continue;
         return;
     }
+#ifdef LCGS_BWD_STATS
+    for (int i = 0; i < 13; ++i) sub_[i] = 0;
+#endif
     uint32_t tx, ty;
     if (tile_order) { // longest-list-first schedule of the forward (scheduling hint only)
         const uint32_t t = tile_order[slot];
@@ -264,6 +281,9 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
             }
         }
         __syncthreads(); // previous round fully flushed
+        LCGS_STAT(4, wave == 0u ? 1u : 0u);
+        LCGS_STAT(6, (unsigned)__popcll(__ballot(have)));
+        LCGS_STAT(7, (unsigned)__popcll(__ballot(have && kmask != 0u)));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned long long m = __ballot((kmask >> k) & 1u);
@@ -297,6 +317,7 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                     asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(l));
                     const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)w * 64u + l));
                     const uint32_t pos = lo + idx; // 0-based list position
+                    LCGS_STAT(0, 1u);
                     const float4   ea = s_a[idx], eb = s_b[idx];
                     const float2   ec = s_c[idx];
                     // the forward's own expression and evaluation order: the same splats pass the same thresholds
@@ -305,10 +326,24 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                     const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
                     const bool  cand  = (pos < last) & !(power > 0.0f) & (power >= ec.y);
                     if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
+                    LCGS_STAT(1, 1u);
                     const float G     = blend_exp(power); // the forward's exp: the same entries pass alpha >= 1/255
                     const float oG    = eb.y * G;
                     const float alpha = __builtin_fminf(0.99f, oG);
                     const bool  valid = cand & !(alpha < 1.0f / 255.0f);
+                    LCGS_STAT(2, (unsigned)__popcll(__builtin_amdgcn_ballot_w64(valid)));
+#ifdef LCGS_BWD_STATS
+                    {   // which sub-blocks of the 16x4 strip does this entry blend into? (lane = 16 * row + column)
+                        const unsigned long long vb = __builtin_amdgcn_ballot_w64(valid);
+                        sub_[0] += (vb & 0x00FF00FF00FF00FFull) != 0, sub_[1] += (vb & 0xFF00FF00FF00FF00ull) != 0; // 8x4 halves
+                        sub_[2] += (vb & 0x00000000FFFFFFFFull) != 0, sub_[3] += (vb & 0xFFFFFFFF00000000ull) != 0; // 16x2 halves
+                        for (int q = 0; q < 4; ++q) {
+                            sub_[4 + q] += (vb & (0x000F000F000F000Full << (4 * q))) != 0; // 4x4 blocks
+                            sub_[8 + q] += (vb & (0xFFFFull << (16 * q))) != 0;            // 16x1 rows
+                        }
+                        sub_[12] += vb != 0;
+                    }
+#endif
                     // A lane that does not blend this entry carries alpha 0 through the recurrences: 1 / (1 - 0) == 1
                     // leaves T alone, B + 0 * (c - B) leaves the colour behind alone, all nine terms come out 0.
                     // (No second wave-level skip: the staging floor already implies alpha >= 1/255 somewhere.)
@@ -411,8 +446,40 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         }
         hi = lo;
     }
-    if (!PERSIST) return;
+#ifdef LCGS_BWD_STATS
+    if (lane == 0u) {
+        const unsigned long long n = st_[0] - st_[3]; // this tile's walked count for my strip (st_[3] = walked before this tile)
+        uint32_t b = 0;
+        while (b < 15u && (1ull << b) < n) ++b;
+        atomicAdd(&g_bwd_stats[8 + b], 1ull);
+        atomicAdd(&g_bwd_stats[3], n ? 1ull : 0ull);
+        if (wave == 0u) atomicAdd(&g_bwd_stats[5], 1ull);
+        // [24..27] sum over strips of the LONGEST sub-block stream (8x4 halves, 16x2 halves, 4x4 blocks, 16x1 rows);
+        // [28] entries that blend anywhere; [29..31] sums of the sub-block streams (8x4, 4x4, 16x1)
+        auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+        atomicAdd(&g_bwd_stats[24], (unsigned long long)mx(sub_[0], sub_[1]));
+        atomicAdd(&g_bwd_stats[25], (unsigned long long)mx(sub_[2], sub_[3]));
+        atomicAdd(&g_bwd_stats[26], (unsigned long long)mx(mx(sub_[4], sub_[5]), mx(sub_[6], sub_[7])));
+        atomicAdd(&g_bwd_stats[27], (unsigned long long)mx(mx(sub_[8], sub_[9]), mx(sub_[10], sub_[11])));
+        atomicAdd(&g_bwd_stats[28], (unsigned long long)sub_[12]);
+        atomicAdd(&g_bwd_stats[29], (unsigned long long)(sub_[0] + sub_[1]));
+        atomicAdd(&g_bwd_stats[30], (unsigned long long)(sub_[4] + sub_[5] + sub_[6] + sub_[7]));
+        atomicAdd(&g_bwd_stats[31], (unsigned long long)(sub_[8] + sub_[9] + sub_[10] + sub_[11]));
+    }
+    st_[3] = st_[0];
+#endif
+    if (!PERSIST) break;
   }
+#ifdef LCGS_BWD_STATS
+    if (lane == 0u) {
+        atomicAdd(&g_bwd_stats[0], st_[0]);
+        atomicAdd(&g_bwd_stats[1], st_[1]);
+        atomicAdd(&g_bwd_stats[2], st_[2]);
+        if (wave == 0u) atomicAdd(&g_bwd_stats[4], st_[4]);
+        atomicAdd(&g_bwd_stats[6], st_[6]);
+        atomicAdd(&g_bwd_stats[7], st_[7]);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1068,3 +1135,16 @@ void launch_preprocess_backward_adam(int64_t v_hint, const CamParams& cp, float 
 }
 
 } // namespace lcgs
+
+#ifdef LCGS_BWD_STATS
+// (measuring builds only; not declared in include/lcgs_hip.h)
+extern "C" __attribute__((visibility("default"))) int lcgs_debug_bwd_stats(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lcgs::g_bwd_stats), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lcgs::g_bwd_stats), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

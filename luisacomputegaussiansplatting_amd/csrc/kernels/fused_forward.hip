@@ -223,6 +223,21 @@ __global__ void __launch_bounds__(256) k_cull_bound(int64_t P, const float* __re
     }
 }
 
+__global__ void __launch_bounds__(256) k_cull_bound_verify(int64_t P, const float* __restrict__ pos, const float* __restrict__ scale,
+                                                             const float* __restrict__ rotq, const float4* __restrict__ rows,
+                                                             unsigned long long* __restrict__ mismatches)
+{
+    uint32_t bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
+        const SplatIn in = load_splat(i, pos, scale, rotq);
+        const float4  want = make_float4(in.px, in.py, in.pz, splat_extent_bound(in.sx, in.sy, in.sz, in.q)), have = rows[i];
+        bad += ((__float_as_uint(want.x) ^ __float_as_uint(have.x)) | (__float_as_uint(want.y) ^ __float_as_uint(have.y)) |
+                (__float_as_uint(want.z) ^ __float_as_uint(have.z)) | (__float_as_uint(want.w) ^ __float_as_uint(have.w))) != 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, 64);
+    if ((threadIdx.x & 63u) == 0u && bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 // BOUND (context-owned scenes, lcgs_context::cull_bound): phase 1 reads ONE 16-byte {position, extent bound} row per splat
 // instead of the 40 bytes of position + scale + rotation in 28 loads per lane -- the pass was bound by that load pipeline,
 // not by arithmetic or bytes (REJECTED.md, "The frame's cull pass") -- and phase 2 fetches scale / rotation / opacity of
@@ -885,6 +900,15 @@ void launch_cull_bound(int64_t P, const float* pos, const float* scale, const fl
                        out);
 }
 
+void launch_cull_bound_verify(int64_t P, const float* pos, const float* scale, const float* rotq, const float4* rows,
+                              unsigned long long* mismatches, hipStream_t stream)
+{
+    if (P <= 0) return;
+    const int64_t blocks = (P + 255) / 256;
+    hipLaunchKernelGGL(k_cull_bound_verify, dim3((unsigned)std::min<int64_t>(blocks, 16384)), dim3(256), 0, stream, P, pos, scale,
+                       rotq, rows, mismatches);
+}
+
 void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const FrameParams* d_fp, const float* pos,
                          const float* scale, const float* rotq, const float* opacity, int32_t* radii, uint4* slab,
                          uint2* chunk_info, const DepthSortFirstPass& first, hipStream_t stream, const float4* bound4)
@@ -961,7 +985,8 @@ __global__ void __launch_bounds__(256) k_unpack_records(uint32_t n, const SplatR
                                                         const uint32_t* __restrict__ rows, const uint32_t* __restrict__ perm,
                                                         uint32_t id_bits, uint32_t tag_shift, uint32_t* __restrict__ keys,
                                                         uint32_t* __restrict__ vals, uint2* __restrict__ rects,
-                                                        uint32_t* __restrict__ vis_index, uint32_t* __restrict__ d_counts)
+                                                        uint32_t* __restrict__ vis_index, uint32_t* __restrict__ d_counts,
+                                                        uint32_t P, uint32_t grid_x, uint32_t grid_y)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         d_counts[0] = n;
@@ -970,10 +995,16 @@ __global__ void __launch_bounds__(256) k_unpack_records(uint32_t n, const SplatR
     }
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const SplatRecord r = recs[i];
-        const uint32_t    row = rows[i];
+        uint32_t          row = rows[i];
+        // The records came from a peer: nothing in them may index past this context's arrays or this frame's grid.  A row
+        // beyond the scene or a rect that leaves the grid (a short or mismatched message) becomes an entry that touches no
+        // tile (empty rect) at row 0 -- it is sorted and dropped like any culled splat, never dereferenced.
+        const uint32_t x0 = r.rect_xy & 0xFFFFu, y0 = r.rect_xy >> 16, w = r.rect_wh & 0xFFFFu, h = r.rect_wh >> 16;
+        const bool     ok = row < P && x0 + w <= grid_x && y0 + h <= grid_y;
+        if (!ok) row = 0u;
         keys[i]      = __float_as_uint(r.depth);
         vals[i]      = perm ? (i | ((perm[row] >> tag_shift) << id_bits)) : i;
-        rects[i]     = make_uint2(r.rect_xy, r.rect_wh);
+        rects[i]     = ok ? make_uint2(r.rect_xy, r.rect_wh) : make_uint2(0u, 0u);
         vis_index[i] = row;
     }
 }
@@ -989,12 +1020,12 @@ void launch_rows_global(const uint32_t* vis, const uint32_t* d_count, uint32_t r
 
 void launch_unpack_records(int64_t n, const SplatRecord* recs, const uint32_t* rows, const uint32_t* perm, uint32_t id_bits,
                            uint32_t tag_shift, uint32_t* keys, uint32_t* vals, uint2* rects, uint32_t* vis_index,
-                           uint32_t* d_counts, hipStream_t stream)
+                           uint32_t* d_counts, uint32_t P, uint32_t grid_x, uint32_t grid_y, hipStream_t stream)
 {
     int64_t b = (n + 255) / 256;
     b         = b < 1 ? 1 : (b > 8192 ? 8192 : b);
     hipLaunchKernelGGL(k_unpack_records, dim3((unsigned)b), dim3(256), 0, stream, (uint32_t)n, recs, rows, perm, id_bits,
-                       tag_shift, keys, vals, rects, vis_index, d_counts);
+                       tag_shift, keys, vals, rects, vis_index, d_counts, P, grid_x, grid_y);
 }
 
 size_t expand_ws_bytes(int P_cap) { return (size_t)((P_cap + kExpandChunk - 1) / kExpandChunk + 8) * sizeof(uint32_t); }

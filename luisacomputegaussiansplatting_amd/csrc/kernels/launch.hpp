@@ -86,6 +86,9 @@ void launch_cull_compact(int P, const CamParams& cp, float scale_modifier, const
                          const float4* bound4 = nullptr);
 // out[i] = {pos[i], |R(q_i)|-bound x max |scale_i|}: the camera-independent inputs of the cull pass's phase-1 test
 void launch_cull_bound(int64_t P, const float* pos, const float* scale, const float* rotq, float4* out, hipStream_t stream);
+// diagnostics: *mismatches += rows of `rows` that are not what launch_cull_bound would write for the arrays now (bit compare)
+void launch_cull_bound_verify(int64_t P, const float* pos, const float* scale, const float* rotq, const float4* rows,
+                              unsigned long long* mismatches, hipStream_t stream);
 // d_counts: [0] V (splats emitting >= 1 pair), [1] reference num_rendered (both written by the depth sort's first
 //           row-scan launch), [2] pairs emitted, [3] overflow flag, [4] pairs wanted (before clamping to capacity)
 void launch_depth_sort_from_chunks(int64_t P, int64_t v_hint, const uint4* slab, const uint2* chunk_info,
@@ -107,7 +110,7 @@ void launch_rows_global(const uint32_t* vis, const uint32_t* d_count, uint32_t r
 // rects, vis_index = rows; d_counts[0] = n, [1] = the sum of the pruned rects' tiles (non-zero iff anything is drawn)
 void launch_unpack_records(int64_t n, const SplatRecord* recs, const uint32_t* rows, const uint32_t* perm, uint32_t id_bits,
                            uint32_t tag_shift, uint32_t* keys, uint32_t* vals, uint2* rects, uint32_t* vis_index,
-                           uint32_t* d_counts, hipStream_t stream);
+                           uint32_t* d_counts, uint32_t P, uint32_t grid_x, uint32_t grid_y, hipStream_t stream);
 struct PairSortFirstPass;
 size_t expand_ws_bytes(int P_cap);
 // v_hint: expected survivor count (bounds the launch; larger live counts are handled by chunk striding)

@@ -101,14 +101,24 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         bg1 = fpp->bg[1];
         bg2 = fpp->bg[2];
     }
-    if (d_counts && d_counts[1] == 0u) return; // image untouched (gs_tile_splatter/impl.cpp:109)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (d_counts && d_counts[1] == 0u) { // image untouched (gs_tile_splatter/impl.cpp:109)
+        // ... but the side job below is owed all the same: the host has already noted the 2-D gradient rows and the
+        // backward's counter block as cleared by this launch (abi_frame.cpp g2d_zeroed)
+        if (KEEP && g2d_zero) {
+            const uint32_t n4 = d_counts[0] * 3u;
+            for (uint32_t i = blockIdx.x * 256u + tid; i < n4; i += gridDim.x * 256u) g2d_zero[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (blockIdx.x == 0u && tid < 32u && bwd_counters) bwd_counters[tid] = 0u;
+        }
+        return;
+    }
     const uint32_t slots = tile_order ? cp.grid_x * cp.grid_y : render_grid_size(cp.grid_x, cp.grid_y);
     uint32_t       slot  = blockIdx.x;
   for (;;) { // (one pass unless PERSIST)
     if (PERSIST) {
+        __syncthreads(); // nobody still reads the previous s_slot (a padding slot's `continue` passes no other barrier)
         if (tid == 0) s_slot = atomicAdd(work_counter, 1u);
-        __syncthreads(); // (s_slot is not written again before every thread has passed the next barrier below)
+        __syncthreads();
         slot = s_slot;
     }
     if (slot >= slots) return; // persistent grids: the exit every workgroup reaches

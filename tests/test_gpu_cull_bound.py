@@ -269,3 +269,120 @@ def test_declared_static_arrays_of_the_caller(lcgs):
     r.declare_static()
     e = _lists(lcgs, r, cam, W, H, False, 1.0)
     assert e[0] == refc[0] and torch.equal(e[2], refc[2])
+
+
+def test_in_place_writes_need_scene_modified_and_the_guard_sees_them(lcgs):
+    """Renderer.scene_tensors() hands out writable aliases of arrays the context derives rows from: a write through them is
+    invisible to the library.  lcgs_debug_verify_derived (the test-mode guard) counts the stale rows; lcgs_scene_modified is
+    the documented notification, after which the frame is the moved scene's."""
+    rng = np.random.default_rng(41)
+    P = 70_003
+    scene = _edge_scene(rng, P)
+    W, H = 640, 360
+    cam = lcgs.get_lookat_cam([-4.0, 0.3, 1.0], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+    own = lcgs.Renderer(lcgs.Context(0))
+    own.upload_scene(scene, order="file")
+    assert own.verify_derived() == 0
+    act = own.scene_tensors()
+    act["pos"][: P // 2] += 0.35        # behind the library's back
+    act["scale"][P // 3:] *= 1.7
+    torch.cuda.synchronize()
+    stale = own.verify_derived()
+    assert stale >= P // 2, stale       # the guard sees every moved row
+    own.scene_modified()
+    assert own.verify_derived() == 0
+    ref = lcgs.Renderer(lcgs.Context(0))
+    d = {k: act[k].clone() for k in act}
+    ref.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    a, b = torch.zeros(3, H, W, device=DEV), torch.zeros(3, H, W, device=DEV)
+    assert own.forward(cam, a, sync=True) == ref.forward(cam, b, sync=True) > 0
+    assert torch.equal(a, b)
+
+
+def test_optimiser_step_through_another_context_drops_the_rows(lcgs):
+    """Context B binds the arrays context A owns and runs lcgs_adam_step on them as `activated`: A's derived rows go with the
+    step (every live context is looked at), so A's next frame is the moved scene's."""
+    rng = np.random.default_rng(43)
+    P = 60_001
+    scene = _edge_scene(rng, P)
+    W, H = 640, 360
+    cam = lcgs.get_lookat_cam([-4.0, 0.3, 1.0], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+    keys = ("pos", "scale", "rotq", "sh", "opacity")
+    A = lcgs.Renderer(lcgs.Context(0))
+    A.upload_scene(scene, order="file")
+    act = A.scene_tensors()
+    before = torch.zeros(3, H, W, device=DEV)
+    A.forward(cam, before, sync=True)
+    B = lcgs.Renderer(lcgs.Context(0))
+    B.bind_scene(*[act[k] for k in keys])
+    grads = {k: torch.from_numpy(rng.normal(size=tuple(act[k].shape)).astype(np.float32)).to(DEV) for k in keys}
+    lr = {"pos": 0.05, "sh_dc": 0.0, "sh_rest": 0.0, "opacity": 0.0, "scale": 0.2, "rot": 0.05}
+    raw = {"pos": act["pos"], "scale": torch.log(act["scale"].abs() + 1e-12), "rotq": act["rotq"].clone(), "sh": act["sh"],
+           "opacity": torch.log(act["opacity"] / (1 - act["opacity"]).clamp_min(1e-6))}
+    m = {k: torch.zeros_like(raw[k]) for k in keys}
+    v = {k: torch.zeros_like(raw[k]) for k in keys}
+    B.adam_step(grads, raw, m, v, act, 1, lr)
+    B.ctx.synchronize()
+    assert A.verify_derived() == 0      # nothing derived is in use any more (the rows were dropped, not left stale)
+    ref = lcgs.Renderer(lcgs.Context(0))
+    d = {k: act[k].clone() for k in act}
+    ref.bind_scene(*[d[k] for k in keys])
+    a, b = torch.zeros(3, H, W, device=DEV), torch.zeros(3, H, W, device=DEV)
+    assert A.forward(cam, a, sync=True) == ref.forward(cam, b, sync=True) > 0
+    assert torch.equal(a, b) and not torch.equal(a, before)
+
+
+def test_destroy_returns_every_byte(lcgs):
+    """create / upload / frame (forward + backward state) / destroy in a loop: free device memory comes back each time
+    (round 4 leaked the 16-byte cull rows of every context that owned a scene)."""
+    rng = np.random.default_rng(47)
+    P = 400_000
+    scene = make_scene(rng, P)
+    W, H = 640, 360
+    cam = lcgs.get_lookat_cam([-3.0, 0.2, 1.0], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+
+    def once():
+        r = lcgs.Renderer(lcgs.Context(0))
+        r.upload_scene(scene)
+        img = torch.zeros(3, H, W, device=DEV)
+        r.forward(cam, img, keep_state=True, sync=True)
+        r.ctx.close()
+        del r, img
+
+    once()  # first use pays for one-off allocations of the runtime
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(4):
+        once()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (2 << 20), f"{(free0 - free1) / 2**20:.1f} MiB lost over four create/destroy rounds (16 B x P = {16 * P / 2**20:.1f} MiB a round)"
+
+
+def test_empty_frame_still_clears_what_the_backward_relies_on(lcgs):
+    """A keep_state frame that draws nothing returns before its tiles -- but the host has noted the 2-D gradient rows and the
+    backward's counters as cleared by that launch: the gradients of the empty frame must be exact zeros, also right after a
+    step that filled them."""
+    rng = np.random.default_rng(53)
+    P = 30_000
+    scene = make_scene(rng, P)
+    W, H = 320, 240
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.upload_scene(scene)
+    d = r.scene_tensors()
+    g = {k: torch.zeros_like(d[k]) for k in ("pos", "scale", "rotq", "sh", "opacity")}
+    img = torch.zeros(3, H, W, device=DEV)
+    dL = torch.randn(3, H, W, device=DEV)
+    see = lcgs.get_lookat_cam([-3.0, 0.2, 1.0], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+    away = lcgs.get_lookat_cam([-3.0, 0.2, 1.0], [-9.0, 0.4, 1.5], [0, 0, 1], width=W, height=H)
+    assert r.forward(see, img, keep_state=True, sync=True) > 0
+    r.backward(dL, g["pos"], g["scale"], g["rotq"], g["sh"], g["opacity"])
+    r.ctx.synchronize()
+    assert float(g["pos"].abs().sum()) > 0
+    assert r.forward(away, img, keep_state=True, sync=True) == 0
+    r.backward(dL, g["pos"], g["scale"], g["rotq"], g["sh"], g["opacity"])
+    r.ctx.synchronize()
+    for k in g:
+        assert not g[k].any(), k
