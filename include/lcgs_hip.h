@@ -501,8 +501,8 @@ LCGS_API lcgs_status lcgs_sparse_accumulate(lcgs_context* ctx, int sh_degree, co
  * lcgs_owner_render_backward returns the 2-D gradients of those rows (LCGS_OWNER_GRAD_FLOATS words a row: mean (2), conic
  * (3), opacity, rgb (3), 3 unused) and lcgs_owner_backward -- on the owner, per view slot -- turns its rows' share into
  * parameter gradients at rows row_first ... of the full-size arrays (the first view of a step zero-fills the range, the
- * others add).  Transport between the two halves is the caller's (multi_gpu.TorchCollective.owner_step: send / recv over
- * a process group).  slot: the view's index inside the step, < LCGS_MAX_OWNER_VIEWS; its buffers live until re-used.
+ * others add).  These four calls leave the transport between the two halves to the caller (multi_gpu.TorchCollective.owner_step:
+ * send / recv over a process group); lcgs_owner_step_forward / _backward below are the same step with RCCL as the wire.  slot: the view's index inside the step, < LCGS_MAX_OWNER_VIEWS; its buffers live until re-used.
  * ------------------------------------------------------------------------------------------ */
 #define LCGS_MAX_OWNER_VIEWS 16
 #define LCGS_OWNER_RECORD_FLOATS 12
@@ -520,6 +520,33 @@ LCGS_API lcgs_status lcgs_owner_render(lcgs_context* ctx, const lcgs_camera* cam
 LCGS_API lcgs_status lcgs_owner_render_backward(lcgs_context* ctx, const float* d_dL_dimg, float* d_grads2d);
 LCGS_API lcgs_status lcgs_owner_backward(lcgs_context* ctx, int slot, const float* d_grads2d, const lcgs_grads* grads,
                                          int accumulate);
+
+/* The ownership step WITH its transport (round 5): rank r of the communicator owns the rows lcgs_comm_owner_rows(P, N, r) of
+ * the scene bound to ctx (equal contiguous shards, the P mod N tail with the last rank) and renders view r of cameras[N].
+ *   lcgs_owner_step_forward   projects the own rows for all N views (asynchronous), agrees the message sizes through one
+ *                             small all-gather + read-back (the step's one host synchronisation besides the view's own
+ *                             pair-buffer check), sends every view's rank its rows ([u32 row] + 48-byte record each,
+ *                             ncclSend / ncclRecv in one group on the communicator's stream), receives every owner's rows of
+ *                             its own view in owner order (= ascending rows) and renders the view into d_img -- the image
+ *                             lcgs_render_forward of the whole scene gives, bit for bit.
+ *   lcgs_owner_step_backward  differentiates the view, returns every owner the 48-byte 2-D gradient rows of its rows,
+ *                             receives those of the own rows for all N views and maps them to parameter gradients at the
+ *                             own rows of the full-size arrays in `grads` (view 0 overwrites, the others add; rows outside
+ *                             the own range are not touched).  The caller applies lcgs_adam_step to its own rows.
+ * Every rank calls both, once per step, in this order.  lcgs_comm_get_stats reports the bytes of the whole step after the
+ * backward call ((4 + 48) bytes a row out as an owner, 48 back as a view's renderer, + the count table).
+ * An in-process stand-in for RCCL exists for tests and single-GPU rehearsals: lcgs_loopback_group_create(N) +
+ * lcgs_comm_create_loopback(ctx_r, group, r) give N communicators for N contexts ON ONE DEVICE, driven by one host thread
+ * each; the two calls above then run the same code with device-to-device copies as the wire (RCCL refuses a second rank on
+ * a device).  A loopback communicator carries the ownership step only. */
+LCGS_API void        lcgs_comm_owner_rows(int64_t num_gaussians, int world_size, int rank, int64_t* first, int64_t* count);
+LCGS_API lcgs_status lcgs_owner_step_forward(lcgs_context* ctx, lcgs_comm* comm, const lcgs_camera* cameras /* [world_size] */,
+                                             const float bg_color[3], float scale_modifier, float* d_img);
+LCGS_API lcgs_status lcgs_owner_step_backward(lcgs_context* ctx, lcgs_comm* comm, const float* d_dL_dimg, const lcgs_grads* grads);
+typedef struct lcgs_loopback_group lcgs_loopback_group;
+LCGS_API lcgs_status lcgs_loopback_group_create(int world_size, lcgs_loopback_group** out);
+LCGS_API lcgs_status lcgs_loopback_group_destroy(lcgs_loopback_group* group); /* after its communicators */
+LCGS_API lcgs_status lcgs_comm_create_loopback(lcgs_context* ctx, lcgs_loopback_group* group, int rank, lcgs_comm** out);
 
 /* ------------------------------------------------------------------------------------------
  * Scene ingest / image egress (host side of `render(ply, camera) -> image`)

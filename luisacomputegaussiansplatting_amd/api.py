@@ -144,6 +144,8 @@ EXPORTED_SYMBOLS = [
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png", "lcgs_l2_loss_backward",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh", "lcgs_scene_modified", "lcgs_debug_verify_derived",
+    "lcgs_comm_owner_rows", "lcgs_owner_step_forward", "lcgs_owner_step_backward", "lcgs_loopback_group_create",
+    "lcgs_loopback_group_destroy", "lcgs_comm_create_loopback",
     "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_set_lod", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_set_transport", "lcgs_comm_shard_rows",
     "lcgs_grads_allreduce", "lcgs_adam_step_sharded", "lcgs_comm_track_touched_rows", "lcgs_comm_get_stats",
     "lcgs_adam_step_sparse", "lcgs_sparse_touched_rows", "lcgs_sparse_message_words", "lcgs_sparse_pack",
@@ -174,7 +176,7 @@ def load_library():
         fn = getattr(lib, name)
         if name not in ("lcgs_version", "lcgs_last_error", "lcgs_get_lookat_cam", "lcgs_local_to_world_matrix",
                         "lcgs_world_to_local_matrix", "lcgs_projection_matrix", "lcgs_scene_host_free",
-                        "lcgs_image_to_rgb8", "lcgs_comm_shard_rows", "lcgs_sparse_message_words"):
+                        "lcgs_image_to_rgb8", "lcgs_comm_shard_rows", "lcgs_sparse_message_words", "lcgs_comm_owner_rows"):
             fn.restype = C.c_int
     lib.lcgs_get_lookat_cam.restype = None
     lib.lcgs_local_to_world_matrix.restype = None
@@ -183,6 +185,7 @@ def load_library():
     lib.lcgs_scene_host_free.restype = None
     lib.lcgs_image_to_rgb8.restype = None
     lib.lcgs_comm_shard_rows.restype = None
+    lib.lcgs_comm_owner_rows.restype = None
     lib.lcgs_sparse_message_words.restype = C.c_int64
     lib.lcgs_sparse_message_words.argtypes = [C.c_int64, C.c_int]
     lib.lcgs_comm_shard_rows.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -749,14 +752,41 @@ def shard_rows(num_gaussians: int, world_size: int, rank: int):
     return first.value, count.value
 
 
+def owner_rows(num_gaussians: int, world_size: int, rank: int):
+    """lcgs_comm_owner_rows: (first, count) of the rows a rank OWNS in the ownership step (the tail with the last rank)"""
+    first, count = C.c_int64(0), C.c_int64(0)
+    load_library().lcgs_comm_owner_rows(C.c_int64(num_gaussians), C.c_int(world_size), C.c_int(rank), C.byref(first), C.byref(count))
+    return int(first.value), int(count.value)
+
+
+class LoopbackGroup:
+    """lcgs_loopback_group: the rendezvous of N in-process communicators (N contexts on ONE device, one host thread each) --
+    the ownership step's C code path with N > 1 participants on a single GPU.  Tests and rehearsals only."""
+
+    def __init__(self, world_size: int):
+        self.world_size = world_size
+        self._h = C.c_void_p(0)
+        _check(load_library().lcgs_loopback_group_create(C.c_int(world_size), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _check(load_library().lcgs_loopback_group_destroy(self._h))
+            self._h = C.c_void_p(0)
+
+
 class Comm:
     """lcgs_comm: the RCCL communicator of a view-parallel job, attached to one context.
 
     `exchange(payload: bytes | None) -> bytes` carries the 128-byte rendezvous token from rank 0 (which passes it in)
     to every other rank (which pass None): any broadcast the host has (torch.distributed, a pipe, a file)."""
 
-    def __init__(self, ctx: Context, rank: int, world_size: int, exchange=None):
+    def __init__(self, ctx: Context, rank: int, world_size: int, exchange=None, loopback: "LoopbackGroup" = None):
         lib = load_library()
+        if loopback is not None:  # an in-process communicator: N contexts on one device, one host thread each
+            self.ctx, self.rank, self.world_size = ctx, rank, loopback.world_size
+            self._h = C.c_void_p(0)
+            _check(lib.lcgs_comm_create_loopback(ctx._h, loopback._h, C.c_int(rank), C.byref(self._h)))
+            return
         token = (C.c_char * 128)()
         if rank == 0:
             _check(lib.lcgs_comm_unique_id(token))
@@ -780,6 +810,17 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+    def owner_step_forward(self, cams, img, bg=(0.0, 0.0, 0.0), scale_modifier: float = 1.0):
+        """lcgs_owner_step_forward: the ownership step's first half with its transport -- this rank's rows projected for every
+        view, records exchanged (RCCL send / recv, or the loopback), this rank's view rendered into img"""
+        arr = (Camera * len(cams))(*cams)
+        _check(load_library().lcgs_owner_step_forward(self.ctx._h, self._h, arr, _f3(bg), C.c_float(scale_modifier), _ptr(img)))
+
+    def owner_step_backward(self, dL_dimg, grads: dict):
+        """lcgs_owner_step_backward: the view's 2-D gradients back to the owners, parameter gradients at this rank's own rows"""
+        g = _Grads(*[_ptr(grads[k]) for k in _KEYS])
+        _check(load_library().lcgs_owner_step_backward(self.ctx._h, self._h, _ptr(dL_dimg), C.byref(g)))
 
     def set_transport(self, transport: str):
         """lcgs_comm_set_transport: "f32" (default, exact) or "f16" (opt-in: half the bytes, ~sqrt(N) x 5e-4 relative)"""

@@ -23,10 +23,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include <rccl/rccl.h> // types and enums only: every entry point is resolved with dlsym
 
@@ -141,6 +144,49 @@ AttrRows attr_rows(const lcgs_params* p, int sh_degree)
 
 } // namespace
 
+// An in-process rendezvous for N communicators on ONE device (lcgs_loopback_*): N contexts, one host thread each, standing in
+// for N ranks.  Carries what the ownership step needs -- a small all-gather and grouped sends / receives, as device-to-
+// device copies ordered by events -- so that the step's C code path (message layout, offsets, slot state, ordering) runs
+// with N > 1 participants on a single GPU, where RCCL refuses a second rank.  Not a transport for production.
+struct lcgs_loopback_group {
+    int                     world = 0;
+    std::mutex              mu;
+    std::condition_variable cv;
+    int                     arrived = 0;
+    uint64_t                generation = 0;
+    bool                    failed = false; // a member gave up: everybody leaves the barriers with an error
+    std::vector<uint32_t>   table;          // all-gather staging: world x count words
+    struct Msg {
+        const void* ptr;
+        size_t      bytes;
+        hipEvent_t  ready; // recorded on the sender's stream behind the data
+    };
+    std::vector<std::deque<Msg>> box;  // box[dst * world + src]: the sends posted in the open group, in order
+    std::vector<hipEvent_t>      done; // per rank: behind the copies of its receives of the last group
+    int                          members = 0;
+
+    bool barrier() // false: the group failed
+    {
+        std::unique_lock<std::mutex> lock(mu);
+        if (failed) return false;
+        const uint64_t g = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lock, [&] { return generation != g || failed; });
+        }
+        return !failed;
+    }
+    void fail()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        failed = true;
+        cv.notify_all();
+    }
+};
+
 struct lcgs_comm {
     lcgs_context* ctx    = nullptr;
     ncclComm_t    comm   = nullptr;
@@ -157,6 +203,18 @@ struct lcgs_comm {
     DeviceBuffer flags, chunk_ws, rows, bounds, matrix, sendbuf, recvbuf; // bounds: [world + 2] positions + [1] total
     uint32_t*    h_matrix = nullptr; // pinned: world x (world + 2) positions (row r = rank r's owner bounds)
     lcgs_comm_stats stats{};
+    // splat-ownership step (lcgs_owner_step_forward / _backward): my rows' records for every view of the step, what I
+    // received for my view (owner order), its 2-D gradients, and the 2-D gradients of my rows that came back
+    lcgs_loopback_group* loop = nullptr; // set: an in-process communicator (lcgs_comm_create_loopback), comm == NULL
+    bool         self_p2p = false;       // test hook LCGS_OWNER_SELF_P2P=1: my own share travels through send / recv too
+    DeviceBuffer own_rows, own_recs, in_rows, in_recs, g2d_all, g_in;
+    struct {
+        bool     valid = false;
+        int64_t  n_all = 0;                     // rows on my view's screen (all owners)
+        int64_t  in_off[LCGS_MAX_RANKS + 1]{};  // owner o's rows start here in in_rows / in_recs / g2d_all
+        uint32_t out[LCGS_MAX_RANKS]{};         // my rows on view v's screen (= table[me][v])
+        std::vector<std::pair<void*, std::pair<size_t, int>>> recvs; // loopback: receives of the open group
+    } own;
 };
 
 namespace lcgs
@@ -291,6 +349,7 @@ lcgs_status lcgs_comm_create(lcgs_context* ctx, const lcgs_comm_id* id, int rank
         return rccl_fail(r, "ncclCommInitRank", __LINE__);
     }
     ctx->comm = c;
+    if (const char* s = getenv("LCGS_OWNER_SELF_P2P")) c->self_p2p = s[0] == '1'; // test hook (see lcgs_owner_step_forward)
     // chunked all-reduce: the dense backward slices its preprocess pass (tuning hook LCGS_GRAD_SLICES; 1 = one chunk)
     int slices = 4;
     if (const char* s = getenv("LCGS_GRAD_SLICES")) slices = atoi(s);
@@ -311,9 +370,15 @@ lcgs_status lcgs_comm_destroy(lcgs_comm* c)
     }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
+    if (c->loop) {
+        std::lock_guard<std::mutex> lock(c->loop->mu);
+        --c->loop->members;
+    }
     c->packed.release();
     c->scales.release();
-    for (DeviceBuffer* b : { &c->flags, &c->chunk_ws, &c->rows, &c->bounds, &c->matrix, &c->sendbuf, &c->recvbuf }) b->release();
+    for (DeviceBuffer* b : { &c->flags, &c->chunk_ws, &c->rows, &c->bounds, &c->matrix, &c->sendbuf, &c->recvbuf, &c->own_rows,
+                             &c->own_recs, &c->in_rows, &c->in_recs, &c->g2d_all, &c->g_in })
+        b->release();
     if (c->h_matrix) (void)hipHostFree(c->h_matrix);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_out) (void)hipEventDestroy(c->ev_out);
@@ -343,6 +408,7 @@ lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* c, int num_gaussi
 {
     LCGS_REQUIRE(ctx && c && grads, "NULL argument");
     LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another (or a destroyed) context");
+    LCGS_REQUIRE(c->loop == nullptr, "an in-process (loopback) communicator carries the ownership step only");
     LCGS_REQUIRE(num_gaussians >= 0 && sh_degree >= 0 && sh_degree <= 3, "bad num_gaussians / sh_degree");
     LCGS_REQUIRE(grads->d_dL_dpos && grads->d_dL_dscale && grads->d_dL_drotq && grads->d_dL_dsh && grads->d_dL_dopacity,
                  "NULL gradient buffer");
@@ -433,6 +499,7 @@ lcgs_status lcgs_adam_step_sharded(lcgs_context* ctx, lcgs_comm* c, int num_gaus
 {
     LCGS_REQUIRE(ctx && c && cfg && grads && raw && m && v && activated, "NULL argument");
     LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another context");
+    LCGS_REQUIRE(c->loop == nullptr, "an in-process (loopback) communicator carries the ownership step only");
     LCGS_REQUIRE(cfg->visible_only == 0, "the sharded step is dense (per-splat rows): visible_only must be 0");
     LCGS_REQUIRE(num_gaussians >= 0 && sh_degree >= 0 && sh_degree <= 3, "bad num_gaussians / sh_degree");
     if (num_gaussians == 0) return LCGS_OK;
@@ -598,6 +665,7 @@ lcgs_status lcgs_adam_step_sparse(lcgs_context* ctx, lcgs_comm* c, int num_gauss
 {
     LCGS_REQUIRE(ctx && c && cfg && grads && raw && m && v && activated, "NULL argument");
     LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another context");
+    LCGS_REQUIRE(c->loop == nullptr, "an in-process (loopback) communicator carries the ownership step only");
     LCGS_REQUIRE(cfg->visible_only == 0, "the sparse step keeps dense-Adam semantics (every row decays): visible_only must be 0");
     LCGS_REQUIRE(num_gaussians >= 0 && sh_degree >= 0 && sh_degree <= 3, "bad num_gaussians / sh_degree");
     if (num_gaussians == 0) return LCGS_OK;
@@ -693,6 +761,346 @@ lcgs_status lcgs_adam_step_sparse(lcgs_context* ctx, lcgs_comm* c, int num_gauss
     // ---- 5. Adam on the own rows (+ the tail), 6. all-gather of the refreshed ACTIVATED rows: as in the sharded step
     LCGS_TRY(adam_own_rows(ctx, c, P, sh_degree, cfg, g, raw, m, v, activated));
     return allgather_activated(ctx, c, P, sh_degree, act);
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The splat-ownership step with its transport (the device halves are abi_owner.cpp's).  What travels: per
+// view v, from every owner o to rank v, the rows of o's range that reach v's screen -- [row index u32] + [48-byte packed
+// record] -- and back, from rank v to every owner, the 48-byte 2-D gradient row of each of them.  Sizes are agreed through
+// ONE small all-gather (the N counts of every owner) and one read-back: the step's only host synchronisation besides the
+// view's own pair-buffer check.  Point-to-point over RCCL (ncclSend / ncclRecv in one group per direction); the same code
+// runs over the in-process loopback with N contexts on one device.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace
+{
+struct Wire { // the transport of one communicator: RCCL, or the loopback group
+    lcgs_comm* c;
+
+    lcgs_status allgather_u32(const uint32_t* d_send, uint32_t* d_recv, size_t count)
+    {
+        if (!c->loop) {
+            LCGS_RCCL_CHECK(rccl().AllGather(d_send, d_recv, count, ncclUint32, c->comm, c->stream));
+            return LCGS_OK;
+        }
+        lcgs_loopback_group* g = c->loop;
+        std::vector<uint32_t> mine(count);
+        LCGS_HIP_CHECK(hipMemcpyAsync(mine.data(), d_send, count * 4, hipMemcpyDeviceToHost, c->stream));
+        LCGS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        {
+            std::lock_guard<std::mutex> lock(g->mu);
+            if (g->table.size() < (size_t)g->world * count) g->table.resize((size_t)g->world * count);
+            std::copy(mine.begin(), mine.end(), g->table.begin() + (size_t)c->rank * count);
+        }
+        if (!g->barrier()) return loop_failed();
+        std::vector<uint32_t> all;
+        {
+            std::lock_guard<std::mutex> lock(g->mu);
+            all.assign(g->table.begin(), g->table.begin() + (size_t)g->world * count);
+        }
+        LCGS_HIP_CHECK(hipMemcpy(d_recv, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+        if (!g->barrier()) return loop_failed(); // nobody overwrites the table before everybody has read it
+        return LCGS_OK;
+    }
+    lcgs_status group_begin()
+    {
+        if (!c->loop) LCGS_RCCL_CHECK(rccl().GroupStart());
+        else c->own.recvs.clear();
+        return LCGS_OK;
+    }
+    lcgs_status send(const void* d_buf, size_t bytes, int peer)
+    {
+        if (!c->loop) {
+            LCGS_RCCL_CHECK(rccl().Send(d_buf, bytes, ncclUint8, peer, c->comm, c->stream));
+            return LCGS_OK;
+        }
+        lcgs_loopback_group::Msg m{ d_buf, bytes, nullptr };
+        LCGS_HIP_CHECK(hipEventCreateWithFlags(&m.ready, hipEventDisableTiming));
+        LCGS_HIP_CHECK(hipEventRecord(m.ready, c->stream));
+        std::lock_guard<std::mutex> lock(c->loop->mu);
+        c->loop->box[(size_t)peer * c->loop->world + c->rank].push_back(m);
+        return LCGS_OK;
+    }
+    lcgs_status recv(void* d_buf, size_t bytes, int peer)
+    {
+        if (!c->loop) {
+            LCGS_RCCL_CHECK(rccl().Recv(d_buf, bytes, ncclUint8, peer, c->comm, c->stream));
+            return LCGS_OK;
+        }
+        c->own.recvs.push_back({ d_buf, { bytes, peer } });
+        return LCGS_OK;
+    }
+    lcgs_status group_end()
+    {
+        if (!c->loop) {
+            LCGS_RCCL_CHECK(rccl().GroupEnd());
+            return LCGS_OK;
+        }
+        lcgs_loopback_group* g = c->loop;
+        if (!g->barrier()) return loop_failed(); // every send of the group has been posted
+        std::vector<hipEvent_t> consumed;
+        for (auto& r : c->own.recvs) {
+            lcgs_loopback_group::Msg m{};
+            {
+                std::lock_guard<std::mutex> lock(g->mu);
+                auto& q = g->box[(size_t)c->rank * g->world + r.second.second];
+                if (q.empty() || q.front().bytes != r.second.first) {
+                    g->failed = true;
+                    g->cv.notify_all();
+                    set_last_error("loopback: a receive has no matching send of the same size (ranks disagree on the message table)");
+                    return LCGS_ERR_STATE;
+                }
+                m = q.front();
+                q.pop_front();
+            }
+            LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, m.ready, 0));
+            if (m.bytes) LCGS_HIP_CHECK(hipMemcpyAsync(r.first, m.ptr, m.bytes, hipMemcpyDeviceToDevice, c->stream));
+            consumed.push_back(m.ready);
+        }
+        LCGS_HIP_CHECK(hipEventRecord(g->done[c->rank], c->stream));
+        if (!g->barrier()) return loop_failed(); // every receive has been enqueued
+        for (int p = 0; p < g->world; ++p) // my send buffers are free once the peers' copies have run
+            if (p != c->rank) LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, g->done[p], 0));
+        for (hipEvent_t e : consumed) (void)hipEventDestroy(e);
+        if (!g->barrier()) return loop_failed(); // (the done events are not re-recorded before everybody has waited on them)
+        return LCGS_OK;
+    }
+    lcgs_status loop_failed()
+    {
+        set_last_error("loopback: another member of the group failed");
+        return LCGS_ERR_STATE;
+    }
+};
+
+// a member of a loopback group that leaves a step early (any error) releases the others from their barriers
+struct LoopGuard {
+    lcgs_comm* c;
+    bool       ok = false;
+    ~LoopGuard()
+    {
+        if (!ok && c && c->loop) c->loop->fail();
+    }
+};
+
+// bytes of one message row
+constexpr size_t kRecBytes = LCGS_OWNER_RECORD_FLOATS * 4, kG2dBytes = LCGS_OWNER_GRAD_FLOATS * 4;
+} // namespace
+
+extern "C" {
+
+void lcgs_comm_owner_rows(int64_t num_gaussians, int world_size, int rank, int64_t* first, int64_t* count)
+{
+    // equal contiguous shards of floor(P / N) rows, the P mod N tail with the last rank (multi_gpu.owner_range)
+    const int64_t c = world_size > 0 ? num_gaussians / world_size : num_gaussians;
+    if (first) *first = c * rank;
+    if (count) *count = rank < world_size - 1 ? c : num_gaussians - c * rank;
+}
+
+lcgs_status lcgs_loopback_group_create(int world_size, lcgs_loopback_group** out)
+{
+    LCGS_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    LCGS_REQUIRE(world_size >= 1 && world_size <= LCGS_MAX_OWNER_VIEWS, "world_size out of range");
+    lcgs_loopback_group* g = new (std::nothrow) lcgs_loopback_group();
+    if (!g) return LCGS_ERR_OUT_OF_MEMORY;
+    g->world = world_size;
+    g->box.resize((size_t)world_size * world_size);
+    g->done.assign(world_size, nullptr);
+    *out = g;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_loopback_group_destroy(lcgs_loopback_group* g)
+{
+    if (!g) return LCGS_OK;
+    LCGS_REQUIRE(g->members == 0, "communicators of this group are still alive");
+    for (hipEvent_t e : g->done)
+        if (e) (void)hipEventDestroy(e);
+    delete g;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_comm_create_loopback(lcgs_context* ctx, lcgs_loopback_group* group, int rank, lcgs_comm** out)
+{
+    LCGS_REQUIRE(ctx && group && out, "NULL argument");
+    *out = nullptr;
+    LCGS_REQUIRE(rank >= 0 && rank < group->world, "rank out of range");
+    LCGS_REQUIRE(ctx->comm == nullptr, "the context already has a communicator attached");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    lcgs_comm* c = new (std::nothrow) lcgs_comm();
+    if (!c) return LCGS_ERR_OUT_OF_MEMORY;
+    c->ctx = ctx, c->device = ctx->device, c->rank = rank, c->world = group->world, c->loop = group;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
+    {
+        std::lock_guard<std::mutex> lock(group->mu);
+        if (e == hipSuccess && !group->done[rank]) e = hipEventCreateWithFlags(&group->done[rank], hipEventDisableTiming);
+        if (e == hipSuccess) ++group->members;
+    }
+    if (e != hipSuccess) {
+        c->loop = nullptr;
+        (void)lcgs_comm_destroy(c);
+        LCGS_HIP_CHECK(e);
+    }
+    ctx->comm = c; // (grad_slices stays 1: a loopback communicator carries the ownership step only)
+    *out      = c;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_owner_step_forward(lcgs_context* ctx, lcgs_comm* c, const lcgs_camera* cameras, const float bg_color[3],
+                                    float scale_modifier, float* d_img)
+{
+    LCGS_REQUIRE(ctx && c && cameras && bg_color && d_img, "NULL argument");
+    LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another (or a destroyed) context");
+    LCGS_REQUIRE(c->world <= LCGS_MAX_OWNER_VIEWS, "world_size above LCGS_MAX_OWNER_VIEWS (one view slot per rank)");
+    LCGS_REQUIRE(ctx->pos != nullptr && ctx->P > 0, "no scene bound");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int N = c->world, me = c->rank;
+    int64_t   first = 0, count = 0;
+    lcgs_comm_owner_rows(ctx->P, N, me, &first, &count);
+    c->own.valid = false;
+    c->stats     = lcgs_comm_stats{};
+    Wire      wire{ c };
+    LoopGuard guard{ c };
+
+    // ---- 1. my rows, every view of the step (view v = rank v's): N asynchronous projections on the context's stream
+    LCGS_TRY(c->own_rows.ensure((size_t)N * (size_t)count * 4 + 16));
+    LCGS_TRY(c->own_recs.ensure((size_t)N * (size_t)count * kRecBytes + 16));
+    for (int v = 0; v < N; ++v)
+        LCGS_TRY(lcgs_owner_project(ctx, v, &cameras[v], scale_modifier, (int)first, (int)count, /*keep_state=*/1,
+                                    c->own_rows.as<uint32_t>() + (size_t)v * count,
+                                    c->own_recs.as<float>() + (size_t)v * count * LCGS_OWNER_RECORD_FLOATS, nullptr));
+    // ---- 2. everybody learns everybody's counts: table[o][v] = rows of owner o on view v's screen
+    LCGS_TRY(c->bounds.ensure((size_t)(N + 2) * 4));
+    LCGS_TRY(c->matrix.ensure((size_t)N * N * 4));
+    if (!c->h_matrix) LCGS_HIP_CHECK(hipHostMalloc((void**)&c->h_matrix, (size_t)LCGS_MAX_RANKS * (LCGS_MAX_RANKS + 2) * 4, 0));
+    LCGS_HIP_CHECK(hipMemsetAsync(c->bounds.ptr, 0, (size_t)N * 4, ctx->stream));
+    for (int v = 0; v < N; ++v)
+        if (ctx->owner[v].valid && ctx->owner[v].row_count > 0)
+            LCGS_HIP_CHECK(hipMemcpyAsync(c->bounds.as<uint32_t>() + v, ctx->owner[v].counts.ptr, 4, hipMemcpyDeviceToDevice, ctx->stream));
+    LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
+    LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    LCGS_TRY(wire.allgather_u32(c->bounds.as<uint32_t>(), c->matrix.as<uint32_t>(), (size_t)N));
+    LCGS_HIP_CHECK(hipMemcpyAsync(c->h_matrix, c->matrix.ptr, (size_t)N * N * 4, hipMemcpyDeviceToHost, c->stream));
+    LCGS_HIP_CHECK(hipStreamSynchronize(c->stream)); // the step's one host synchronisation for message sizes
+    auto table = [&](int o, int v) -> int64_t { return (int64_t)c->h_matrix[o * N + v]; };
+    int64_t n_all = 0;
+    for (int o = 0; o < N; ++o) {
+        int64_t of = 0, oc = 0;
+        lcgs_comm_owner_rows(ctx->P, N, o, &of, &oc);
+        for (int v = 0; v < N; ++v) LCGS_REQUIRE(table(o, v) <= oc, "an owner reports more on-screen rows than it owns");
+        c->own.in_off[o] = n_all;
+        n_all += table(o, me);
+    }
+    c->own.in_off[N] = n_all;
+    for (int v = 0; v < N; ++v) {
+        c->own.out[v] = (uint32_t)table(me, v);
+        if (ctx->owner[v].valid && ctx->owner[v].row_count > 0) ctx->owner[v].num = (int)table(me, v);
+    }
+    // ---- 3. the records travel: mine to every view's rank, every owner's to me (owner order = ascending rows)
+    LCGS_TRY(c->in_rows.ensure((size_t)n_all * 4 + 16));
+    LCGS_TRY(c->in_recs.ensure((size_t)n_all * kRecBytes + 16));
+    int64_t sent = 0, received = 0;
+    LCGS_TRY(wire.group_begin());
+    for (int o = 0; o < N; ++o) {
+        const int64_t n_out = table(me, o), n_in = table(o, me);
+        const uint32_t* rows_out = c->own_rows.as<uint32_t>() + (size_t)o * count;
+        const float*    recs_out = c->own_recs.as<float>() + (size_t)o * count * LCGS_OWNER_RECORD_FLOATS;
+        uint32_t*       rows_in  = c->in_rows.as<uint32_t>() + c->own.in_off[o];
+        float*          recs_in  = c->in_recs.as<float>() + (size_t)c->own.in_off[o] * LCGS_OWNER_RECORD_FLOATS;
+        if (o == me && !c->self_p2p) { // my own share stays on the device
+            if (n_in > 0) {
+                LCGS_HIP_CHECK(hipMemcpyAsync(rows_in, rows_out, (size_t)n_in * 4, hipMemcpyDeviceToDevice, c->stream));
+                LCGS_HIP_CHECK(hipMemcpyAsync(recs_in, recs_out, (size_t)n_in * kRecBytes, hipMemcpyDeviceToDevice, c->stream));
+            }
+            continue;
+        }
+        if (n_out > 0) {
+            LCGS_TRY(wire.send(rows_out, (size_t)n_out * 4, o));
+            LCGS_TRY(wire.send(recs_out, (size_t)n_out * kRecBytes, o));
+            sent += n_out * (int64_t)(4 + kRecBytes);
+        }
+        if (n_in > 0) {
+            LCGS_TRY(wire.recv(rows_in, (size_t)n_in * 4, o));
+            LCGS_TRY(wire.recv(recs_in, (size_t)n_in * kRecBytes, o));
+            received += n_in * (int64_t)(4 + kRecBytes);
+        }
+    }
+    LCGS_TRY(wire.group_end());
+    LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
+    LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
+    c->stats.bytes_sent        = sent + (int64_t)(N - 1) * N * 4;
+    c->stats.bytes_received    = received + (int64_t)(N - 1) * N * 4;
+    c->stats.touched_rows      = n_all; // rows on this rank's screen
+    c->stats.collective_groups = 2;     // the counts, the records
+    c->own.n_all               = n_all;
+    // ---- 4. my view from everybody's rows
+    LCGS_TRY(lcgs_owner_render(ctx, &cameras[me], bg_color, (int)n_all, c->in_rows.as<uint32_t>(), c->in_recs.as<float>(), d_img,
+                               /*keep_state=*/1));
+    c->own.valid = true;
+    guard.ok     = true;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_owner_step_backward(lcgs_context* ctx, lcgs_comm* c, const float* d_dL_dimg, const lcgs_grads* grads)
+{
+    LCGS_REQUIRE(ctx && c && d_dL_dimg && grads, "NULL argument");
+    LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another (or a destroyed) context");
+    if (!c->own.valid) {
+        set_last_error("lcgs_owner_step_backward needs a preceding lcgs_owner_step_forward");
+        return LCGS_ERR_STATE;
+    }
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int     N = c->world, me = c->rank;
+    const int64_t n_all = c->own.n_all;
+    c->own.valid        = false;
+    Wire      wire{ c };
+    LoopGuard guard{ c };
+    // ---- 1. my view's 2-D gradients, one 48-byte row per received row (owner order)
+    LCGS_TRY(c->g2d_all.ensure((size_t)n_all * kG2dBytes + 16));
+    if (n_all > 0) LCGS_TRY(lcgs_owner_render_backward(ctx, d_dL_dimg, c->g2d_all.as<float>()));
+    // ---- 2. every owner gets its rows' share back; I get my rows' share of every view
+    int64_t gin_off[LCGS_MAX_RANKS + 1], total_in = 0;
+    for (int v = 0; v < N; ++v) {
+        gin_off[v] = total_in;
+        total_in += c->own.out[v];
+    }
+    LCGS_TRY(c->g_in.ensure((size_t)total_in * kG2dBytes + 16));
+    LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
+    LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    int64_t sent = 0, received = 0;
+    LCGS_TRY(wire.group_begin());
+    for (int o = 0; o < N; ++o) {
+        const int64_t n_out = c->own.in_off[o + 1] - c->own.in_off[o]; // owner o's rows on my screen: their gradients go back
+        const int64_t n_in  = c->own.out[o];                           // my rows on view o's screen: their gradients come in
+        const float*  out   = c->g2d_all.as<float>() + (size_t)c->own.in_off[o] * LCGS_OWNER_GRAD_FLOATS;
+        float*        in    = c->g_in.as<float>() + (size_t)gin_off[o] * LCGS_OWNER_GRAD_FLOATS;
+        if (o == me && !c->self_p2p) {
+            if (n_in > 0) LCGS_HIP_CHECK(hipMemcpyAsync(in, out, (size_t)n_in * kG2dBytes, hipMemcpyDeviceToDevice, c->stream));
+            continue;
+        }
+        if (n_out > 0) {
+            LCGS_TRY(wire.send(out, (size_t)n_out * kG2dBytes, o));
+            sent += n_out * (int64_t)kG2dBytes;
+        }
+        if (n_in > 0) {
+            LCGS_TRY(wire.recv(in, (size_t)n_in * kG2dBytes, o));
+            received += n_in * (int64_t)kG2dBytes;
+        }
+    }
+    LCGS_TRY(wire.group_end());
+    LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
+    LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
+    c->stats.bytes_sent += sent;
+    c->stats.bytes_received += received;
+    c->stats.collective_groups += 1;
+    // ---- 3. my rows: the 2-D gradients of every view -> parameter gradients, summed in view order
+    for (int v = 0; v < N; ++v)
+        LCGS_TRY(lcgs_owner_backward(ctx, v, c->g_in.as<float>() + (size_t)gin_off[v] * LCGS_OWNER_GRAD_FLOATS, grads, v > 0));
+    guard.ok = true;
+    return LCGS_OK;
 }
 
 } // extern "C"

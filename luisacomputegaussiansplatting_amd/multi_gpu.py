@@ -68,9 +68,11 @@ class RcclCollective:
 
     name = "rccl (lcgs_comm C ABI)"
 
-    def __init__(self, ctx: "api.Context", rank: int, world_size: int, exchange: Optional[Callable] = None):
-        self.comm = api.Comm(ctx, rank, world_size, exchange)
+    def __init__(self, ctx: "api.Context", rank: int, world_size: int, exchange: Optional[Callable] = None, loopback=None):
+        """loopback: an api.LoopbackGroup -- N contexts on one device, one host thread per rank (rehearsals / tests)"""
+        self.comm = api.Comm(ctx, rank, world_size, exchange, loopback=loopback)
         self.rank, self.world_size = rank, world_size
+        self._img = None
 
     def allreduce_grads(self, grads: dict):
         self.comm.allreduce_grads(grads)
@@ -85,6 +87,22 @@ class RcclCollective:
     def sparse_adam(self, engine, grads: dict, step: int):
         engine.adam_sparse(self.comm, grads, step)
         self.last_stats = self.comm.stats()
+
+    def owner_step(self, engine, cams, dL_dimg, grads: dict, step: int, optimise: bool = True):
+        """The splat-ownership step through the C ABI: lcgs_owner_step_forward / _backward move the records and
+        the 2-D gradients over RCCL point-to-point; Adam then touches this rank's own rows only."""
+        import torch
+
+        cam = cams[self.rank]
+        if self._img is None or tuple(self._img.shape) != (3, cam.height, cam.width):
+            self._img = torch.zeros(3, cam.height, cam.width, device=grads["pos"].device, dtype=torch.float32)
+        self.comm.owner_step_forward(cams, self._img)
+        self.comm.owner_step_backward(dL_dimg, grads)
+        if optimise:
+            engine.adam(grads, step, rows=api.owner_rows(int(grads["pos"].shape[0]), self.world_size, self.rank))
+        st = self.comm.stats()
+        self.last_stats = {"bytes_sent": st["bytes_sent"], "bytes_received": st["bytes_received"],
+                           "on_screen_rows_received": st["touched_rows"], "collective_groups": st["collective_groups"]}
 
     def close(self):
         self.comm.close()

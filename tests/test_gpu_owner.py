@@ -243,3 +243,134 @@ def test_every_view_of_a_step_with_one_read_back(lcgs):
     assert lib.lcgs_owner_counts(r.ctx._h, C.c_int(0), C.c_int(1), n) == 0 and n[0] == together[0][0].numel()
     r.owner_backward(0, g2d[:n[0]].contiguous(), *[g[k] for k in KEYS], accumulate=False)
     r.ctx.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The ownership step WITH its transport through the C ABI (lcgs_owner_step_forward / _backward, host/comm.cpp)
+# ---------------------------------------------------------------------------------------------------------------------
+def _reference_views(lcgs, scene, cams, dLs, bg):
+    """the ordinary path: every view's fused frame + the gradients of all views summed (file-order arrays)"""
+    act = upload_scene(scene)
+    ref = lcgs.Renderer(lcgs.Context(0))
+    ref.bind_scene(*[act[k] for k in KEYS])
+    imgs, g = [], {k: torch.zeros_like(act[k]) for k in KEYS}
+    vis = []
+    for j, (cam, dL) in enumerate(zip(cams, dLs)):
+        img = torch.full((3, H, W), -1.0, device=DEV)
+        assert ref.forward(cam, img, bg=bg, keep_state=True, sync=True) > 0
+        vis.append(ref.frame_stats()["num_visible"])
+        ref.backward(dL, *[g[k] for k in KEYS], accumulate=j > 0)
+        imgs.append(img)
+    ref.ctx.synchronize()
+    return imgs, g, vis
+
+
+@pytest.mark.parametrize("self_p2p", [False, True])
+def test_owner_step_through_rccl_at_world_size_one(lcgs, monkeypatch, self_p2p):
+    """One rank owns everything: the step is the fused frame + its backward.  With LCGS_OWNER_SELF_P2P=1 the rank's own share
+    travels through ncclSend / ncclRecv to itself -- RCCL's point-to-point path, the one N > 1 ranks use."""
+    if self_p2p:
+        monkeypatch.setenv("LCGS_OWNER_SELF_P2P", "1")
+    rng = np.random.default_rng(71)
+    P = 40_003
+    scene = make_scene(rng, P, log_scale=(-4.0, 0.8))
+    cams = [lcgs.get_lookat_cam(*POSE, width=W, height=H)]
+    dLs = [torch.from_numpy(rng.normal(size=(3, H, W)).astype(np.float32)).to(DEV)]
+    bg = (0.1, 0.2, 0.3)
+    imgs, g_ref, vis = _reference_views(lcgs, scene, cams, dLs, bg)
+    act = upload_scene(scene)
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.bind_scene(*[act[k] for k in KEYS])
+    comm = lcgs.Comm(r.ctx, 0, 1)
+    try:
+        g = {k: torch.full_like(act[k], 9.0) for k in KEYS}
+        for _ in range(2):  # twice: buffers re-used, slots re-used
+            img = torch.full((3, H, W), -1.0, device=DEV)
+            comm.owner_step_forward(cams, img, bg=bg)
+            comm.owner_step_backward(dLs[0], g)
+            r.ctx.synchronize()
+            assert torch.equal(img, imgs[0])
+            for k in KEYS:
+                assert _rel(g[k], g_ref[k]) <= 1e-4, k
+        st = comm.stats()
+        assert st["touched_rows"] == vis[0]
+        want = vis[0] * (4 + 48 + 48) if self_p2p else 0
+        assert st["bytes_sent"] == want and st["bytes_received"] == want, (st, want)
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("world,reordered", [(2, False), (3, True), (8, False)])
+def test_owner_step_with_n_ranks_in_process(lcgs, world, reordered):
+    """N contexts on the one GPU, one host thread each, joined by the in-process loopback transport: the SAME C code path as
+    the RCCL step (message table, offsets, slot state, stream ordering) with N > 1 participants.  Every rank's image is its
+    view's fused frame bit for bit; every rank's rows hold the gradients of all N views summed; the byte counts are the
+    design's (4 + 48) out as an owner, 48 back as a renderer."""
+    import threading
+
+    rng = np.random.default_rng(80 + world)
+    P = 50_007
+    scene = make_scene(rng, P, log_scale=(-4.0, 0.8))
+    scene["pos"][100:200] = scene["pos"][300:400]  # equal depths across owners' ranges
+    cams = [lcgs.get_lookat_cam([-3 * np.cos(a), -0.5 + 3 * np.sin(a), 2.3], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+            for a in np.linspace(0.0, 1.4, world)]
+    dLs = [torch.from_numpy(rng.normal(size=(3, H, W)).astype(np.float32)).to(DEV) for _ in cams]
+    bg = (0.1, 0.2, 0.3)
+    imgs_ref, g_ref, vis = _reference_views(lcgs, scene, cams, dLs, bg)
+    group = lcgs.api.LoopbackGroup(world)
+    out, errors = [None] * world, []
+
+    def rank_main(me):
+        try:
+            side = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(side):
+                r = lcgs.Renderer(lcgs.Context(0, side.cuda_stream))
+                if reordered:
+                    r.upload_scene(scene)  # spatial order: the ranks own ranges of the RE-ORDERED rows
+                    act = r.scene_tensors()
+                    perm = r.permutation().long()
+                else:
+                    act = upload_scene(scene)
+                    r.bind_scene(*[act[k] for k in KEYS])
+                    perm = None
+                comm = lcgs.Comm(r.ctx, me, world, loopback=group)
+                g = {k: torch.full_like(act[k], 9.0) for k in KEYS}
+                img = torch.full((3, H, W), -1.0, device=DEV)
+                for _ in range(2):
+                    comm.owner_step_forward(cams, img, bg=bg)
+                    comm.owner_step_backward(dLs[me], g)
+                r.ctx.synchronize()
+                side.synchronize()
+                out[me] = (img, g, comm.stats(), perm)
+                comm.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((me, repr(e)))
+
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=rank_main, args=(me,)) for me in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank hangs"
+    group.close()
+    sent = received = 0
+    for me in range(world):
+        img, g, st, perm = out[me]
+        assert torch.equal(img, imgs_ref[me]), f"rank {me}: {int((img != imgs_ref[me]).any(0).sum())} pixels differ"
+        assert st["touched_rows"] == vis[me]
+        first, count = lcgs.api.owner_rows(P, world, me)
+        for k in KEYS:
+            mine = g[k][first:first + count]
+            ref = (g_ref[k][perm] if perm is not None else g_ref[k])[first:first + count]  # (row r of a re-ordered scene = file row perm[r])
+            assert _rel(mine, ref) <= 1e-4, (me, k, _rel(mine, ref))
+            rest = torch.cat([g[k][:first], g[k][first + count:]])
+            assert bool((rest == 9.0).all()), (me, k)  # rows of other owners are not touched
+        sent += st["bytes_sent"]
+        received += st["bytes_received"]
+    assert sent == received
+    # every on-screen row of every view travels once as (4 + 48) bytes and its gradient once as 48, except an owner's own view
+    table_bytes = world * (world - 1) * world * 4
+    assert (sent - table_bytes) % 4 == 0 and sent - table_bytes <= sum(vis) * 100
+    assert sent - table_bytes >= (sum(vis) * 100) * (world - 1) // world // 2  # (views see the ranges unevenly; not an exact law)
