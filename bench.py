@@ -733,6 +733,15 @@ def main():
                 out["fwd_bwd"]["note"] = ("gradient collective: lcgs_grads_allreduce (RCCL, chunked behind the backward's "
                                           "slices)" if args.collective == "rccl" else "gradient collective: torch.distributed")
                 out["fwd_bwd"]["grad_transport"] = args.grad_transport if args.collective == "rccl" else "f32"
+                if isinstance(coll, mg.RcclCollective):
+                    # what RCCL itself saw: the communicator's size (ncclCommInitRank's, via lcgs_comm_info) and what the last
+                    # gradient sum of the timed loop issued / moved (lcgs_comm_get_stats) -- so that the line certifies by itself
+                    # that N ranks exchanged gradients through the library's communicator
+                    tr_sum.step(dL, optimise=False)
+                    st_c = coll.comm.stats()
+                    out["fwd_bwd"]["rccl_ranks"] = coll.comm.info()[1]
+                    out["fwd_bwd"]["collective_groups"] = st_c["collective_groups"]
+                    out["fwd_bwd"]["rccl_bytes_sent_last_step"] = st_c["bytes_sent"]
             if el_compact is not None:
                 out["fwd_bwd"]["compact_rows"] = {"value": round(P * args.steps / el_compact / 1e6, 1), "unit": "Msplats/s",
                                                   "ms_per_step": round(el_compact * 1e3 / args.steps, 4)}
@@ -871,21 +880,24 @@ def main():
                 if dist is not None:
                     # ---- splat ownership: nothing replicated, nothing all-gathered -- every rank owns P / N rows,
                     # projects them for every view of the step and exchanges 48-byte records / 48-byte 2-D gradients of
-                    # on-screen rows with the views' renderers.  Transport: torch.distributed point-to-point on the process
-                    # group (= RCCL send / recv on a node); a leg of its own, so a failure costs nothing else.
+                    # on-screen rows with the views' renderers.  Transport: the library's own (lcgs_owner_step_forward / _backward:
+                    # ncclSend / ncclRecv groups on the communicator's stream) with --collective rccl, torch.distributed
+                    # point-to-point on the process group with --collective torch; a leg of its own, so a failure costs nothing else.
                     try:
                         cams_o = [L.get_lookat_cam(*view_pose(k), width=W, height=H) for k in range(8)]
-                        tcoll = mg.TorchCollective(dist, rank, world)
-                        tr_o = mg.ViewParallelTrainer(eng2, tcoll, cams_o, views, mode="owner")
+                        ocoll = coll if isinstance(coll, mg.RcclCollective) else mg.TorchCollective(dist, rank, world)
+                        tr_o = mg.ViewParallelTrainer(eng2, ocoll, cams_o, views, mode="owner")
                         el_o = timed(lambda i: tr_o.step(dL, optimise=True), args.steps, 2)
-                        st_o = getattr(tcoll, "last_stats", None) or {}
+                        st_o = getattr(ocoll, "last_stats", None) or {}
                         out["train_step"]["owner"] = {
                             "value": round(world * P * args.steps / el_o / 1e6, 1), "unit": "Msplats/s",
                             "ms_per_step": round(el_o * 1e3 / args.steps, 4),
+                            "transport": ocoll.name,
                             "xgmi_bytes_sent_per_gpu": st_o.get("bytes_sent"),
                             "on_screen_rows_rendered": st_o.get("on_screen_rows_received"),
+                            "collective_groups": st_o.get("collective_groups"),
                             "note": "splat ownership: 2-D records / 2-D gradients of on-screen rows travel, Adam on the own rows only, "
-                                    "no all-gather; one host synchronisation per step for the N row counts (lcgs_owner_counts) + one inside the view's frame"}
+                                    "no all-gather; one host synchronisation per step for the N row counts + one inside the view's frame"}
                     except Exception as e:  # noqa: BLE001
                         out.setdefault("leg_errors", {})["train_step.owner"] = f"{type(e).__name__}: {e}"[:400]
                 eng2.close()

@@ -811,6 +811,12 @@ class Comm:
         except Exception:
             pass
 
+    def info(self):
+        """lcgs_comm_info: (rank, world_size) as the communicator itself -- i.e. RCCL -- sees them"""
+        rk, ws = C.c_int(-1), C.c_int(-1)
+        _check(load_library().lcgs_comm_info(self._h, C.byref(rk), C.byref(ws)))
+        return int(rk.value), int(ws.value)
+
     def owner_step_forward(self, cams, img, bg=(0.0, 0.0, 0.0), scale_modifier: float = 1.0):
         """lcgs_owner_step_forward: the ownership step's first half with its transport -- this rank's rows projected for every
         view, records exchanged (RCCL send / recv, or the loopback), this rank's view rendered into img"""

@@ -1,7 +1,7 @@
 // lcgs-app -- CLI work-alike of the reference's app/main.cpp on the MI355X library.
 //   lcgs-app --ply <path> [--res WxH] [--out dir] [--world colmap|blender] [--exp_N N] [--backend hip]
 //            [--path fused|stage|deferred] [--synth kind:count:seed] [--ingest device|host] [--cameras file]
-//            [--order file|spatial] [--pose garden|lego] [--gpus N] [--backward] [--fit K]
+//            [--order file|spatial] [--pose garden|lego] [--gpus N] [--backward [--owner]] [--fit K]
 // Same flags (app/main.cpp:52-124; `--key=value` and `--key value`, app/command_parser.hpp:5-79), the same
 // hard-coded look-at camera (app/main.cpp:191-207), the same frame loop (:266-308), the same output:
 // <out>/<ply stem>_<backend>.png, CHW float -> vertically flipped RGB8 with a truncating *255 (:323-339).
@@ -60,6 +60,9 @@ void usage(const char* argv0)
     printf("  --cameras <file>         Render every camera of the file: `px py pz tx ty tz ux uy uz [fov]` per line\n");
     printf("  --gpus <N>               Shard the views of --cameras over N GPUs (one process per GPU; default 1)\n");
     printf("  --backward               Per round of views: backward (dL/dimg = 1) + RCCL sum of the gradients over the GPUs\n");
+    printf("  --owner                  With --backward: the splat-ownership step instead (every GPU owns P / N rows; 48-byte\n"
+           "                           records and 2-D gradients of on-screen rows travel by RCCL send / recv, no dense sum).\n"
+           "                           The printed norms come from a verification all-reduce outside the step\n");
     printf("  --fit <K>                Training without a Python binding (doc/roadmap.md:4), as a demonstration: the loaded scene's\n"
            "                           frame is the target, opacities and base colours are perturbed, K optimiser steps\n"
            "                           (forward, L2 loss, backward, Adam) pull them back; prints the loss per step.  With\n"
@@ -84,7 +87,7 @@ int main(int argc, char** argv)
     std::string ply_path = "gsplat.ply", backend = "hip", out_dir = "out", world = "colmap", path = "fused", synth;
     std::string ingest = "device", cameras_file, order = "auto", pose = "garden";
     int         exp_N = 1, gpus = 1, fit_steps = 0;
-    bool        backward = false, fused_adam = false;
+    bool        backward = false, fused_adam = false, owner = false;
     // parse_command (app/command_parser.hpp:5-79): strip leading dashes, `key=value` or `key value`
     for (int i = 1; i < argc; ++i) {
         std::string arg = argv[i];
@@ -138,6 +141,7 @@ int main(int argc, char** argv)
             gpus = std::stoi(value);
             if (gpus < 1 || gpus > 64) die("--gpus out of range");
         } else if (key == "backward") backward = true;
+        else if (key == "owner") owner = true;
         else if (key == "fit") {
             if (value.empty()) die("--fit requires a value");
             fit_steps = std::stoi(value);
@@ -443,7 +447,41 @@ int main(int argc, char** argv)
             }
             const size_t rounds = (views.size() + (size_t)gpus - 1) / (size_t)gpus;
             auto         t0     = std::chrono::steady_clock::now();
-            for (size_t round = 0; round < rounds; ++round) {
+            if (owner) {
+                if (!backward) die("--owner goes with --backward");
+                if (views.size() % (size_t)gpus != 0) die("--owner needs a multiple of --gpus views (every rank renders one per round)");
+            }
+            for (size_t round = 0; owner && round < rounds; ++round) {
+                // ---- splat ownership: this rank owns P / N rows and renders view round * N + rank; records out,
+                // 2-D gradients back, over RCCL point-to-point (lcgs_owner_step_forward / _backward)
+                std::vector<lcgs::Camera> cams;
+                for (int q = 0; q < gpus; ++q) cams.push_back(make_camera(views[round * (size_t)gpus + (size_t)q]));
+                float* gp[5] = { g_pos.data(), g_scale.data(), g_rotq.data(), g_sh.data(), g_op.data() };
+                for (int a = 0; a < 5; ++a) // rows of other owners stay zero: the verification sum below needs that
+                    if (hipMemsetAsync(gp[a], 0, (size_t)P * widths[a] * 4, nullptr) != hipSuccess) die("memset failed");
+                if (hipDeviceSynchronize() != hipSuccess) die("sync failed");
+                comm->owner_step_forward(cams.data(), bg, d_img.data());
+                save_view(d_img.data(), round * (size_t)gpus + (size_t)rank);
+                comm->owner_step_backward(d_ones.data(), grads);
+                device.synchronize();
+                const lcgs_comm_stats st = comm->stats();
+                comm->allreduce(P, grads); // VERIFICATION only (the step itself never sums dense rows): norms as --backward prints them
+                device.synchronize();
+                if (root) {
+                    static const char* names[5] = { "pos", "scale", "rotq", "sh", "opacity" };
+                    printf("round %zu (%d view%s, ownership step: %lld bytes sent by rank 0): grad_l2", round, gpus, gpus > 1 ? "s" : "",
+                           (long long)st.bytes_sent);
+                    for (int a = 0; a < 5; ++a) {
+                        std::vector<float> h((size_t)P * widths[a]);
+                        if (hipMemcpy(h.data(), gp[a], h.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) die("D2H copy failed");
+                        double acc = 0.0;
+                        for (float x : h) acc += (double)x * x;
+                        printf(" %s %.9e", names[a], std::sqrt(acc));
+                    }
+                    printf("\n");
+                }
+            }
+            for (size_t round = 0; !owner && round < rounds; ++round) {
                 const size_t vi   = round * (size_t)gpus + (size_t)rank;
                 const bool   mine = vi < views.size();
                 int          n    = 0;

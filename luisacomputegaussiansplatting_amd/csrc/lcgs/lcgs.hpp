@@ -297,6 +297,22 @@ public:
     {
         check(lcgs_adam_step_sparse(m_dev->ctx(), m_comm, num_gaussians, sh_degree, &cfg, &grads, &raw, &m, &v, &activated));
     }
+    // Splat ownership: rank r owns the rows owner_rows(P, N, r) and renders view r of cameras[N].  forward:
+    // own rows projected for every view, records exchanged over RCCL point-to-point, this rank's view rendered into d_img
+    // (the whole scene's fused frame, bit for bit); backward: the view's 2-D gradients back to the owners, parameter
+    // gradients at the own rows of `grads` (apply lcgs_adam_step to those rows).  Every rank calls both, in this order.
+    static void owner_rows(int64_t num_gaussians, int world_size, int rank, int64_t& first, int64_t& count)
+    {
+        lcgs_comm_owner_rows(num_gaussians, world_size, rank, &first, &count);
+    }
+    void owner_step_forward(const lcgs_camera* cameras, const float bg_color[3], float* d_img, float scale_modifier = 1.0f)
+    {
+        check(lcgs_owner_step_forward(m_dev->ctx(), m_comm, cameras, bg_color, scale_modifier, d_img));
+    }
+    void owner_step_backward(const float* d_dL_dimg, const lcgs_grads& grads)
+    {
+        check(lcgs_owner_step_backward(m_dev->ctx(), m_comm, d_dL_dimg, &grads));
+    }
     lcgs_comm_stats stats() const
     {
         lcgs_comm_stats st;

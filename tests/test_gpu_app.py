@@ -117,6 +117,36 @@ def test_lcgs_app_view_sharded_backward_with_gradient_sum(lcgs, oracle, tmp_path
         assert os.path.exists(os.path.join(out, f"synth0_{P}_hip_{k}.png"))
 
 
+def test_lcgs_app_ownership_step_prints_the_same_norms(lcgs, tmp_path):
+    """--backward --owner: the C++ caller of lcgs_owner_step_forward / _backward (lcgs.hpp Comm::owner_step_*), RCCL at world
+    size 1; its verification norms are the dense --backward path's."""
+    import re
+
+    app = os.path.join(ROOT, "luisacomputegaussiansplatting_amd", "lcgs-app")
+    P, W, H = 8000, 256, 192
+    views = [([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1]), ([2.5, 1.5, 1.0], [0, 0, 0.5], [0, 0, 1])]
+    cams = str(tmp_path / "cams.txt")
+    with open(cams, "w") as f:
+        for p, t, u in views:
+            f.write(" ".join(str(x) for x in p + t + u) + "\n")
+    got = {}
+    for tag, extra in (("dense", []), ("owner", ["--owner"])):
+        out = str(tmp_path / tag)
+        res = subprocess.run([app, "--synth", f"0:{P}:1001", f"--res={W}x{H}", "--out", out, "--cameras", cams, "--gpus", "1",
+                              "--backward"] + extra, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr
+        got[tag] = re.findall(r"round (\d+) \(1 view[^)]*\): grad_l2 pos (\S+) scale (\S+) rotq (\S+) sh (\S+) opacity (\S+)", res.stdout)
+        assert len(got[tag]) == len(views), res.stdout
+        for k in range(len(views)):
+            assert os.path.exists(os.path.join(out, f"synth0_{P}_hip_{k}.png"))
+    for a, b in zip(got["dense"], got["owner"]):
+        for x, y in zip(a[1:], b[1:]):
+            assert abs(float(x) - float(y)) <= 1e-4 * float(x), (a, b)
+    for k in range(len(views)):  # the same images, byte for byte
+        pa, pb = (os.path.join(str(tmp_path / t), f"synth0_{P}_hip_{k}.png") for t in ("dense", "owner"))
+        assert open(pa, "rb").read() == open(pb, "rb").read()
+
+
 @pytest.mark.parametrize("extra", [[], ["--fused-adam"]])
 def test_lcgs_app_fit_trains_through_the_c_abi_only(lcgs, tmp_path, extra):
     """--fit K: "training without python binding" (doc/roadmap.md:4) -- forward, lcgs_l2_loss_backward, lcgs_render_backward,

@@ -190,3 +190,89 @@ def test_c5_shape_with_eight_virtual_owners(lcgs, bicycle):
         rel = float((a - b).norm() / b.norm())
         # (two runs of ONE path differ by ~1e-4 here: float atomics into the 2-D sums, amplified on screen-filling splats)
         assert rel <= 5e-4, (k, rel)
+
+
+def test_c5_all_eight_views_through_the_native_ownership_step(lcgs, bicycle):
+    """BASELINE config C5 itself -- mip360_bicycle, the 8-view batch, forward + backward, eight ranks -- on the one GPU of the
+    box: eight contexts (one host thread each) joined by the in-process loopback transport run lcgs_owner_step_forward /
+    _backward, i.e. the C code path the 8 x MI355X node runs over RCCL (message table, offsets, slot state, stream order) with
+    device-to-device copies as the wire.  Rank k renders C5 view k (bench.view_pose(k)): its frame must be the fused frame's bit
+    for bit, and its own 1/8 of the rows must hold the gradients of ALL EIGHT views summed."""
+    import math
+    import threading
+
+    scene, r_ref, d = bicycle
+    P = scene["pos"].shape[0]
+    KEYS = ("pos", "scale", "rotq", "sh", "opacity")
+    N = 8
+
+    def c5_cam(k):  # base pose rotated about world-up (0,-1,0) by k x 45 degrees (bench.view_pose)
+        a = math.radians(45.0 * k)
+        c, s_ = math.cos(a), math.sin(a)
+        rot = lambda v: [c * v[0] + s_ * v[2], v[1], -s_ * v[0] + c * v[2]]
+        return lcgs.get_lookat_cam(rot(BICYCLE_POSE[0]), rot(BICYCLE_POSE[1]), BICYCLE_POSE[2], width=W, height=H)
+
+    cams = [c5_cam(k) for k in range(N)]
+    dLs = [torch.randn(3, H, W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(70 + j)) for j in range(N)]
+    g_ref = {k: torch.empty_like(d[k]) for k in KEYS}
+    imgs_ref, vis = [], []
+    for j, cam in enumerate(cams):
+        img = torch.zeros(3, H, W, device=DEV)
+        assert r_ref.forward(cam, img, keep_state=True, sync=True) > 0
+        vis.append(r_ref.frame_stats()["num_visible"])
+        r_ref.backward(dLs[j], *[g_ref[k] for k in KEYS], accumulate=j > 0)
+        imgs_ref.append(img)
+    r_ref.ctx.synchronize()
+    torch.cuda.synchronize()
+    group = lcgs.api.LoopbackGroup(N)
+    results, errors = [None] * N, []
+
+    def rank_main(me):
+        try:
+            side = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(side):
+                r = lcgs.Renderer(lcgs.Context(0, side.cuda_stream))
+                r.bind_scene(*[d[k] for k in KEYS])  # (the ranks of this rehearsal share one copy of the arrays)
+                comm = lcgs.Comm(r.ctx, me, N, loopback=group)
+                first, count = lcgs.api.owner_rows(P, N, me)
+                # a rank only ever writes its own rows: the gradient arrays are sized for them (offset pointers)
+                g_own = {k: torch.full_like(d[k][first:first + count], 9.0) for k in KEYS}
+                # lcgs_owner_step_backward addresses full-size arrays at row `first`: hand it views that start `first` rows early
+                base = {k: g_own[k].data_ptr() - first * g_own[k][0:1].numel() * 4 for k in KEYS}
+                img = torch.zeros(3, H, W, device=DEV)
+                comm.owner_step_forward(cams, img)
+                grads = lcgs.api._Grads(*[base[k] for k in KEYS])
+                import ctypes as C_
+                lcgs.api._check(lcgs.load_library().lcgs_owner_step_backward(r.ctx._h, comm._h, lcgs.api._ptr(dLs[me]), C_.byref(grads)))
+                r.ctx.synchronize()
+                side.synchronize()
+                results[me] = (img, g_own, comm.stats())
+                comm.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((me, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(me,)) for me in range(N)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank hangs"
+    group.close()
+    sent = 0
+    for me in range(N):
+        img, g_own, st = results[me]
+        assert torch.equal(img, imgs_ref[me]), f"view {me}: {int((img != imgs_ref[me]).any(0).sum())} pixels differ from the fused frame"
+        assert st["touched_rows"] == vis[me]
+        first, count = lcgs.api.owner_rows(P, N, me)
+        for k in KEYS:
+            a, b = g_own[k].double().flatten(), g_ref[k][first:first + count].double().flatten()
+            rel = float((a - b).norm() / b.norm())
+            assert rel <= 5e-4, (me, k, rel)  # (float-atomic order of the 2-D sums, as in the four-call test above)
+        sent += st["bytes_sent"]
+    # DESIGN 7's table: (N-1)/N of every view's on-screen rows travel as 52 bytes out + 48 back (this scene's rows are i.i.d.
+    # over the file, so every owner holds 1/N of every view's rows to within a per cent)
+    want = sum(vis) * 100 * (N - 1) / N
+    assert abs(sent - N * (N - 1) * N * 4 - want) <= 0.02 * want, (sent, want)
+    print(f"[C5 rehearsal] 8 ranks in process: {sent / N / 1e6:.1f} MB sent per rank and step "
+          f"(dense all-reduce: {2 * 7 / 8 * 236 * P / 1e6:.0f} MB)")
