@@ -199,6 +199,7 @@ lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx)
     if (const char* e = getenv("LCGS_BWD_WGS_PER_CU")) ctx->persist_bwd_forced = atoi(e);
     if (const char* e = getenv("LCGS_BWD_WGS_IN_FLIGHT")) ctx->persist_bwd_in_flight = atoi(e);
     if (const char* e = getenv("LCGS_GRAPH")) ctx->use_graph = (e[0] == '1'); // tuning hook
+    if (const char* e = getenv("LCGS_STAGE_SIDE_COPY")) ctx->stage_side_copy = e[0] != '0'; // A/B hook
     if (const char* e = getenv("LCGS_STAGE_SORT")) ctx->stage_sort = e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0); // test hook
     // The auxiliary stream has the LOWEST dispatch priority: its bandwidth-bound workgroups fill the gaps the main
     // stream's short, latency-bound kernels leave instead of competing with them.
@@ -277,7 +278,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
                              &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order[0], &ctx->tile_order[1], &ctx->st_keys_tmp,
                              &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac, &ctx->tie_ws, &ctx->fused_grads, &ctx->bwd_counter, &ctx->st_flags, &ctx->st_keys_exp, &ctx->st_vals_exp,
                              &ctx->st_u32[0], &ctx->st_u32[1], &ctx->st_u32[2], &ctx->st_u32[3], &ctx->st_u32[4], &ctx->st_u32[5], &ctx->st_u32[6], &ctx->st_u32[7],
-                             &ctx->cull_bound_buf, &ctx->verify_ws };
+                             &ctx->cull_bound_buf, &ctx->verify_ws, &ctx->st_win, &ctx->st_win2, &ctx->st_offs };
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& s : ctx->owner)
         for (DeviceBuffer* b : { &s.vis, &s.shjac, &s.counts }) b->release();

@@ -216,11 +216,8 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
     LCGS_TRY(ctx->st_scalar.ensure(16));
     uint32_t* d_hole = ctx->st_scalar.as<uint32_t>();
     LCGS_HIP_CHECK(hipMemsetAsync(d_hole, 0, 4, st));
-    launch_allocate_tiles(P, cp, use_focal != 0, input->depth_features, input->means_2d, input->conic,
-                          accel->tiles_touched, output->radii, st, d_hole); // impl.cpp:87-99
-    LCGS_TRY(ctx->st_scan_temp.ensure(scan_temp_bytes(P)));
-    launch_inclusive_sum_u32(accel->tiles_touched, accel->point_offsets, P, ctx->st_scan_temp.ptr, st); // impl.cpp:104
-    // (for the sort below: the splats that claim pair slots, ascending -- compacted before the one synchronisation)
+    // (for the sort below: the splats that claim pair slots, ascending -- flagged by the allocation pass itself, compacted
+    //  before the one synchronisation)
     const size_t fbytes = sparse_flag_bytes(P);
     LCGS_TRY(ctx->st_flags.ensure(fbytes));
     LCGS_TRY(ctx->st_u32[0].ensure((size_t)sparse_flag_chunks(P) * 4 + 4));
@@ -229,7 +226,10 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
     uint32_t* d_vis   = ctx->st_u32[1].as<uint32_t>();
     uint32_t* d_nvis  = d_hole + 1;
     if (fbytes > (size_t)P) LCGS_HIP_CHECK(hipMemsetAsync(d_flags + P, 0, fbytes - (size_t)P, st)); // the padding
-    launch_tile_flags(P, accel->tiles_touched, d_flags, st);
+    launch_allocate_tiles(P, cp, use_focal != 0, input->depth_features, input->means_2d, input->conic,
+                          accel->tiles_touched, output->radii, st, d_hole, d_flags); // impl.cpp:87-99
+    LCGS_TRY(ctx->st_scan_temp.ensure(scan_temp_bytes(P)));
+    launch_inclusive_sum_u32(accel->tiles_touched, accel->point_offsets, P, ctx->st_scan_temp.ptr, st); // impl.cpp:104
     launch_compact_flags(d_flags, P, ctx->st_u32[0].as<uint32_t>(), d_vis, d_nvis, st);
     // the frame's one read-back (impl.cpp:106-107): num_rendered beside the two scalars of this implementation, as ONE copy
     // into pinned memory (three 4-byte copies into pageable words left the GPU idle for ~80 us per frame)
@@ -255,8 +255,6 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
         LCGS_HIP_CHECK(hipMemsetAsync(accel->point_list_unsorted, 0, (size_t)L * 4, st));      // impl.cpp:117
         LCGS_HIP_CHECK(hipMemsetAsync(accel->point_list_keys_unsorted, 0, (size_t)L * 8, st)); // impl.cpp:118
     }
-    launch_copy_with_keys(P, cp, input->means_2d, accel->point_offsets, output->radii, input->depth_features,
-                          accel->point_list_keys_unsorted, accel->point_list_unsorted, st); // impl.cpp:120-130
     // impl.cpp:135-143 sorts all 64 key bits; only 32 + ceil(log2 G) of them can differ
     const int tile_bits = std::max(1, ceil_log2_u32(cp.grid_x * cp.grid_y));
     LCGS_TRY(ctx->st_keys_tmp.ensure((size_t)L * 8));
@@ -265,6 +263,36 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
     // (small frames: the six passes over few pairs beat the longer chain of short launches -- 0.36 M pairs: 4270 vs 3930
     //  frames/s, 2.0 M: equal, 13 M: 610 vs 710; LCGS_STAGE_SORT=literal|splats forces either, a tuning / test hook)
     const bool literal = ctx->stage_sort ? ctx->stage_sort == 1 : L < (4 << 20); // (the hook is read once, at lcgs_create)
+    // The reference's unsorted pair buffers (impl.cpp:120-130).  On the sort-before-duplicate route nothing downstream reads
+    // them -- they are outputs only -- so their copy runs on the auxiliary stream beside the depth sort's short, latency-bound
+    // launches and is joined before the renderer (round 5: -60 us of the frame); every exit path joins (SideJoin).
+    struct SideJoin {
+        lcgs_context* c      = nullptr;
+        bool          forked = false;
+        ~SideJoin()
+        {
+            if (forked) (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+        }
+    } side{ ctx };
+    if (ctx->ev_fork) LCGS_HIP_CHECK(hipEventRecord(ctx->ev_fork, st)); // "the frame's counts are known": where the side copy may start
+    const bool splat_route = !(hole || n_vis == 0 || literal);
+    auto copy_unsorted = [&](hipStream_t cs) -> lcgs_status { // impl.cpp:120-130
+        if (hole) { // (slots a NaN-covariance splat claims stay unwritten: the per-splat kernel skips them as shader.cpp:41-42 does)
+            launch_copy_with_keys(P, cp, input->means_2d, accel->point_offsets, output->radii, input->depth_features,
+                                  accel->point_list_keys_unsorted, accel->point_list_unsorted, cs);
+            return LCGS_OK;
+        }
+        // the same pairs from workgroups that own consecutive output slots (coalesced stores): the sources are the n_vis
+        // splats that claim slots, in index order, with their own inclusive offsets (= point_offsets at their rows)
+        LCGS_TRY(ctx->st_offs.ensure((size_t)n_vis * 4 + 16));
+        LCGS_TRY(ctx->st_win2.ensure(copy_with_keys_windows_bytes((uint32_t)L)));
+        launch_gather_u32((int)n_vis, d_vis, accel->point_offsets, ctx->st_offs.as<uint32_t>(), cs);
+        launch_copy_with_keys_balanced((int)n_vis, cp, input->means_2d, ctx->st_offs.as<uint32_t>(), output->radii,
+                                       input->depth_features, d_vis, accel->point_list_keys_unsorted, accel->point_list_unsorted,
+                                       (uint32_t)L, ctx->st_win2.as<uint32_t>(), cs);
+        return LCGS_OK;
+    };
+    if (!splat_route) LCGS_TRY(copy_unsorted(st)); // (the literal sort reads them)
     if (hole || n_vis == 0 || literal) {
         // the reference's sort as it stands: all live key bits of the unsorted pairs (always for frames with zero-filled
         // slots, whose pairs exist nowhere but in those buffers)
@@ -284,14 +312,26 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
                  *vb = ctx->st_u32[5].as<uint32_t>(), *cnt = ctx->st_u32[6].as<uint32_t>(), *offs = ctx->st_u32[7].as<uint32_t>();
         launch_gather_depth_keys(n, d_vis, input->depth_features, ka, va, st);
         const int which = launch_pair_sort_u32(ka, kb, va, vb, d_nvis, n, n, 0, 32, ctx->st_sort_temp.ptr, st);
+        // (enqueued behind the depth sort's launches: right after the frame's synchronisation the host's launch rate is what
+        //  the GPU waits for, and the main chain goes first; the copy still has the whole chain to hide behind)
+        if (ctx->stage_side_copy && ctx->aux_stream && ctx->ev_fork && ctx->ev_join) {
+            LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+            LCGS_TRY(copy_unsorted(ctx->aux_stream));
+            LCGS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+            side.forked = true;
+        } else {
+            LCGS_TRY(copy_unsorted(st));
+        }
         const uint32_t* order = which ? vb : va;
         launch_gather_u32(n, order, accel->tiles_touched, cnt, st);
         LCGS_TRY(ctx->st_scan_temp.ensure(scan_temp_bytes(n)));
         launch_inclusive_sum_u32(cnt, offs, n, ctx->st_scan_temp.ptr, st);
         LCGS_TRY(ctx->st_keys_exp.ensure((size_t)L * 8));
         LCGS_TRY(ctx->st_vals_exp.ensure((size_t)L * 4));
-        launch_copy_with_keys_ordered(n, cp, input->means_2d, offs, output->radii, input->depth_features, order,
-                                      ctx->st_keys_exp.as<uint64_t>(), ctx->st_vals_exp.as<uint32_t>(), st);
+        LCGS_TRY(ctx->st_win.ensure(copy_with_keys_windows_bytes((uint32_t)L)));
+        launch_copy_with_keys_balanced(n, cp, input->means_2d, offs, output->radii, input->depth_features, order,
+                                       ctx->st_keys_exp.as<uint64_t>(), ctx->st_vals_exp.as<uint32_t>(), (uint32_t)L,
+                                       ctx->st_win.as<uint32_t>(), st);
         launch_pair_sort_u64_preserve(ctx->st_keys_exp.as<uint64_t>(), ctx->st_vals_exp.as<uint32_t>(), accel->point_list_keys,
                                       accel->point_list, ctx->st_keys_tmp.as<uint64_t>(), ctx->st_vals_tmp.as<uint32_t>(), L,
                                       32, 32 + tile_bits, ctx->st_sort_temp.ptr, st);
@@ -299,6 +339,10 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
     const size_t G = (size_t)cp.grid_x * cp.grid_y;
     LCGS_HIP_CHECK(hipMemsetAsync(accel->ranges, 0, G * 2 * 4, st)); // impl.cpp:147
     launch_get_ranges_u64(L, accel->point_list_keys, accel->ranges, st); // impl.cpp:150-156
+    if (side.forked) { // the unsorted buffers are complete before anything the caller enqueues behind this call
+        LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        side.forked = false;
+    }
     launch_render_forward_aos(cp, input->bg_color, accel->ranges, accel->point_list, input->means_2d, input->conic,
                               input->opacity_features, input->color_features, output->target_img, output->final_T,
                               output->n_contrib, st); // impl.cpp:159-174

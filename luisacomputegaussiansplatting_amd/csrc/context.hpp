@@ -142,6 +142,7 @@ struct lcgs_context {
     // workspace of the stage-level path / primitives
     DeviceBuffer st_keys_tmp, st_vals_tmp, st_sort_temp, st_scan_temp, st_scalar;
     DeviceBuffer st_flags, st_u32[8], st_keys_exp, st_vals_exp; // the splatter's sort-before-duplicate (lcgs_tile_splat_forward)
+    DeviceBuffer st_win, st_win2, st_offs; // ... and the output-balanced pair copies' window table (one word per 1024 pairs) and offsets
     uint32_t     pair_capacity = 0;
     uint32_t*    h_counts      = nullptr; // pinned, 8 x u32
     uint32_t*    h_stage       = nullptr; // pinned, 4 x u32: the stage-level splatter's one read-back (num_rendered & co.)
@@ -171,6 +172,7 @@ struct lcgs_context {
     // their arguments instead of running; a GSTileSplatter::forward whose inputs are exactly their outputs then renders
     // the fused frame from the 3-D arrays (same image, radii, num_rendered); anything else runs the recorded calls first.
     int stage_mode = 0; // LCGS_STAGES_EXACT
+    bool stage_side_copy = true; // the unsorted pair buffers' copy beside the depth sort (A/B hook LCGS_STAGE_SIDE_COPY=0)
     int stage_sort = 0; // lcgs_tile_splat_forward's sort route: 0 = by frame size, 1 = literal six passes, 2 = sort-before-duplicate
                         // (LCGS_STAGE_SORT=literal|splats, read once when the context is created)
     struct {

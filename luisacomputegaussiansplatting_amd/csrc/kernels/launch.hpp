@@ -18,20 +18,29 @@ void launch_project(int P, const CamParams& cp, bool use_focal, const float* pos
                     hipStream_t stream);
 // hole_flag (optional, device word, cleared by the caller): set when a splat claims pair slots that copy_with_keys leaves
 // unwritten (radius <= 0 with tiles > 0: a NaN covariance) -- only then does the reference's zero-fill of the pair buffers matter
+// flags (nullable): flags[i] = splat i claims pair slots (tiles_touched[i] > 0), for the splatter's compaction; the caller
+// zero-fills the padding behind P
 void launch_allocate_tiles(int P, const CamParams& cp, bool use_focal, const float* depth, float* means_2d,
                            float* covs_2d, uint32_t* tiles_touched, int32_t* radii, hipStream_t stream,
-                           uint32_t* hole_flag = nullptr);
+                           uint32_t* hole_flag = nullptr, uint8_t* flags = nullptr);
 void launch_copy_with_keys(int P, const CamParams& cp, const float* means_2d, const uint32_t* offsets,
                            const int32_t* radii, const float* depth, uint64_t* keys, uint32_t* values,
                            hipStream_t stream);
 // the splatter's sort-before-duplicate (abi_stages.cpp lcgs_tile_splat_forward): which splats claim pair slots, their depth
 // keys, a gather through the sorted order, and copy_with_keys over the splats IN THAT ORDER
-void launch_tile_flags(int P, const uint32_t* tiles_touched, uint8_t* flags, hipStream_t stream);
 void launch_gather_depth_keys(int n, const uint32_t* vis, const float* depth, uint32_t* keys, uint32_t* vals, hipStream_t stream);
 void launch_gather_u32(int n, const uint32_t* order, const uint32_t* src, uint32_t* dst, hipStream_t stream);
 void launch_copy_with_keys_ordered(int n, const CamParams& cp, const float* means_2d, const uint32_t* offsets_sorted,
                                    const int32_t* radii, const float* depth, const uint32_t* order, uint64_t* keys,
                                    uint32_t* values, hipStream_t stream);
+// the same pairs as launch_copy_with_keys_ordered (with order = the ascending list of the splats that claim slots: as
+// launch_copy_with_keys), written by workgroups that own 1024 consecutive OUTPUT slots (coalesced stores, bounded work per
+// workgroup).  The n sources are the splats that CLAIM slots (tiles > 0, radius > 0), source e = splat order[e]; offsets: the
+// inclusive sums of their tile counts, L = offsets[n - 1] (known on the host).  win_first: copy_with_keys_windows_bytes(L).
+void   launch_copy_with_keys_balanced(int n, const CamParams& cp, const float* means_2d, const uint32_t* offsets,
+                                      const int32_t* radii, const float* depth, const uint32_t* order, uint64_t* keys,
+                                      uint32_t* values, uint32_t L, uint32_t* win_first, hipStream_t stream);
+size_t copy_with_keys_windows_bytes(uint32_t L);
 void launch_get_ranges_u64(int64_t L, const uint64_t* keys, uint32_t* ranges, hipStream_t stream);
 
 // ---- scan.hip : DeviceScan::InclusiveSum<uint> ----

@@ -98,13 +98,15 @@ __global__ void __launch_bounds__(kThreads) k_allocate_tiles(int P, CamParams cp
                                                                float* __restrict__ covs_2d,
                                                                uint32_t* __restrict__ tiles_touched,
                                                                int32_t* __restrict__ radii,
-                                                               uint32_t* __restrict__ hole_flag)
+                                                               uint32_t* __restrict__ hole_flag,
+                                                               uint8_t* __restrict__ flags)
 {
     const int idx = blockIdx.x * kThreads + threadIdx.x;
     if (idx >= P) return;
     if (depth[idx] < 0.2f) { // :120-121
         radii[idx]         = 0;
         tiles_touched[idx] = 0u;
+        if (flags) flags[idx] = 0;
         return;
     }
     const float ndc_x = means_2d[2 * (size_t)idx + 0], ndc_y = means_2d[2 * (size_t)idx + 1];
@@ -127,6 +129,7 @@ __global__ void __launch_bounds__(kThreads) k_allocate_tiles(int P, CamParams cp
     covs_2d[3 * (size_t)idx + 2]  = conic[2];
     means_2d[2 * (size_t)idx + 0] = pix_x;
     means_2d[2 * (size_t)idx + 1] = pix_y;
+    if (flags) flags[idx] = tiles > 0u ? 1 : 0;
 }
 
 // shad_copy_with_keys (lcgs/src/gs_tile_splatter/shader.cpp:26-69).  The reference walks each
@@ -188,15 +191,72 @@ __global__ void __launch_bounds__(kThreads) k_copy_with_keys(int P, CamParams cp
     }
 }
 
-// ---- helpers of the splatter's sort-before-duplicate (lcgs_tile_splat_forward) ----
-// flags[i] = splat i claims pair slots; the array is padded with zeros to whole compaction chunks by the caller's memset
-__global__ void __launch_bounds__(kThreads) k_tile_flags(int P, const uint32_t* __restrict__ tiles_touched,
-                                                           uint8_t* __restrict__ flags)
+// The same pairs written OUTPUT-balanced (round 5): the kernel above gives every splat to one lane, so a wave's stores go to
+// 64 different runs of the pair arrays (5.4 pairs a splat on average: scattered 8- and 4-byte stores, 100-120 us for the
+// stand-in's 13 M pairs).  Here a workgroup owns kCopyWindow consecutive OUTPUT slots: k_window_sources notes, per window,
+// the source whose slot range contains the window's first slot; the workgroup compacts the sources that overlap its window
+// (rect, depth bits) into LDS, and every lane then finds its slot's source by binary search there -- fully coalesced stores,
+// the work per workgroup bounded by the window whatever the sizes of the rects.  Frames with a NaN-covariance splat (slots
+// claimed but never written, shader.cpp:41-42) keep the kernel above.
+constexpr uint32_t kCopyWindow = 1024;
+
+__global__ void __launch_bounds__(kThreads) k_window_sources(int n, const uint32_t* __restrict__ offsets,
+                                                               uint32_t* __restrict__ win_first)
 {
-    const int idx = blockIdx.x * kThreads + threadIdx.x;
-    if (idx < P) flags[idx] = tiles_touched[idx] > 0u ? 1 : 0;
+    const int s = blockIdx.x * kThreads + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t start = s >= 1 ? offsets[s - 1] : 0u, end = offsets[s];
+    if (end <= start) return;
+    for (uint32_t w = (start + kCopyWindow - 1u) / kCopyWindow; w * kCopyWindow < end; ++w) win_first[w] = (uint32_t)s;
 }
 
+// sources: the n splats that claim slots (every one with tiles > 0 and a radius > 0), source e = splat order[e], its slots
+// [offsets[e - 1], offsets[e])
+__global__ void __launch_bounds__(kThreads) k_copy_with_keys_balanced(int n, CamParams cp, const float* __restrict__ means_2d,
+                                                                        const uint32_t* __restrict__ offsets,
+                                                                        const int32_t* __restrict__ radii,
+                                                                        const float* __restrict__ depth,
+                                                                        uint64_t* __restrict__ keys,
+                                                                        uint32_t* __restrict__ values,
+                                                                        const uint32_t* __restrict__ order,
+                                                                        const uint32_t* __restrict__ win_first, uint32_t L,
+                                                                        uint32_t num_windows)
+{
+    __shared__ uint32_t s_start[kCopyWindow + 1], s_sid[kCopyWindow + 1], s_xy[kCopyWindow + 1], s_w[kCopyWindow + 1],
+        s_db[kCopyWindow + 1];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t win = blockIdx.x, o0 = win * kCopyWindow, o1 = o0 + kCopyWindow < L ? o0 + kCopyWindow : L;
+    const uint32_t first = win_first[win];
+    uint32_t       last  = win + 1u < num_windows ? win_first[win + 1u] : (uint32_t)n - 1u;
+    if (last - first > kCopyWindow) last = first + kCopyWindow; // (never: every source of a window holds >= 1 of its slots)
+    const uint32_t m = last - first + 1u; // sources that overlap the window, ascending = the order of their slots
+    for (uint32_t e = tid; e < m; e += kThreads) {
+        const uint32_t idx = first + e, sid = order[idx];
+        uint32_t       rmin[2], rmax[2];
+        get_rect(means_2d[2 * (size_t)sid + 0], means_2d[2 * (size_t)sid + 1], radii[sid], cp.grid_x, cp.grid_y, rmin, rmax);
+        s_start[e] = idx >= 1u ? offsets[idx - 1u] : 0u;
+        s_sid[e]   = sid;
+        s_xy[e]    = rmin[0] | (rmin[1] << 16);
+        s_w[e]     = rmax[0] - rmin[0];
+        s_db[e]    = __float_as_uint(depth[sid]);
+    }
+    __syncthreads();
+    for (uint32_t slot = o0 + tid; slot < o1; slot += kThreads) {
+        uint32_t lo = 0, hi = m - 1u; // the last source whose first slot is <= slot
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            if (s_start[mid] <= slot) lo = mid;
+            else hi = mid - 1u;
+        }
+        const uint32_t k = slot - s_start[lo], w = s_w[lo], xy = s_xy[lo];
+        const uint32_t j = k / w, i = k - j * w;
+        const uint32_t tile = ((xy & 0xFFFFu) + i) + ((xy >> 16) + j) * cp.grid_x; // shader.cpp:50-66: rows of the rect, x fastest
+        keys[slot]   = ((uint64_t)tile << 32) | (uint64_t)s_db[lo];
+        values[slot] = s_sid[lo];
+    }
+}
+
+// ---- helpers of the splatter's sort-before-duplicate (lcgs_tile_splat_forward) ----
 // the depth sort's input: (depth bits, splat index) of the n splats that claim slots, in index order
 __global__ void __launch_bounds__(kThreads) k_gather_depth_keys(int n, const uint32_t* __restrict__ vis,
                                                                   const float* __restrict__ depth,
@@ -256,11 +316,12 @@ void launch_project(int P, const CamParams& cp, bool use_focal, const float* pos
 }
 
 void launch_allocate_tiles(int P, const CamParams& cp, bool use_focal, const float* depth, float* means_2d,
-                           float* covs_2d, uint32_t* tiles_touched, int32_t* radii, hipStream_t stream, uint32_t* hole_flag)
+                           float* covs_2d, uint32_t* tiles_touched, int32_t* radii, hipStream_t stream, uint32_t* hole_flag,
+                           uint8_t* flags)
 {
     if (P <= 0) return;
     hipLaunchKernelGGL(k_allocate_tiles, dim3(blocks_for(P)), dim3(kThreads), 0, stream, P, cp, use_focal, depth,
-                       means_2d, covs_2d, tiles_touched, radii, hole_flag);
+                       means_2d, covs_2d, tiles_touched, radii, hole_flag, flags);
 }
 
 void launch_copy_with_keys(int P, const CamParams& cp, const float* means_2d, const uint32_t* offsets,
@@ -272,6 +333,18 @@ void launch_copy_with_keys(int P, const CamParams& cp, const float* means_2d, co
                        radii, depth, keys, values, (const uint32_t*)nullptr);
 }
 
+void launch_copy_with_keys_balanced(int n, const CamParams& cp, const float* means_2d, const uint32_t* offsets,
+                                    const int32_t* radii, const float* depth, const uint32_t* order, uint64_t* keys,
+                                    uint32_t* values, uint32_t L, uint32_t* win_first, hipStream_t stream)
+{
+    if (n <= 0 || L == 0u) return;
+    const uint32_t windows = (L + kCopyWindow - 1u) / kCopyWindow;
+    hipLaunchKernelGGL(k_window_sources, dim3(blocks_for(n)), dim3(kThreads), 0, stream, n, offsets, win_first);
+    hipLaunchKernelGGL(k_copy_with_keys_balanced, dim3(windows), dim3(kThreads), 0, stream, n, cp, means_2d, offsets, radii, depth,
+                       keys, values, order, win_first, L, windows);
+}
+size_t copy_with_keys_windows_bytes(uint32_t L) { return ((size_t)(L + kCopyWindow - 1u) / kCopyWindow + 1) * 4; }
+
 void launch_copy_with_keys_ordered(int n, const CamParams& cp, const float* means_2d, const uint32_t* offsets_sorted,
                                    const int32_t* radii, const float* depth, const uint32_t* order, uint64_t* keys,
                                    uint32_t* values, hipStream_t stream)
@@ -279,12 +352,6 @@ void launch_copy_with_keys_ordered(int n, const CamParams& cp, const float* mean
     if (n <= 0) return;
     hipLaunchKernelGGL(k_copy_with_keys<true>, dim3(blocks_for(n)), dim3(kThreads), 0, stream, n, cp, means_2d, offsets_sorted,
                        radii, depth, keys, values, order);
-}
-
-void launch_tile_flags(int P, const uint32_t* tiles_touched, uint8_t* flags, hipStream_t stream)
-{
-    if (P <= 0) return;
-    hipLaunchKernelGGL(k_tile_flags, dim3(blocks_for(P)), dim3(kThreads), 0, stream, P, tiles_touched, flags);
 }
 
 void launch_gather_depth_keys(int n, const uint32_t* vis, const float* depth, uint32_t* keys, uint32_t* vals, hipStream_t stream)
