@@ -118,6 +118,7 @@ def check_gradients(g, ref32, ref64, P, radii, tag, report=None):
         if report is not None:
             report.append({"tag": tag, "k": k, "e": e, "e32": e32, "eg": eg, "eg32": eg32, "giants": int(giant.sum())})
             continue
+        print(f"[gradients vs f64] {tag} {k}: kernels {e:.2e}, f32 oracle {e32:.2e}; {int(giant.sum())} giants: {eg:.2e} / {eg32:.2e}")
         assert e <= max(1e-3, GRAD_F32_FACTOR * e32), (
             f"{tag} {k}: {e:.2e} vs the f64 oracle (f32 oracle vs f64: {e32:.2e}; giants alone {eg:.2e} / {eg32:.2e})")
         assert eg <= max(GRAD_GIANT_BAR, GRAD_F32_FACTOR * eg32), (

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import baseline_scene
-from gpu_util import DEV, assert_image_parity, assert_parity_vs_libm_expf, dev, upload_scene
+from gpu_util import DEV, assert_image_parity, assert_parity_vs_libm_expf, check_gradients, dev, upload_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -115,6 +115,34 @@ def test_c4_garden_forward_backward_gradients(lcgs, oracle):
         assert np.isfinite(a).all()
         rel = np.linalg.norm(a - b) / np.linalg.norm(b)
         assert rel <= 1e-3, f"{name}: relative L2 error {rel:.2e} (BASELINE tolerance 1e-3)"
+
+
+def test_c4_garden_gradients_against_the_f64_oracle_at_full_splat_count(lcgs, oracle, oracle64):
+    """The f64 yardstick at BASELINE scale (the test above compares with the f32 oracle, which shares the kernels' exp and
+    threshold decisions): the whole garden scene -- every one of its 5.8 M splats through cull, projection, sort and both
+    backward kernels -- with the camera's raster cut to 480 x 270 so that the f64 oracle finishes in seconds on the box's
+    cores.  Same pose, same field of view, same splats on screen, 16 x fewer pixels per splat.  Bar: gpu_util.check_gradients
+    (1e-3 relative against f64 per attribute over ALL rows, or 3 x the f32 oracle's own error on ill-conditioned rows)."""
+    scene, _ = baseline_scene(lcgs, "garden")
+    P = scene["pos"].shape[0]
+    w, h = 480, 270
+    cam = lcgs.get_lookat_cam(*GARDEN_POSE, width=w, height=h)
+    r = lcgs.Renderer(lcgs.Context(0))
+    d = upload_scene(scene)
+    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+    img = torch.zeros(3, h, w, device=DEV)
+    n = r.forward(cam, img, keep_state=True, sync=True)
+    dL = np.random.default_rng(44).normal(size=(3, h, w)).astype(np.float32)
+    g = {k: torch.full_like(d[k], 3.0) for k in ("pos", "scale", "rotq", "sh", "opacity")}
+    r.backward(dev(dL), g["pos"], g["scale"], g["rotq"], g["sh"], g["opacity"])
+    r.ctx.synchronize()
+    ocam = oracle.lookat(*GARDEN_POSE, width=w, height=h)
+    fwd = oracle.render(scene, ocam)
+    assert n == fwd["num_rendered"] > 1_000_000  # (a real scene only has to be non-trivial; the stand-in: ~0.9 M pairs)
+    assert_image_parity(img.cpu().numpy(), fwd)
+    ref32 = oracle.render_backward_full(scene, ocam, dL)
+    ref64 = oracle64.render_backward_full(scene, oracle64.lookat(*GARDEN_POSE, width=w, height=h), dL)
+    check_gradients(g, ref32, ref64, P, fwd["radii"], "C4 garden, 480x270, f64")
 
 
 def test_very_large_frame_more_than_65536_tiles(lcgs, oracle):
