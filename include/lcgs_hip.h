@@ -198,8 +198,7 @@ LCGS_API lcgs_status lcgs_scene_upload(lcgs_context* ctx, int num_gaussians, int
 LCGS_API lcgs_status lcgs_scene_load_ply(lcgs_context* ctx, const char* path, int* num_gaussians);
 /* Splat order of a scene the CONTEXT owns (lcgs_scene_load_ply, lcgs_scene_upload).  Default LCGS_ORDER_SPATIAL: both
  * finish with lcgs_scene_reorder_spatial -- same images (the blend order is by depth; see that call for the one caveat on exactly
- * equal depths), the splats of a view in runs of consecutive rows: +7 % forward frames/s, +18 % forward+backward on the
- * i.i.d.-ordered bicycle stand-in.  Per-splat outputs (radii, gradients) then follow the new order;
+ * equal depths), the splats of a view in runs of consecutive rows (what it buys: DESIGN.md 9).  Per-splat outputs (radii, gradients) then follow the new order;
  * lcgs_scene_permutation maps rows back to file indices.  LCGS_ORDER_FILE keeps the file's order, like the reference
  * (app/gaussians.cpp:93-168).  Arrays bound with lcgs_scene_bind always keep the caller's order. */
 typedef enum lcgs_splat_order { LCGS_ORDER_FILE = 0, LCGS_ORDER_SPATIAL = 1 } lcgs_splat_order;
@@ -230,8 +229,8 @@ LCGS_API lcgs_status lcgs_debug_verify_derived(lcgs_context* ctx, int64_t* stale
  * app/main.cpp:180-223 uploads once) can have the same derived rows as a context-owned scene: the three arrays are declared
  * static, the context builds the 16-byte {position, extent bound} rows once (on its stream), and every fused frame whose
  * position / scale / rotation arrays are EXACTLY these pointers (lcgs_render_forward after lcgs_scene_bind) and that asks for
- * no radii culls from them (forward +2 %; a frame that returns the reference's radii array -- the stage operators in deferred
- * mode do -- projects every splat anyway).  The declaration lasts until it is repeated (same
+ * no radii culls from them (a frame that returns the reference's radii array -- the stage operators in deferred mode do --
+ * projects every splat anyway; measured effect: DESIGN.md 3).  The declaration lasts until it is repeated (same
  * pointers: "the contents changed"), withdrawn (num_gaussians = 0 or d_pos = NULL), or the library itself writes the arrays
  * (lcgs_adam_step & co.), or the context builds rows for a scene of its own (lcgs_scene_upload / lcgs_scene_load_ply /
  * lcgs_scene_reorder_spatial: one set of rows per context).  Changing the arrays behind a standing declaration gives wrong
@@ -324,12 +323,11 @@ typedef struct lcgs_grads {
 LCGS_API lcgs_status lcgs_render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads);
 /* The same dense gradients ADDED to what the arrays hold (no zero-fill): the second and later views of a multi-view batch
  * whose first view went through lcgs_render_backward.  One optimiser step (and, on several GPUs, one gradient collective)
- * per batch instead of per view: B views per GPU amortise the 1.45 GB all-reduce B times. */
+ * per batch instead of per view: B views per GPU amortise the gradient all-reduce B times. */
 LCGS_API lcgs_status lcgs_render_backward_accumulate(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads);
 /* The same gradients as compact rows: row r of every output belongs to the r-th on-screen splat of that forward
  * frame (ascending splat index; lcgs_visible_rows names the splats).  Only those rows are written -- consecutive
- * rows, no zero-fill of the other P - V (the dense variant's stores land on a 39 %-dense row pattern and cost twice
- * as much).  Buffers need one row per on-screen splat (lcgs_frame_stats.num_visible; P rows always
+ * rows, no zero-fill of the other P - V (what the dense variant's scattered stores cost: DESIGN.md 5).  Buffers need one row per on-screen splat (lcgs_frame_stats.num_visible; P rows always
  * suffice).  For single-GPU steps: lcgs_adam_step(visible_only = 2) consumes this layout directly; gradients that
  * are to be summed over views (RCCL all-reduce) need the dense variant. */
 LCGS_API lcgs_status lcgs_render_backward_compact(lcgs_context* ctx, const float* d_dL_dimg, const lcgs_grads* grads);
@@ -345,8 +343,8 @@ LCGS_API lcgs_status lcgs_visible_rows(lcgs_context* ctx, const uint32_t** d_row
  * lcgs_scene_pointers returns the new arrays.  Images are unchanged: the blend order is by depth, and splats of exactly
  * equal depth are still blended in ascending FILE index like the reference (a pass behind the depth sort restores that
  * order inside every run of equal depth keys, of any length).  Why: the splats of a view then sit in long runs
- * of consecutive rows instead of being scattered over every DRAM page (bicycle stand-in: +4 % forward frames/s,
- * +20 % forward+backward, +28 % on-screen-only training step).  Synchronises the context's stream. */
+ * of consecutive rows instead of being scattered over every DRAM page (figures: DESIGN.md 9).  Synchronises the context's
+ * stream. */
 LCGS_API lcgs_status lcgs_scene_reorder_spatial(lcgs_context* ctx, uint32_t* d_perm);
 
 /* Optimiser step (the reference only names training on its roadmap, doc/roadmap.md:4).
@@ -596,7 +594,7 @@ LCGS_API lcgs_status lcgs_l2_loss_backward(lcgs_context* ctx, int width, int hei
  * view overwrites, the others add) and d_losses[j] = view j's loss (device, num_views floats).  Same results as those
  * calls one view after the other (gradient sums up to float addition order), but the views alternate between the context
  * and its sibling (the one lcgs_render_forward_batch uses), so that a view's forward runs beside the previous view's
- * backward: +8 % views/s on the bicycle stand-in.  The last view runs on `ctx`: with a communicator attached its
+ * backward.  The last view runs on `ctx`: with a communicator attached its
  * preprocess-backward is sliced and lcgs_grads_allreduce overlaps it as usual.  Ordered after prior work on the context's
  * stream; the stream waits for the whole batch.  Afterwards the context holds the LAST view's frame state. */
 LCGS_API lcgs_status lcgs_fit_views(lcgs_context* ctx, int num_views, const lcgs_camera* cameras, const float bg_color[3],

@@ -34,4 +34,7 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_WAI
 python3 profiles/pmc_summary.py $O/sqi > $O/pmc_sq_issue.txt
 rm -rf $O/sqi
 echo "sq issue done"
+# LDS-side counters of the renderers (round 5): instruction counts by kind, LDS issue stalls, bank conflicts, lane utilisation.  (No
+# counter separates waves parked at s_waitcnt from waves parked at s_barrier; see tools/gpu/pmc_wait_split.sh.)
+bash tools/gpu/pmc_wait_split.sh $O "$CMD" || exit 1
 ls -la $O
