@@ -127,7 +127,7 @@ def algorithmic_bytes(P, V, L, G, W, H):
     return (236 * P + 48 * V + 8 * P + (8 * P + 12 * L) + (8 + 24 * n) * L + (8 * L + 8 * G) + 40 * L + 12 * W * H)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -156,97 +156,125 @@ def main():
     ap.add_argument("--collective", choices=("rccl", "torch"), default="rccl",
                     help="N > 1 gradient collective: the library's own RCCL path (lcgs_comm C ABI, default) or "
                          "torch.distributed's (cross-check)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    # The contract is ONE JSON line on stdout.  Libraries below print there too (RCCL's version banner at communicator
-    # creation, gloo's "connected to N peer ranks"): from here on file descriptor 1 points at stderr, and the line is
-    # written to the saved descriptor by emit().
-    sys.stdout.flush()
-    line_out = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
 
-    import torch
+def leg_moving_camera(L, r, cam, img, args, rank, world, W, H, timed):
+    # ---- moving camera: the eight C5 poses (base pose rotated about world-up by k x 45 deg) cycled INSIDE the timed
+    # loop, a different view every frame: the previous frame's tile schedule is stale, V / L change from frame to frame
+    # (launch sizes and buffer hints come from whichever frame synchronised last).  Beside `value`, never instead of it.
+    cams8 = [L.get_lookat_cam(*view_pose(k), width=W, height=H) for k in range(8)]
+    per_view = []
+    for c in cams8:  # one synchronising frame per view: sizes the pair buffers for the largest of them
+        r.forward(c, img, sync=True)
+        st8 = r.frame_stats()
+        per_view.append({"visible_splats": st8["num_visible"], "tile_pairs_sorted": st8["num_pairs"]})
+    el_m = timed(lambda i: r.forward(cams8[(i + rank) % 8], img, sync=False), args.steps, max(args.warmup, 8))
+    # the same eight views one at a time, each repeated: what a static camera gives on THESE views (the headline
+    # pose is view 0 only), so that the cost of motion is separated from the cost of the other views
+    el_each = []
+    for c in cams8:
+        el_each.append(timed(lambda i, c=c: r.forward(c, img, sync=False), max(8, args.steps // 4), 3) /
+                       max(8, args.steps // 4))
+    static_mean_ms = 1e3 * sum(el_each) / len(el_each)
+    moving = {"value": round(world * args.steps / el_m, 2), "unit": "frames/s",
+              "ms_per_step": round(el_m * 1e3 / args.steps, 4), "views": 8,
+              "same_views_static_ms_per_step": round(static_mean_ms, 4),
+              "motion_overhead": round(el_m * 1e3 / args.steps / static_mean_ms - 1.0, 4),
+              "per_view": per_view}
+    r.forward(cam, img, sync=True)  # back to the headline view (hints, schedule)
 
-    import luisacomputegaussiansplatting_amd as L
-    import luisacomputegaussiansplatting_amd.multi_gpu as mg
+    return moving
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        # launched without torchrun: start the N ranks as children and exit with their code
-        import subprocess
 
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"), __file__] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd, stdout=line_out))  # (the children's stdout is the real one)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: liblcgs_hip has no CPU path")
-    # a launcher that narrows each rank's visibility to one GPU leaves fewer devices than local ranks
-    local_rank %= max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    dist = None
-    backend = os.environ.get("LCGS_BENCH_BACKEND", "nccl")
-    # (LCGS_BENCH_FORCE_DIST=1: a rehearsal hook -- one rank, but through the process group, so that every N > 1 code
-    #  path of this file, collectives included, runs on a one-GPU box)
-    if world > 1 or os.environ.get("LCGS_BENCH_FORCE_DIST") == "1":
-        import torch.distributed as dist
+def leg_camera_batch(torch, r, cam, img, args, world, W, H, dev, dist, red_dev, barrier):
+    # ---- the same K frames as one camera batch (lcgs_render_forward_batch: two frames in flight on sibling
+    # workspaces, so one frame's latency-bound sort chain overlaps the other's bandwidth- and VALU-bound kernels).
+    # Reported beside `value` (which stays the strictly in-order figure), never instead of it.
+    # (four target images in rotation: frames that may be in flight together never share one)
+    imgs = [img] + [torch.zeros(3, H, W, device=dev) for _ in range(3)]
+    cams_k = [cam] * args.steps
+    imgs_k = [imgs[i & 3] for i in range(args.steps)]
+    r.forward_batch([cam] * max(4, args.warmup), [imgs[i & 3] for i in range(max(4, args.warmup))])
+    barrier()
+    t0 = time.perf_counter()
+    r.forward_batch(cams_k, imgs_k)
+    barrier()
+    el_p = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el_p], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el_p = float(t.item())
+    pipelined = {"api": "lcgs_render_forward_batch", "frames_in_flight": 2, "value": round(world * args.steps / el_p, 2),
+                 "unit": "frames/s", "ms_per_step": round(el_p * 1e3 / args.steps, 4),
+                 "images_equal": bool(all(torch.equal(imgs[0], x) for x in imgs[1:]))}
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        # (LCGS_BENCH_BACKEND=gloo: a second rehearsal hook -- several ranks on ONE GPU, which RCCL refuses: the launch,
-        #  the per-rank views, the barriers and the max-over-ranks timing run as on a node; the gradient legs then fail
-        #  on every rank ("duplicate GPU") and exercise the leg-error path below)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    W, H = (int(x) for x in args.res.lower().split("x"))
-    dev = torch.device("cuda", local_rank)
-    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the timing reductions live
-    KEYS = mg.KEYS
+    return pipelined
 
-    # ---- scene (replicated on every GPU), through the library's own ingest: the context owns the device arrays and keeps
-    # them in spatial (Morton) order, its default for scenes it owns (lcgs_set_ingest_order; same images -- the blend
-    # order is by depth).  The file-order figure is reported beside `value` (`file_order`).
-    data = "synthetic"
-    side = torch.cuda.Stream(device=dev)  # a dedicated (non-NULL) HIP stream for the context
-    torch.cuda.set_stream(side)
-    ctx = L.Context(local_rank, side.cuda_stream)
-    r = L.Renderer(ctx)
-    if args.ply and os.path.exists(args.ply):
-        r.load_ply(args.ply)  # records -> GPU -> activated arrays (lcgs_scene_load_ply)
-        scene = L.read_gs_ply(args.ply)  # host copy, file order: the CPU baseline's input
-        scene.pop("sh_degree", None)
-        workload = os.path.basename(args.ply)
-        data = "real"
-    else:
-        scene = L.synth_scene(1, 2001, args.splats)
-        # host arrays -> context-owned device arrays (lcgs_scene_upload); LCGS_BENCH_FILE_ORDER=1 is a profiling hook:
-        # every leg then runs on the file-order scene (the workload name says so)
-        file_order = os.environ.get("LCGS_BENCH_FILE_ORDER") == "1"
-        r.upload_scene(scene, order="file" if file_order else None)
-        workload = f"mip360_bicycle stand-in: synth_unbounded(seed=2001, P={args.splats})"
-    workload += " [ingest order: file (LCGS_BENCH_FILE_ORDER)]" if r.permutation() is None else \
-                " [ingest order: spatial (library default)]"
-    P = scene["pos"].shape[0]
-    d = r.scene_tensors()  # torch views of the context's arrays (the order the library keeps them in)
-    torch.cuda.synchronize(dev)
-    cam = L.get_lookat_cam(*view_pose(rank), width=W, height=H)
-    img = torch.zeros(3, H, W, device=dev)
 
-    # first frame synchronises: sizes the pair buffers for this view
-    n_rendered = r.forward(cam, img, sync=True)
-    stats = r.frame_stats()
+def leg_stage_path(torch, L, ctx, d, cam, img, args, world, P, W, H, dev, barrier):
+    # ---- the drop-in boundary itself: the reference's three operators in its own call order (app/main.cpp:266-308)
+    # on the same frame -- SHProcessor.process, GSProjector.forward, GSTileSplatter.forward (which synchronises once
+    # per frame for num_rendered, like impl.cpp:106-107).  Informational: `value` is the fused frame.
+    shp, prj, spl = L.SHProcessor(), L.GSProjector(), L.GSTileSplatter()
+    for op in (shp, prj, spl):
+        op.create(ctx)
+    z = lambda *sh_, dt=torch.float32: torch.zeros(*sh_, dtype=dt, device=dev)
+    Lcap = 20_000_000  # app/main.cpp:245
+    G_ = ((W + 15) // 16) * ((H + 15) // 16)
+    color, means, covs, depth = z(P, 3), z(P, 2), z(P, 3), z(P)
+    accel = L.GSTileSplatterAccelProxy(z(P, dt=torch.int32), z(P, dt=torch.int32), z(Lcap, dt=torch.int64),
+                                       z(Lcap, dt=torch.int32), z(Lcap, dt=torch.int64), z(Lcap, dt=torch.int32),
+                                       z(2 * G_, dt=torch.int32))
+    radii_s, img_s = z(P, dt=torch.int32), z(3, H, W)
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    def stage_frame():
+        shp.process(L.GPUPointsProxy(P, 3, d["pos"]), cam, d["sh"], color, 3, 3)
+        prj.forward(L.GSProjectorInputProxy(P, d["pos"], d["scale"], d["rotq"], 1.0),
+                    L.GSProjectorOutputProxy(means, covs, depth), cam)
+        return spl.forward(accel, L.GSTileSplatterInputProxy(P, (0.0, 0.0, 0.0), means, depth, covs, color, d["opacity"]),
+                           L.GSSplatForwardOutputProxy(H, W, img_s, radii_s))
+    n_stage = 0
+    for _ in range(max(1, args.warmup)):
+        n_stage = stage_frame()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stage_frame()
+    barrier()
+    el_s = time.perf_counter() - t0
+    stage_path = {"value": round(world * args.steps / el_s, 2), "unit": "frames/s",
+                  "ms_per_step": round(el_s * 1e3 / args.steps, 4), "num_rendered": int(n_stage),
+                  "max_abs_diff_vs_fused": float((img_s - img).abs().max().item()),
+                  "mode": "LCGS_STAGES_EXACT: every operator runs at once, every buffer of the reference is produced"}
+    # the same three calls, same loop, with lcgs_set_stage_mode(LCGS_STAGES_DEFERRED): process / forward are recorded, the
+    # splatter renders the fused frame from the 3-D arrays (intermediates not written; same image, radii, num_rendered)
+    exact_img = img_s.clone()
+    ctx.set_stage_mode("deferred")
+    img_s.zero_()
+    n_def = 0
+    for _ in range(max(1, args.warmup)):
+        n_def = stage_frame()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stage_frame()
+    barrier()
+    el_d = time.perf_counter() - t0
+    ctx.set_stage_mode("exact")
+    stage_path["deferred"] = {"value": round(world * args.steps / el_d, 2), "unit": "frames/s",
+                              "ms_per_step": round(el_d * 1e3 / args.steps, 4), "num_rendered": int(n_def),
+                              "image_equal_to_exact_mode": bool(torch.equal(img_s, exact_img)),
+                              "mode": "LCGS_STAGES_DEFERRED (opt-in): same calls, the splatter renders the fused frame"}
+    del accel, color, means, covs, depth, radii_s, img_s, exact_img
 
+    return stage_path
+
+
+def leg_half_sh(r, cam, img, args, world, barrier):
+    # ---- opt-in f16 SH coefficients for the colour pass (outside the 1e-4 bar, never `value`)
+    ref_img = img.clone()
+    r.use_half_sh(True)
     for _ in range(args.warmup):
         r.forward(cam, img, sync=False)
     barrier()
@@ -254,208 +282,35 @@ def main():
     for _ in range(args.steps):
         r.forward(cam, img, sync=False)
     barrier()
-    elapsed = time.perf_counter() - t0
-    # SURVEY 8d's protocol beside the contract's: the median of >= 50 frames on hipEvent pairs -- one event behind every
-    # frame on the context's stream (torch's current stream here).  Its own loop, so that `value` above is not perturbed
-    # by the event packets; reported beside `value`, never instead of it.
-    n_ev = max(50, args.steps)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev + 1)]
-    marks[0].record()
-    for i in range(n_ev):
-        r.forward(cam, img, sync=False)
-        marks[i + 1].record()
-    barrier()
-    frame_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_ev))
-    per_frame = {"frames": n_ev, "median_ms": round(frame_ms[n_ev // 2], 4), "min_ms": round(frame_ms[0], 4),
-                 "p90_ms": round(frame_ms[(n_ev * 9) // 10], 4), "frames_per_s_at_median": round(1e3 / frame_ms[n_ev // 2], 1),
-                 "how": "hipEvent pairs between consecutive frames on the context's stream (SURVEY 8d)"}
-    if dist is not None:
-        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = world * args.steps / elapsed
+    el_h = time.perf_counter() - t0
+    half_sh = {"value": round(world * args.steps / el_h, 2), "unit": "frames/s",
+               "max_abs_diff_vs_f32": float((img - ref_img).abs().max().item())}
+    r.use_half_sh(False)
+    r.forward(cam, img, sync=True)
 
-    # N > 1 bookkeeping: every timed leg carries its ordinal and the rank's failure flag through the max-reduction, so a
-    # rank that failed alone and moved on can never have its reduction paired with another leg's on its peers (the
-    # figures would silently mix): a mismatch raises on every rank that sees it.
-    leg = {"no": 0, "failed": False}
+    return half_sh
 
-    def reduce_leg(el):
-        if dist is None:
-            return el
-        tt = torch.tensor([el, leg["no"], -leg["no"], 1.0 if leg["failed"] else 0.0], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        if tt[1].item() != -tt[2].item():
-            leg["failed"] = True
-            raise RuntimeError(f"ranks are in different legs ({int(-tt[2].item())} .. {int(tt[1].item())}): a rank failed alone")
-        if tt[3].item() > 0 and not leg["failed"]:
-            leg["failed"] = True
-            raise RuntimeError("another rank reported a leg error")
-        return float(tt[0].item())
 
-    def timed(fn, steps, warm):
-        """warm untimed calls, then `steps` timed ones between barriers; max over ranks; seconds"""
-        leg["no"] += 1
-        for i in range(warm):
-            fn(i)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            fn(warm + i)
-        barrier()
-        return reduce_leg(time.perf_counter() - t0)
-
-    # ---- moving camera: the eight C5 poses (base pose rotated about world-up by k x 45 deg) cycled INSIDE the timed
-    # loop, a different view every frame: the previous frame's tile schedule is stale, V / L change from frame to frame
-    # (launch sizes and buffer hints come from whichever frame synchronised last).  Beside `value`, never instead of it.
-    moving = None
-    if not args.no_moving_camera:
-        cams8 = [L.get_lookat_cam(*view_pose(k), width=W, height=H) for k in range(8)]
-        per_view = []
-        for c in cams8:  # one synchronising frame per view: sizes the pair buffers for the largest of them
-            r.forward(c, img, sync=True)
-            st8 = r.frame_stats()
-            per_view.append({"visible_splats": st8["num_visible"], "tile_pairs_sorted": st8["num_pairs"]})
-        el_m = timed(lambda i: r.forward(cams8[(i + rank) % 8], img, sync=False), args.steps, max(args.warmup, 8))
-        # the same eight views one at a time, each repeated: what a static camera gives on THESE views (the headline
-        # pose is view 0 only), so that the cost of motion is separated from the cost of the other views
-        el_each = []
-        for c in cams8:
-            el_each.append(timed(lambda i, c=c: r.forward(c, img, sync=False), max(8, args.steps // 4), 3) /
-                           max(8, args.steps // 4))
-        static_mean_ms = 1e3 * sum(el_each) / len(el_each)
-        moving = {"value": round(world * args.steps / el_m, 2), "unit": "frames/s",
-                  "ms_per_step": round(el_m * 1e3 / args.steps, 4), "views": 8,
-                  "same_views_static_ms_per_step": round(static_mean_ms, 4),
-                  "motion_overhead": round(el_m * 1e3 / args.steps / static_mean_ms - 1.0, 4),
-                  "per_view": per_view}
-        r.forward(cam, img, sync=True)  # back to the headline view (hints, schedule)
-
-    # ---- per-stage device times (HIP events on the context's stream), outside the timed region
-    r.set_profiling(True)
-    acc = {}
-    reps = 10
-    for _ in range(reps):
-        r.forward(cam, img, sync=True)
-        for k, v in r.stage_times().items():
-            acc[k] = acc.get(k, 0.0) + v / reps
-    r.set_profiling(False)
-
-    # ---- the same K frames as one camera batch (lcgs_render_forward_batch: two frames in flight on sibling
-    # workspaces, so one frame's latency-bound sort chain overlaps the other's bandwidth- and VALU-bound kernels).
-    # Reported beside `value` (which stays the strictly in-order figure), never instead of it.
-    pipelined = None
-    if not args.no_batch:
-        # (four target images in rotation: frames that may be in flight together never share one)
-        imgs = [img] + [torch.zeros(3, H, W, device=dev) for _ in range(3)]
-        cams_k = [cam] * args.steps
-        imgs_k = [imgs[i & 3] for i in range(args.steps)]
-        r.forward_batch([cam] * max(4, args.warmup), [imgs[i & 3] for i in range(max(4, args.warmup))])
-        barrier()
-        t0 = time.perf_counter()
-        r.forward_batch(cams_k, imgs_k)
-        barrier()
-        el_p = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([el_p], device=red_dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el_p = float(t.item())
-        pipelined = {"api": "lcgs_render_forward_batch", "frames_in_flight": 2, "value": round(world * args.steps / el_p, 2),
-                     "unit": "frames/s", "ms_per_step": round(el_p * 1e3 / args.steps, 4),
-                     "images_equal": bool(all(torch.equal(imgs[0], x) for x in imgs[1:]))}
-
-    # ---- the drop-in boundary itself: the reference's three operators in its own call order (app/main.cpp:266-308)
-    # on the same frame -- SHProcessor.process, GSProjector.forward, GSTileSplatter.forward (which synchronises once
-    # per frame for num_rendered, like impl.cpp:106-107).  Informational: `value` is the fused frame.
-    stage_path = None
-    if not args.no_stage_path:
-        shp, prj, spl = L.SHProcessor(), L.GSProjector(), L.GSTileSplatter()
-        for op in (shp, prj, spl):
-            op.create(ctx)
-        z = lambda *sh_, dt=torch.float32: torch.zeros(*sh_, dtype=dt, device=dev)
-        Lcap = 20_000_000  # app/main.cpp:245
-        G_ = ((W + 15) // 16) * ((H + 15) // 16)
-        color, means, covs, depth = z(P, 3), z(P, 2), z(P, 3), z(P)
-        accel = L.GSTileSplatterAccelProxy(z(P, dt=torch.int32), z(P, dt=torch.int32), z(Lcap, dt=torch.int64),
-                                           z(Lcap, dt=torch.int32), z(Lcap, dt=torch.int64), z(Lcap, dt=torch.int32),
-                                           z(2 * G_, dt=torch.int32))
-        radii_s, img_s = z(P, dt=torch.int32), z(3, H, W)
-
-        def stage_frame():
-            shp.process(L.GPUPointsProxy(P, 3, d["pos"]), cam, d["sh"], color, 3, 3)
-            prj.forward(L.GSProjectorInputProxy(P, d["pos"], d["scale"], d["rotq"], 1.0),
-                        L.GSProjectorOutputProxy(means, covs, depth), cam)
-            return spl.forward(accel, L.GSTileSplatterInputProxy(P, (0.0, 0.0, 0.0), means, depth, covs, color, d["opacity"]),
-                               L.GSSplatForwardOutputProxy(H, W, img_s, radii_s))
-        n_stage = 0
-        for _ in range(max(1, args.warmup)):
-            n_stage = stage_frame()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            stage_frame()
-        barrier()
-        el_s = time.perf_counter() - t0
-        stage_path = {"value": round(world * args.steps / el_s, 2), "unit": "frames/s",
-                      "ms_per_step": round(el_s * 1e3 / args.steps, 4), "num_rendered": int(n_stage),
-                      "max_abs_diff_vs_fused": float((img_s - img).abs().max().item()),
-                      "mode": "LCGS_STAGES_EXACT: every operator runs at once, every buffer of the reference is produced"}
-        # the same three calls, same loop, with lcgs_set_stage_mode(LCGS_STAGES_DEFERRED): process / forward are recorded, the
-        # splatter renders the fused frame from the 3-D arrays (intermediates not written; same image, radii, num_rendered)
-        exact_img = img_s.clone()
-        ctx.set_stage_mode("deferred")
-        img_s.zero_()
-        n_def = 0
-        for _ in range(max(1, args.warmup)):
-            n_def = stage_frame()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            stage_frame()
-        barrier()
-        el_d = time.perf_counter() - t0
-        ctx.set_stage_mode("exact")
-        stage_path["deferred"] = {"value": round(world * args.steps / el_d, 2), "unit": "frames/s",
-                                  "ms_per_step": round(el_d * 1e3 / args.steps, 4), "num_rendered": int(n_def),
-                                  "image_equal_to_exact_mode": bool(torch.equal(img_s, exact_img)),
-                                  "mode": "LCGS_STAGES_DEFERRED (opt-in): same calls, the splatter renders the fused frame"}
-        del accel, color, means, covs, depth, radii_s, img_s, exact_img
-
-    # ---- opt-in f16 SH coefficients for the colour pass (SURVEY 8f rank 4; outside the 1e-4 bar, never `value`)
-    half_sh = None
-    if args.half_sh:
-        ref_img = img.clone()
-        r.use_half_sh(True)
-        for _ in range(args.warmup):
-            r.forward(cam, img, sync=False)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            r.forward(cam, img, sync=False)
-        barrier()
-        el_h = time.perf_counter() - t0
-        half_sh = {"value": round(world * args.steps / el_h, 2), "unit": "frames/s",
-                   "max_abs_diff_vs_f32": float((img - ref_img).abs().max().item())}
-        r.use_half_sh(False)
-        r.forward(cam, img, sync=True)
-
+def leg_lod(r, cam, img, args, world, timed):
     # ---- opt-in footprint (LOD) cull (SURVEY 8f rank 4; changes the image, never `value`)
-    lod = None
-    if args.lod > 0:
-        ref_img = img.clone()
-        r.set_lod(args.lod)
-        n_lod = r.forward(cam, img, sync=True)
-        st_lod = r.frame_stats()
-        el_l = timed(lambda i: r.forward(cam, img, sync=False), args.steps, args.warmup)
-        lod = {"min_radius_px": args.lod, "value": round(world * args.steps / el_l, 2), "unit": "frames/s",
-               "num_rendered": int(n_lod), "visible_splats": st_lod["num_visible"], "tile_pairs_sorted": st_lod["num_pairs"],
-               "max_abs_diff_vs_unculled": float((img - ref_img).abs().max().item()),
-               "mean_abs_diff_vs_unculled": float((img - ref_img).abs().mean().item())}
-        r.set_lod(0)
-        r.forward(cam, img, sync=True)
-        del ref_img
+    ref_img = img.clone()
+    r.set_lod(args.lod)
+    n_lod = r.forward(cam, img, sync=True)
+    st_lod = r.frame_stats()
+    el_l = timed(lambda i: r.forward(cam, img, sync=False), args.steps, args.warmup)
+    lod = {"min_radius_px": args.lod, "value": round(world * args.steps / el_l, 2), "unit": "frames/s",
+           "num_rendered": int(n_lod), "visible_splats": st_lod["num_visible"], "tile_pairs_sorted": st_lod["num_pairs"],
+           "max_abs_diff_vs_unculled": float((img - ref_img).abs().max().item()),
+           "mean_abs_diff_vs_unculled": float((img - ref_img).abs().mean().item())}
+    r.set_lod(0)
+    r.forward(cam, img, sync=True)
+    del ref_img
 
+    return lod
+
+
+def rooflines(r, stats, acc, data, P, W, H, ms_per_step):
+    """the dominant kernel's roofline (HBM figures + the measured VALU issue fraction) and the whole frame three ways"""
     V, Lref, Lp, G = stats["num_visible"], stats["num_rendered"], stats["num_pairs"], stats["num_tiles"]
     # Algorithmic bytes per launch of each stage = per-unit figure x units (DESIGN.md section 4)
     stage_bytes = {
@@ -588,67 +443,60 @@ def main():
     frame_views["target_60pct_hbm"] = (f"{'met' if by >= 0.6 else 'not met'}: {by:.2f} of 8 TB/s by {basis}; the frame's time goes to "
                                        "VALU-issue-bound compositing and latency-bound sort launches, not to bandwidth")
 
-    out = {
-        "metric": "forward fps @1080p, mip360_bicycle", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": data,
-        "config": {"workload": workload, "resolution": f"{W}x{H}", "splats": P, "visible_splats": V,
-                   "tile_pairs_reference": Lref, "tile_pairs_sorted": Lp, "views_per_gpu": 1,
-                   "parallelism": f"view-parallel x{world}"},
-        "roofline": roofline,
-        "frame_roofline": {"peak": HBM_PEAK_GBS, "attainable_peak": HBM_ATTAINABLE_GBS,
-                           "attainable_peak_source": "tools/microbench/fetch_calib.hip: plain 12- / 16-byte-per-lane read streams "
-                                                     "over 1 GiB run at 6.3-6.55 TB/s on this part "
-                                                     "(profiles/r02_fetch_calibration.txt); 8 TB/s is the spec figure",
-                           "unit": "GB/s", **frame_views},
-        "per_frame_events": per_frame,
-        "stages_ms": {k: round(v, 4) for k, v in acc.items()},
-    }
-    if stage_path is not None:
-        out["stage_path"] = stage_path
-    if half_sh is not None:
-        out["half_sh"] = half_sh
-    if lod is not None:
-        out["lod"] = lod
-    if pipelined is not None:
-        out["camera_batch"] = pipelined
-    if moving is not None:
-        out["moving_camera"] = moving
+    return {"roofline": roofline, "frame_views": frame_views, "V": V, "Lref": Lref, "Lp": Lp, "pmc_all": pmc_all,
+            "pmc_source": pmc_source, "same_workload": same_workload, "src_hash": src_hash,
+            "sq_issue_kernels": sq_issue_kernels, "sq_issue_src": sq_issue_src}
 
-    # ---- N > 1 insurance.  The legs below (RCCL communicator of the library, collectives, sharded optimiser) have only
-    # ever run on one GPU (`LCGS_BENCH_FORCE_DIST=1`) and on gloo: on a real multi-GPU node a rank that fails alone
-    # leaves the others waiting in a collective.  The forward measurement above is complete at this point, so a
-    # watchdog prints the line with what has been measured (plus `error`) instead of hanging the whole run.
-    printed = threading.Lock()
-    watchdog = None
 
-    def emit(error=None):
-        if not printed.acquire(blocking=False):
-            return
-        if error is not None:
-            out["error"] = error
-        if rank == 0:
-            print(json.dumps(out), file=line_out, flush=True)
+def leg_cpu_baseline_and_parity(out, scene, r, cam, img, P, W, H):
+    # ---- CPU baseline: the oracle (CPU restatement of the reference) on this box's host cores, rank 0, N = 1 only
+    from oracle import Oracle
 
-    if dist is not None:
-        def give_up():
-            done = printed.locked()  # (the line is out: only the teardown is stuck)
-            emit(f"the legs after the forward measurement did not finish within {args.leg_timeout} s on rank {rank}")
-            sys.stdout.flush()
-            # A timeout is a failure on EVERY rank (the line, with `error`, is on stdout for whoever wants to parse it) --
-            # unless only an AUXILIARY leg hung: a run whose line was already complete (the teardown alone is stuck), or
-            # one that has both halves of BASELINE's metric (forward frames/s in `value`, forward+backward Msplats/s in
-            # `fwd_bwd.value`), ends with 0 so that a harness keyed on the exit code keeps the measured figures.
-            headline = args.no_backward or ("value" in out.get("fwd_bwd", {}))
-            os._exit(0 if done or headline else 3)
-        watchdog = threading.Timer(args.leg_timeout, give_up)
-        watchdog.daemon = True
-        watchdog.start()
+    o = Oracle("f32")
+    o.set_threads(0)
+    ocam = o.lookat(*view_pose(0), width=W, height=H)
+    t0 = time.perf_counter()
+    frames = 0
+    while True:
+        ref = o.render(scene, ocam)
+        frames += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or frames >= 8:
+            break
+    out["cpu_baseline"] = {"value": round(frames / el, 4), "unit": "frames/s", "cores": o.get_threads(), "kind": "port",
+                           "sample": f"{frames} full frame(s) of the same workload ({P} splats, {W}x{H}) in {el:.1f} s"}
+    n_rendered = r.forward(cam, img, sync=True)  # the frame the oracle is compared with
+    gi = img.cpu().numpy()
+    diff = np.abs(gi - ref["img"]).max(axis=0)
+    # the blend's exp is one defined sequence of binary32 operations in the kernels and in the oracle (round 3), so
+    # the two frames are expected to be EQUAL; anything else is reported, never hidden behind a tolerance
+    out["parity"] = {"num_rendered_equal": bool(ref["num_rendered"] == n_rendered),
+                     "bit_identical": bool(np.array_equal(gi, ref["img"])),
+                     "pixels_different": int((diff > 0).sum()),
+                     "pixels_over_1e-4": int((diff > 1e-4).sum()), "max_abs_diff": float(diff.max())}
+    # ... and the distance to a STANDARD exp in the blend (the reference says `exp(power)`, gs_tile_splatter/shader.cpp:259;
+    # north_star's bar: 1e-4 per-pixel L-inf): the same frame against the oracle run with libm's expf.  Pixels beyond 1e-4
+    # are threshold flips (an ulp of exp moves `alpha < 1/255` or `T < 1e-4`); `all_flagged` says every one of them is
+    # marked threshold-ambiguous (within 1e-5 relative) by the libm oracle itself.
+    o.set_blend_exp(True)
+    ref_libm = o.render(scene, ocam, ambig_eps=1e-5)
+    o.set_blend_exp(False)
+    with np.errstate(invalid="ignore"):
+        dl = np.abs(gi.astype(np.float64) - ref_libm["img"].astype(np.float64)).max(axis=0)
+    amb = ref_libm["ambig"].astype(bool)
+    over = dl > 1e-4
+    out["parity"]["vs_libm_expf"] = {
+        "pixels_over_1e-4": int(over.sum()), "max_abs_diff": float(dl.max()),
+        "all_flagged": bool((~over | amb).all()), "ambiguous_pixels": int(amb.sum()),
+        "max_abs_diff_unflagged": float(dl[~amb].max()) if (~amb).any() else 0.0, "pixels": int(dl.size)}
 
-    # ---- forward + backward (+ the RCCL sum of the dense per-splat gradients when N > 1): one training-style step per
-    # view through the package's view-parallel protocol (luisacomputegaussiansplatting_amd.multi_gpu: the same
-    # ViewParallelTrainer tests/test_distributed.py runs on gloo); Msplats/s = splats x views / time.
-    # Same barrier / max-over-ranks timing.
+
+def leg_gradients(S):
+    """forward + backward (+ the gradient collective at N > 1), the multi-view steps, BASELINE C4, the training-step variants and
+    the ownership step.  Fills out["fwd_bwd"] / ["train_step"] / ["c4_garden"]; returns (collective, timed_steps) for the legs
+    behind it.  N > 1: whatever a leg throws goes into the line (leg_errors), N = 1: it raises."""
+    (args, dist, dev, P, W, H, r, cam, img, d, ctx, rank, world, out, timed, barrier, leg, KEYS, mg, L, torch, local_rank, side, Lp, V, pmc_all, same_workload, pmc_source, sq_issue_kernels, sq_issue_src, src_hash) = (S.args, S.dist, S.dev, S.P, S.W, S.H, S.r, S.cam, S.img, S.d, S.ctx, S.rank, S.world, S.out, S.timed, S.barrier, S.leg, S.KEYS, S.mg, S.L, S.torch, S.local_rank, S.side, S.Lp, S.V, S.pmc_all, S.same_workload, S.pmc_source, S.sq_issue_kernels, S.sq_issue_src, S.src_hash)
+    timed_steps = None
     coll = None
     try:
         if dist is not None and os.environ.get("LCGS_BENCH_INJECT_LEG_FAILURE") == "1":  # (test hook)
@@ -908,6 +756,247 @@ def main():
             raise
         leg["failed"] = True
         out.setdefault("leg_errors", {})["fwd_bwd / train_step"] = f"{type(e).__name__}: {e}"[:400]
+    return coll, timed_steps
+
+
+def main():
+    args = parse_args()
+
+    # The contract is ONE JSON line on stdout.  Libraries below print there too (RCCL's version banner at communicator
+    # creation, gloo's "connected to N peer ranks"): from here on file descriptor 1 points at stderr, and the line is
+    # written to the saved descriptor by emit().
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    import torch
+
+    import luisacomputegaussiansplatting_amd as L
+    import luisacomputegaussiansplatting_amd.multi_gpu as mg
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        # launched without torchrun: start the N ranks as children and exit with their code
+        import subprocess
+
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"), __file__] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, stdout=line_out))  # (the children's stdout is the real one)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: liblcgs_hip has no CPU path")
+    # a launcher that narrows each rank's visibility to one GPU leaves fewer devices than local ranks
+    local_rank %= max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    dist = None
+    backend = os.environ.get("LCGS_BENCH_BACKEND", "nccl")
+    # (LCGS_BENCH_FORCE_DIST=1: a rehearsal hook -- one rank, but through the process group, so that every N > 1 code
+    #  path of this file, collectives included, runs on a one-GPU box)
+    if world > 1 or os.environ.get("LCGS_BENCH_FORCE_DIST") == "1":
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        # (LCGS_BENCH_BACKEND=gloo: a second rehearsal hook -- several ranks on ONE GPU, which RCCL refuses: the launch,
+        #  the per-rank views, the barriers and the max-over-ranks timing run as on a node; the gradient legs then fail
+        #  on every rank ("duplicate GPU") and exercise the leg-error path below)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    W, H = (int(x) for x in args.res.lower().split("x"))
+    dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the timing reductions live
+    KEYS = mg.KEYS
+
+    # ---- scene (replicated on every GPU), through the library's own ingest: the context owns the device arrays and keeps
+    # them in spatial (Morton) order, its default for scenes it owns (lcgs_set_ingest_order; same images -- the blend
+    # order is by depth).  The file-order figure is reported beside `value` (`file_order`).
+    data = "synthetic"
+    side = torch.cuda.Stream(device=dev)  # a dedicated (non-NULL) HIP stream for the context
+    torch.cuda.set_stream(side)
+    ctx = L.Context(local_rank, side.cuda_stream)
+    r = L.Renderer(ctx)
+    if args.ply and os.path.exists(args.ply):
+        r.load_ply(args.ply)  # records -> GPU -> activated arrays (lcgs_scene_load_ply)
+        scene = L.read_gs_ply(args.ply)  # host copy, file order: the CPU baseline's input
+        scene.pop("sh_degree", None)
+        workload = os.path.basename(args.ply)
+        data = "real"
+    else:
+        scene = L.synth_scene(1, 2001, args.splats)
+        # host arrays -> context-owned device arrays (lcgs_scene_upload); LCGS_BENCH_FILE_ORDER=1 is a profiling hook:
+        # every leg then runs on the file-order scene (the workload name says so)
+        file_order = os.environ.get("LCGS_BENCH_FILE_ORDER") == "1"
+        r.upload_scene(scene, order="file" if file_order else None)
+        workload = f"mip360_bicycle stand-in: synth_unbounded(seed=2001, P={args.splats})"
+    workload += " [ingest order: file (LCGS_BENCH_FILE_ORDER)]" if r.permutation() is None else \
+                " [ingest order: spatial (library default)]"
+    P = scene["pos"].shape[0]
+    d = r.scene_tensors()  # torch views of the context's arrays (the order the library keeps them in)
+    torch.cuda.synchronize(dev)
+    cam = L.get_lookat_cam(*view_pose(rank), width=W, height=H)
+    img = torch.zeros(3, H, W, device=dev)
+
+    # first frame synchronises: sizes the pair buffers for this view
+    n_rendered = r.forward(cam, img, sync=True)
+    stats = r.frame_stats()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        r.forward(cam, img, sync=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r.forward(cam, img, sync=False)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # SURVEY 8d's protocol beside the contract's: the median of >= 50 frames on hipEvent pairs -- one event behind every
+    # frame on the context's stream (torch's current stream here).  Its own loop, so that `value` above is not perturbed
+    # by the event packets; reported beside `value`, never instead of it.
+    n_ev = max(50, args.steps)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev + 1)]
+    marks[0].record()
+    for i in range(n_ev):
+        r.forward(cam, img, sync=False)
+        marks[i + 1].record()
+    barrier()
+    frame_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_ev))
+    per_frame = {"frames": n_ev, "median_ms": round(frame_ms[n_ev // 2], 4), "min_ms": round(frame_ms[0], 4),
+                 "p90_ms": round(frame_ms[(n_ev * 9) // 10], 4), "frames_per_s_at_median": round(1e3 / frame_ms[n_ev // 2], 1),
+                 "how": "hipEvent pairs between consecutive frames on the context's stream (SURVEY 8d)"}
+    if dist is not None:
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * args.steps / elapsed
+
+    # N > 1 bookkeeping: every timed leg carries its ordinal and the rank's failure flag through the max-reduction, so a
+    # rank that failed alone and moved on can never have its reduction paired with another leg's on its peers (the
+    # figures would silently mix): a mismatch raises on every rank that sees it.
+    leg = {"no": 0, "failed": False}
+
+    def reduce_leg(el):
+        if dist is None:
+            return el
+        tt = torch.tensor([el, leg["no"], -leg["no"], 1.0 if leg["failed"] else 0.0], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if tt[1].item() != -tt[2].item():
+            leg["failed"] = True
+            raise RuntimeError(f"ranks are in different legs ({int(-tt[2].item())} .. {int(tt[1].item())}): a rank failed alone")
+        if tt[3].item() > 0 and not leg["failed"]:
+            leg["failed"] = True
+            raise RuntimeError("another rank reported a leg error")
+        return float(tt[0].item())
+
+    def timed(fn, steps, warm):
+        """warm untimed calls, then `steps` timed ones between barriers; max over ranks; seconds"""
+        leg["no"] += 1
+        for i in range(warm):
+            fn(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(warm + i)
+        barrier()
+        return reduce_leg(time.perf_counter() - t0)
+
+    moving = None if args.no_moving_camera else leg_moving_camera(L, r, cam, img, args, rank, world, W, H, timed)
+
+    # ---- per-stage device times (HIP events on the context's stream), outside the timed region
+    r.set_profiling(True)
+    acc = {}
+    reps = 10
+    for _ in range(reps):
+        r.forward(cam, img, sync=True)
+        for k, v in r.stage_times().items():
+            acc[k] = acc.get(k, 0.0) + v / reps
+    r.set_profiling(False)
+
+    pipelined = None if args.no_batch else leg_camera_batch(torch, r, cam, img, args, world, W, H, dev, dist, red_dev, barrier)
+    stage_path = None if args.no_stage_path else leg_stage_path(torch, L, ctx, d, cam, img, args, world, P, W, H, dev, barrier)
+    half_sh = leg_half_sh(r, cam, img, args, world, barrier) if args.half_sh else None
+    lod = leg_lod(r, cam, img, args, world, timed) if args.lod > 0 else None
+
+    rf = rooflines(r, stats, acc, data, P, W, H, ms_per_step)
+    roofline, frame_views, V, Lref, Lp = rf["roofline"], rf["frame_views"], rf["V"], rf["Lref"], rf["Lp"]
+    pmc_all, pmc_source, same_workload, src_hash = rf["pmc_all"], rf["pmc_source"], rf["same_workload"], rf["src_hash"]
+    sq_issue_kernels, sq_issue_src = rf["sq_issue_kernels"], rf["sq_issue_src"]
+
+    out = {
+        "metric": "forward fps @1080p, mip360_bicycle", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": data,
+        "config": {"workload": workload, "resolution": f"{W}x{H}", "splats": P, "visible_splats": V,
+                   "tile_pairs_reference": Lref, "tile_pairs_sorted": Lp, "views_per_gpu": 1,
+                   "parallelism": f"view-parallel x{world}"},
+        "roofline": roofline,
+        "frame_roofline": {"peak": HBM_PEAK_GBS, "attainable_peak": HBM_ATTAINABLE_GBS,
+                           "attainable_peak_source": "tools/microbench/fetch_calib.hip: plain 12- / 16-byte-per-lane read streams "
+                                                     "over 1 GiB run at 6.3-6.55 TB/s on this part "
+                                                     "(profiles/r02_fetch_calibration.txt); 8 TB/s is the spec figure",
+                           "unit": "GB/s", **frame_views},
+        "per_frame_events": per_frame,
+        "stages_ms": {k: round(v, 4) for k, v in acc.items()},
+    }
+    if stage_path is not None:
+        out["stage_path"] = stage_path
+    if half_sh is not None:
+        out["half_sh"] = half_sh
+    if lod is not None:
+        out["lod"] = lod
+    if pipelined is not None:
+        out["camera_batch"] = pipelined
+    if moving is not None:
+        out["moving_camera"] = moving
+
+    # ---- N > 1 insurance.  The legs below (RCCL communicator of the library, collectives, sharded optimiser) have only
+    # ever run on one GPU (`LCGS_BENCH_FORCE_DIST=1`) and on gloo: on a real multi-GPU node a rank that fails alone
+    # leaves the others waiting in a collective.  The forward measurement above is complete at this point, so a
+    # watchdog prints the line with what has been measured (plus `error`) instead of hanging the whole run.
+    printed = threading.Lock()
+    watchdog = None
+
+    def emit(error=None):
+        if not printed.acquire(blocking=False):
+            return
+        if error is not None:
+            out["error"] = error
+        if rank == 0:
+            print(json.dumps(out), file=line_out, flush=True)
+
+    if dist is not None:
+        def give_up():
+            done = printed.locked()  # (the line is out: only the teardown is stuck)
+            emit(f"the legs after the forward measurement did not finish within {args.leg_timeout} s on rank {rank}")
+            sys.stdout.flush()
+            # A timeout is a failure on EVERY rank (the line, with `error`, is on stdout for whoever wants to parse it) --
+            # unless only an AUXILIARY leg hung: a run whose line was already complete (the teardown alone is stuck), or
+            # one that has both halves of BASELINE's metric (forward frames/s in `value`, forward+backward Msplats/s in
+            # `fwd_bwd.value`), ends with 0 so that a harness keyed on the exit code keeps the measured figures.
+            headline = args.no_backward or ("value" in out.get("fwd_bwd", {}))
+            os._exit(0 if done or headline else 3)
+        watchdog = threading.Timer(args.leg_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
+    # ---- forward + backward (+ the RCCL sum of the dense per-splat gradients when N > 1): one training-style step per
+    # view through the package's view-parallel protocol (luisacomputegaussiansplatting_amd.multi_gpu: the same
+    # ViewParallelTrainer tests/test_distributed.py runs on gloo); Msplats/s = splats x views / time (SURVEY 8d).
+    # Same barrier / max-over-ranks timing.
+    import types
+
+    coll, timed_steps = leg_gradients(types.SimpleNamespace(
+        args=args, dist=dist, dev=dev, P=P, W=W, H=H, r=r, cam=cam, img=img, d=d, ctx=ctx, rank=rank, world=world, out=out, timed=timed, barrier=barrier, leg=leg, KEYS=KEYS, mg=mg, L=L, torch=torch, local_rank=local_rank, side=side, Lp=Lp, V=V, pmc_all=pmc_all, same_workload=same_workload, pmc_source=pmc_source, sq_issue_kernels=sq_issue_kernels, sq_issue_src=sq_issue_src, src_hash=src_hash))
 
     # ---- the same frames with the splats in FILE order (caller-bound arrays in the order of the file: for this stand-in
     # i.i.d., the worst case -- a view's splats are scattered over every DRAM page).  Same splats, same image.
@@ -950,45 +1039,7 @@ def main():
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference) on this box's host cores, rank 0, N = 1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import Oracle
-
-        o = Oracle("f32")
-        o.set_threads(0)
-        ocam = o.lookat(*view_pose(0), width=W, height=H)
-        t0 = time.perf_counter()
-        frames = 0
-        while True:
-            ref = o.render(scene, ocam)
-            frames += 1
-            el = time.perf_counter() - t0
-            if el > 12.0 or frames >= 8:
-                break
-        out["cpu_baseline"] = {"value": round(frames / el, 4), "unit": "frames/s", "cores": o.get_threads(), "kind": "port",
-                               "sample": f"{frames} full frame(s) of the same workload ({P} splats, {W}x{H}) in {el:.1f} s"}
-        n_rendered = r.forward(cam, img, sync=True)  # the frame the oracle is compared with
-        gi = img.cpu().numpy()
-        diff = np.abs(gi - ref["img"]).max(axis=0)
-        # the blend's exp is one defined sequence of binary32 operations in the kernels and in the oracle (round 3), so
-        # the two frames are expected to be EQUAL; anything else is reported, never hidden behind a tolerance
-        out["parity"] = {"num_rendered_equal": bool(ref["num_rendered"] == n_rendered),
-                         "bit_identical": bool(np.array_equal(gi, ref["img"])),
-                         "pixels_different": int((diff > 0).sum()),
-                         "pixels_over_1e-4": int((diff > 1e-4).sum()), "max_abs_diff": float(diff.max())}
-        # ... and the distance to a STANDARD exp in the blend (the reference says `exp(power)`, gs_tile_splatter/shader.cpp:259;
-        # north_star's bar: 1e-4 per-pixel L-inf): the same frame against the oracle run with libm's expf.  Pixels beyond 1e-4
-        # are threshold flips (an ulp of exp moves `alpha < 1/255` or `T < 1e-4`); `all_flagged` says every one of them is
-        # marked threshold-ambiguous (within 1e-5 relative) by the libm oracle itself.
-        o.set_blend_exp(True)
-        ref_libm = o.render(scene, ocam, ambig_eps=1e-5)
-        o.set_blend_exp(False)
-        with np.errstate(invalid="ignore"):
-            dl = np.abs(gi.astype(np.float64) - ref_libm["img"].astype(np.float64)).max(axis=0)
-        amb = ref_libm["ambig"].astype(bool)
-        over = dl > 1e-4
-        out["parity"]["vs_libm_expf"] = {
-            "pixels_over_1e-4": int(over.sum()), "max_abs_diff": float(dl.max()),
-            "all_flagged": bool((~over | amb).all()), "ambiguous_pixels": int(amb.sum()),
-            "max_abs_diff_unflagged": float(dl[~amb].max()) if (~amb).any() else 0.0, "pixels": int(dl.size)}
+        leg_cpu_baseline_and_parity(out, scene, r, cam, img, P, W, H)
     emit()
     if coll is not None:
         barrier()
