@@ -123,6 +123,20 @@ def test_comm_entry_points_without_a_gpu(lcgs):
     assert lib.lcgs_comm_create(None, a, C.c_int(0), C.c_int(1), C.byref(h)) == 1 and not h.value
     assert lib.lcgs_comm_destroy(None) == 0
     assert lcgs.shard_rows(10, 4, 3) == (6, 2)  # floor(10 / 4) rows each; rows 8, 9 are the tail every rank keeps
+    # the ownership step's rows: equal contiguous shards, the tail with the LAST rank (= multi_gpu.owner_range)
+    import luisacomputegaussiansplatting_amd.multi_gpu as mg
+
+    for P, N in ((10, 4), (6_131_954, 8), (5, 8), (64, 1)):
+        spans = [lcgs.api.owner_rows(P, N, r) for r in range(N)]
+        assert spans == [mg.owner_range(P, N, r) for r in range(N)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == P and all(spans[r][0] + spans[r][1] == spans[r + 1][0] for r in range(N - 1))
+    # the in-process loopback group needs no device either; the step's entry points refuse NULL arguments
+    g = lcgs.api.LoopbackGroup(3)
+    assert lib.lcgs_comm_create_loopback(None, g._h, C.c_int(0), C.byref(h)) == 1 and not h.value
+    g.close()
+    assert lib.lcgs_loopback_group_create(C.c_int(0), C.byref(h)) == 1  # world size out of range
+    assert lib.lcgs_owner_step_forward(None, None, None, None, C.c_float(1.0), None) == 1
+    assert lib.lcgs_owner_step_backward(None, None, None, None) == 1
 
 
 def test_real_scene_env_hooks_switch_the_full_size_tests_to_the_file(lcgs, tmp_path, monkeypatch):
