@@ -25,7 +25,7 @@ namespace lcgs
 
 namespace
 {
-using namespace tile; // tile_of_workgroup / render_grid_size / splat_may_touch_rect: shared with render.hip
+using namespace tile; // tile_of_workgroup / render_grid_size / splat_strip_mask: shared with render.hip
 
 // ---------------------------------------------------------------------------------------------------------------
 // Wave reduction of the per-pixel gradient terms, four list entries at a time.
@@ -273,11 +273,7 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
             }
             if (!KNOWN) {
                 const float rx0 = (float)(tx * kBlockX), ry0 = (float)(ty * kBlockY), rx1 = rx0 + (float)(kBlockX - 1);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float y0 = ry0 + 4.0f * k;
-                    if (splat_may_touch_rect(a.x, a.y, a.z, a.w, b.x, t, rx0, y0, rx1, y0 + 3.0f)) kmask |= 1u << k;
-                }
+                kmask = splat_strip_mask(a.x, a.y, a.z, a.w, b.x, t, rx0, ry0, rx1);
             }
         }
         __syncthreads(); // previous round fully flushed

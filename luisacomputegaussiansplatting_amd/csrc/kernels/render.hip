@@ -175,14 +175,7 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         const float4   a = na, b = nb;
         const float    c = nc;
         const float    t = have ? (2.0f * __logf(255.0f * b.y)) * 1.0001f + 2e-4f : -1.0f;
-        uint32_t       kmask = 0;
-        if (have) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float y0 = ry0 + 4.0f * k;
-                if (splat_may_touch_rect(a.x, a.y, a.z, a.w, b.x, t, rx0, y0, rx1, y0 + 3.0f)) kmask |= 1u << k;
-            }
-        }
+        const uint32_t kmask = have ? splat_strip_mask(a.x, a.y, a.z, a.w, b.x, t, rx0, ry0, rx1) : 0u;
         // (kept for the backward, which walks the same list positions: it need not repeat the four strip tests)
         if (KEEP && strip_masks && have) strip_masks[e] = (uint8_t)kmask;
         __syncthreads(); // previous round's readers are done with the slab and the masks
