@@ -213,9 +213,12 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
     cp.grid_x = div_up(cp.width, kBlockX); // impl.cpp:76-79
     cp.grid_y = div_up(cp.height, kBlockY);
 
-    LCGS_TRY(ctx->st_scalar.ensure(16));
-    uint32_t* d_hole = ctx->st_scalar.as<uint32_t>();
-    LCGS_HIP_CHECK(hipMemsetAsync(d_hole, 0, 4, st));
+    if (!ctx->st_scalar.ptr) { // (once: the hole word starts at zero and is only ever set to a frame's own mark)
+        LCGS_TRY(ctx->st_scalar.ensure(16));
+        LCGS_HIP_CHECK(hipMemsetAsync(ctx->st_scalar.ptr, 0, 16, st));
+    }
+    uint32_t*      d_hole    = ctx->st_scalar.as<uint32_t>();
+    const uint32_t hole_mark = ++ctx->stage_serial ? ctx->stage_serial : ++ctx->stage_serial; // never 0
     // (for the sort below: the splats that claim pair slots, ascending -- flagged by the allocation pass itself, compacted
     //  before the one synchronisation)
     const size_t fbytes = sparse_flag_bytes(P);
@@ -225,22 +228,24 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
     uint8_t*  d_flags = ctx->st_flags.as<uint8_t>();
     uint32_t* d_vis   = ctx->st_u32[1].as<uint32_t>();
     uint32_t* d_nvis  = d_hole + 1;
-    if (fbytes > (size_t)P) LCGS_HIP_CHECK(hipMemsetAsync(d_flags + P, 0, fbytes - (size_t)P, st)); // the padding
     launch_allocate_tiles(P, cp, use_focal != 0, input->depth_features, input->means_2d, input->conic,
-                          accel->tiles_touched, output->radii, st, d_hole, d_flags); // impl.cpp:87-99
+                          accel->tiles_touched, output->radii, st, d_hole, hole_mark, d_flags, fbytes); // impl.cpp:87-99
     LCGS_TRY(ctx->st_scan_temp.ensure(scan_temp_bytes(P)));
     launch_inclusive_sum_u32(accel->tiles_touched, accel->point_offsets, P, ctx->st_scan_temp.ptr, st); // impl.cpp:104
-    launch_compact_flags(d_flags, P, ctx->st_u32[0].as<uint32_t>(), d_vis, d_nvis, st);
+    // (the compaction's scan launch also carries num_rendered = point_offsets[P - 1] (impl.cpp:106) next to the two scalars)
+    launch_compact_flags(d_flags, P, ctx->st_u32[0].as<uint32_t>(), d_vis, d_nvis, st, accel->point_offsets + (P - 1), d_hole + 2);
     // the frame's one read-back (impl.cpp:106-107): num_rendered beside the two scalars of this implementation, as ONE copy
     // into pinned memory (three 4-byte copies into pageable words left the GPU idle for ~80 us per frame)
     if (!ctx->h_stage) LCGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), 16, hipHostMallocDefault));
-    LCGS_HIP_CHECK(hipMemcpyAsync(d_hole + 2, accel->point_offsets + (P - 1), 4, hipMemcpyDeviceToDevice, st)); // impl.cpp:106
     LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_stage, d_hole, 12, hipMemcpyDeviceToHost, st));
     LCGS_HIP_CHECK(hipStreamSynchronize(st));                                                        // impl.cpp:107
-    const uint32_t hole = ctx->h_stage[0], n_vis = ctx->h_stage[1];
+    const uint32_t hole = ctx->h_stage[0] == hole_mark ? 1u : 0u, n_vis = ctx->h_stage[1];
     const int32_t  L    = (int32_t)ctx->h_stage[2];
     if (num_rendered) *num_rendered = L;
     if (L <= 0) return LCGS_OK; // impl.cpp:109
+    // impl.cpp:147's zero-fill of the ranges, issued here: right behind the synchronisation the GPU waits for the host's first
+    // launches anyway, and nothing before get_ranges touches the buffer
+    LCGS_HIP_CHECK(hipMemsetAsync(accel->ranges, 0, (size_t)cp.grid_x * cp.grid_y * 2 * 4, st));
     if ((int64_t)L > accel->capacity) {
         char buf[160];
         snprintf(buf, sizeof(buf), "num_rendered = %d exceeds the pair buffer capacity %lld", L, (long long)accel->capacity);
@@ -331,13 +336,11 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
         LCGS_TRY(ctx->st_win.ensure(copy_with_keys_windows_bytes((uint32_t)L)));
         launch_copy_with_keys_balanced(n, cp, input->means_2d, offs, output->radii, input->depth_features, order,
                                        ctx->st_keys_exp.as<uint64_t>(), ctx->st_vals_exp.as<uint32_t>(), (uint32_t)L,
-                                       ctx->st_win.as<uint32_t>(), st);
+                                       ctx->st_win.as<uint32_t>(), st, /*the sorted depth keys:*/ which ? kb : ka);
         launch_pair_sort_u64_preserve(ctx->st_keys_exp.as<uint64_t>(), ctx->st_vals_exp.as<uint32_t>(), accel->point_list_keys,
                                       accel->point_list, ctx->st_keys_tmp.as<uint64_t>(), ctx->st_vals_tmp.as<uint32_t>(), L,
                                       32, 32 + tile_bits, ctx->st_sort_temp.ptr, st);
     }
-    const size_t G = (size_t)cp.grid_x * cp.grid_y;
-    LCGS_HIP_CHECK(hipMemsetAsync(accel->ranges, 0, G * 2 * 4, st)); // impl.cpp:147
     launch_get_ranges_u64(L, accel->point_list_keys, accel->ranges, st); // impl.cpp:150-156
     if (side.forked) { // the unsorted buffers are complete before anything the caller enqueues behind this call
         LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));

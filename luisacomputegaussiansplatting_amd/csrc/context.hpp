@@ -172,6 +172,7 @@ struct lcgs_context {
     // their arguments instead of running; a GSTileSplatter::forward whose inputs are exactly their outputs then renders
     // the fused frame from the 3-D arrays (same image, radii, num_rendered); anything else runs the recorded calls first.
     int stage_mode = 0; // LCGS_STAGES_EXACT
+    uint32_t stage_serial = 0;   // lcgs_tile_splat_forward's per-frame mark of the "unwritten pair slots" word
     bool stage_side_copy = true; // the unsorted pair buffers' copy beside the depth sort (A/B hook LCGS_STAGE_SIDE_COPY=0)
     int stage_sort = 0; // lcgs_tile_splat_forward's sort route: 0 = by frame size, 1 = literal six passes, 2 = sort-before-duplicate
                         // (LCGS_STAGE_SORT=literal|splats, read once when the context is created)

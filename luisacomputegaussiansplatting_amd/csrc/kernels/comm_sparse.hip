@@ -57,7 +57,9 @@ __global__ void __launch_bounds__(256) k_flag_count(const uint8_t* __restrict__ 
 }
 
 // one workgroup: exclusive scan of the chunk counts (in place) and the total
-__global__ void __launch_bounds__(1024) k_flag_scan(uint32_t* __restrict__ chunk_count, uint32_t chunks, uint32_t* __restrict__ d_total)
+// (copy_src / copy_dst, nullable: one more word carried along -- a caller that reads *d_total back with another scalar saves a copy launch)
+__global__ void __launch_bounds__(1024) k_flag_scan(uint32_t* __restrict__ chunk_count, uint32_t chunks, uint32_t* __restrict__ d_total,
+                                                    const uint32_t* __restrict__ copy_src, uint32_t* __restrict__ copy_dst)
 {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
@@ -83,6 +85,7 @@ __global__ void __launch_bounds__(1024) k_flag_scan(uint32_t* __restrict__ chunk
         __syncthreads();
     }
     if (tid == 0) *d_total = s_carry;
+    if (tid == 64u && copy_dst) *copy_dst = *copy_src;
 }
 
 __global__ void __launch_bounds__(256) k_flag_scatter(const uint8_t* __restrict__ flags, uint32_t P,
@@ -190,15 +193,16 @@ void launch_mark_rows(const uint32_t* vis_index, const uint32_t* d_counts, uint8
 
 // flags (sparse_flag_bytes(P), zero beyond P) -> rows[0 .. *d_total) ascending; chunk_ws: sparse_flag_chunks(P) x u32
 void launch_compact_flags(const uint8_t* flags, int64_t P, uint32_t* chunk_ws, uint32_t* rows, uint32_t* d_total,
-                          hipStream_t stream)
+                          hipStream_t stream, const uint32_t* copy_src, uint32_t* copy_dst)
 {
     const uint32_t chunks = sparse_flag_chunks(P);
     if (chunks == 0) {
         (void)hipMemsetAsync(d_total, 0, 4, stream);
+        if (copy_dst) (void)hipMemcpyAsync(copy_dst, copy_src, 4, hipMemcpyDeviceToDevice, stream);
         return;
     }
     hipLaunchKernelGGL(k_flag_count, dim3(chunks), dim3(256), 0, stream, flags, (uint32_t)P, chunk_ws);
-    hipLaunchKernelGGL(k_flag_scan, dim3(1), dim3(1024), 0, stream, chunk_ws, chunks, d_total);
+    hipLaunchKernelGGL(k_flag_scan, dim3(1), dim3(1024), 0, stream, chunk_ws, chunks, d_total, copy_src, copy_dst);
     hipLaunchKernelGGL(k_flag_scatter, dim3(chunks), dim3(256), 0, stream, flags, (uint32_t)P, chunk_ws, rows);
 }
 

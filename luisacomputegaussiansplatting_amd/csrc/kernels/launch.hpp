@@ -18,11 +18,12 @@ void launch_project(int P, const CamParams& cp, bool use_focal, const float* pos
                     hipStream_t stream);
 // hole_flag (optional, device word, cleared by the caller): set when a splat claims pair slots that copy_with_keys leaves
 // unwritten (radius <= 0 with tiles > 0: a NaN covariance) -- only then does the reference's zero-fill of the pair buffers matter
-// flags (nullable): flags[i] = splat i claims pair slots (tiles_touched[i] > 0), for the splatter's compaction; the caller
-// zero-fills the padding behind P
+// hole_flag (nullable): set to hole_mark (a value the caller has not used before: no zero-fill per frame) when a splat claims pair
+// slots its copy_with_keys will not write.  flags (nullable, flags_len >= P bytes): flags[i] = splat i claims pair slots
+// (tiles_touched[i] > 0), zeros behind P -- the splatter's compaction input
 void launch_allocate_tiles(int P, const CamParams& cp, bool use_focal, const float* depth, float* means_2d,
                            float* covs_2d, uint32_t* tiles_touched, int32_t* radii, hipStream_t stream,
-                           uint32_t* hole_flag = nullptr, uint8_t* flags = nullptr);
+                           uint32_t* hole_flag = nullptr, uint32_t hole_mark = 1u, uint8_t* flags = nullptr, size_t flags_len = 0);
 void launch_copy_with_keys(int P, const CamParams& cp, const float* means_2d, const uint32_t* offsets,
                            const int32_t* radii, const float* depth, uint64_t* keys, uint32_t* values,
                            hipStream_t stream);
@@ -39,7 +40,8 @@ void launch_copy_with_keys_ordered(int n, const CamParams& cp, const float* mean
 // inclusive sums of their tile counts, L = offsets[n - 1] (known on the host).  win_first: copy_with_keys_windows_bytes(L).
 void   launch_copy_with_keys_balanced(int n, const CamParams& cp, const float* means_2d, const uint32_t* offsets,
                                       const int32_t* radii, const float* depth, const uint32_t* order, uint64_t* keys,
-                                      uint32_t* values, uint32_t L, uint32_t* win_first, hipStream_t stream);
+                                      uint32_t* values, uint32_t L, uint32_t* win_first, hipStream_t stream,
+                                      const uint32_t* dbits_of_source = nullptr); // (nullable) source e's depth bits, in source order
 size_t copy_with_keys_windows_bytes(uint32_t L);
 void launch_get_ranges_u64(int64_t L, const uint64_t* keys, uint32_t* ranges, hipStream_t stream);
 
@@ -244,7 +246,7 @@ uint32_t sparse_flag_chunks(int64_t P);
 void     launch_mark_rows(const uint32_t* vis_index, const uint32_t* d_counts, uint8_t* flags, int64_t P, int64_t hint_V,
                           hipStream_t stream);
 void     launch_compact_flags(const uint8_t* flags, int64_t P, uint32_t* chunk_ws, uint32_t* rows, uint32_t* d_total,
-                              hipStream_t stream);
+                              hipStream_t stream, const uint32_t* copy_src = nullptr, uint32_t* copy_dst = nullptr);
 void     launch_owner_bounds(const uint32_t* rows, const uint32_t* d_total, int64_t shard, int world, uint32_t* d_bounds,
                              hipStream_t stream);
 int64_t  sparse_message_words(int64_t count, int sh_degree);

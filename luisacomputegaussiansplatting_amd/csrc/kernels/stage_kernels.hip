@@ -5,7 +5,10 @@
 // one-submission frame lives in fused_forward.hip and shares gs_math.hpp with these kernels.
 //
 // All kernels here are HBM-streaming, one splat per lane, 256 lanes per block (4 wave64s).
+#include <algorithm>
+
 #include "launch.hpp"
+#include "stream_access.hpp"
 
 namespace lcgs
 {
@@ -33,7 +36,7 @@ __global__ void __launch_bounds__(kThreads) k_sh_process(int P, int deg, CamPara
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             const int c = i * 64 + lane; // chunk c of the wave's slab = row c / 12, part c % 12
-            q[i]        = c < rows * 12 ? src[c] : make_float4(0, 0, 0, 0);
+            q[i]        = c < rows * 12 ? ld_stream(src + c) : make_float4(0, 0, 0, 0); // (1.2 GB read once: streaming loads)
         }
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
@@ -98,11 +101,14 @@ __global__ void __launch_bounds__(kThreads) k_allocate_tiles(int P, CamParams cp
                                                                float* __restrict__ covs_2d,
                                                                uint32_t* __restrict__ tiles_touched,
                                                                int32_t* __restrict__ radii,
-                                                               uint32_t* __restrict__ hole_flag,
-                                                               uint8_t* __restrict__ flags)
+                                                               uint32_t* __restrict__ hole_flag, uint32_t hole_mark,
+                                                               uint8_t* __restrict__ flags, int flags_len)
 {
     const int idx = blockIdx.x * kThreads + threadIdx.x;
-    if (idx >= P) return;
+    if (idx >= P) {
+        if (flags && idx < flags_len) flags[idx] = 0; // the compaction's padding behind P (no separate fill launch)
+        return;
+    }
     if (depth[idx] < 0.2f) { // :120-121
         radii[idx]         = 0;
         tiles_touched[idx] = 0u;
@@ -123,7 +129,7 @@ __global__ void __launch_bounds__(kThreads) k_allocate_tiles(int P, CamParams cp
     // A splat that claims pair slots (tiles > 0) which copy_with_keys will leave unwritten (it skips radius <= 0,
     // shader.cpp:41-42): only a NaN covariance gets here.  Its slots keep the value of the reference's BufferFiller pass
     // (impl.cpp:117-118) -- the caller learns whether that fill is needed at all this frame.
-    if (hole_flag && radius <= 0 && tiles > 0u) *hole_flag = 1u;
+    if (hole_flag && radius <= 0 && tiles > 0u) *hole_flag = hole_mark; // (a per-frame mark: the word is never zero-filled)
     covs_2d[3 * (size_t)idx + 0]  = conic[0];
     covs_2d[3 * (size_t)idx + 1]  = conic[1];
     covs_2d[3 * (size_t)idx + 2]  = conic[2];
@@ -220,7 +226,8 @@ __global__ void __launch_bounds__(kThreads) k_copy_with_keys_balanced(int n, Cam
                                                                         uint32_t* __restrict__ values,
                                                                         const uint32_t* __restrict__ order,
                                                                         const uint32_t* __restrict__ win_first, uint32_t L,
-                                                                        uint32_t num_windows)
+                                                                        uint32_t num_windows,
+                                                                        const uint32_t* __restrict__ dbits_of_source)
 {
     __shared__ uint32_t s_start[kCopyWindow + 1], s_sid[kCopyWindow + 1], s_xy[kCopyWindow + 1], s_w[kCopyWindow + 1],
         s_db[kCopyWindow + 1];
@@ -238,7 +245,8 @@ __global__ void __launch_bounds__(kThreads) k_copy_with_keys_balanced(int n, Cam
         s_sid[e]   = sid;
         s_xy[e]    = rmin[0] | (rmin[1] << 16);
         s_w[e]     = rmax[0] - rmin[0];
-        s_db[e]    = __float_as_uint(depth[sid]);
+        // (depth-ordered sources come with their sorted depth keys: a coalesced read instead of a gather)
+        s_db[e]    = dbits_of_source ? dbits_of_source[idx] : __float_as_uint(depth[sid]);
     }
     __syncthreads();
     for (uint32_t slot = o0 + tid; slot < o1; slot += kThreads) {
@@ -317,11 +325,12 @@ void launch_project(int P, const CamParams& cp, bool use_focal, const float* pos
 
 void launch_allocate_tiles(int P, const CamParams& cp, bool use_focal, const float* depth, float* means_2d,
                            float* covs_2d, uint32_t* tiles_touched, int32_t* radii, hipStream_t stream, uint32_t* hole_flag,
-                           uint8_t* flags)
+                           uint32_t hole_mark, uint8_t* flags, size_t flags_len)
 {
     if (P <= 0) return;
-    hipLaunchKernelGGL(k_allocate_tiles, dim3(blocks_for(P)), dim3(kThreads), 0, stream, P, cp, use_focal, depth,
-                       means_2d, covs_2d, tiles_touched, radii, hole_flag, flags);
+    const int64_t threads = flags ? std::max<int64_t>(P, (int64_t)flags_len) : P;
+    hipLaunchKernelGGL(k_allocate_tiles, dim3(blocks_for(threads)), dim3(kThreads), 0, stream, P, cp, use_focal, depth,
+                       means_2d, covs_2d, tiles_touched, radii, hole_flag, hole_mark, flags, (int)flags_len);
 }
 
 void launch_copy_with_keys(int P, const CamParams& cp, const float* means_2d, const uint32_t* offsets,
@@ -335,13 +344,14 @@ void launch_copy_with_keys(int P, const CamParams& cp, const float* means_2d, co
 
 void launch_copy_with_keys_balanced(int n, const CamParams& cp, const float* means_2d, const uint32_t* offsets,
                                     const int32_t* radii, const float* depth, const uint32_t* order, uint64_t* keys,
-                                    uint32_t* values, uint32_t L, uint32_t* win_first, hipStream_t stream)
+                                    uint32_t* values, uint32_t L, uint32_t* win_first, hipStream_t stream,
+                                    const uint32_t* dbits_of_source)
 {
     if (n <= 0 || L == 0u) return;
     const uint32_t windows = (L + kCopyWindow - 1u) / kCopyWindow;
     hipLaunchKernelGGL(k_window_sources, dim3(blocks_for(n)), dim3(kThreads), 0, stream, n, offsets, win_first);
     hipLaunchKernelGGL(k_copy_with_keys_balanced, dim3(windows), dim3(kThreads), 0, stream, n, cp, means_2d, offsets, radii, depth,
-                       keys, values, order, win_first, L, windows);
+                       keys, values, order, win_first, L, windows, dbits_of_source);
 }
 size_t copy_with_keys_windows_bytes(uint32_t L) { return ((size_t)(L + kCopyWindow - 1u) / kCopyWindow + 1) * 4; }
 
