@@ -1028,6 +1028,11 @@ def main():
                     fo["fwd_bwd_compact_rows" if compact else "fwd_bwd"] = {
                         "value": round(world * P * args.steps / el_b / 1e6, 1), "unit": "Msplats/s",
                         "ms_per_step": round(el_b * 1e3 / args.steps, 4)}
+            if not args.no_stage_path and dist is None:
+                # the reference's three operators on the file-order arrays (what app/main.cpp:180-223 hands them)
+                sp = leg_stage_path(torch, L, ctx, df, cam, img, args, world, P, W, H, dev, barrier)
+                fo["stage_path"] = {"value": sp["value"], "unit": "frames/s", "ms_per_step": sp["ms_per_step"],
+                                    "deferred": sp["deferred"]["value"], "max_abs_diff_vs_fused": sp["max_abs_diff_vs_fused"]}
             out["file_order"] = fo
             r.bind_scene(*[d[k] for k in KEYS])
             del df, ref_img
