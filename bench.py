@@ -989,6 +989,20 @@ def main():
         watchdog.daemon = True
         watchdog.start()
 
+        # ... and a rank that DIES in one of those legs (not hangs: a fault inside a first-contact RCCL path) makes the launcher
+        # send SIGTERM to the others: the survivors print what has been measured before they go, by the same exit-code rule
+        import signal
+
+        def terminated(signum, frame):  # noqa: ARG001
+            done = printed.locked()
+            emit(f"terminated by the launcher (signal {signum}) during the legs after the forward measurement: another rank failed")
+            sys.stdout.flush()
+            os._exit(0 if done or args.no_backward or ("value" in out.get("fwd_bwd", {})) else 3)
+        try:
+            signal.signal(signal.SIGTERM, terminated)
+        except ValueError:  # (not the main thread)
+            pass
+
     # ---- forward + backward (+ the RCCL sum of the dense per-splat gradients when N > 1): one training-style step per
     # view through the package's view-parallel protocol (luisacomputegaussiansplatting_amd.multi_gpu: the same
     # ViewParallelTrainer tests/test_distributed.py runs on gloo); Msplats/s = splats x views / time.
