@@ -535,8 +535,9 @@ LCGS_API lcgs_status lcgs_owner_backward(lcgs_context* ctx, int slot, const floa
  * backward call ((4 + 48) bytes a row out as an owner, 48 back as a view's renderer, + the count table).
  * An in-process stand-in for RCCL exists for tests and single-GPU rehearsals: lcgs_loopback_group_create(N) +
  * lcgs_comm_create_loopback(ctx_r, group, r) give N communicators for N contexts ON ONE DEVICE, driven by one host thread
- * each; the two calls above then run the same code with device-to-device copies as the wire (RCCL refuses a second rank on
- * a device).  A loopback communicator carries the ownership step only. */
+ * each (N <= LCGS_MAX_OWNER_VIEWS).  Every collective call of this header (lcgs_grads_allreduce with the f32 transport,
+ * lcgs_adam_step_sharded, lcgs_adam_step_sparse, the two calls above) then runs the same code with device-to-device copies
+ * and rank-ordered sums as the wire (RCCL refuses a second rank on a device).  Not a production transport. */
 LCGS_API void        lcgs_comm_owner_rows(int64_t num_gaussians, int world_size, int rank, int64_t* first, int64_t* count);
 LCGS_API lcgs_status lcgs_owner_step_forward(lcgs_context* ctx, lcgs_comm* comm, const lcgs_camera* cameras /* [world_size] */,
                                              const float bg_color[3], float scale_modifier, float* d_img);

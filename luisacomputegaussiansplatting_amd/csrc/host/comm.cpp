@@ -164,6 +164,14 @@ struct lcgs_loopback_group {
     std::vector<std::deque<Msg>> box;  // box[dst * world + src]: the sends posted in the open group, in order
     std::vector<hipEvent_t>      done; // per rank: behind the copies of its receives of the last group
     int                          members = 0;
+    // collectives of the open group (all-reduce / reduce-scatter / all-gather): what every rank passed, op by op
+    struct CollArgs {
+        const float* send;
+        float*       recv;
+    };
+    std::vector<std::vector<CollArgs>> coll;    // coll[op][rank]
+    std::vector<float*>                scratch; // per rank: where it leaves its reduced slices (phase 1 of an all-reduce)
+    std::vector<hipEvent_t>            ready, reduced; // per rank: inputs complete / phase 1 complete
 
     bool barrier() // false: the group failed
     {
@@ -208,6 +216,14 @@ struct lcgs_comm {
     lcgs_loopback_group* loop = nullptr; // set: an in-process communicator (lcgs_comm_create_loopback), comm == NULL
     bool         self_p2p = false;       // test hook LCGS_OWNER_SELF_P2P=1: my own share travels through send / recv too
     DeviceBuffer own_rows, own_recs, in_rows, in_recs, g2d_all, g_in;
+    DeviceBuffer loop_scratch; // loopback: this rank's reduced slices of the open group's all-reduces
+    struct LoopOp {
+        int          kind; // 0 all-reduce (in place), 1 reduce-scatter, 2 all-gather
+        const float* send;
+        float*       recv;
+        size_t       count; // all-reduce: elements; the others: elements per rank
+    };
+    std::vector<LoopOp> loop_ops; // loopback: the collectives of the open group, executed at its end
     struct {
         bool     valid = false;
         int64_t  n_all = 0;                     // rows on my view's screen (all owners)
@@ -229,6 +245,220 @@ void comm_forget_context(lcgs_comm* c)
 
 namespace
 {
+// ---------------------------------------------------------------------------------------------------------------------
+// The transport of one communicator: RCCL over xGMI, or the in-process loopback (N contexts on one device, one host thread
+// each).  Every collective and point-to-point call of this file goes through it, so the code above this seam -- chunking,
+// shard and message arithmetic, stream ordering -- is the same whichever carries the bytes.  Calls between group_begin and
+// group_end form one group (RCCL: ncclGroupStart / End; loopback: recorded, executed by group_end, which every member of
+// the group reaches with the same sequence of calls).  Streams: everything is enqueued on the communicator's stream.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Wire {
+    lcgs_comm* c;
+
+    lcgs_status loop_failed()
+    {
+        set_last_error("loopback: another member of the group failed");
+        return LCGS_ERR_STATE;
+    }
+    lcgs_status group_begin()
+    {
+        if (!c->loop) LCGS_RCCL_CHECK(rccl().GroupStart());
+        else {
+            c->own.recvs.clear();
+            c->loop_ops.clear();
+        }
+        return LCGS_OK;
+    }
+    // (RCCL: an error inside an open group closes it before it is reported)
+    lcgs_status rccl_call(ncclResult_t r, const char* what, int line)
+    {
+        if (r == ncclSuccess) return LCGS_OK;
+        (void)rccl().GroupEnd();
+        return rccl_fail(r, what, line);
+    }
+    lcgs_status allreduce_sum(float* p, size_t count) // in place
+    {
+        if (!c->loop) return rccl_call(rccl().AllReduce(p, p, count, ncclFloat32, ncclSum, c->comm, c->stream), "ncclAllReduce", __LINE__);
+        c->loop_ops.push_back({ 0, p, p, count });
+        return LCGS_OK;
+    }
+    lcgs_status reduce_scatter_sum(const float* send, float* recv, size_t count_per_rank)
+    {
+        if (!c->loop)
+            return rccl_call(rccl().ReduceScatter(send, recv, count_per_rank, ncclFloat32, ncclSum, c->comm, c->stream),
+                             "ncclReduceScatter", __LINE__);
+        c->loop_ops.push_back({ 1, send, recv, count_per_rank });
+        return LCGS_OK;
+    }
+    lcgs_status allgather(const float* send, float* recv, size_t count_per_rank)
+    {
+        if (!c->loop)
+            return rccl_call(rccl().AllGather(send, recv, count_per_rank, ncclFloat32, c->comm, c->stream), "ncclAllGather", __LINE__);
+        c->loop_ops.push_back({ 2, send, recv, count_per_rank });
+        return LCGS_OK;
+    }
+    lcgs_status send(const void* d_buf, size_t bytes, int peer)
+    {
+        if (!c->loop) return rccl_call(rccl().Send(d_buf, bytes, ncclUint8, peer, c->comm, c->stream), "ncclSend", __LINE__);
+        lcgs_loopback_group::Msg m{ d_buf, bytes, nullptr };
+        LCGS_HIP_CHECK(hipEventCreateWithFlags(&m.ready, hipEventDisableTiming));
+        LCGS_HIP_CHECK(hipEventRecord(m.ready, c->stream));
+        std::lock_guard<std::mutex> lock(c->loop->mu);
+        c->loop->box[(size_t)peer * c->loop->world + c->rank].push_back(m);
+        return LCGS_OK;
+    }
+    lcgs_status recv(void* d_buf, size_t bytes, int peer)
+    {
+        if (!c->loop) return rccl_call(rccl().Recv(d_buf, bytes, ncclUint8, peer, c->comm, c->stream), "ncclRecv", __LINE__);
+        c->own.recvs.push_back({ d_buf, { bytes, peer } });
+        return LCGS_OK;
+    }
+    // a small all-gather of `count` words per rank, outside any group (message sizes: the host reads the result back)
+    lcgs_status allgather_u32(const uint32_t* d_send, uint32_t* d_recv, size_t count)
+    {
+        if (!c->loop) {
+            LCGS_RCCL_CHECK(rccl().AllGather(d_send, d_recv, count, ncclUint32, c->comm, c->stream));
+            return LCGS_OK;
+        }
+        lcgs_loopback_group* g = c->loop;
+        std::vector<uint32_t> mine(count);
+        LCGS_HIP_CHECK(hipMemcpyAsync(mine.data(), d_send, count * 4, hipMemcpyDeviceToHost, c->stream));
+        LCGS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        {
+            std::lock_guard<std::mutex> lock(g->mu);
+            if (g->table.size() < (size_t)g->world * count) g->table.resize((size_t)g->world * count);
+            std::copy(mine.begin(), mine.end(), g->table.begin() + (size_t)c->rank * count);
+        }
+        if (!g->barrier()) return loop_failed();
+        std::vector<uint32_t> all;
+        {
+            std::lock_guard<std::mutex> lock(g->mu);
+            all.assign(g->table.begin(), g->table.begin() + (size_t)g->world * count);
+        }
+        LCGS_HIP_CHECK(hipMemcpy(d_recv, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+        if (!g->barrier()) return loop_failed(); // nobody overwrites the table before everybody has read it
+        return LCGS_OK;
+    }
+    lcgs_status group_end()
+    {
+        if (!c->loop) {
+            LCGS_RCCL_CHECK(rccl().GroupEnd());
+            return LCGS_OK;
+        }
+        lcgs_loopback_group* g  = c->loop;
+        const int            N  = g->world, me = c->rank;
+        hipStream_t          st = c->stream;
+        // ---- what this rank's collectives of the group need as scratch: its slice of every all-reduce
+        size_t scratch_elems = 0;
+        for (const auto& op : c->loop_ops)
+            if (op.kind == 0) scratch_elems += (op.count + N - 1) / N;
+        LCGS_TRY(c->loop_scratch.ensure(scratch_elems * 4 + 16));
+        {
+            std::lock_guard<std::mutex> lock(g->mu);
+            if (g->coll.size() < c->loop_ops.size()) g->coll.resize(c->loop_ops.size());
+            for (size_t k = 0; k < c->loop_ops.size(); ++k) {
+                g->coll[k].resize(N);
+                g->coll[k][me] = { c->loop_ops[k].send, c->loop_ops[k].recv };
+            }
+            g->scratch[me] = c->loop_scratch.as<float>();
+        }
+        LCGS_HIP_CHECK(hipEventRecord(g->ready[me], st)); // my inputs (and my posted sends) are complete behind this
+        if (!g->barrier()) return loop_failed();           // every rank has posted its sends and its collectives' buffers
+        for (int r = 0; r < N; ++r)
+            if (r != me) LCGS_HIP_CHECK(hipStreamWaitEvent(st, g->ready[r], 0));
+        // ---- point-to-point: copy what was sent to me
+        std::vector<hipEvent_t> consumed;
+        for (auto& r : c->own.recvs) {
+            lcgs_loopback_group::Msg m{};
+            {
+                std::lock_guard<std::mutex> lock(g->mu);
+                auto& q = g->box[(size_t)me * N + r.second.second];
+                if (q.empty() || q.front().bytes != r.second.first) {
+                    g->failed = true;
+                    g->cv.notify_all();
+                    set_last_error("loopback: a receive has no matching send of the same size (ranks disagree on the message table)");
+                    return LCGS_ERR_STATE;
+                }
+                m = q.front();
+                q.pop_front();
+            }
+            LCGS_HIP_CHECK(hipStreamWaitEvent(st, m.ready, 0));
+            if (m.bytes) LCGS_HIP_CHECK(hipMemcpyAsync(r.first, m.ptr, m.bytes, hipMemcpyDeviceToDevice, st));
+            consumed.push_back(m.ready);
+        }
+        // ---- collectives, phase 1: reductions that only READ the other ranks' buffers (sums in rank order)
+        std::vector<lcgs_loopback_group::CollArgs> args; // (a private copy: the shared table is re-used by the next group)
+        size_t                                      at = 0;
+        for (size_t k = 0; k < c->loop_ops.size(); ++k) {
+            const auto& op = c->loop_ops[k];
+            {
+                std::lock_guard<std::mutex> lock(g->mu);
+                args = g->coll[k];
+            }
+            const float* srcs[16];
+            if (op.kind == 0) { // all-reduce: I reduce slice `me` of everybody's array into my scratch
+                const size_t per = (op.count + N - 1) / N, lo = std::min(op.count, per * (size_t)me),
+                             n = std::min(op.count, lo + per) - lo;
+                for (int r = 0; r < N; ++r) srcs[r] = args[r].send + lo;
+                launch_sum_sources(srcs, N, n, c->loop_scratch.as<float>() + at, st);
+                at += per;
+            } else if (op.kind == 1) { // reduce-scatter: my slice of everybody's send array, straight into my recv
+                for (int r = 0; r < N; ++r) srcs[r] = args[r].send + op.count * (size_t)me;
+                launch_sum_sources(srcs, N, op.count, op.recv, st);
+            }
+        }
+        LCGS_HIP_CHECK(hipGetLastError());
+        LCGS_HIP_CHECK(hipEventRecord(g->reduced[me], st));
+        if (!g->barrier()) return loop_failed(); // every rank's phase 1 is enqueued
+        for (int r = 0; r < N; ++r)
+            if (r != me) LCGS_HIP_CHECK(hipStreamWaitEvent(st, g->reduced[r], 0));
+        // ---- phase 2: gathers that WRITE my own arrays from what the others left (their scratch slices / send arrays)
+        std::vector<float*> scr;
+        {
+            std::lock_guard<std::mutex> lock(g->mu);
+            scr = g->scratch;
+        }
+        at = 0;
+        for (size_t k = 0; k < c->loop_ops.size(); ++k) {
+            const auto& op = c->loop_ops[k];
+            {
+                std::lock_guard<std::mutex> lock(g->mu);
+                args = g->coll[k];
+            }
+            if (op.kind == 0) {
+                const size_t per = (op.count + N - 1) / N;
+                for (int r = 0; r < N; ++r) {
+                    const size_t lo = std::min(op.count, per * (size_t)r), n = std::min(op.count, lo + per) - lo;
+                    if (n) LCGS_HIP_CHECK(hipMemcpyAsync(op.recv + lo, scr[r] + at, n * 4, hipMemcpyDeviceToDevice, st));
+                }
+                at += per;
+            } else if (op.kind == 2) {
+                for (int r = 0; r < N; ++r)
+                    if (op.count && args[r].send != op.recv + op.count * (size_t)r) // (in place: my own slice is where it belongs)
+                        LCGS_HIP_CHECK(hipMemcpyAsync(op.recv + op.count * (size_t)r, args[r].send, op.count * 4,
+                                                      hipMemcpyDeviceToDevice, st));
+            }
+        }
+        LCGS_HIP_CHECK(hipEventRecord(g->done[me], st));
+        if (!g->barrier()) return loop_failed(); // every copy out of my buffers / scratch has been enqueued
+        for (int p = 0; p < N; ++p)               // ... and has run before I touch them again
+            if (p != me) LCGS_HIP_CHECK(hipStreamWaitEvent(st, g->done[p], 0));
+        for (hipEvent_t e : consumed) (void)hipEventDestroy(e);
+        if (!g->barrier()) return loop_failed(); // (the shared events are not re-recorded before everybody has waited on them)
+        return LCGS_OK;
+    }
+};
+
+// a member of a loopback group that leaves a step early (any error) releases the others from their barriers
+struct LoopGuard {
+    lcgs_comm* c;
+    bool       ok = false;
+    ~LoopGuard()
+    {
+        if (!ok && c && c->loop) c->loop->fail();
+    }
+};
+
 size_t row_bytes(int sh_degree) { return (size_t)(3 + 3 + 4 + (sh_degree + 1) * (sh_degree + 1) * 3 + 1) * 4; }
 
 // lcgs_adam_step on the rank's own rows [first, first + count) and on the tail rows every rank keeps (fewer than N)
@@ -271,16 +501,11 @@ lcgs_status allgather_activated(lcgs_context* ctx, lcgs_comm* c, int64_t P, int 
     LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
     LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
     if (count > 0) {
-        LCGS_RCCL_CHECK(rccl().GroupStart());
-        for (int i = 0; i < 5; ++i) {
-            ncclResult_t r = rccl().AllGather(act.ptr[i] + (size_t)first * act.width[i], act.ptr[i],
-                                              (size_t)count * act.width[i], ncclFloat32, c->comm, c->stream);
-            if (r != ncclSuccess) {
-                (void)rccl().GroupEnd();
-                return rccl_fail(r, "ncclAllGather", __LINE__);
-            }
-        }
-        LCGS_RCCL_CHECK(rccl().GroupEnd());
+        Wire wire{ c };
+        LCGS_TRY(wire.group_begin());
+        for (int i = 0; i < 5; ++i)
+            LCGS_TRY(wire.allgather(act.ptr[i] + (size_t)first * act.width[i], act.ptr[i], (size_t)count * act.width[i]));
+        LCGS_TRY(wire.group_end());
         c->stats.collective_groups += 1;
         const int64_t b = (int64_t)((uint64_t)(c->world - 1) * (uint64_t)count * row_bytes(sh_degree));
         c->stats.bytes_sent += b;
@@ -377,7 +602,7 @@ lcgs_status lcgs_comm_destroy(lcgs_comm* c)
     c->packed.release();
     c->scales.release();
     for (DeviceBuffer* b : { &c->flags, &c->chunk_ws, &c->rows, &c->bounds, &c->matrix, &c->sendbuf, &c->recvbuf, &c->own_rows,
-                             &c->own_recs, &c->in_rows, &c->in_recs, &c->g2d_all, &c->g_in })
+                             &c->own_recs, &c->in_rows, &c->in_recs, &c->g2d_all, &c->g_in, &c->loop_scratch })
         b->release();
     if (c->h_matrix) (void)hipHostFree(c->h_matrix);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
@@ -408,7 +633,7 @@ lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* c, int num_gaussi
 {
     LCGS_REQUIRE(ctx && c && grads, "NULL argument");
     LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another (or a destroyed) context");
-    LCGS_REQUIRE(c->loop == nullptr, "an in-process (loopback) communicator carries the ownership step only");
+    LCGS_REQUIRE(c->loop == nullptr || c->transport == LCGS_TRANSPORT_F32, "the in-process (loopback) transport moves f32 only");
     LCGS_REQUIRE(num_gaussians >= 0 && sh_degree >= 0 && sh_degree <= 3, "bad num_gaussians / sh_degree");
     LCGS_REQUIRE(grads->d_dL_dpos && grads->d_dL_dscale && grads->d_dL_drotq && grads->d_dL_dsh && grads->d_dL_dopacity,
                  "NULL gradient buffer");
@@ -462,6 +687,8 @@ lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* c, int num_gaussi
                           ctx->P == num_gaussians;
     LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
     if (!by_slice) LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    Wire      wire{ c };
+    LoopGuard guard{ c };
     for (int k = 0; k < K; ++k) {
         if (by_slice) LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, ctx->ev_slice[k], 0));
         // the last chunk also waits for whatever was enqueued on the context's stream behind the backward
@@ -469,16 +696,9 @@ lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* c, int num_gaussi
         const int64_t r0 = (int64_t)(((uint64_t)P * (uint64_t)k) / (uint64_t)K);       // (k_slice_bounds' split)
         const int64_t r1 = (int64_t)(((uint64_t)P * (uint64_t)(k + 1)) / (uint64_t)K);
         if (r1 <= r0) continue;
-        LCGS_RCCL_CHECK(rccl().GroupStart());
-        for (int i = 0; i < 5; ++i) {
-            float* p = a.ptr[i] + (size_t)r0 * a.width[i];
-            ncclResult_t r = rccl().AllReduce(p, p, (size_t)(r1 - r0) * a.width[i], ncclFloat32, ncclSum, c->comm, c->stream);
-            if (r != ncclSuccess) {
-                (void)rccl().GroupEnd();
-                return rccl_fail(r, "ncclAllReduce", __LINE__);
-            }
-        }
-        LCGS_RCCL_CHECK(rccl().GroupEnd());
+        LCGS_TRY(wire.group_begin());
+        for (int i = 0; i < 5; ++i) LCGS_TRY(wire.allreduce_sum(a.ptr[i] + (size_t)r0 * a.width[i], (size_t)(r1 - r0) * a.width[i]));
+        LCGS_TRY(wire.group_end());
         c->stats.collective_groups += 1;
     }
     {
@@ -490,6 +710,7 @@ lcgs_status lcgs_grads_allreduce(lcgs_context* ctx, lcgs_comm* c, int num_gaussi
     // whatever the caller enqueues next on the context's stream (the optimiser) sees the sums
     LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
     LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
+    guard.ok = true;
     return LCGS_OK;
 }
 
@@ -499,7 +720,7 @@ lcgs_status lcgs_adam_step_sharded(lcgs_context* ctx, lcgs_comm* c, int num_gaus
 {
     LCGS_REQUIRE(ctx && c && cfg && grads && raw && m && v && activated, "NULL argument");
     LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another context");
-    LCGS_REQUIRE(c->loop == nullptr, "an in-process (loopback) communicator carries the ownership step only");
+    LCGS_REQUIRE(c->loop == nullptr || c->transport == LCGS_TRANSPORT_F32, "the in-process (loopback) transport moves f32 only");
     LCGS_REQUIRE(cfg->visible_only == 0, "the sharded step is dense (per-splat rows): visible_only must be 0");
     LCGS_REQUIRE(num_gaussians >= 0 && sh_degree >= 0 && sh_degree <= 3, "bad num_gaussians / sh_degree");
     if (num_gaussians == 0) return LCGS_OK;
@@ -515,22 +736,15 @@ lcgs_status lcgs_adam_step_sharded(lcgs_context* ctx, lcgs_comm* c, int num_gaus
     LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
     LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
     ctx->slices_recorded = 0;
-    LCGS_RCCL_CHECK(rccl().GroupStart());
+    Wire      wire{ c };
+    LoopGuard guard{ c };
+    LCGS_TRY(wire.group_begin());
     for (int i = 0; i < 5; ++i) {
-        ncclResult_t r = ncclSuccess;
         if (count > 0)
-            r = rccl().ReduceScatter(g.ptr[i], g.ptr[i] + (size_t)first * g.width[i], (size_t)count * g.width[i], ncclFloat32,
-                                     ncclSum, c->comm, c->stream);
-        if (r == ncclSuccess && tail > 0) {
-            float* t = g.ptr[i] + (size_t)tail0 * g.width[i];
-            r        = rccl().AllReduce(t, t, (size_t)tail * g.width[i], ncclFloat32, ncclSum, c->comm, c->stream);
-        }
-        if (r != ncclSuccess) {
-            (void)rccl().GroupEnd();
-            return rccl_fail(r, "ncclReduceScatter", __LINE__);
-        }
+            LCGS_TRY(wire.reduce_scatter_sum(g.ptr[i], g.ptr[i] + (size_t)first * g.width[i], (size_t)count * g.width[i]));
+        if (tail > 0) LCGS_TRY(wire.allreduce_sum(g.ptr[i] + (size_t)tail0 * g.width[i], (size_t)tail * g.width[i]));
     }
-    LCGS_RCCL_CHECK(rccl().GroupEnd());
+    LCGS_TRY(wire.group_end());
     LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
     LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
 
@@ -540,7 +754,9 @@ lcgs_status lcgs_adam_step_sharded(lcgs_context* ctx, lcgs_comm* c, int num_gaus
 
     // ---- 2. Adam on the own rows (and on the tail, identically on every rank); 3. all-gather of the ACTIVATED rows
     LCGS_TRY(adam_own_rows(ctx, c, P, sh_degree, cfg, g, raw, m, v, activated));
-    return allgather_activated(ctx, c, P, sh_degree, act);
+    LCGS_TRY(allgather_activated(ctx, c, P, sh_degree, act));
+    guard.ok = true;
+    return LCGS_OK;
 }
 
 
@@ -665,7 +881,7 @@ lcgs_status lcgs_adam_step_sparse(lcgs_context* ctx, lcgs_comm* c, int num_gauss
 {
     LCGS_REQUIRE(ctx && c && cfg && grads && raw && m && v && activated, "NULL argument");
     LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another context");
-    LCGS_REQUIRE(c->loop == nullptr, "an in-process (loopback) communicator carries the ownership step only");
+    LCGS_REQUIRE(c->loop == nullptr || c->transport == LCGS_TRANSPORT_F32, "the in-process (loopback) transport moves f32 only");
     LCGS_REQUIRE(cfg->visible_only == 0, "the sparse step keeps dense-Adam semantics (every row decays): visible_only must be 0");
     LCGS_REQUIRE(num_gaussians >= 0 && sh_degree >= 0 && sh_degree <= 3, "bad num_gaussians / sh_degree");
     if (num_gaussians == 0) return LCGS_OK;
@@ -689,7 +905,9 @@ lcgs_status lcgs_adam_step_sparse(lcgs_context* ctx, lcgs_comm* c, int num_gauss
     LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
     // ---- 2. everybody learns everybody's counts (message sizes are host arguments of send / recv): one small
     //         all-gather + read-back, the step's only host synchronisation
-    LCGS_RCCL_CHECK(rccl().AllGather(c->bounds.ptr, c->matrix.ptr, (size_t)W, ncclUint32, c->comm, c->stream));
+    Wire      wire{ c };
+    LoopGuard guard{ c };
+    LCGS_TRY(wire.allgather_u32(c->bounds.as<uint32_t>(), c->matrix.as<uint32_t>(), (size_t)W));
     LCGS_HIP_CHECK(hipMemcpyAsync(c->h_matrix, c->matrix.ptr, (size_t)N * W * 4, hipMemcpyDeviceToHost, c->stream));
     LCGS_HIP_CHECK(hipStreamSynchronize(c->stream));
     auto rows_of = [&](int src, int owner) -> int64_t { // rows rank `src` holds for owner's shard
@@ -717,34 +935,18 @@ lcgs_status lcgs_adam_step_sparse(lcgs_context* ctx, lcgs_comm* c, int num_gauss
     LCGS_HIP_CHECK(hipGetLastError());
     LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
     LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
-    LCGS_RCCL_CHECK(rccl().GroupStart());
-    {
-        ncclResult_t r = ncclSuccess;
-        for (int o = 0; o < N && r == ncclSuccess; ++o) {
-            if (o == me) continue;
-            const int64_t sw = sparse_message_words(rows_of(me, o), sh_degree), rw = sparse_message_words(rows_of(o, me), sh_degree);
-            if (sw > 0) r = rccl().Send(c->sendbuf.as<float>() + send_off[o], (size_t)sw, ncclFloat32, o, c->comm, c->stream);
-            if (r == ncclSuccess && rw > 0)
-                r = rccl().Recv(c->recvbuf.as<float>() + recv_off[o], (size_t)rw, ncclFloat32, o, c->comm, c->stream);
-        }
-        if (r != ncclSuccess) {
-            (void)rccl().GroupEnd();
-            return rccl_fail(r, "ncclSend / ncclRecv", __LINE__);
-        }
+    LCGS_TRY(wire.group_begin());
+    for (int o = 0; o < N; ++o) {
+        if (o == me) continue;
+        const int64_t sw = sparse_message_words(rows_of(me, o), sh_degree), rw = sparse_message_words(rows_of(o, me), sh_degree);
+        if (sw > 0) LCGS_TRY(wire.send(c->sendbuf.as<float>() + send_off[o], (size_t)sw * 4, o));
+        if (rw > 0) LCGS_TRY(wire.recv(c->recvbuf.as<float>() + recv_off[o], (size_t)rw * 4, o));
     }
-    LCGS_RCCL_CHECK(rccl().GroupEnd());
+    LCGS_TRY(wire.group_end());
     if (tail > 0) { // (its own group: point-to-point and collective calls are not mixed in one)
-        LCGS_RCCL_CHECK(rccl().GroupStart());
-        ncclResult_t r = ncclSuccess;
-        for (int i = 0; i < 5 && r == ncclSuccess; ++i) {
-            float* t = g.ptr[i] + (size_t)tail0 * g.width[i];
-            r        = rccl().AllReduce(t, t, (size_t)tail * g.width[i], ncclFloat32, ncclSum, c->comm, c->stream);
-        }
-        if (r != ncclSuccess) {
-            (void)rccl().GroupEnd();
-            return rccl_fail(r, "ncclAllReduce (tail rows)", __LINE__);
-        }
-        LCGS_RCCL_CHECK(rccl().GroupEnd());
+        LCGS_TRY(wire.group_begin());
+        for (int i = 0; i < 5; ++i) LCGS_TRY(wire.allreduce_sum(g.ptr[i] + (size_t)tail0 * g.width[i], (size_t)tail * g.width[i]));
+        LCGS_TRY(wire.group_end());
     }
     c->stats.collective_groups = 2 + (tail > 0 ? 1 : 0); // the counts, the messages, the tail
     c->stats.bytes_sent        = send_words * 4 + (int64_t)(N - 1) * W * 4;
@@ -760,7 +962,9 @@ lcgs_status lcgs_adam_step_sparse(lcgs_context* ctx, lcgs_comm* c, int num_gauss
 
     // ---- 5. Adam on the own rows (+ the tail), 6. all-gather of the refreshed ACTIVATED rows: as in the sharded step
     LCGS_TRY(adam_own_rows(ctx, c, P, sh_degree, cfg, g, raw, m, v, activated));
-    return allgather_activated(ctx, c, P, sh_degree, act);
+    LCGS_TRY(allgather_activated(ctx, c, P, sh_degree, act));
+    guard.ok = true;
+    return LCGS_OK;
 }
 
 } // extern "C"
@@ -775,114 +979,6 @@ lcgs_status lcgs_adam_step_sparse(lcgs_context* ctx, lcgs_comm* c, int num_gauss
 // ---------------------------------------------------------------------------------------------------------------------
 namespace
 {
-struct Wire { // the transport of one communicator: RCCL, or the loopback group
-    lcgs_comm* c;
-
-    lcgs_status allgather_u32(const uint32_t* d_send, uint32_t* d_recv, size_t count)
-    {
-        if (!c->loop) {
-            LCGS_RCCL_CHECK(rccl().AllGather(d_send, d_recv, count, ncclUint32, c->comm, c->stream));
-            return LCGS_OK;
-        }
-        lcgs_loopback_group* g = c->loop;
-        std::vector<uint32_t> mine(count);
-        LCGS_HIP_CHECK(hipMemcpyAsync(mine.data(), d_send, count * 4, hipMemcpyDeviceToHost, c->stream));
-        LCGS_HIP_CHECK(hipStreamSynchronize(c->stream));
-        {
-            std::lock_guard<std::mutex> lock(g->mu);
-            if (g->table.size() < (size_t)g->world * count) g->table.resize((size_t)g->world * count);
-            std::copy(mine.begin(), mine.end(), g->table.begin() + (size_t)c->rank * count);
-        }
-        if (!g->barrier()) return loop_failed();
-        std::vector<uint32_t> all;
-        {
-            std::lock_guard<std::mutex> lock(g->mu);
-            all.assign(g->table.begin(), g->table.begin() + (size_t)g->world * count);
-        }
-        LCGS_HIP_CHECK(hipMemcpy(d_recv, all.data(), all.size() * 4, hipMemcpyHostToDevice));
-        if (!g->barrier()) return loop_failed(); // nobody overwrites the table before everybody has read it
-        return LCGS_OK;
-    }
-    lcgs_status group_begin()
-    {
-        if (!c->loop) LCGS_RCCL_CHECK(rccl().GroupStart());
-        else c->own.recvs.clear();
-        return LCGS_OK;
-    }
-    lcgs_status send(const void* d_buf, size_t bytes, int peer)
-    {
-        if (!c->loop) {
-            LCGS_RCCL_CHECK(rccl().Send(d_buf, bytes, ncclUint8, peer, c->comm, c->stream));
-            return LCGS_OK;
-        }
-        lcgs_loopback_group::Msg m{ d_buf, bytes, nullptr };
-        LCGS_HIP_CHECK(hipEventCreateWithFlags(&m.ready, hipEventDisableTiming));
-        LCGS_HIP_CHECK(hipEventRecord(m.ready, c->stream));
-        std::lock_guard<std::mutex> lock(c->loop->mu);
-        c->loop->box[(size_t)peer * c->loop->world + c->rank].push_back(m);
-        return LCGS_OK;
-    }
-    lcgs_status recv(void* d_buf, size_t bytes, int peer)
-    {
-        if (!c->loop) {
-            LCGS_RCCL_CHECK(rccl().Recv(d_buf, bytes, ncclUint8, peer, c->comm, c->stream));
-            return LCGS_OK;
-        }
-        c->own.recvs.push_back({ d_buf, { bytes, peer } });
-        return LCGS_OK;
-    }
-    lcgs_status group_end()
-    {
-        if (!c->loop) {
-            LCGS_RCCL_CHECK(rccl().GroupEnd());
-            return LCGS_OK;
-        }
-        lcgs_loopback_group* g = c->loop;
-        if (!g->barrier()) return loop_failed(); // every send of the group has been posted
-        std::vector<hipEvent_t> consumed;
-        for (auto& r : c->own.recvs) {
-            lcgs_loopback_group::Msg m{};
-            {
-                std::lock_guard<std::mutex> lock(g->mu);
-                auto& q = g->box[(size_t)c->rank * g->world + r.second.second];
-                if (q.empty() || q.front().bytes != r.second.first) {
-                    g->failed = true;
-                    g->cv.notify_all();
-                    set_last_error("loopback: a receive has no matching send of the same size (ranks disagree on the message table)");
-                    return LCGS_ERR_STATE;
-                }
-                m = q.front();
-                q.pop_front();
-            }
-            LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, m.ready, 0));
-            if (m.bytes) LCGS_HIP_CHECK(hipMemcpyAsync(r.first, m.ptr, m.bytes, hipMemcpyDeviceToDevice, c->stream));
-            consumed.push_back(m.ready);
-        }
-        LCGS_HIP_CHECK(hipEventRecord(g->done[c->rank], c->stream));
-        if (!g->barrier()) return loop_failed(); // every receive has been enqueued
-        for (int p = 0; p < g->world; ++p) // my send buffers are free once the peers' copies have run
-            if (p != c->rank) LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, g->done[p], 0));
-        for (hipEvent_t e : consumed) (void)hipEventDestroy(e);
-        if (!g->barrier()) return loop_failed(); // (the done events are not re-recorded before everybody has waited on them)
-        return LCGS_OK;
-    }
-    lcgs_status loop_failed()
-    {
-        set_last_error("loopback: another member of the group failed");
-        return LCGS_ERR_STATE;
-    }
-};
-
-// a member of a loopback group that leaves a step early (any error) releases the others from their barriers
-struct LoopGuard {
-    lcgs_comm* c;
-    bool       ok = false;
-    ~LoopGuard()
-    {
-        if (!ok && c && c->loop) c->loop->fail();
-    }
-};
-
 // bytes of one message row
 constexpr size_t kRecBytes = LCGS_OWNER_RECORD_FLOATS * 4, kG2dBytes = LCGS_OWNER_GRAD_FLOATS * 4;
 } // namespace
@@ -907,6 +1003,9 @@ lcgs_status lcgs_loopback_group_create(int world_size, lcgs_loopback_group** out
     g->world = world_size;
     g->box.resize((size_t)world_size * world_size);
     g->done.assign(world_size, nullptr);
+    g->ready.assign(world_size, nullptr);
+    g->reduced.assign(world_size, nullptr);
+    g->scratch.assign(world_size, nullptr);
     *out = g;
     return LCGS_OK;
 }
@@ -915,8 +1014,9 @@ lcgs_status lcgs_loopback_group_destroy(lcgs_loopback_group* g)
 {
     if (!g) return LCGS_OK;
     LCGS_REQUIRE(g->members == 0, "communicators of this group are still alive");
-    for (hipEvent_t e : g->done)
-        if (e) (void)hipEventDestroy(e);
+    for (auto* evs : { &g->done, &g->ready, &g->reduced })
+        for (hipEvent_t e : *evs)
+            if (e) (void)hipEventDestroy(e);
     delete g;
     return LCGS_OK;
 }
@@ -936,7 +1036,8 @@ lcgs_status lcgs_comm_create_loopback(lcgs_context* ctx, lcgs_loopback_group* gr
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
     {
         std::lock_guard<std::mutex> lock(group->mu);
-        if (e == hipSuccess && !group->done[rank]) e = hipEventCreateWithFlags(&group->done[rank], hipEventDisableTiming);
+        for (auto* evs : { &group->done, &group->ready, &group->reduced })
+            if (e == hipSuccess && !(*evs)[rank]) e = hipEventCreateWithFlags(&(*evs)[rank], hipEventDisableTiming);
         if (e == hipSuccess) ++group->members;
     }
     if (e != hipSuccess) {
@@ -944,8 +1045,11 @@ lcgs_status lcgs_comm_create_loopback(lcgs_context* ctx, lcgs_loopback_group* gr
         (void)lcgs_comm_destroy(c);
         LCGS_HIP_CHECK(e);
     }
-    ctx->comm = c; // (grad_slices stays 1: a loopback communicator carries the ownership step only)
-    *out      = c;
+    ctx->comm = c;
+    int slices = 4; // (as lcgs_comm_create: the dense backward slices its preprocess pass for the chunked all-reduce)
+    if (const char* sl = getenv("LCGS_GRAD_SLICES")) slices = atoi(sl);
+    ctx->grad_slices = std::min(std::max(slices, 1), kMaxGradSlices);
+    *out             = c;
     return LCGS_OK;
 }
 

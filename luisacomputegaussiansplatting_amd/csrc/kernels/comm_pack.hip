@@ -159,4 +159,31 @@ void launch_unpack_f16(const uint16_t* in, size_t n, const float* d_inv, float* 
     LCGS_VEC_DISPATCH(v, k_unpack_f16, n, reinterpret_cast<const __half*>(in), n, d_inv, x);
 }
 
+
+// dst[i] = sum over the n source arrays of src[r][i], r ascending (the in-process loopback transport's reductions: N contexts on
+// one device stand in for N ranks, host/comm.cpp)
+struct SumSources {
+    const float* p[16];
+};
+namespace
+{
+__global__ void __launch_bounds__(256) k_sum_sources(SumSources src, int n, size_t count, float* dst)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        float acc = src.p[0][i];
+        for (int r = 1; r < n; ++r) acc += src.p[r][i];
+        dst[i] = acc;
+    }
+}
+} // namespace
+void launch_sum_sources(const float* const* srcs, int n, size_t count, float* dst, hipStream_t stream)
+{
+    if (count == 0 || n <= 0 || n > 16) return;
+    SumSources s{};
+    for (int r = 0; r < n; ++r) s.p[r] = srcs[r];
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_sum_sources, dim3((unsigned)blocks), dim3(256), 0, stream, s, n, count, dst);
+}
+
 } // namespace lcgs

@@ -236,6 +236,8 @@ bool render_forward_writes_strip_masks();
 // ---- comm_pack.hip : the opt-in f16 transport of the gradient all-reduce (host/comm.cpp) ----
 // |max| of n floats, atomically max-ed into *d_out_bits (float bits; zero it first)
 void launch_absmax(const float* x, size_t n, uint32_t* d_out_bits, hipStream_t stream);
+// dst[i] = srcs[0][i] + ... + srcs[n - 1][i] (n <= 16; dst may be one of the sources): the loopback transport's reductions
+void launch_sum_sources(const float* const* srcs, int n, size_t count, float* dst, hipStream_t stream);
 // five power-of-two scales (and their inverses) from the five all-reduced magnitudes: max * scale <= 16384 / world
 void launch_transport_scales(const float* d_absmax5, int world, float* d_scale5, float* d_inv5, hipStream_t stream);
 void launch_pack_f16(const float* x, size_t n, const float* d_scale, uint16_t* out, hipStream_t stream);

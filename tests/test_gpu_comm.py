@@ -477,3 +477,148 @@ def test_sparse_adam_step_at_world_size_one_equals_the_dense_step(lcgs, P):
     for a, b in zip(*results):
         for k in KEYS:
             assert torch.equal(a[k], b[k]), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 on one GPU: the in-process loopback transport (lcgs_comm_create_loopback) behind every collective of the C ABI.
+# N contexts, one host thread each; what differs from a node is only who copies the bytes (device-to-device copies ordered
+# by events instead of RCCL over xGMI): chunking, shard / tail / message arithmetic and stream ordering are the shipped code.
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_ranks(world, rank_main):
+    """rank_main(rank, side_stream) in `world` host threads; returns the per-rank results, raises what a rank raised"""
+    import threading
+
+    out, errors = [None] * world, []
+
+    def run(me):
+        try:
+            side = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(side):
+                out[me] = rank_main(me, side)
+                side.synchronize()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+
+            errors.append((me, repr(e), traceback.format_exc()))
+
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=run, args=(me,)) for me in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank hangs"
+    return out
+
+
+@pytest.mark.parametrize("world,P", [(2, 4097), (3, 20000), (8, 4099)])
+def test_allreduce_and_sharded_step_with_n_ranks_in_process(lcgs, world, P):
+    """lcgs_grads_allreduce and lcgs_adam_step_sharded with N participants: every rank ends with the rank-ordered sum of
+    the N gradient sets (bit for bit: the loopback adds in rank order), and the sharded step -- reduce-scatter, Adam on the
+    own rows + the P mod N tail, all-gather of the activated rows -- leaves every rank with the dense step's activated
+    arrays and, on its own rows and the tail, the dense step's raw parameters and moments."""
+    from functools import reduce
+
+    rng = np.random.default_rng(P + world)
+    scene = make_scene(rng, P)
+    gsets = [{k: torch.from_numpy(np.random.default_rng(100 * r + i).normal(size=tuple(upload_scene(scene)[k].shape)).astype(np.float32)).to(DEV)
+              for i, k in enumerate(KEYS)} for r in range(world)]
+    gsum = {k: reduce(lambda a, b: a + b, [gsets[r][k] for r in range(world)]) for k in KEYS}
+    # the dense reference: one context, the summed gradients
+    raw0, act0 = _raw_act(scene)
+    m0 = {k: torch.zeros_like(raw0[k]) for k in KEYS}
+    v0 = {k: torch.zeros_like(raw0[k]) for k in KEYS}
+    ref = lcgs.Renderer(lcgs.Context(0))
+    ref.adam_step(gsum, raw0, m0, v0, act0, 1, LR, eps=1e-8)
+    ref.ctx.synchronize()
+    group = lcgs.api.LoopbackGroup(world)
+
+    def rank_main(me, side):
+        ctx = lcgs.Context(0, side.cuda_stream)
+        comm = lcgs.Comm(ctx, me, world, loopback=group)
+        g = {k: gsets[me][k].clone() for k in KEYS}
+        comm.allreduce_grads(g)
+        ctx.synchronize()
+        summed = {k: g[k].clone() for k in KEYS}
+        raw, act = _raw_act(scene)
+        m = {k: torch.zeros_like(raw[k]) for k in KEYS}
+        v = {k: torch.zeros_like(raw[k]) for k in KEYS}
+        g2 = {k: gsets[me][k].clone() for k in KEYS}
+        comm.adam_step_sharded(g2, raw, m, v, act, 1, LR, eps=1e-8)
+        ctx.synchronize()
+        st = comm.stats()
+        comm.close()
+        return summed, raw, m, v, act, st
+
+    res = _run_ranks(world, rank_main)
+    group.close()
+    for me, (summed, raw, m, v, act, st) in enumerate(res):
+        first, count = lcgs.shard_rows(P, world, me)
+        tail0 = count * world
+        for k in KEYS:
+            assert torch.equal(summed[k], gsum[k]), (me, k)
+            assert torch.equal(act[k], act0[k]), (me, k)  # complete on every rank after the all-gather
+            for mine, want in ((raw, raw0), (m, m0), (v, v0)):
+                assert torch.equal(mine[k][first:first + count], want[k][first:first + count]), (me, k)
+                assert torch.equal(mine[k][tail0:], want[k][tail0:]), (me, k)
+        assert st["collective_groups"] >= 1
+
+
+def test_view_parallel_trainer_with_three_ranks_in_process(lcgs):
+    """ViewParallelTrainer + HipEngine + RcclCollective over the loopback, three ranks x three views, every mode: the
+    rendered views' gradients are summed by the chunked all-reduce behind the sliced backward ("allreduce"), reduce-scattered
+    ("sharded"), sent as touched rows to their owners ("sparse"), or never formed densely at all ("owner").  Reference: one
+    context that renders the three views one after the other, accumulates and runs dense Adam.  (Bounds as in the world-size-1
+    test above: float atomics make two runs differ in the last place, Adam turns a near-zero gradient's sign into +-lr.)"""
+    world, steps = 3, 3
+    rng = np.random.default_rng(12)
+    scene = make_scene(rng, 20000, log_scale=(-3.8, 0.7))
+    cams = [lcgs.get_lookat_cam([-3 * np.cos(a), -0.5 + 3 * np.sin(a), 2.3], [0, 0, 0.5], [0, 0, 1], width=320, height=240)
+            for a in (0.0, 0.4, 0.8)]
+    dL = torch.randn(3, 240, 320, device=DEV)
+    # reference: every step renders all three views (rank r's view at step s is cams[(s * 3 + r) % 3]: all of them)
+    raw_ref, act_ref = _raw_act(scene)
+    ctx = lcgs.Context(0)
+    eng = mg.HipEngine(lcgs.Renderer(ctx), raw_ref, act_ref, LR, eps=1e-8)
+    g = _grads_like(act_ref, 0.0)
+    for s in range(steps):
+        for j, cam in enumerate(cams):
+            eng.forward_backward(cam, dL, g, accumulate=j > 0)
+        eng.adam(g, s + 1)
+    ctx.synchronize()
+    lr_of = {"pos": LR["pos"], "scale": LR["scale"], "rotq": LR["rot"], "sh": LR["sh_dc"], "opacity": LR["opacity"]}
+    for mode in ("allreduce", "sharded", "sparse", "owner"):
+        group = lcgs.api.LoopbackGroup(world)
+
+        def rank_main(me, side, mode=mode, group=group):
+            raw, act = _raw_act(scene)
+            c = lcgs.Context(0, side.cuda_stream)
+            e = mg.HipEngine(lcgs.Renderer(c), raw, act, LR, eps=1e-8)
+            coll = mg.RcclCollective(c, me, world, loopback=group)
+            tr = mg.ViewParallelTrainer(e, coll, cams, _grads_like(act, 0.0), mode=mode)
+            for _ in range(steps):
+                tr.step(dL)
+            c.synchronize()
+            out = {k: raw[k].clone() for k in KEYS}, {k: act[k].clone() for k in KEYS}
+            e.close()
+            coll.close()
+            return out
+
+        res = _run_ranks(world, rank_main)
+        group.close()
+        for me, (raw, act) in enumerate(res):
+            if mode == "owner":
+                first, count = lcgs.api.owner_rows(20000, world, me)
+            elif mode == "allreduce":
+                first, count = 0, 20000
+            else:
+                first, count = lcgs.shard_rows(20000, world, me)
+            for k in KEYS:
+                diff = (raw[k][first:first + count] - raw_ref[k][first:first + count]).abs()
+                assert float(diff.max()) <= 2.02 * steps * lr_of[k], (mode, me, k, float(diff.max()))
+                assert float((diff > 0.05 * lr_of[k]).float().mean()) < 0.01, (mode, me, k)
+                if mode != "owner":  # every rank holds the whole refreshed scene (the ownership step replicates nothing)
+                    da = (act[k] - act_ref[k]).abs()
+                    scale = max(float(act_ref[k].abs().max()), 1e-6)
+                    assert float((da > 1e-3 * scale).float().mean()) < 0.01, (mode, me, k)
