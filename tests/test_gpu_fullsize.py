@@ -304,3 +304,76 @@ def test_c5_all_eight_views_through_the_native_ownership_step(lcgs, bicycle):
     assert abs(sent - N * (N - 1) * N * 4 - want) <= 0.02 * want, (sent, want)
     print(f"[C5 rehearsal] 8 ranks in process: {sent / N / 1e6:.1f} MB sent per rank and step "
           f"(dense all-reduce: {2 * 7 / 8 * 236 * P / 1e6:.0f} MB)")
+
+
+def test_c5_eight_views_dense_gradient_allreduce_with_eight_ranks_in_process(lcgs, bicycle):
+    """BASELINE config C5 as north_star words it -- the 8-view batch, one view per rank, forward + backward, the dense per-splat
+    gradients summed over the ranks by the library's all-reduce (lcgs_grads_allreduce: chunked behind the sliced backward) --
+    with eight in-process ranks on the box's one GPU (loopback transport: the shipped chunking, events and stream order; device
+    copies and rank-ordered sums instead of RCCL).  Every rank must end with the same arrays: the sum over the eight views of
+    the ordinary backward, to the float-atomic noise of the 2-D sums."""
+    import math
+    import threading
+
+    scene, r_ref, d = bicycle
+    P = scene["pos"].shape[0]
+    KEYS = ("pos", "scale", "rotq", "sh", "opacity")
+    N = 8
+
+    def c5_cam(k):
+        a = math.radians(45.0 * k)
+        c, s_ = math.cos(a), math.sin(a)
+        rot = lambda v: [c * v[0] + s_ * v[2], v[1], -s_ * v[0] + c * v[2]]
+        return lcgs.get_lookat_cam(rot(BICYCLE_POSE[0]), rot(BICYCLE_POSE[1]), BICYCLE_POSE[2], width=W, height=H)
+
+    cams = [c5_cam(k) for k in range(N)]
+    dLs = [torch.randn(3, H, W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(170 + j)) for j in range(N)]
+    g_ref = {k: torch.empty_like(d[k]) for k in KEYS}
+    img = torch.zeros(3, H, W, device=DEV)
+    for j, cam in enumerate(cams):
+        r_ref.forward(cam, img, keep_state=True, sync=True)
+        r_ref.backward(dLs[j], *[g_ref[k] for k in KEYS], accumulate=j > 0)
+    r_ref.ctx.synchronize()
+    torch.cuda.synchronize()
+    group = lcgs.api.LoopbackGroup(N)
+    results, errors = [None] * N, []
+
+    def rank_main(me):
+        try:
+            side = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(side):
+                r = lcgs.Renderer(lcgs.Context(0, side.cuda_stream))
+                r.bind_scene(*[d[k] for k in KEYS])
+                comm = lcgs.Comm(r.ctx, me, N, loopback=group)
+                g = {k: torch.empty_like(d[k]) for k in KEYS}
+                im = torch.zeros(3, H, W, device=DEV)
+                r.forward(cams[me], im, keep_state=True, sync=True)
+                r.backward(dLs[me], *[g[k] for k in KEYS])  # sliced: the communicator is attached
+                comm.allreduce_grads(g)
+                r.ctx.synchronize()
+                side.synchronize()
+                # (keep only what the comparison needs: 8 x 1.45 GB of gradients would be held otherwise)
+                rel = {}
+                for k in KEYS:
+                    a, b = g[k].double().flatten(), g_ref[k].double().flatten()
+                    rel[k] = float((a - b).norm() / b.norm())
+                results[me] = (rel, comm.stats(), {k: g[k][::997].clone() for k in KEYS})
+                comm.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((me, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(me,)) for me in range(N)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank hangs"
+    group.close()
+    for me in range(N):
+        rel, st, sample = results[me]
+        for k in KEYS:
+            assert rel[k] <= 5e-4, (me, k, rel[k])
+            assert torch.equal(sample[k], results[0][2][k]), (me, k)  # every rank holds the SAME sums, bit for bit
+        assert st["collective_groups"] == 4  # the four chunks behind the backward's four slices
+        assert st["bytes_sent"] == 2 * (N - 1) * P * 236 // N  # DESIGN 7's dense column
