@@ -92,6 +92,9 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
     // test needs);  [2]: opacity, r, g, b (read only by entries that pass it)
     __shared__ float4             s_rows[3][256];
     __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
+    // KEEP: [strip][staging wave] the entries of the round that some pixel of the strip actually BLENDED -- what the backward has to
+    // walk (the reach test above is conservative, and pixels finish: a quarter of the masks' set bits blend nothing)
+    __shared__ unsigned long long s_blend[4][4];
     __shared__ uint32_t           s_live_waves;
     __shared__ uint32_t           s_slot;
 
@@ -176,9 +179,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         const float    c = nc;
         const float    t = have ? (2.0f * __logf(255.0f * b.y)) * 1.0001f + 2e-4f : -1.0f;
         const uint32_t kmask = have ? splat_strip_mask(a.x, a.y, a.z, a.w, b.x, t, rx0, ry0, rx1) : 0u;
-        // (kept for the backward, which walks the same list positions: it need not repeat the four strip tests)
-        if (KEEP && strip_masks && have) strip_masks[e] = (uint8_t)kmask;
         __syncthreads(); // previous round's readers are done with the slab and the masks
+        if (KEEP && lane < 4u) s_blend[wave][lane] = 0ull; // (strips that are finished, or finish mid-round, blend nothing)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned long long m = __ballot((kmask >> k) & 1u);
@@ -195,7 +197,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
 
         if (alive) {
             for (uint32_t w = 0; w < 4u && alive; ++w) {
-                unsigned long long m = s_mask[w][wave];
+                unsigned long long bm = 0ull; // (scalar) entries of staging wave w that this strip blended
+                unsigned long long m  = s_mask[w][wave];
                 // readfirstlane returns int: cast through uint32_t so the low half is not sign-extended
                 m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) |
                     (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
@@ -245,7 +248,10 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     float       nT  = test_T;
                     // T >= 1e-4 holds for every lane (a saturating update is never applied)
                     const unsigned long long satm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & vmask;
-                    if (KEEP) last_contrib = (valid & !(test_T < 0.0001f)) ? base - range_start + idx + 1u : last_contrib;
+                    if (KEEP) {
+                        last_contrib = (valid & !(test_T < 0.0001f)) ? base - range_start + idx + 1u : last_contrib;
+                        bm |= (unsigned long long)((vmask & ~satm) != 0ull) << l; // some pixel takes this entry into its sum
+                    }
                     if (satm != 0ull) { // rare: some pixel of the strip just saturated
                         const bool sat = (satm & lane_bit) != 0ull;
                         wgt   = sat ? 0.0f : wgt; // shader.cpp:268-272: the saturating entry is not blended
@@ -275,10 +281,20 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                                      : "scc");
                     }
                 }
+                if (KEEP && lane == 0) s_blend[wave][w] = bm;
             }
             if (!alive && lane == 0) atomicSub(&s_live_waves, 1u);
         }
         __syncthreads();
+        if (KEEP && strip_masks && have) {
+            // The backward walks the same list positions through these masks (it need not repeat the strip tests) -- and only
+            // the entries a strip BLENDED: bit k = strip k took this entry into at least one pixel's sum.  Entries that merely
+            // could reach a strip contribute exact zeros to every gradient; a quarter of the backward's walks were those.
+            uint32_t kref = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) kref |= (uint32_t)((s_blend[k][wave] >> lane) & 1ull) << k;
+            strip_masks[e] = (uint8_t)kref;
+        }
     }
 
     if (inside) {
