@@ -228,17 +228,16 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     float half = qx + qy;
                     asm volatile("" : "+v"(half));
                     const float power = half - cross * dy;
-                    const bool  cand  = !(power > 0.0f) & (power >= eb.y);
+                    // candidate lanes: !(power > 0) and power >= the staged floor --
                     // (lane masks from ballots of plain compares, combined with scalar ANDs: a ballot of a compound
                     //  condition is lowered through a select and a second compare)
                     const unsigned long long cmask =
                         __builtin_amdgcn_ballot_w64(!(power > 0.0f)) & __builtin_amdgcn_ballot_w64(power >= eb.y);
                     if (cmask == 0ull) continue; // scalar test of the lane mask
                     const float4 ec    = *reinterpret_cast<const float4*>(rows + 8192); // one 16-byte read for the survivors
-                    // (alpha is never NaN where cand holds, so the hardware minimum equals min(0.99, x); on a lane where
+                    // (alpha is never NaN on a candidate lane, so the hardware minimum equals min(0.99, x); on a lane where
                     //  it does not hold, power may lie outside blend_exp's domain and alpha is arbitrary bits -- masked)
                     const float alpha  = __builtin_fminf(0.99f, ec.x * blend_exp(power));
-                    const bool  valid  = cand & !(alpha < 1.0f / 255.0f);
                     // Lanes that skip the entry sit the update out under the EXEC mask: what the arithmetic produces on
                     // them is never written anywhere, and the select that used to zero their alpha is gone.  (Written as
                     // one asm block because the compiler turns `if (valid) { ... }` back into four selects.)
@@ -248,9 +247,19 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     float       nT  = test_T;
                     // T >= 1e-4 holds for every lane (a saturating update is never applied)
                     const unsigned long long satm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & vmask;
+                    // KEEP: the pixels that take this entry into their sum (blend it and do not saturate on it)
+                    const unsigned long long live = vmask & ~satm;
                     if (KEEP) {
-                        last_contrib = (valid & !(test_T < 0.0001f)) ? base - range_start + idx + 1u : last_contrib;
-                        bm |= (unsigned long long)((vmask & ~satm) != 0ull) << l; // some pixel takes this entry into its sum
+                        // bm |= (live != 0) << l, on the SCALAR side (left to the compiler the mask moves into vector registers:
+                        // seven vector instructions per blended entry)
+                        unsigned long long t_;
+                        asm volatile("s_cmp_lg_u64 %[live], 0\n\t"
+                                     "s_cselect_b64 %[t], 1, 0\n\t"
+                                     "s_lshl_b64 %[t], %[t], %[l]\n\t"
+                                     "s_or_b64 %[bm], %[bm], %[t]"
+                                     : [bm] "+s"(bm), [t] "=&s"(t_)
+                                     : [live] "s"(live), [l] "s"(l)
+                                     : "scc");
                     }
                     if (satm != 0ull) { // rare: some pixel of the strip just saturated
                         const bool sat = (satm & lane_bit) != 0ull;
@@ -262,7 +271,27 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                             m     = 0ull;
                         }
                     }
-                    {
+                    if (KEEP) { // the same block + the position of the pixel's last contributor (1-based), under `live`
+                        float              t0, t1, t2;
+                        unsigned long long sv;
+                        const uint32_t     lc = base - range_start + idx + 1u;
+                        asm volatile("s_and_saveexec_b64 %[sv], %[vm]\n\t"
+                                     "v_mul_f32 %[t0], %[w], %[cr]\n\t"
+                                     "v_mul_f32 %[t1], %[w], %[cg]\n\t"
+                                     "v_mul_f32 %[t2], %[w], %[cb]\n\t"
+                                     "v_add_f32 %[Cr], %[Cr], %[t0]\n\t"
+                                     "v_add_f32 %[Cg], %[Cg], %[t1]\n\t"
+                                     "v_add_f32 %[Cb], %[Cb], %[t2]\n\t"
+                                     "v_mov_b32 %[T], %[nT]\n\t"
+                                     "s_and_b64 exec, %[sv], %[lv]\n\t"
+                                     "v_mov_b32 %[lcv], %[lc]\n\t"
+                                     "s_mov_b64 exec, %[sv]"
+                                     : [Cr] "+v"(Cr), [Cg] "+v"(Cgb.x), [Cb] "+v"(Cgb.y), [T] "+v"(T), [t0] "=&v"(t0),
+                                       [t1] "=&v"(t1), [t2] "=&v"(t2), [sv] "=&s"(sv), [lcv] "+v"(last_contrib)
+                                     : [w] "v"(wgt), [cr] "v"(ec.y), [cg] "v"(ec.z), [cb] "v"(ec.w), [nT] "v"(nT),
+                                       [vm] "s"(vmask), [lv] "s"(live), [lc] "s"(lc)
+                                     : "scc");
+                    } else {
                         float              t0, t1, t2;
                         unsigned long long sv;
                         asm volatile("s_and_saveexec_b64 %[sv], %[vm]\n\t"
