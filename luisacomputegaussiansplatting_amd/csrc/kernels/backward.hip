@@ -140,9 +140,11 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                                                            const uint32_t* __restrict__ d_counts,
                                                            uint32_t* __restrict__ work_counter, DenseFill fill)
 {
-    __shared__ float4             s_a[256]; // mean.x, mean.y, conic.x, conic.y
-    __shared__ float4             s_b[256]; // conic.z, opacity, r, g
-    __shared__ float2             s_c[256]; // b, power floor
+    // one 16-byte row per entry in each of three slabs (ONE address register serves an entry's three reads, as in the forward):
+    // [0] mean.x, mean.y, -conic.x / 2, conic.y   [1] -conic.z / 2, opacity, r, g   [2] b, power floor, -, -
+    // (the halved, negated diagonal: `power` then needs no multiplication by -1/2 -- a power of two commutes with rounding, so
+    //  the value is the forward's bit for bit)
+    __shared__ float4             s_rows[3][256];
     __shared__ uint32_t           s_vid[256];
     __shared__ float              s_grad[9][256];
     __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
@@ -285,9 +287,9 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
             const unsigned long long m = __ballot((kmask >> k) & 1u);
             if (lane == 0) s_mask[wave][k] = m;
         }
-        s_a[tid]   = a;
-        s_b[tid]   = b;
-        s_c[tid]   = make_float2(c, fmax_(-0.5f * t, kBlendExpMin));
+        s_rows[0][tid] = make_float4(a.x, a.y, -0.5f * a.z, a.w);
+        s_rows[1][tid] = make_float4(-0.5f * b.x, b.y, b.z, b.w);
+        *reinterpret_cast<float2*>(&s_rows[2][tid]) = make_float2(c, fmax_(-0.5f * t, kBlendExpMin));
         s_vid[tid] = vid;
 #pragma unroll
         for (int g = 0; g < 9; ++g) s_grad[g][tid] = 0.0f;
@@ -314,12 +316,16 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                     const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)w * 64u + l));
                     const uint32_t pos = lo + idx; // 0-based list position
                     LCGS_STAT(0, 1u);
-                    const float4   ea = s_a[idx], eb = s_b[idx];
-                    const float2   ec = s_c[idx];
+                    uint32_t roff = idx * 16u; // (byte offset of the entry's row in every slab; pinned: one scalar-to-vector move)
+                    asm volatile("" : "+v"(roff));
+                    const char*    rows = reinterpret_cast<const char*>(&s_rows[0][0]) + roff;
+                    const float4   ea = *reinterpret_cast<const float4*>(rows);
+                    const float4   eb = *reinterpret_cast<const float4*>(rows + 4096);
+                    const float2   ec = *reinterpret_cast<const float2*>(rows + 8192);
                     // the forward's own expression and evaluation order: the same splats pass the same thresholds
                     const float dx    = ea.x - pxf;
                     const float dy    = ea.y - pyf;
-                    const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
+                    const float power = (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy; // (ea.z, eb.x: -ca / 2, -cc / 2)
                     const bool  cand  = (pos < last) & !(power > 0.0f) & (power >= ec.y);
                     if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
                     LCGS_STAT(1, 1u);
@@ -441,9 +447,9 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                 // sums -> gradients: d/dmean = -(conic . (S hx, S hy)), d/dconic = (-1/2, -1, -1/2) (S hx dx, ...)
                 float s = s_grad[g][idx];
                 if (g < 2u) {
-                    const float4 ea = s_a[idx];
-                    const float  cc = s_b[idx].x, s0 = s_grad[0][idx], s1 = s_grad[1][idx];
-                    s = (g == 0u) ? -(ea.z * s0 + ea.w * s1) : -(cc * s1 + ea.w * s0);
+                    const float4 ea = s_rows[0][idx];
+                    const float  ca = -2.0f * ea.z, cc = -2.0f * s_rows[1][idx].x, s0 = s_grad[0][idx], s1 = s_grad[1][idx];
+                    s = (g == 0u) ? -(ca * s0 + ea.w * s1) : -(cc * s1 + ea.w * s0);
                 } else if (g < 5u) {
                     s *= (g == 3u) ? -1.0f : -0.5f;
                 }
