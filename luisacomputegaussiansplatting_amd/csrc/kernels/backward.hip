@@ -228,7 +228,6 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         dpg = dL_dimg[pix + hw];
         dpb = dL_dimg[pix + 2 * hw];
     }
-    const float bg_dot = bg0 * dpr + bg1 * dpg + bg2 * dpb;
 
     uint32_t wmax = last;
 #pragma unroll
@@ -247,10 +246,8 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         hi                 = hi < len ? hi : len;
     }
 
-    // per-pixel recurrences, walked back to front: T = transmittance in front of the current splat,
-    // B = colour composited behind it
-    float             T = T_final, Br = 0.0f, Bg = 0.0f, Bb = 0.0f;
-    const float       nTf_bg     = -T_final * bg_dot;
+    // per-pixel recurrences, walked back to front: B = colour composited behind the current splat
+    float             Pr = 1.0f, Br = bg0, Bg = bg1, Bb = bg2; // Pr: product of (1 - alpha) over the entries walked so far
     const bool        is_row_end = (lane & 15u) == 15u;
     const uint32_t    grad_base  = (uint32_t)(uintptr_t)&s_grad[0][0]; // low half of a flat LDS address = LDS offset
 
@@ -326,8 +323,13 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                     const float dx    = ea.x - pxf;
                     const float dy    = ea.y - pyf;
                     const float power = (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy; // (ea.z, eb.x: -ca / 2, -cc / 2)
-                    const bool  cand  = (pos < last) & !(power > 0.0f) & (power >= ec.y);
-                    if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
+                    const bool  c_pos = pos < last, c_neg = !(power > 0.0f), c_flr = power >= ec.y;
+                    const bool  cand  = c_pos & c_neg & c_flr;
+                    // (three ballots of plain compares are the compares' own lane masks; a ballot of the conjunction costs a
+                    //  select and another compare -- two vector instructions per walked entry)
+                    if ((__builtin_amdgcn_ballot_w64(c_pos) & __builtin_amdgcn_ballot_w64(c_neg) &
+                         __builtin_amdgcn_ballot_w64(c_flr)) == 0ull)
+                        continue;
                     LCGS_STAT(1, 1u);
                     // exp(power): the hardware's v_exp_f32 (1 ulp; two instructions) since round 5, not the forward's DEFINED
                     // function (ten).  The forward needs that one for bit-identical images; here the tolerance is 1e-3 and what
@@ -356,32 +358,26 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                         sub_[12] += vb != 0;
                     }
 #endif
-                    // A lane that does not blend this entry carries alpha 0 through the recurrences: 1 / (1 - 0) == 1
-                    // leaves T alone, B + 0 * (c - B) leaves the colour behind alone, all nine terms come out 0.
+                    // A lane that does not blend this entry carries alpha 0 through the recurrences: the product keeps its
+                    // value, B + 0 * (c - B) leaves the colour behind alone, all nine terms come out 0.
                     // (No second wave-level skip: the staging floor already implies alpha >= 1/255 somewhere.)
                     const float a   = valid ? alpha : 0.0f;
-                    // T in front of this splat = T / (1 - a).  v_rcp_f32 alone (1 ulp, not unbiased) is not enough HERE: T is
-                    // carried through every entry of the list, so a splat at the front of a few thousand entries saw the
-                    // rounding of every division behind it, and a screen-filling splat -- whose geometry gradients are sums
-                    // of ~1e5 cancelling per-pixel terms -- amplified that drift to a few 1e-3 (round 3's excluded "giants").
-                    // One Newton step on the quotient (two FMAs) gives T / (1 - a) to within an ulp, errors of either sign.
-                    const float oma = 1.0f - a;
-                    const float inv = __builtin_amdgcn_rcpf(oma);
-                    const float q0  = T * inv;
-#ifdef LCGS_BWD_NO_NEWTON // (A/B builds only: round 3's plain T * rcp(1 - a))
-                    const float Tn = q0;
-#else
-                    const float Tn = __builtin_fmaf(__builtin_fmaf(-oma, q0, T), inv, q0); // the forward's T in front of this splat
-#endif
+                    // T in front of this splat = T_final / prod(1 - a) over this entry and everything behind it.  The product is
+                    // carried (one rounded multiplication per entry: errors of either sign, ~sqrt(n) half-ulps at the front of
+                    // n entries) and divided out ONCE per entry with v_rcp_f32 (1 ulp, not carried).  Dividing T itself entry
+                    // by entry with v_rcp_f32 is what drifted in round 3 (its bias was seen by every splat in front: a
+                    // screen-filling splat, whose geometry gradients are sums of ~1e5 cancelling per-pixel terms, amplified it
+                    // to a few 1e-3); rounds 4-5 paid a Newton step on that quotient (two FMAs) -- this form needs neither.
+                    Pr = Pr * (1.0f - a);
+                    const float Tn  = T_final * __builtin_amdgcn_rcpf(Pr); // the forward's T in front of this splat
                     const float wgt = a * Tn;
-                    // colour behind this splat (B) enters dL/dalpha, then absorbs the splat
+                    // colour behind this splat (B, the background included: it is the last layer, with weight T_final) enters
+                    // dL/dalpha = T (c - B) . dL/dpixel, then B absorbs the splat
                     const float dr = eb.z - Br, dg = eb.w - Bg, db = ec.x - Bb;
-                    const float dL_dalpha =
-                        __builtin_fmaf(__builtin_fmaf(dr, dpr, __builtin_fmaf(dg, dpg, db * dpb)), Tn, nTf_bg * inv);
+                    const float dL_dalpha = __builtin_fmaf(dr, dpr, __builtin_fmaf(dg, dpg, db * dpb)) * Tn;
                     Br = __builtin_fmaf(a, dr, Br);
                     Bg = __builtin_fmaf(a, dg, Bg);
                     Bb = __builtin_fmaf(a, db, Bb);
-                    T  = Tn;
                     // the 0.99 cap passes no gradient to G / opacity
                     // (selected AFTER the product: on a lane that is not a candidate `power` lies outside blend_exp's
                     //  domain and G is arbitrary bits, possibly NaN -- it must not meet a multiplication by 0)
