@@ -123,6 +123,9 @@ __device__ unsigned long long g_bwd_stats[32];
 #ifndef LCGS_BWD_WAVES
 #define LCGS_BWD_WAVES 6
 #endif
+#ifndef LCGS_BWD_KO // knock-out builds (tools/gpu/bwd_knockout.sh): 1 no reduction, 2 no evaluation, 3 no flush -- wrong results, timing only
+#define LCGS_BWD_KO 0
+#endif
 // fill: the dense per-splat gradient rows' zero-fill as a side job (launch.hpp DenseFill): slot s clears its share of the five
 // arrays' 16-byte-aligned interiors with fire-and-forget stores before it turns to its tile -- 1.45 GB through a memory
 // system this VALU-bound kernel leaves idle, instead of 0.33 ms of memset kernels beside it that cost it 0.13 ms.
@@ -313,6 +316,11 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                     const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)w * 64u + l));
                     const uint32_t pos = lo + idx; // 0-based list position
                     LCGS_STAT(0, 1u);
+#if LCGS_BWD_KO == 2 // (measuring builds only: no evaluation -- the walk and the reduction alone)
+                    for (int g = 0; g < 9; ++g) v[g] = pxf + (float)pos;
+                    row = grad_base + idx * 4u;
+                    return true;
+#endif
                     uint32_t roff = idx * 16u; // (byte offset of the entry's row in every slab; pinned: one scalar-to-vector move)
                     asm volatile("" : "+v"(roff));
                     const char*    rows = reinterpret_cast<const char*>(&s_rows[0][0]) + roff;
@@ -327,8 +335,10 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                     const bool  cand  = c_pos & c_neg & c_flr;
                     // (three ballots of plain compares are the compares' own lane masks; a ballot of the conjunction costs a
                     //  select and another compare -- two vector instructions per walked entry)
-                    if ((__builtin_amdgcn_ballot_w64(c_pos) & __builtin_amdgcn_ballot_w64(c_neg) &
-                         __builtin_amdgcn_ballot_w64(c_flr)) == 0ull)
+                    // (KNOWN: the kept bits are those of entries the forward BLENDED somewhere in this strip -- nothing to skip,
+                    //  and no vector-compare -> scalar -> branch round trip in front of the exponential)
+                    if (!KNOWN && (__builtin_amdgcn_ballot_w64(c_pos) & __builtin_amdgcn_ballot_w64(c_neg) &
+                                   __builtin_amdgcn_ballot_w64(c_flr)) == 0ull)
                         continue;
                     LCGS_STAT(1, 1u);
                     // exp(power): the hardware's v_exp_f32 (1 ulp; two instructions) since round 5, not the forward's DEFINED
@@ -397,6 +407,18 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                 }
             };
             uint32_t    rows     = grad_base; // rows of unused slots receive +0.0f
+#if LCGS_BWD_KO == 1 // (measuring builds only: no reduction -- the walk and the evaluation alone)
+            {
+                float    A[9], sink = 0.0f;
+                uint32_t row;
+                while (next_entry(A, row)) {
+                    for (int g = 0; g < 9; ++g) sink += A[g];
+                    sink += __builtin_bit_cast(float, row);
+                }
+                if (sink == 12345.678f) s_grad[0][tid] = sink;
+            }
+            if (false)
+#endif
             for (;;) {
                 float    A[9], B[9], pair[9], quad[9];
                 uint32_t row;
@@ -435,6 +457,9 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         // entry (9 of them active; shifts and masks instead of a division by 12 in a loop that runs every round).
         s_vid[tid] = (have && kmask != 0u) ? vid : 0xFFFFFFFFu;
         __syncthreads();
+#if LCGS_BWD_KO == 3 // (measuring builds only: no flush)
+        if (lo == 0xFFFFFFFFu)
+#endif
 #pragma unroll 4
         for (uint32_t cidx = tid; cidx < 256u * 16u; cidx += 256u) {
             const uint32_t idx = cidx >> 4, g = cidx & 15u;
