@@ -87,7 +87,7 @@ __device__ __forceinline__ void row_sum9_to_lane15(float v[9])
 }
 
 // Steps 2 and 3 on (AB, CD) and the LDS adds.  rows: lanes 15 / 31 / 47 / 63 hold the LDS byte address of the
-// accumulator row (&s_grad[0][idx]) of entry A / C / B / D; value g goes to row + g * 1024.
+// accumulator row (&s_grad[0][idx]) of entry A / C / B / D; value g goes to row + g * 1028 (kRows floats).
 __device__ __forceinline__ void reduce_quad_and_add(float pair[9], float quad[9], uint32_t rows,
                                                     bool is_row_end)
 {
@@ -98,10 +98,14 @@ __device__ __forceinline__ void reduce_quad_and_add(float pair[9], float quad[9]
         // a raw ds_add_f32: hipcc's atomic optimiser would wrap a C++ atomicAdd in a per-lane scan loop
 #pragma unroll
         for (int g = 0; g < 9; ++g)
-            asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(rows), "v"(r[g]), "n"(g * 256 * 4) : "memory");
+            asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(rows), "v"(r[g]), "n"(g * 257 * 4) : "memory");
     }
 }
 
+constexpr uint32_t kNullEntry  = 256u;                // LDS row of the entry that blends nowhere
+constexpr uint32_t kRows       = 257u;                // rows per slab / accumulator columns: a round's 256 entries + the null entry
+constexpr uint32_t kSlab       = kRows * 16u;         // bytes per slab of s_rows
+constexpr uint32_t kListStride = 264u;                // 256 entries + 3 of padding, a multiple of four (8-byte rows)
 constexpr int kG2D = 12; // floats per splat in the 2-D gradient buffer: mean(2) conic(3) opacity(1) rgb(3) pad(3)
 
 #ifdef LCGS_BWD_STATS // (measuring builds only, tools/gpu/bwd_stats.py: what the render-backward's waves actually walk)
@@ -147,9 +151,12 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
     // [0] mean.x, mean.y, -conic.x / 2, conic.y   [1] -conic.z / 2, opacity, r, g   [2] b, power floor, -, -
     // (the halved, negated diagonal: `power` then needs no multiplication by -1/2 -- a power of two commutes with rounding, so
     //  the value is the forward's bit for bit)
-    __shared__ float4             s_rows[3][256];
+    // (row kNullEntry of every slab is the null entry that pads a strip's list to a multiple of four: opacity 0, blends nowhere;
+    //  its accumulator column is never read)
+    __shared__ float4             s_rows[3][kRows];
     __shared__ uint32_t           s_vid[256];
-    __shared__ float              s_grad[9][256];
+    __shared__ float              s_grad[9][kRows];
+    __shared__ __attribute__((aligned(8))) uint16_t s_list[4][kListStride]; // [strip]: the round's entries to walk, back to front
     __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
     __shared__ uint32_t           s_max[4];
     __shared__ uint32_t           s_slot;
@@ -254,6 +261,11 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
     const bool        is_row_end = (lane & 15u) == 15u;
     const uint32_t    grad_base  = (uint32_t)(uintptr_t)&s_grad[0][0]; // low half of a flat LDS address = LDS offset
 
+    if (tid == 0u) { // the null entry (visible to every wave behind the first round's barriers)
+        s_rows[0][kNullEntry] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_rows[1][kNullEntry] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_rows[2][kNullEntry] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     while (hi > 0u) {
         const uint32_t lo   = hi > 256u ? hi - 256u : 0u;
         const uint32_t e    = lo + tid;
@@ -295,159 +307,151 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         for (int g = 0; g < 9; ++g) s_grad[g][tid] = 0.0f;
         __syncthreads();
 
-        // ---- walk "my" strip's entries back to front, four at a time (see the reduction notes above)
+        // ---- this strip's entries of the round as a list, back to front: the four ballots' set bits, highest first, padded to
+        // a multiple of four with the null entry.  The walk below then has no data-dependent branch at all: one 8-byte LDS
+        // read names four entries, their evaluations are straight-line code the scheduler can overlap (what a scalar bit
+        // walk with a branch per entry cost: profiles/r05_bwd_list_walk_ab.txt).
+        uint32_t n_walk = 0u; // (scalar)
         {
-            int                w = 4;   // staging wave whose mask is being walked (scalar)
-            unsigned long long m = 0ull; // its remaining entries for this strip (scalar)
-            // Finds the next entry (back to front) that blends into at least one pixel of the strip and evaluates
-            // its nine per-pixel terms; false when the round's entries are exhausted.  Instantiated once per slot
-            // of the four-entry group so that every slot's values live in fixed registers (no copies).
-            auto next_entry = [&](float v[9], uint32_t& row) -> bool {
-                for (;;) {
-                    while (m == 0ull) {
-                        if (w == 0) return false;
-                        w = __builtin_amdgcn_readfirstlane(w - 1);
-                        const unsigned long long mm = s_mask[w][wave];
-                        m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mm >> 32)) << 32) |
-                            (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mm);
-                    }
-                    const uint32_t l = 63u - (uint32_t)__clzll((long long)m);
-                    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(l));
-                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)w * 64u + l));
-                    const uint32_t pos = lo + idx; // 0-based list position
-                    LCGS_STAT(0, 1u);
-#if LCGS_BWD_KO == 2 // (measuring builds only: no evaluation -- the walk and the reduction alone)
-                    for (int g = 0; g < 9; ++g) v[g] = pxf + (float)pos;
-                    row = grad_base + idx * 4u;
-                    return true;
-#endif
-                    uint32_t roff = idx * 16u; // (byte offset of the entry's row in every slab; pinned: one scalar-to-vector move)
-                    asm volatile("" : "+v"(roff));
-                    const char*    rows = reinterpret_cast<const char*>(&s_rows[0][0]) + roff;
-                    const float4   ea = *reinterpret_cast<const float4*>(rows);
-                    const float4   eb = *reinterpret_cast<const float4*>(rows + 4096);
-                    const float2   ec = *reinterpret_cast<const float2*>(rows + 8192);
-                    // the forward's own expression and evaluation order: the same splats pass the same thresholds
-                    const float dx    = ea.x - pxf;
-                    const float dy    = ea.y - pyf;
-                    const float power = (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy; // (ea.z, eb.x: -ca / 2, -cc / 2)
-                    const bool  c_pos = pos < last, c_neg = !(power > 0.0f), c_flr = power >= ec.y;
-                    const bool  cand  = c_pos & c_neg & c_flr;
-                    // (three ballots of plain compares are the compares' own lane masks; a ballot of the conjunction costs a
-                    //  select and another compare -- two vector instructions per walked entry)
-                    // (KNOWN: the kept bits are those of entries the forward BLENDED somewhere in this strip -- nothing to skip,
-                    //  and no vector-compare -> scalar -> branch round trip in front of the exponential)
-                    if (!KNOWN && (__builtin_amdgcn_ballot_w64(c_pos) & __builtin_amdgcn_ballot_w64(c_neg) &
-                                   __builtin_amdgcn_ballot_w64(c_flr)) == 0ull)
-                        continue;
-                    LCGS_STAT(1, 1u);
-                    // exp(power): the hardware's v_exp_f32 (1 ulp; two instructions) since round 5, not the forward's DEFINED
-                    // function (ten).  The forward needs that one for bit-identical images; here the tolerance is 1e-3 and what
-                    // the two differ by -- ~1e-7 relative in alpha, an entry within that of alpha = 1/255 blended on one side
-                    // only (its weight is <= T / 255) -- is far inside it: every gradient test, the f64 checks at full size and
-                    // the soak's error distribution are unchanged.  render-backward 0.66-0.68 -> 0.63-0.64 ms, forward+backward
-                    // +2.2 % in same-box A/B (profiles/r05_bwd_hw_exp_ab.txt; -DLCGS_BWD_DEFINED_EXP builds the old form).
-#ifdef LCGS_BWD_DEFINED_EXP
-                    const float G     = blend_exp(power);
-#else
-                    const float G     = __builtin_amdgcn_exp2f(power * kExpLog2e);
-#endif
-                    const float oG    = eb.y * G;
-                    const float alpha = __builtin_fminf(0.99f, oG);
-                    const bool  valid = cand & !(alpha < 1.0f / 255.0f);
-                    LCGS_STAT(2, (unsigned)__popcll(__builtin_amdgcn_ballot_w64(valid)));
-#ifdef LCGS_BWD_STATS
-                    {   // which sub-blocks of the 16x4 strip does this entry blend into? (lane = 16 * row + column)
-                        const unsigned long long vb = __builtin_amdgcn_ballot_w64(valid);
-                        sub_[0] += (vb & 0x00FF00FF00FF00FFull) != 0, sub_[1] += (vb & 0xFF00FF00FF00FF00ull) != 0; // 8x4 halves
-                        sub_[2] += (vb & 0x00000000FFFFFFFFull) != 0, sub_[3] += (vb & 0xFFFFFFFF00000000ull) != 0; // 16x2 halves
-                        for (int q = 0; q < 4; ++q) {
-                            sub_[4 + q] += (vb & (0x000F000F000F000Full << (4 * q))) != 0; // 4x4 blocks
-                            sub_[8 + q] += (vb & (0xFFFFull << (16 * q))) != 0;            // 16x1 rows
-                        }
-                        sub_[12] += vb != 0;
-                    }
-#endif
-                    // A lane that does not blend this entry carries alpha 0 through the recurrences: the product keeps its
-                    // value, B + 0 * (c - B) leaves the colour behind alone, all nine terms come out 0.
-                    // (No second wave-level skip: the staging floor already implies alpha >= 1/255 somewhere.)
-                    const float a   = valid ? alpha : 0.0f;
-                    // T in front of this splat = T_final / prod(1 - a) over this entry and everything behind it.  The product is
-                    // carried (one rounded multiplication per entry: errors of either sign, ~sqrt(n) half-ulps at the front of
-                    // n entries) and divided out ONCE per entry with v_rcp_f32 (1 ulp, not carried).  Dividing T itself entry
-                    // by entry with v_rcp_f32 is what drifted in round 3 (its bias was seen by every splat in front: a
-                    // screen-filling splat, whose geometry gradients are sums of ~1e5 cancelling per-pixel terms, amplified it
-                    // to a few 1e-3); rounds 4-5 paid a Newton step on that quotient (two FMAs) -- this form needs neither.
-                    Pr = Pr * (1.0f - a);
-                    const float Tn  = T_final * __builtin_amdgcn_rcpf(Pr); // the forward's T in front of this splat
-                    const float wgt = a * Tn;
-                    // colour behind this splat (B, the background included: it is the last layer, with weight T_final) enters
-                    // dL/dalpha = T (c - B) . dL/dpixel, then B absorbs the splat
-                    const float dr = eb.z - Br, dg = eb.w - Bg, db = ec.x - Bb;
-                    const float dL_dalpha = __builtin_fmaf(dr, dpr, __builtin_fmaf(dg, dpg, db * dpb)) * Tn;
-                    Br = __builtin_fmaf(a, dr, Br);
-                    Bg = __builtin_fmaf(a, dg, Bg);
-                    Bb = __builtin_fmaf(a, db, Bb);
-                    // the 0.99 cap passes no gradient to G / opacity
-                    // (selected AFTER the product: on a lane that is not a candidate `power` lies outside blend_exp's
-                    //  domain and G is arbitrary bits, possibly NaN -- it must not meet a multiplication by 0)
-                    v[5] = (valid & (oG < 0.99f)) ? G * dL_dalpha : 0.0f; // dL/dopacity
-                    const float h  = eb.y * v[5]; // G * dL/dG
-                    const float hx = h * dx, hy = h * dy;
-                    v[0] = hx;                    // the entry-uniform factors (conic, -1, -0.5) are applied once
-                    v[1] = hy;                    // per entry when the round is flushed
-                    v[2] = hx * dx;
-                    v[3] = hx * dy;
-                    v[4] = hy * dy;
-                    v[6] = wgt * dpr;
-                    v[7] = wgt * dpg;
-                    v[8] = wgt * dpb;
-                    row  = grad_base + idx * 4u;
-                    return true;
-                }
-            };
-            uint32_t    rows     = grad_base; // rows of unused slots receive +0.0f
-#if LCGS_BWD_KO == 1 // (measuring builds only: no reduction -- the walk and the evaluation alone)
-            {
-                float    A[9], sink = 0.0f;
-                uint32_t row;
-                while (next_entry(A, row)) {
-                    for (int g = 0; g < 9; ++g) sink += A[g];
-                    sink += __builtin_bit_cast(float, row);
-                }
-                if (sink == 12345.678f) s_grad[0][tid] = sink;
+            uint16_t* list = &s_list[wave][0];
+#pragma unroll
+            for (int w = 3; w >= 0; --w) {
+                const unsigned long long mm  = s_mask[w][wave];
+                const uint32_t           mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mm);
+                const uint32_t           mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mm >> 32));
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)); // set bits under my lane
+                const uint32_t total = (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi);
+                const uint32_t mine  = lane < 32u ? mlo >> lane : mhi >> (lane - 32u);
+                if (mine & 1u) list[n_walk + (total - 1u - below)] = (uint16_t)((uint32_t)w * 64u + lane);
+                n_walk += total;
             }
-            if (false)
+            if (lane < 4u) list[n_walk + lane] = (uint16_t)kNullEntry;
+            asm volatile("" ::: "memory"); // (the list is read back as 8-byte words below)
+        }
+
+        // ---- walk them, four at a time (see the reduction notes above)
+        {
+            // the nine per-pixel terms of entry idx (an LDS row of this round, or the null entry)
+            auto evaluate = [&](const uint32_t idx, float v[9], uint32_t& row) {
+                const uint32_t pos = lo + idx; // 0-based list position (the null entry: >= hi, never below `last`)
+                LCGS_STAT(0, idx < 256u ? 1u : 0u);
+#if LCGS_BWD_KO == 2 // (measuring builds only: no evaluation -- the walk and the reduction alone)
+                for (int g = 0; g < 9; ++g) v[g] = pxf + (float)pos;
+                row = grad_base + idx * 4u;
+                return;
 #endif
-            for (;;) {
-                float    A[9], B[9], pair[9], quad[9];
-                uint32_t row;
-                if (!next_entry(A, row)) break;
-                asm volatile("v_writelane_b32 %0, %1, 15" : "+v"(rows) : "s"(row));
-                if (!next_entry(B, row)) { // pad the open group with zero value sets (their rows receive +0.0f)
-                    float z1[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, z2[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-                    swap32_add9(A, z1, pair);
-                    reduce_quad_and_add(pair, z2, rows, is_row_end);
-                    break;
+                uint32_t roff = idx * 16u; // (byte offset of the entry's row in every slab; pinned: one scalar-to-vector move)
+                asm("" : "+v"(roff));
+                const char*    rows = reinterpret_cast<const char*>(&s_rows[0][0]) + roff;
+                const float4   ea = *reinterpret_cast<const float4*>(rows);
+                const float4   eb = *reinterpret_cast<const float4*>(rows + kSlab);
+                const float2   ec = *reinterpret_cast<const float2*>(rows + 2 * kSlab);
+                // the forward's own expression and evaluation order: the same splats pass the same thresholds
+                const float dx    = ea.x - pxf;
+                const float dy    = ea.y - pyf;
+                const float power = (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy; // (ea.z, eb.x: -ca / 2, -cc / 2)
+                const bool  c_pos = pos < last, c_neg = !(power > 0.0f), c_flr = power >= ec.y;
+                const bool  cand  = c_pos & c_neg & c_flr;
+                // (three ballots of plain compares are the compares' own lane masks; a ballot of the conjunction costs a
+                //  select and another compare -- two vector instructions per walked entry)
+                LCGS_STAT(1, 1u);
+                // exp(power): the hardware's v_exp_f32 (1 ulp; two instructions) since round 5, not the forward's DEFINED
+                // function (ten).  The forward needs that one for bit-identical images; here the tolerance is 1e-3 and what
+                // the two differ by -- ~1e-7 relative in alpha, an entry within that of alpha = 1/255 blended on one side
+                // only (its weight is <= T / 255) -- is far inside it: every gradient test, the f64 checks at full size and
+                // the soak's error distribution are unchanged.  render-backward 0.66-0.68 -> 0.63-0.64 ms, forward+backward
+                // +2.2 % in same-box A/B (profiles/r05_bwd_hw_exp_ab.txt; -DLCGS_BWD_DEFINED_EXP builds the old form).
+#ifdef LCGS_BWD_DEFINED_EXP
+                const float G     = blend_exp(power);
+#else
+                const float G     = __builtin_amdgcn_exp2f(power * kExpLog2e);
+#endif
+                const float oG    = eb.y * G;
+                const float alpha = __builtin_fminf(0.99f, oG);
+                const bool  valid = cand & !(alpha < 1.0f / 255.0f);
+                LCGS_STAT(2, (unsigned)__popcll(__builtin_amdgcn_ballot_w64(valid)));
+#ifdef LCGS_BWD_STATS
+                {   // which sub-blocks of the 16x4 strip does this entry blend into? (lane = 16 * row + column)
+                    const unsigned long long vb = __builtin_amdgcn_ballot_w64(valid);
+                    sub_[0] += (vb & 0x00FF00FF00FF00FFull) != 0, sub_[1] += (vb & 0xFF00FF00FF00FF00ull) != 0; // 8x4 halves
+                    sub_[2] += (vb & 0x00000000FFFFFFFFull) != 0, sub_[3] += (vb & 0xFFFFFFFF00000000ull) != 0; // 16x2 halves
+                    for (int q = 0; q < 4; ++q) {
+                        sub_[4 + q] += (vb & (0x000F000F000F000Full << (4 * q))) != 0; // 4x4 blocks
+                        sub_[8 + q] += (vb & (0xFFFFull << (16 * q))) != 0;            // 16x1 rows
+                    }
+                    sub_[12] += vb != 0;
                 }
-                asm volatile("v_writelane_b32 %0, %1, 47" : "+v"(rows) : "s"(row));
+#endif
+                // A lane that does not blend this entry carries alpha 0 through the recurrences: the product keeps its
+                // value, B + 0 * (c - B) leaves the colour behind alone, all nine terms come out 0.
+                // (No second wave-level skip: the staging floor already implies alpha >= 1/255 somewhere.)
+                const float a   = valid ? alpha : 0.0f;
+                // T in front of this splat = T_final / prod(1 - a) over this entry and everything behind it.  The product is
+                // carried (one rounded multiplication per entry: errors of either sign, ~sqrt(n) half-ulps at the front of
+                // n entries) and divided out ONCE per entry with v_rcp_f32 (1 ulp, not carried).  Dividing T itself entry
+                // by entry with v_rcp_f32 is what drifted in round 3 (its bias was seen by every splat in front: a
+                // screen-filling splat, whose geometry gradients are sums of ~1e5 cancelling per-pixel terms, amplified it
+                // to a few 1e-3); rounds 4-5 paid a Newton step on that quotient (two FMAs) -- this form needs neither.
+                Pr = Pr * (1.0f - a);
+                const float Tn  = T_final * __builtin_amdgcn_rcpf(Pr); // the forward's T in front of this splat
+                const float wgt = a * Tn;
+                // colour behind this splat (B, the background included: it is the last layer, with weight T_final) enters
+                // dL/dalpha = T (c - B) . dL/dpixel, then B absorbs the splat
+                const float dr = eb.z - Br, dg = eb.w - Bg, db = ec.x - Bb;
+                const float dL_dalpha = __builtin_fmaf(dr, dpr, __builtin_fmaf(dg, dpg, db * dpb)) * Tn;
+                Br = __builtin_fmaf(a, dr, Br);
+                Bg = __builtin_fmaf(a, dg, Bg);
+                Bb = __builtin_fmaf(a, db, Bb);
+                // the 0.99 cap passes no gradient to G / opacity
+                // (selected AFTER the product: on a lane that is not a candidate `power` lies outside blend_exp's
+                //  domain and G is arbitrary bits, possibly NaN -- it must not meet a multiplication by 0)
+                v[5] = (valid & (oG < 0.99f)) ? G * dL_dalpha : 0.0f; // dL/dopacity
+                const float h  = eb.y * v[5]; // G * dL/dG
+                const float hx = h * dx, hy = h * dy;
+                v[0] = hx;                    // the entry-uniform factors (conic, -1, -0.5) are applied once
+                v[1] = hy;                    // per entry when the round is flushed
+                v[2] = hx * dx;
+                v[3] = hx * dy;
+                v[4] = hy * dy;
+                v[6] = wgt * dpr;
+                v[7] = wgt * dpg;
+                v[8] = wgt * dpb;
+                row  = grad_base + idx * 4u;
+            };
+            uint32_t rows = grad_base;
+#if LCGS_BWD_KO == 1 // (measuring builds only: no reduction -- the walk and the evaluation alone)
+            float sink = 0.0f;
+#endif
+            for (uint32_t i = 0u; i < n_walk; i += 4u) {
+                const uint2    four = *reinterpret_cast<const uint2*>(&s_list[wave][i]);
+                const uint32_t p0   = (uint32_t)__builtin_amdgcn_readfirstlane((int)four.x);
+                const uint32_t p1   = (uint32_t)__builtin_amdgcn_readfirstlane((int)four.y);
+                float          A[9], B[9], pair[9], quad[9];
+                uint32_t       row;
+                evaluate(p0 & 0xFFFFu, A, row);
+                asm("v_writelane_b32 %0, %1, 15" : "+v"(rows) : "s"(row));
+                evaluate(p0 >> 16, B, row);
+                asm("v_writelane_b32 %0, %1, 47" : "+v"(rows) : "s"(row));
+#if LCGS_BWD_KO == 1
+                for (int g = 0; g < 9; ++g) sink += A[g] + B[g];
+#else
                 swap32_add9(A, B, pair);
-                if (!next_entry(A, row)) {
-                    float z1[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-                    reduce_quad_and_add(pair, z1, rows, is_row_end);
-                    break;
-                }
-                asm volatile("v_writelane_b32 %0, %1, 31" : "+v"(rows) : "s"(row));
-                if (!next_entry(B, row)) {
-                    float z1[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-                    swap32_add9(A, z1, quad);
-                    reduce_quad_and_add(pair, quad, rows, is_row_end);
-                    break;
-                }
-                asm volatile("v_writelane_b32 %0, %1, 63" : "+v"(rows) : "s"(row));
+#endif
+                evaluate(p1 & 0xFFFFu, A, row);
+                asm("v_writelane_b32 %0, %1, 31" : "+v"(rows) : "s"(row));
+                evaluate(p1 >> 16, B, row);
+                asm("v_writelane_b32 %0, %1, 63" : "+v"(rows) : "s"(row));
+#if LCGS_BWD_KO == 1
+                for (int g = 0; g < 9; ++g) sink += A[g] + B[g];
+                sink += __builtin_bit_cast(float, rows);
+#else
                 swap32_add9(A, B, quad);
                 reduce_quad_and_add(pair, quad, rows, is_row_end);
+#endif
             }
+#if LCGS_BWD_KO == 1
+            if (sink == 12345.678f) s_grad[0][tid] = sink;
+#endif
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the raw LDS adds above have landed
         __syncthreads();
