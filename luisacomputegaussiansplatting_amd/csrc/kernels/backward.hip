@@ -42,19 +42,21 @@ using namespace tile; // tile_of_workgroup / render_grid_size / splat_strip_mask
 // (inline asm rather than __builtin_amdgcn_permlane32_swap: the builtin returns fresh values, and the compiler copies
 // both operands first -- two extra moves per swap; x and y are dead after the call, the swap may clobber them.  The
 // s_nop covers the 2-wait-state VALU-write -> permlane-read hazard, which nothing pads inside asm.)
-__device__ __forceinline__ void swap32_add9(float x[9], float y[9], float out[9])
+template <int N>
+__device__ __forceinline__ void swap32_add(float x[N], float y[N], float out[N])
 {
 #pragma unroll
-    for (int g = 0; g < 9; ++g) {
+    for (int g = 0; g < N; ++g) {
         // lanes 0-31: x = own x, y = partner's x;  lanes 32-63: x = partner's y, y = own y
         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x[g]), "+v"(y[g]));
         out[g] = x[g] + y[g];
     }
 }
-__device__ __forceinline__ void swap16_add9(float x[9], float y[9], float out[9])
+template <int N>
+__device__ __forceinline__ void swap16_add(float x[N], float y[N], float out[N])
 {
 #pragma unroll
-    for (int g = 0; g < 9; ++g) {
+    for (int g = 0; g < N; ++g) {
         // rows 1 and 3 of x trade places with rows 0 and 2 of y: after the add the rows hold x.lo, y.lo, x.hi, y.hi
         asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x[g]), "+v"(y[g]));
         out[g] = x[g] + y[g];
@@ -88,11 +90,25 @@ __device__ __forceinline__ void row_sum9_to_lane15(float v[9])
 
 // Steps 2 and 3 on (AB, CD) and the LDS adds.  rows: lanes 15 / 31 / 47 / 63 hold the LDS byte address of the
 // accumulator row (&s_grad[0][idx]) of entry A / C / B / D; value g goes to row + g * 1028 (kRows floats).
-__device__ __forceinline__ void reduce_quad_and_add(float pair[9], float quad[9], uint32_t rows,
+// The five geometry sums separate: dx depends on the pixel's COLUMN only, and steps 1-2 sum over the strip's four rows of one
+// column, so only (h, h dy, h dy dy) go through them; behind step 2 a lane holds those three summed over its column for the
+// entry of its 16-lane row, multiplies by THAT entry's dx (dx_row) and step 3 sums the five products over the columns:
+//   S hx = S_c dx (S_r h)   S hx dx = S_c dx dx (S_r h)   S hx dy = S_c dx (S_r h dy)   S hy = S_c S_r h dy   S hy dy = S_c S_r h dy dy
+// -- seven values through the permlane steps instead of nine, two multiplications per entry instead of five.
+__device__ __forceinline__ void reduce_quad_and_add(float pair[7], float quad[7], float dx_row, uint32_t rows,
                                                     bool is_row_end)
 {
-    float r[9];
-    swap16_add9(pair, quad, r);
+    float c[7], r[9];
+    swap16_add<7>(pair, quad, c);
+    r[0] = dx_row * c[0]; // S hx
+    r[1] = c[1];          // S hy
+    r[2] = dx_row * r[0]; // S hx dx
+    r[3] = dx_row * c[1]; // S hx dy
+    r[4] = c[2];          // S hy dy
+    r[5] = c[3];
+    r[6] = c[4];
+    r[7] = c[5];
+    r[8] = c[6];
     row_sum9_to_lane15(r);
     if (is_row_end) {
         // a raw ds_add_f32: hipcc's atomic optimiser would wrap a C++ atomicAdd in a per-lane scan loop
@@ -255,9 +271,11 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         const uint32_t len = ranges[2 * (size_t)tile + 1] - range_start;
         hi                 = hi < len ? hi : len;
     }
+    hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi); // (uniform by construction: keeps the round bounds on the scalar side)
 
     // per-pixel recurrences, walked back to front: B = colour composited behind the current splat
-    float             Pr = 1.0f, Br = bg0, Bg = bg1, Bb = bg2; // Pr: product of (1 - alpha) over the entries walked so far
+    // Qr: product of (1 - alpha) over the entries walked so far, over T_final (a pixel outside the image: infinity, T = 0)
+    float             Qr = 1.0f / T_final, Br = bg0, Bg = bg1, Bb = bg2;
     const bool        is_row_end = (lane & 15u) == 15u;
     const uint32_t    grad_base  = (uint32_t)(uintptr_t)&s_grad[0][0]; // low half of a flat LDS address = LDS offset
 
@@ -302,7 +320,7 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         s_rows[0][tid] = make_float4(a.x, a.y, -0.5f * a.z, a.w);
         s_rows[1][tid] = make_float4(-0.5f * b.x, b.y, b.z, b.w);
         *reinterpret_cast<float2*>(&s_rows[2][tid]) = make_float2(c, fmax_(-0.5f * t, kBlendExpMin));
-        s_vid[tid] = vid;
+        s_vid[tid] = (have && kmask != 0u) ? vid : 0xFFFFFFFFu; // (read by the flush only)
 #pragma unroll
         for (int g = 0; g < 9; ++g) s_grad[g][tid] = 0.0f;
         __syncthreads();
@@ -332,11 +350,12 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         // ---- walk them, four at a time (see the reduction notes above)
         {
             // the nine per-pixel terms of entry idx (an LDS row of this round, or the null entry)
-            auto evaluate = [&](const uint32_t idx, float v[9], uint32_t& row) {
+            // (h = G dL/dG; h dy; h dy dy; dL/dopacity; the three colour terms)
+            auto evaluate = [&](const uint32_t idx, float v[7], uint32_t& row) {
                 const uint32_t pos = lo + idx; // 0-based list position (the null entry: >= hi, never below `last`)
                 LCGS_STAT(0, idx < 256u ? 1u : 0u);
 #if LCGS_BWD_KO == 2 // (measuring builds only: no evaluation -- the walk and the reduction alone)
-                for (int g = 0; g < 9; ++g) v[g] = pxf + (float)pos;
+                for (int g = 0; g < 7; ++g) v[g] = pxf + (float)pos;
                 row = grad_base + idx * 4u;
                 return;
 #endif
@@ -386,14 +405,14 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                 // value, B + 0 * (c - B) leaves the colour behind alone, all nine terms come out 0.
                 // (No second wave-level skip: the staging floor already implies alpha >= 1/255 somewhere.)
                 const float a   = valid ? alpha : 0.0f;
-                // T in front of this splat = T_final / prod(1 - a) over this entry and everything behind it.  The product is
-                // carried (one rounded multiplication per entry: errors of either sign, ~sqrt(n) half-ulps at the front of
+                // T in front of this splat = T_final / prod(1 - a) over this entry and everything behind it.  The product (over
+                // T_final: Qr) is carried (one rounded multiplication per entry: errors of either sign, ~sqrt(n) half-ulps at the front of
                 // n entries) and divided out ONCE per entry with v_rcp_f32 (1 ulp, not carried).  Dividing T itself entry
                 // by entry with v_rcp_f32 is what drifted in round 3 (its bias was seen by every splat in front: a
                 // screen-filling splat, whose geometry gradients are sums of ~1e5 cancelling per-pixel terms, amplified it
                 // to a few 1e-3); rounds 4-5 paid a Newton step on that quotient (two FMAs) -- this form needs neither.
-                Pr = Pr * (1.0f - a);
-                const float Tn  = T_final * __builtin_amdgcn_rcpf(Pr); // the forward's T in front of this splat
+                Qr = Qr * (1.0f - a);
+                const float Tn  = __builtin_amdgcn_rcpf(Qr); // the forward's T in front of this splat
                 const float wgt = a * Tn;
                 // colour behind this splat (B, the background included: it is the last layer, with weight T_final) enters
                 // dL/dalpha = T (c - B) . dL/dpixel, then B absorbs the splat
@@ -405,20 +424,18 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                 // the 0.99 cap passes no gradient to G / opacity
                 // (selected AFTER the product: on a lane that is not a candidate `power` lies outside blend_exp's
                 //  domain and G is arbitrary bits, possibly NaN -- it must not meet a multiplication by 0)
-                v[5] = (valid & (oG < 0.99f)) ? G * dL_dalpha : 0.0f; // dL/dopacity
-                const float h  = eb.y * v[5]; // G * dL/dG
-                const float hx = h * dx, hy = h * dy;
-                v[0] = hx;                    // the entry-uniform factors (conic, -1, -0.5) are applied once
-                v[1] = hy;                    // per entry when the round is flushed
-                v[2] = hx * dx;
-                v[3] = hx * dy;
-                v[4] = hy * dy;
-                v[6] = wgt * dpr;
-                v[7] = wgt * dpg;
-                v[8] = wgt * dpb;
+                v[3] = (valid & (oG < 0.99f)) ? G * dL_dalpha : 0.0f; // dL/dopacity
+                v[0] = eb.y * v[3];           // h = G * dL/dG; the entry-uniform factors (conic, -1, -0.5) are applied once
+                v[1] = v[0] * dy;             // per entry when the round is flushed, dx behind the row sums (reduce_quad_and_add)
+                v[2] = v[1] * dy;
+                v[4] = wgt * dpr;
+                v[5] = wgt * dpg;
+                v[6] = wgt * dpb;
                 row  = grad_base + idx * 4u;
             };
             uint32_t rows = grad_base;
+            // rows 0 .. 3 of the wave hold entries A, C, B, D of a group = list slots 0, 2, 1, 3 (bytes into the group's four u16)
+            const uint32_t my_slot = 2u * ((((lane >> 4) & 1u) << 1) | (lane >> 5));
 #if LCGS_BWD_KO == 1 // (measuring builds only: no reduction -- the walk and the evaluation alone)
             float sink = 0.0f;
 #endif
@@ -426,27 +443,30 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                 const uint2    four = *reinterpret_cast<const uint2*>(&s_list[wave][i]);
                 const uint32_t p0   = (uint32_t)__builtin_amdgcn_readfirstlane((int)four.x);
                 const uint32_t p1   = (uint32_t)__builtin_amdgcn_readfirstlane((int)four.y);
-                float          A[9], B[9], pair[9], quad[9];
+                float          A[7], B[7], pair[7], quad[7];
                 uint32_t       row;
+                // the entry my 16-lane row will hold behind the two swaps, and its dx at my column
+                const uint32_t mine   = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(&s_list[wave][i]) + my_slot);
+                const float    dx_row = s_rows[0][mine].x - pxf;
                 evaluate(p0 & 0xFFFFu, A, row);
                 asm("v_writelane_b32 %0, %1, 15" : "+v"(rows) : "s"(row));
                 evaluate(p0 >> 16, B, row);
                 asm("v_writelane_b32 %0, %1, 47" : "+v"(rows) : "s"(row));
 #if LCGS_BWD_KO == 1
-                for (int g = 0; g < 9; ++g) sink += A[g] + B[g];
+                for (int g = 0; g < 7; ++g) sink += A[g] + B[g];
 #else
-                swap32_add9(A, B, pair);
+                swap32_add<7>(A, B, pair);
 #endif
                 evaluate(p1 & 0xFFFFu, A, row);
                 asm("v_writelane_b32 %0, %1, 31" : "+v"(rows) : "s"(row));
                 evaluate(p1 >> 16, B, row);
                 asm("v_writelane_b32 %0, %1, 63" : "+v"(rows) : "s"(row));
 #if LCGS_BWD_KO == 1
-                for (int g = 0; g < 9; ++g) sink += A[g] + B[g];
-                sink += __builtin_bit_cast(float, rows);
+                for (int g = 0; g < 7; ++g) sink += A[g] + B[g];
+                sink += __builtin_bit_cast(float, rows) + dx_row;
 #else
-                swap32_add9(A, B, quad);
-                reduce_quad_and_add(pair, quad, rows, is_row_end);
+                swap32_add<7>(A, B, quad);
+                reduce_quad_and_add(pair, quad, dx_row, rows, is_row_end);
 #endif
             }
 #if LCGS_BWD_KO == 1
@@ -459,8 +479,6 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         // contiguous bytes (MI355X_MICROARCH "Global float atomics": 64 lanes in 64 different rows are ~17x
         // slower), so consecutive lanes own one entry's gradient row instead of one lane per entry: 16 lanes per
         // entry (9 of them active; shifts and masks instead of a division by 12 in a loop that runs every round).
-        s_vid[tid] = (have && kmask != 0u) ? vid : 0xFFFFFFFFu;
-        __syncthreads();
 #if LCGS_BWD_KO == 3 // (measuring builds only: no flush)
         if (lo == 0xFFFFFFFFu)
 #endif
