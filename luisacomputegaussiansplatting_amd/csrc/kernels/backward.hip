@@ -273,9 +273,10 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
     }
     hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi); // (uniform by construction: keeps the round bounds on the scalar side)
 
-    // per-pixel recurrences, walked back to front: B = colour composited behind the current splat
+    // per-pixel recurrences, walked back to front
     // Qr: product of (1 - alpha) over the entries walked so far, over T_final (a pixel outside the image: infinity, T = 0)
-    float             Qr = 1.0f / T_final, Br = bg0, Bg = bg1, Bb = bg2;
+    // Bd: (colour composited behind the current splat) . dL/dpixel, the background being the last layer
+    float             Qr = 1.0f / T_final, Bd = bg0 * dpr + bg1 * dpg + bg2 * dpb;
     const bool        is_row_end = (lane & 15u) == 15u;
     const uint32_t    grad_base  = (uint32_t)(uintptr_t)&s_grad[0][0]; // low half of a flat LDS address = LDS offset
 
@@ -402,7 +403,7 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                 }
 #endif
                 // A lane that does not blend this entry carries alpha 0 through the recurrences: the product keeps its
-                // value, B + 0 * (c - B) leaves the colour behind alone, all nine terms come out 0.
+                // value, Bd + 0 * d leaves the colour behind alone, all terms come out 0.
                 // (No second wave-level skip: the staging floor already implies alpha >= 1/255 somewhere.)
                 const float a   = valid ? alpha : 0.0f;
                 // T in front of this splat = T_final / prod(1 - a) over this entry and everything behind it.  The product (over
@@ -415,12 +416,11 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                 const float Tn  = __builtin_amdgcn_rcpf(Qr); // the forward's T in front of this splat
                 const float wgt = a * Tn;
                 // colour behind this splat (B, the background included: it is the last layer, with weight T_final) enters
-                // dL/dalpha = T (c - B) . dL/dpixel, then B absorbs the splat
-                const float dr = eb.z - Br, dg = eb.w - Bg, db = ec.x - Bb;
-                const float dL_dalpha = __builtin_fmaf(dr, dpr, __builtin_fmaf(dg, dpg, db * dpb)) * Tn;
-                Br = __builtin_fmaf(a, dr, Br);
-                Bg = __builtin_fmaf(a, dg, Bg);
-                Bb = __builtin_fmaf(a, db, Bb);
+                // dL/dalpha = T (c - B) . dL/dpixel, then B absorbs the splat: B <- B + a (c - B).  Only B . dL/dpixel is ever
+                // used, and the recurrence is linear: ONE carried value (Bd) instead of three colours
+                const float d         = __builtin_fmaf(eb.z, dpr, __builtin_fmaf(eb.w, dpg, ec.x * dpb)) - Bd; // (c - B) . dL/dpixel
+                const float dL_dalpha = d * Tn;
+                Bd                    = __builtin_fmaf(a, d, Bd);
                 // the 0.99 cap passes no gradient to G / opacity
                 // (selected AFTER the product: on a lane that is not a candidate `power` lies outside blend_exp's
                 //  domain and G is arbitrary bits, possibly NaN -- it must not meet a multiplication by 0)
