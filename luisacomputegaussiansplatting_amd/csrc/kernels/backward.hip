@@ -90,25 +90,27 @@ __device__ __forceinline__ void row_sum9_to_lane15(float v[9])
 
 // Steps 2 and 3 on (AB, CD) and the LDS adds.  rows: lanes 15 / 31 / 47 / 63 hold the LDS byte address of the
 // accumulator row (&s_grad[0][idx]) of entry A / C / B / D; value g goes to row + g * 1028 (kRows floats).
-// The five geometry sums separate: dx depends on the pixel's COLUMN only, and steps 1-2 sum over the strip's four rows of one
-// column, so only (h, h dy, h dy dy) go through them; behind step 2 a lane holds those three summed over its column for the
-// entry of its 16-lane row, multiplies by THAT entry's dx (dx_row) and step 3 sums the five products over the columns:
-//   S hx = S_c dx (S_r h)   S hx dx = S_c dx dx (S_r h)   S hx dy = S_c dx (S_r h dy)   S hy = S_c S_r h dy   S hy dy = S_c S_r h dy dy
-// -- seven values through the permlane steps instead of nine, two multiplications per entry instead of five.
-__device__ __forceinline__ void reduce_quad_and_add(float pair[7], float quad[7], float dx_row, uint32_t rows,
+// The five geometry sums separate: with q = dL/dopacity per pixel (G dL/dG = opacity x q, the opacity applied at the flush), dx depends
+// on the pixel's COLUMN only, and steps 1-2 sum over the strip's four rows of one column, so only (q, q dy, q dy dy) go through
+// them; behind step 2 a lane holds those three summed over its column for the entry of its 16-lane row, multiplies by THAT entry's
+// dx (dx_row) and step 3 sums the products over the columns:
+//   S hx = S_c dx (S_r q)   S hx dx = S_c dx dx (S_r q)   S hx dy = S_c dx (S_r q dy)   S hy = S_c S_r q dy   S hy dy = S_c S_r q dy dy
+// and S_c S_r q is dL/dopacity itself -- SIX values through the permlane steps instead of nine, two multiplications per entry
+// instead of six.
+__device__ __forceinline__ void reduce_quad_and_add(float pair[6], float quad[6], float dx_row, uint32_t rows,
                                                     bool is_row_end)
 {
-    float c[7], r[9];
-    swap16_add<7>(pair, quad, c);
-    r[0] = dx_row * c[0]; // S hx
+    float c[6], r[9];
+    swap16_add<6>(pair, quad, c);
+    r[0] = dx_row * c[0]; // S hx     (all five / opacity)
     r[1] = c[1];          // S hy
     r[2] = dx_row * r[0]; // S hx dx
     r[3] = dx_row * c[1]; // S hx dy
     r[4] = c[2];          // S hy dy
-    r[5] = c[3];
-    r[6] = c[4];
-    r[7] = c[5];
-    r[8] = c[6];
+    r[5] = c[0];          // dL/dopacity
+    r[6] = c[3];
+    r[7] = c[4];
+    r[8] = c[5];
     row_sum9_to_lane15(r);
     if (is_row_end) {
         // a raw ds_add_f32: hipcc's atomic optimiser would wrap a C++ atomicAdd in a per-lane scan loop
@@ -351,12 +353,13 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         // ---- walk them, four at a time (see the reduction notes above)
         {
             // the nine per-pixel terms of entry idx (an LDS row of this round, or the null entry)
-            // (h = G dL/dG; h dy; h dy dy; dL/dopacity; the three colour terms)
-            auto evaluate = [&](const uint32_t idx, float v[7], uint32_t& row) {
+            // (q = dL/dopacity = G dL/dalpha; q dy; q dy dy; the three colour terms.  G dL/dG = opacity x q: the entry-uniform
+            //  opacity joins the other entry-uniform factors at the flush)
+            auto evaluate = [&](const uint32_t idx, float v[6], uint32_t& row) {
                 const uint32_t pos = lo + idx; // 0-based list position (the null entry: >= hi, never below `last`)
                 LCGS_STAT(0, idx < 256u ? 1u : 0u);
 #if LCGS_BWD_KO == 2 // (measuring builds only: no evaluation -- the walk and the reduction alone)
-                for (int g = 0; g < 7; ++g) v[g] = pxf + (float)pos;
+                for (int g = 0; g < 6; ++g) v[g] = pxf + (float)pos;
                 row = grad_base + idx * 4u;
                 return;
 #endif
@@ -424,13 +427,12 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                 // the 0.99 cap passes no gradient to G / opacity
                 // (selected AFTER the product: on a lane that is not a candidate `power` lies outside blend_exp's
                 //  domain and G is arbitrary bits, possibly NaN -- it must not meet a multiplication by 0)
-                v[3] = (valid & (oG < 0.99f)) ? G * dL_dalpha : 0.0f; // dL/dopacity
-                v[0] = eb.y * v[3];           // h = G * dL/dG; the entry-uniform factors (conic, -1, -0.5) are applied once
-                v[1] = v[0] * dy;             // per entry when the round is flushed, dx behind the row sums (reduce_quad_and_add)
-                v[2] = v[1] * dy;
-                v[4] = wgt * dpr;
-                v[5] = wgt * dpg;
-                v[6] = wgt * dpb;
+                v[0] = (valid & (oG < 0.99f)) ? G * dL_dalpha : 0.0f; // q = dL/dopacity
+                v[1] = v[0] * dy;             // the entry-uniform factors (opacity, conic, -1, -0.5) are applied once per entry
+                v[2] = v[1] * dy;             // when the round is flushed, dx behind the row sums (reduce_quad_and_add)
+                v[3] = wgt * dpr;
+                v[4] = wgt * dpg;
+                v[5] = wgt * dpb;
                 row  = grad_base + idx * 4u;
             };
             uint32_t rows = grad_base;
@@ -443,7 +445,7 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                 const uint2    four = *reinterpret_cast<const uint2*>(&s_list[wave][i]);
                 const uint32_t p0   = (uint32_t)__builtin_amdgcn_readfirstlane((int)four.x);
                 const uint32_t p1   = (uint32_t)__builtin_amdgcn_readfirstlane((int)four.y);
-                float          A[7], B[7], pair[7], quad[7];
+                float          A[6], B[6], pair[6], quad[6];
                 uint32_t       row;
                 // the entry my 16-lane row will hold behind the two swaps, and its dx at my column
                 const uint32_t mine   = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(&s_list[wave][i]) + my_slot);
@@ -453,19 +455,19 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                 evaluate(p0 >> 16, B, row);
                 asm("v_writelane_b32 %0, %1, 47" : "+v"(rows) : "s"(row));
 #if LCGS_BWD_KO == 1
-                for (int g = 0; g < 7; ++g) sink += A[g] + B[g];
+                for (int g = 0; g < 6; ++g) sink += A[g] + B[g];
 #else
-                swap32_add<7>(A, B, pair);
+                swap32_add<6>(A, B, pair);
 #endif
                 evaluate(p1 & 0xFFFFu, A, row);
                 asm("v_writelane_b32 %0, %1, 31" : "+v"(rows) : "s"(row));
                 evaluate(p1 >> 16, B, row);
                 asm("v_writelane_b32 %0, %1, 63" : "+v"(rows) : "s"(row));
 #if LCGS_BWD_KO == 1
-                for (int g = 0; g < 7; ++g) sink += A[g] + B[g];
+                for (int g = 0; g < 6; ++g) sink += A[g] + B[g];
                 sink += __builtin_bit_cast(float, rows) + dx_row;
 #else
-                swap32_add<7>(A, B, quad);
+                swap32_add<6>(A, B, quad);
                 reduce_quad_and_add(pair, quad, dx_row, rows, is_row_end);
 #endif
             }
@@ -487,14 +489,19 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
             const uint32_t idx = cidx >> 4, g = cidx & 15u;
             const uint32_t v   = s_vid[idx];
             if (g < 9u && v != 0xFFFFFFFFu) {
-                // sums -> gradients: d/dmean = -(conic . (S hx, S hy)), d/dconic = (-1/2, -1, -1/2) (S hx dx, ...)
+                // sums -> gradients: d/dmean = -(conic . (S hx, S hy)), d/dconic = (-1/2, -1, -1/2) (S hx dx, ...), the five of them
+                // times the opacity (the sums were formed from q = h / opacity)
                 float s = s_grad[g][idx];
-                if (g < 2u) {
-                    const float4 ea = s_rows[0][idx];
-                    const float  ca = -2.0f * ea.z, cc = -2.0f * s_rows[1][idx].x, s0 = s_grad[0][idx], s1 = s_grad[1][idx];
-                    s = (g == 0u) ? -(ca * s0 + ea.w * s1) : -(cc * s1 + ea.w * s0);
-                } else if (g < 5u) {
-                    s *= (g == 3u) ? -1.0f : -0.5f;
+                if (g < 5u) {
+                    const float4 eb = s_rows[1][idx]; // -cc / 2, opacity, ..
+                    if (g < 2u) {
+                        const float4 ea = s_rows[0][idx];
+                        const float  ca = -2.0f * ea.z, cc = -2.0f * eb.x, s0 = s_grad[0][idx], s1 = s_grad[1][idx];
+                        s = (g == 0u) ? -(ca * s0 + ea.w * s1) : -(cc * s1 + ea.w * s0);
+                    } else {
+                        s *= (g == 3u) ? -1.0f : -0.5f;
+                    }
+                    s *= eb.y;
                 }
                 if (s != 0.0f) atomicAdd(&grads2d[(size_t)v * kG2D + g], s);
             }
