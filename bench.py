@@ -575,7 +575,7 @@ def leg_gradients(S):
                     "unit": "GB/s", "frac": round(rb_gbs / HBM_PEAK_GBS, 4), "traffic": rb_traffic,
                     "algorithmic_bytes_per_launch": rb_bytes, "avg_launch_ms": round(rb_ms, 4), "valu_issue": rb_valu,
                     "kernel_sources_sha256": src_hash,
-                    "note": "the step's dominant kernel: VALU-issue-bound (nine 64-lane reductions per list entry and strip); "
+                    "note": "the step's dominant kernel: VALU-issue-bound (per-pixel terms and nine 64-lane sums per list entry and strip); "
                             "`frac` is its HBM fraction, valu_issue.frac the measured share of SIMD cycles issuing VALU work"}
             if dist is not None:
                 out["fwd_bwd"]["note"] = ("gradient collective: lcgs_grads_allreduce (RCCL, chunked behind the backward's "
