@@ -12,6 +12,8 @@
 #include <vector>
 
 #include "abi_internal.hpp"
+#include <atomic>
+#include <chrono>
 
 using namespace lcgs;
 using namespace lcgs::abi;
@@ -233,12 +235,46 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
     LCGS_TRY(ctx->st_scan_temp.ensure(scan_temp_bytes(P)));
     launch_inclusive_sum_u32(accel->tiles_touched, accel->point_offsets, P, ctx->st_scan_temp.ptr, st); // impl.cpp:104
     // (the compaction's scan launch also carries num_rendered = point_offsets[P - 1] (impl.cpp:106) next to the two scalars)
-    launch_compact_flags(d_flags, P, ctx->st_u32[0].as<uint32_t>(), d_vis, d_nvis, st, accel->point_offsets + (P - 1), d_hole + 2);
-    // the frame's one read-back (impl.cpp:106-107): num_rendered beside the two scalars of this implementation, as ONE copy
-    // into pinned memory (three 4-byte copies into pageable words left the GPU idle for ~80 us per frame)
-    if (!ctx->h_stage) LCGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), 16, hipHostMallocDefault));
-    LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_stage, d_hole, 12, hipMemcpyDeviceToHost, st));
-    LCGS_HIP_CHECK(hipStreamSynchronize(st));                                                        // impl.cpp:107
+    // the frame's one read-back (impl.cpp:106-107): num_rendered beside the two scalars of this implementation.  The
+    // compaction's one-workgroup scan launch POSTS the three words and the frame's serial to pinned host memory and this thread
+    // polls the serial: no copy launch, no stream synchronisation (whose wake-up alone costs tens of microseconds), and the
+    // host's next launches overlap the scatter launch still running behind the scan.  (Round 4: one 12-byte copy + a
+    // synchronisation; before that three 4-byte copies into pageable words, ~80 us of idle GPU per frame.)
+    if (!ctx->h_stage) {
+        LCGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), 16, hipHostMallocDefault));
+        memset(ctx->h_stage, 0, 16);
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->h_stage_dev), ctx->h_stage, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->h_stage_dev = nullptr;
+        }
+    }
+    uint32_t* box = ctx->stage_mailbox ? ctx->h_stage_dev : nullptr;
+    launch_compact_flags(d_flags, P, ctx->st_u32[0].as<uint32_t>(), d_vis, d_nvis, st, accel->point_offsets + (P - 1), d_hole + 2,
+                         d_hole, box, hole_mark);
+    bool posted = false;
+    if (box) {
+        LCGS_HIP_CHECK(hipGetLastError());
+        volatile uint32_t* hs = ctx->h_stage;
+        // (bounded: a launch that failed never posts -- after ~2 s, or at the first error the stream reports, fall back to the
+        //  synchronising read-back, which returns that error)
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0;; ++spins) {
+            if (hs[3] == hole_mark) {
+                posted = true;
+                break;
+            }
+            if ((spins & 0xFFFFu) == 0xFFFFu) {
+                if (hipStreamQuery(st) != hipErrorNotReady) break; // finished (posted by now, re-checked below) or failed
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+            }
+        }
+        if (!posted && hs[3] == hole_mark) posted = true;
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!posted) {
+        LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_stage, d_hole, 12, hipMemcpyDeviceToHost, st));
+        LCGS_HIP_CHECK(hipStreamSynchronize(st));                                                    // impl.cpp:107
+    }
     const uint32_t hole = ctx->h_stage[0] == hole_mark ? 1u : 0u, n_vis = ctx->h_stage[1];
     const int32_t  L    = (int32_t)ctx->h_stage[2];
     if (num_rendered) *num_rendered = L;

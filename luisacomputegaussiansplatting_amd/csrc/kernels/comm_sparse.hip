@@ -58,8 +58,12 @@ __global__ void __launch_bounds__(256) k_flag_count(const uint8_t* __restrict__ 
 
 // one workgroup: exclusive scan of the chunk counts (in place) and the total
 // (copy_src / copy_dst, nullable: one more word carried along -- a caller that reads *d_total back with another scalar saves a copy launch)
+// (host_box, nullable: host-visible pinned words.  Three scalars -- *box_word0, the total, the copied word -- are
+//  posted there (word 0 = *box_word0, a scalar of the caller's) followed by `serial`, so that a host thread polling host_box[3] has them without a copy launch and a stream
+//  synchronisation, and while the scatter launch behind this one is still running)
 __global__ void __launch_bounds__(1024) k_flag_scan(uint32_t* __restrict__ chunk_count, uint32_t chunks, uint32_t* __restrict__ d_total,
-                                                    const uint32_t* __restrict__ copy_src, uint32_t* __restrict__ copy_dst)
+                                                    const uint32_t* __restrict__ copy_src, uint32_t* __restrict__ copy_dst,
+                                                    const uint32_t* box_word0, volatile uint32_t* host_box, uint32_t serial)
 {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
@@ -85,7 +89,17 @@ __global__ void __launch_bounds__(1024) k_flag_scan(uint32_t* __restrict__ chunk
         __syncthreads();
     }
     if (tid == 0) *d_total = s_carry;
-    if (tid == 64u && copy_dst) *copy_dst = *copy_src;
+    if (tid == 64u && copy_dst) {
+        const uint32_t carried = *copy_src;
+        *copy_dst              = carried;
+        if (host_box) {
+            host_box[0] = *box_word0;
+            host_box[1] = s_carry;
+            host_box[2] = carried;
+            __threadfence_system();
+            host_box[3] = serial;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) k_flag_scatter(const uint8_t* __restrict__ flags, uint32_t P,
@@ -193,16 +207,19 @@ void launch_mark_rows(const uint32_t* vis_index, const uint32_t* d_counts, uint8
 
 // flags (sparse_flag_bytes(P), zero beyond P) -> rows[0 .. *d_total) ascending; chunk_ws: sparse_flag_chunks(P) x u32
 void launch_compact_flags(const uint8_t* flags, int64_t P, uint32_t* chunk_ws, uint32_t* rows, uint32_t* d_total,
-                          hipStream_t stream, const uint32_t* copy_src, uint32_t* copy_dst)
+                          hipStream_t stream, const uint32_t* copy_src, uint32_t* copy_dst, const uint32_t* box_word0,
+                          uint32_t* host_box, uint32_t serial)
 {
     const uint32_t chunks = sparse_flag_chunks(P);
     if (chunks == 0) {
         (void)hipMemsetAsync(d_total, 0, 4, stream);
         if (copy_dst) (void)hipMemcpyAsync(copy_dst, copy_src, 4, hipMemcpyDeviceToDevice, stream);
+        (void)host_box; // (P == 0 never comes with a host box: the caller reads the scalars back itself)
         return;
     }
     hipLaunchKernelGGL(k_flag_count, dim3(chunks), dim3(256), 0, stream, flags, (uint32_t)P, chunk_ws);
-    hipLaunchKernelGGL(k_flag_scan, dim3(1), dim3(1024), 0, stream, chunk_ws, chunks, d_total, copy_src, copy_dst);
+    hipLaunchKernelGGL(k_flag_scan, dim3(1), dim3(1024), 0, stream, chunk_ws, chunks, d_total, copy_src, copy_dst,
+                       box_word0, (volatile uint32_t*)host_box, serial);
     hipLaunchKernelGGL(k_flag_scatter, dim3(chunks), dim3(256), 0, stream, flags, (uint32_t)P, chunk_ws, rows);
 }
 

@@ -248,7 +248,8 @@ uint32_t sparse_flag_chunks(int64_t P);
 void     launch_mark_rows(const uint32_t* vis_index, const uint32_t* d_counts, uint8_t* flags, int64_t P, int64_t hint_V,
                           hipStream_t stream);
 void     launch_compact_flags(const uint8_t* flags, int64_t P, uint32_t* chunk_ws, uint32_t* rows, uint32_t* d_total,
-                              hipStream_t stream, const uint32_t* copy_src = nullptr, uint32_t* copy_dst = nullptr);
+                              hipStream_t stream, const uint32_t* copy_src = nullptr, uint32_t* copy_dst = nullptr,
+                              const uint32_t* box_word0 = nullptr, uint32_t* host_box = nullptr, uint32_t serial = 0);
 void     launch_owner_bounds(const uint32_t* rows, const uint32_t* d_total, int64_t shard, int world, uint32_t* d_bounds,
                              hipStream_t stream);
 int64_t  sparse_message_words(int64_t count, int sh_degree);

@@ -63,6 +63,63 @@ __global__ void __launch_bounds__(kThreads) k_sh_process(int P, int deg, CamPara
     for (int c = 0; c < 3; ++c) color[3 * (size_t)idx + c] = clamp_(raw[c], 0.0f, 1.0f); // :153
 }
 
+// The same for degree 3 with 16-byte-aligned coefficient rows -- the only shape the reference's app produces -- as a STREAMING
+// kernel: a bounded grid of waves, each walking slabs of 64 consecutive splats (12 KiB of coefficients) with a fixed stride and
+// issuing the NEXT slab's twelve 16-byte loads (and its positions) before it evaluates the current one from LDS, so that every
+// wave always has a slab in flight.  (The one-slab-per-wave form above leaves a wave's memory pipe empty while it computes and
+// stores: 5.1 TB/s over the 1.33 GB of this pass on the bicycle stand-in; this form: see profiles/r05_sh_stream_ab.txt.)
+__global__ void __launch_bounds__(kThreads) k_sh_process_stream(int P, CamParams cp, const float* __restrict__ pos,
+                                                                  const float* __restrict__ sh, float* __restrict__ color)
+{
+    __shared__ float4 s_sh[kThreads / 64][64 * 13];
+    const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t slabs  = ((int64_t)P + 63) / 64;
+    const int64_t stride = (int64_t)gridDim.x * (kThreads / 64);
+    int64_t       slab   = (int64_t)blockIdx.x * (kThreads / 64) + wave;
+    float4        q[12];
+    float         px = 0.0f, py = 0.0f, pz = 0.0f;
+    auto          fetch = [&](int64_t sl) {
+        const int64_t first = sl * 64;
+        const int64_t rows  = P - first < 64 ? P - first : 64;
+        const float4* src   = reinterpret_cast<const float4*>(sh + (size_t)first * 48);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int c = i * 64 + lane; // chunk c of the slab = row c / 12, part c % 12
+            q[i]        = c < rows * 12 ? ld_stream(src + c) : make_float4(0, 0, 0, 0);
+        }
+        if (lane < rows) {
+            px = pos[3 * (size_t)(first + lane) + 0];
+            py = pos[3 * (size_t)(first + lane) + 1];
+            pz = pos[3 * (size_t)(first + lane) + 2];
+        }
+    };
+    if (slab < slabs) fetch(slab);
+    while (slab < slabs) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int c = i * 64 + lane;
+            s_sh[wave][(c / 12) * 13 + (c % 12)] = q[i];
+        }
+        const float   cx = px, cy = py, cz = pz;
+        const int64_t idx = slab * 64 + lane;
+        __builtin_amdgcn_wave_barrier(); // a wave reads only what it wrote
+        const int64_t next = slab + stride;
+        if (next < slabs) fetch(next); // in flight while this slab is evaluated
+        if (idx < P) {
+            float4 r[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) r[k] = s_sh[wave][lane * 13 + k];
+            const float* f = reinterpret_cast<const float*>(r);
+            float        raw[3];
+            sh_to_color(3, cp.campos, cx, cy, cz, [&](int k, int c) { return f[k * 3 + c]; }, raw);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) color[3 * (size_t)idx + c] = clamp_(raw[c], 0.0f, 1.0f); // :153
+        }
+        __builtin_amdgcn_wave_barrier(); // the slab's reads are done before the next one's writes
+        slab = next;
+    }
+}
+
 // shad_project_gs_focal / shad_project_gs (lcgs/src/gs_projector/shader.cpp:82-139 / :20-80)
 __global__ void __launch_bounds__(kThreads) k_project(int P, CamParams cp, bool use_focal,
                                                         const float* __restrict__ pos, const float* __restrict__ scale,
@@ -311,6 +368,14 @@ void launch_sh_process(int P, int deg, const CamParams& cp, const float* pos, co
                        hipStream_t stream)
 {
     if (P <= 0) return;
+    static const bool stream_form = [] { const char* e = getenv("LCGS_STAGE_SH_STREAM"); return !e || e[0] != '0'; }(); // A/B hook
+    if (stream_form && deg == 3 && (reinterpret_cast<uintptr_t>(sh) & 15) == 0 && P >= (1 << 16)) {
+        // three workgroups per CU is what the 52 KB LDS slab allows; every wave then walks ~ P / 64 / (3072) slabs
+        static const int cus = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+        const int grid = std::min<int64_t>(blocks_for(P), (int64_t)cus * 3);
+        hipLaunchKernelGGL(k_sh_process_stream, dim3(grid), dim3(kThreads), 0, stream, P, cp, pos, sh, color);
+        return;
+    }
     hipLaunchKernelGGL(k_sh_process, dim3(blocks_for(P)), dim3(kThreads), 0, stream, P, deg, cp, pos, sh, color);
 }
 
