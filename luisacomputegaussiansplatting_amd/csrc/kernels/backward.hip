@@ -6,12 +6,13 @@
 //
 //   k_render_backward      one workgroup per tile, wave k = 16x4 strip k, one pixel per lane (same geometry as the
 //                          forward renderer).  The tile list is walked BACK TO FRONT in rounds of 256 entries; per
-//                          entry a wave derives the per-pixel gradients w.r.t. {pixel mean, conic, opacity, rgb},
-//                          reduces them over its 64 lanes with DPP row shifts/broadcasts (no LDS traffic), and adds the
-//                          9 sums to a per-round LDS accumulator; after the round one lane per entry flushes the
+//                          round a wave lists the entries the forward BLENDED in its strip and walks that list four
+//                          entries at a time with no data-dependent branch: six per-pixel terms per entry (the sums'
+//                          algebra: see reduce_quad_and_add) go through two permlane-swap folds, become the nine sums
+//                          w.r.t. {pixel mean, conic, opacity, rgb} behind them, are finished with DPP row shifts and
+//                          added to a per-round LDS accumulator; after the round 16 lanes per entry flush the
 //                          workgroup's totals with global float atomics -- 9 atomics per (tile, splat) instead of per
-//                          (pixel, splat).  Global float atomics run at ~1.3 TB/s of added bytes chip-wide
-//                          (MI355X_MICROARCH "Global float atomics"); at ~6.5 M pairs x 36 B this is ~0.2 ms.
+//                          (pixel, splat).  VALU-bound: DESIGN.md 5, profiles/r05_bwd_list_walk_ab.txt.
 //   k_preprocess_backward  one lane per surviving splat: 2-D gradients -> dL/d{pos, scale, rotq, sh, opacity};
 //                          the 192-byte SH gradient rows leave through LDS as coalesced 16-byte stores.
 // Thresholds are constants for the derivative: near cull, alpha < 1/255 skip, T < 1e-4 stop and power > 0 gate the
@@ -29,15 +30,15 @@ using namespace tile; // tile_of_workgroup / render_grid_size / splat_strip_mask
 
 // ---------------------------------------------------------------------------------------------------------------
 // Wave reduction of the per-pixel gradient terms, four list entries at a time.
-// Every entry yields nine per-lane values that must be summed over the 64 pixels of the strip.  Reducing each entry
-// on its own costs 9 x 6 cross-lane adds; instead the sums of FOUR entries (A, B, C, D) are folded together so that
+// Every entry yields per-lane values that must be summed over the 64 pixels of the strip.  Reducing each entry on its
+// own costs 6 cross-lane adds per value; instead the sums of FOUR entries (A, B, C, D) are folded together so that
 // each cross-lane step works on registers that are full of useful data (costs from tools/microbench/issue_rates):
 //   1. v_permlane32_swap + add on (A, B): lanes 0-31 now hold A summed over lane pairs (l, l+32), lanes 32-63 hold B;
-//      the same on (C, D)                                                   2 x 9 x (8.1 + 2.3) cycles
-//   2. v_permlane16_swap + add on (AB, CD): the four 16-lane rows hold A, C, B, D, each summed over rows   9 x 10.4
-//   3. four DPP row-shift adds: lane 15 of every row holds that entry's total                               36 x 4.2
-// = 112 issue cycles per entry instead of 224, and one LDS add instruction per value and FOUR entries (lanes 15, 31,
-// 47 and 63, each to its own entry's accumulator row) instead of one per value and entry.
+//      the same on (C, D)                                                   2 x N x (8.1 + 2.3) cycles
+//   2. v_permlane16_swap + add on (AB, CD): the four 16-lane rows hold A, C, B, D, each summed over rows   N x 10.4
+//   3. four DPP row-shift adds: lane 15 of every row holds that entry's total                               9 x 4 x 4.2
+// and one LDS add instruction per value and FOUR entries (lanes 15, 31, 47 and 63, each to its own entry's accumulator
+// row) instead of one per value and entry.  N = 6 values go through steps 1-2, nine through step 3 (reduce_quad_and_add).
 // ---------------------------------------------------------------------------------------------------------------
 // (inline asm rather than __builtin_amdgcn_permlane32_swap: the builtin returns fresh values, and the compiler copies
 // both operands first -- two extra moves per swap; x and y are dead after the call, the swap may clobber them.  The
@@ -172,7 +173,8 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
     // (row kNullEntry of every slab is the null entry that pads a strip's list to a multiple of four: opacity 0, blends nowhere;
     //  its accumulator column is never read)
     __shared__ float4             s_rows[3][kRows];
-    __shared__ uint32_t           s_vid[256];
+    __shared__ uint2              s_flush[256]; // the round's entries that reach a strip at all, compacted: (LDS row, splat)
+    __shared__ uint32_t           s_fcnt[4];    // ... how many of them each staging wave holds
     __shared__ float              s_grad[9][kRows];
     __shared__ __attribute__((aligned(8))) uint16_t s_list[4][kListStride]; // [strip]: the round's entries to walk, back to front
     __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
@@ -192,7 +194,7 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
 #endif
   for (;;) { // (one pass unless PERSIST)
     if (PERSIST) {
-        __syncthreads(); // the previous tile's last flush has read s_vid / s_grad; nobody still reads s_slot
+        __syncthreads(); // the previous tile's last flush has read s_flush / s_grad; nobody still reads s_slot
         if (tid == 0) s_slot = atomicAdd(work_counter, 1u);
         __syncthreads();
         slot = s_slot;
@@ -323,10 +325,24 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         s_rows[0][tid] = make_float4(a.x, a.y, -0.5f * a.z, a.w);
         s_rows[1][tid] = make_float4(-0.5f * b.x, b.y, b.z, b.w);
         *reinterpret_cast<float2*>(&s_rows[2][tid]) = make_float2(c, fmax_(-0.5f * t, kBlendExpMin));
-        s_vid[tid] = (have && kmask != 0u) ? vid : 0xFFFFFFFFu; // (read by the flush only)
+        const unsigned long long fm = __ballot(have && kmask != 0u); // entries with something to flush
+        if (lane == 0) s_fcnt[wave] = (uint32_t)__popcll(fm);
 #pragma unroll
         for (int g = 0; g < 9; ++g) s_grad[g][tid] = 0.0f;
         __syncthreads();
+
+        // ---- the flush list: the entries some strip will add to, compacted (a round holds ~150 of 256 on the bench frames, and
+        // the flush spends 16 lanes on each)
+        uint32_t n_flush;
+        {
+            const uint32_t c0 = s_fcnt[0], c1 = s_fcnt[1], c2 = s_fcnt[2], c3 = s_fcnt[3];
+            const uint32_t before = (wave > 0u ? c0 : 0u) + (wave > 1u ? c1 : 0u) + (wave > 2u ? c2 : 0u);
+            n_flush               = c0 + c1 + c2 + c3;
+            if (have && kmask != 0u) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                s_flush[before + rank] = make_uint2(tid, vid);
+            }
+        }
 
         // ---- this strip's entries of the round as a list, back to front: the four ballots' set bits, highest first, padded to
         // a multiple of four with the null entry.  The walk below then has no data-dependent branch at all: one 8-byte LDS
@@ -484,11 +500,11 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
 #if LCGS_BWD_KO == 3 // (measuring builds only: no flush)
         if (lo == 0xFFFFFFFFu)
 #endif
-#pragma unroll 4
-        for (uint32_t cidx = tid; cidx < 256u * 16u; cidx += 256u) {
-            const uint32_t idx = cidx >> 4, g = cidx & 15u;
-            const uint32_t v   = s_vid[idx];
-            if (g < 9u && v != 0xFFFFFFFFu) {
+        for (uint32_t cidx = tid; cidx < n_flush * 16u; cidx += 256u) {
+            const uint32_t g   = cidx & 15u;
+            const uint2    fe  = s_flush[cidx >> 4];
+            const uint32_t idx = fe.x, v = fe.y;
+            if (g < 9u) {
                 // sums -> gradients: d/dmean = -(conic . (S hx, S hy)), d/dconic = (-1/2, -1, -1/2) (S hx dx, ...), the five of them
                 // times the opacity (the sums were formed from q = h / opacity)
                 float s = s_grad[g][idx];
