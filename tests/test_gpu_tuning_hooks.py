@@ -29,3 +29,13 @@ def test_parity_suites_under_tuning_hook(hook):
     res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + FILES,
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+# The stage path's A/B hooks of round 5: the splatter's scalars by copy + synchronisation instead of the posted mailbox, the
+# one-slab-per-wave SH kernel instead of the streaming one.  Both routes must produce the reference's buffers entry for entry.
+@pytest.mark.parametrize("hook", [{"LCGS_STAGE_MAILBOX": "0"}, {"LCGS_STAGE_SH_STREAM": "0"}], ids=["sync-readback", "sh-one-slab"])
+def test_stage_suite_under_stage_hooks(hook):
+    env = dict(os.environ, **hook)
+    res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          "tests/test_gpu_stages.py"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
