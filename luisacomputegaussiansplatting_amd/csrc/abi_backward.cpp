@@ -179,7 +179,7 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
     launch_render_backward(ctx->last.cp, ctx->last.bg, ctx->ranges, ctx->pairv[ctx->last.list_buf].as<uint32_t>(),
                            ctx->recs.as<SplatRecord>(), ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(),
                            d_dL_dimg, ctx->grads2d.as<float>(), ctx->last_tile_order, st,
-                           render_forward_writes_strip_masks() ? ctx->strip_masks.as<uint8_t>() : nullptr,
+                           render_forward_writes_strip_masks() && ctx->bwd_use_masks ? ctx->strip_masks.as<uint8_t>() : nullptr,
                            ctx->counts.as<uint32_t>(), ctx->bwd_counter.as<uint32_t>(), bwd_wgs, fill_in_kernel ? &fill : nullptr);
     LCGS_TRY(mark(ctx, "render_backward"));
     if (overlap) LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));

@@ -263,6 +263,7 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
                 posted = true;
                 break;
             }
+            __builtin_ia32_pause();
             if ((spins & 0xFFFFu) == 0xFFFFu) {
                 if (hipStreamQuery(st) != hipErrorNotReady) break; // finished (posted by now, re-checked below) or failed
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;

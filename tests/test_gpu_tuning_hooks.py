@@ -39,3 +39,13 @@ def test_stage_suite_under_stage_hooks(hook):
     res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                           "tests/test_gpu_stages.py"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+# The render-backward's other instantiation: no kept strip bits (the launcher's form for a caller without them), the strip tests
+# repeated in the kernel, every reachable entry walked.  Same gradients within the suite's tolerances.
+def test_backward_suite_without_kept_masks():
+    env = dict(os.environ, LCGS_BWD_USE_MASKS="0")
+    res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          "tests/test_gpu_backward.py", "tests/test_gpu_random_sweep.py"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=1200)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
