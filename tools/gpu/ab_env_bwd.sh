@@ -1,9 +1,8 @@
-# A/B of tuning hooks (environment variables) on the forward+backward step, one library, one box:
-#   gpurun -- bash tools/gpu/ab_env_bwd.sh "LCGS_X=0" "LCGS_X=1" ...
+# A/B of environment hooks on the backward legs: gpurun -- bash tools/gpu/ab_env_bwd.sh "A=1" "B=2" ...
 cd $GRAFT_REPO_ROOT
-B="python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-train-step --no-stage-path --no-spatial --no-batch --no-moving-camera"
-for rep in 1 2; do for v in "$@"; do
-env $v timeout 200 $B 2>/dev/null | python -c "
+for rep in 1 2 3; do for v in "$@"; do
+env $v timeout 200 python bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-stage-path --no-batch 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); f=d['fwd_bwd']; print('$v', 'fwd', d['value'], 'fwd_bwd', f['value'], f['ms_per_step'], 'compact', f['compact_rows']['value'])"
+d=json.loads(sys.stdin.readline()); fb=d['fwd_bwd']; ts=d.get('train_step',{}); fo=d.get('file_order',{})
+print('$v fwd', d['value'], 'fwd_bwd', fb['value'], fb['ms_per_step'], 'compact', fb.get('compact_rows',{}).get('value'), 'moving', fb.get('moving_camera',{}).get('value'), 'fit4', fb.get('multi_view_step_4',{}).get('lcgs_fit_views',{}).get('value'), 'file_order', fo.get('fwd_bwd',{}).get('value'), 'train', ts.get('dense',{}).get('value'), ts.get('visible_only',{}).get('value'), flush=True)"
 done; done
