@@ -197,11 +197,16 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
 
         if (alive) {
             for (uint32_t w = 0; w < 4u && alive; ++w) {
-                unsigned long long bm = 0ull; // (scalar) entries of staging wave w that this strip blended
                 unsigned long long m  = s_mask[w][wave];
                 // readfirstlane returns int: cast through uint32_t so the low half is not sign-extended
                 m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) |
                     (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+                // KEEP: (scalar) the entries of staging wave w that pass this strip's wave-level candidate test -- on the bench
+                // frames 99.99 % of them are blended by some pixel (4 195 020 against 4 194 674 pairs, profiles/r05_bwd_walk_stats.txt),
+                // and ONE scalar instruction per passing entry replaces the four that an exact "some pixel took it into its sum" bit
+                // cost (the backward only needs a superset).  (On the passing path only: an instruction on the `continue` path
+                // makes the compiler merge the two paths through seven register copies per entry.)
+                unsigned long long bm = 0ull;
                 while (m != 0ull) { // scalar loop control
                     const uint32_t l   = (uint32_t)__ffsll((long long)m) - 1u;
                     asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(l)); // one scalar op instead of add/addc/and
@@ -234,6 +239,7 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     const unsigned long long cmask =
                         __builtin_amdgcn_ballot_w64(!(power > 0.0f)) & __builtin_amdgcn_ballot_w64(power >= eb.y);
                     if (cmask == 0ull) continue; // scalar test of the lane mask
+                    if (KEEP) asm("s_bitset1_b64 %0, %1" : "+s"(bm) : "s"(l));
                     const float4 ec    = *reinterpret_cast<const float4*>(rows + 8192); // one 16-byte read for the survivors
                     // (alpha is never NaN on a candidate lane, so the hardware minimum equals min(0.99, x); on a lane where
                     //  it does not hold, power may lie outside blend_exp's domain and alpha is arbitrary bits -- masked)
@@ -249,18 +255,6 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     const unsigned long long satm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & vmask;
                     // KEEP: the pixels that take this entry into their sum (blend it and do not saturate on it)
                     const unsigned long long live = vmask & ~satm;
-                    if (KEEP) {
-                        // bm |= (live != 0) << l, on the SCALAR side (left to the compiler the mask moves into vector registers:
-                        // seven vector instructions per blended entry)
-                        unsigned long long t_;
-                        asm volatile("s_cmp_lg_u64 %[live], 0\n\t"
-                                     "s_cselect_b64 %[t], 1, 0\n\t"
-                                     "s_lshl_b64 %[t], %[t], %[l]\n\t"
-                                     "s_or_b64 %[bm], %[bm], %[t]"
-                                     : [bm] "+s"(bm), [t] "=&s"(t_)
-                                     : [live] "s"(live), [l] "s"(l)
-                                     : "scc");
-                    }
                     if (satm != 0ull) { // rare: some pixel of the strip just saturated
                         const bool sat = (satm & lane_bit) != 0ull;
                         wgt   = sat ? 0.0f : wgt; // shader.cpp:268-272: the saturating entry is not blended
@@ -271,11 +265,13 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                             m     = 0ull;
                         }
                     }
-                    if (KEEP) { // the same block + the position of the pixel's last contributor (1-based), under `live`
+                    if (KEEP) { // the same block + the position of the pixel's last contributor (1-based), all of it under `live`:
+                        // a pixel that saturates on this entry sits it out altogether (its weight was zeroed above anyway), so ONE
+                        // exec region serves the sums and the position (two regions cost 6 us of the 0.24 ms)
                         float              t0, t1, t2;
                         unsigned long long sv;
                         const uint32_t     lc = base - range_start + idx + 1u;
-                        asm volatile("s_and_saveexec_b64 %[sv], %[vm]\n\t"
+                        asm volatile("s_and_saveexec_b64 %[sv], %[lv]\n\t"
                                      "v_mul_f32 %[t0], %[w], %[cr]\n\t"
                                      "v_mul_f32 %[t1], %[w], %[cg]\n\t"
                                      "v_mul_f32 %[t2], %[w], %[cb]\n\t"
@@ -283,13 +279,12 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                                      "v_add_f32 %[Cg], %[Cg], %[t1]\n\t"
                                      "v_add_f32 %[Cb], %[Cb], %[t2]\n\t"
                                      "v_mov_b32 %[T], %[nT]\n\t"
-                                     "s_and_b64 exec, %[sv], %[lv]\n\t"
                                      "v_mov_b32 %[lcv], %[lc]\n\t"
                                      "s_mov_b64 exec, %[sv]"
                                      : [Cr] "+v"(Cr), [Cg] "+v"(Cgb.x), [Cb] "+v"(Cgb.y), [T] "+v"(T), [t0] "=&v"(t0),
                                        [t1] "=&v"(t1), [t2] "=&v"(t2), [sv] "=&s"(sv), [lcv] "+v"(last_contrib)
                                      : [w] "v"(wgt), [cr] "v"(ec.y), [cg] "v"(ec.z), [cb] "v"(ec.w), [nT] "v"(nT),
-                                       [vm] "s"(vmask), [lv] "s"(live), [lc] "s"(lc)
+                                       [lv] "s"(live), [lc] "s"(lc)
                                      : "scc");
                     } else {
                         float              t0, t1, t2;
