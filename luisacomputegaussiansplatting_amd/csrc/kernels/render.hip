@@ -92,8 +92,9 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
     // test needs);  [2]: opacity, r, g, b (read only by entries that pass it)
     __shared__ float4             s_rows[3][256];
     __shared__ unsigned long long s_mask[4][4]; // [staging wave][strip]
-    // KEEP: [strip][staging wave] the entries of the round that some pixel of the strip actually BLENDED -- what the backward has to
-    // walk (the reach test above is conservative, and pixels finish: a quarter of the masks' set bits blend nothing)
+    // KEEP: [strip][staging wave] the entries of the round that passed the strip's wave-level candidate test while it was walked --
+    // what the backward has to walk (the reach test at staging is conservative, and pixels finish: a quarter of the masks' set bits
+    // blend nothing; of the entries that pass the candidate test 99.99 % are blended by some pixel)
     __shared__ unsigned long long s_blend[4][4];
     __shared__ uint32_t           s_live_waves;
     __shared__ uint32_t           s_slot;
@@ -219,19 +220,14 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                     const float4   ea = *reinterpret_cast<const float4*>(rows);
                     const float2   eb = *reinterpret_cast<const float2*>(rows + 4096);
                     // power = -0.5 (ca dx dx + cc dy dy) - cb dx dy, products left to right (shader.cpp:256)
-                    // (plain, not packed, arithmetic: on gfx950 a packed op costs two plain ones AND drags a wait state
-                    // behind it -- tools/microbench/issue_rates.hip; the empty asms stop the vectoriser from pairing
-                    // the operations up again.  Renderer 0.227 -> 0.221 ms in same-box A/B runs, same bits.)
+                    // (plain, not packed, arithmetic: on gfx950 a packed op costs two plain ones AND drags a wait state behind it
+                    //  -- tools/microbench/issue_rates.hip; the library is built with -fno-slp-vectorize for that reason)
                     float dx = ea.x - pxy.x, dy = ea.y - pxy.y;
-                    asm volatile("" : "+v"(dx), "+v"(dy));
                     // ea.z / ea.w hold -0.5 ca / -0.5 cc (scaled by a power of two when staged: the same bits as scaling
                     // the sum afterwards, one multiplication fewer per entry and strip)
                     float qx = (ea.z * dx) * dx, cross = eb.x * dx;
-                    asm volatile("" : "+v"(qx), "+v"(cross));
                     float qy = (ea.w * dy) * dy;
-                    asm volatile("" : "+v"(qy));
                     float half = qx + qy;
-                    asm volatile("" : "+v"(half));
                     const float power = half - cross * dy;
                     // candidate lanes: !(power > 0) and power >= the staged floor --
                     // (lane masks from ballots of plain compares, combined with scalar ANDs: a ballot of a compound
@@ -312,8 +308,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         __syncthreads();
         if (KEEP && strip_masks && have) {
             // The backward walks the same list positions through these masks (it need not repeat the strip tests) -- and only
-            // the entries a strip BLENDED: bit k = strip k took this entry into at least one pixel's sum.  Entries that merely
-            // could reach a strip contribute exact zeros to every gradient; a quarter of the backward's walks were those.
+            // the entries a strip's pixels could blend when it walked them: bit k = the entry passed strip k's candidate test.  Entries
+            // that merely could reach a strip contribute exact zeros to every gradient; a quarter of the backward's walks were those.
             uint32_t kref = 0u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) kref |= (uint32_t)((s_blend[k][wave] >> lane) & 1ull) << k;
