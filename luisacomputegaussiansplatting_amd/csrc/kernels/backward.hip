@@ -4,7 +4,8 @@
 // render.hip / gs_math.hpp (= gs_tile_splatter/shader.cpp:171-288, gs_projector/shader.cpp:82-158,
 // sh_preprocessor.cpp:27-157); the specification is DESIGN.md "Backward" (SURVEY Appendix B).
 //
-//   k_render_backward      one workgroup per tile, wave k = 16x4 strip k, one pixel per lane (same geometry as the
+//   k_render_backward      one workgroup per tile, wave k = "strip" k (the tile's 8x8 quadrant k, 16x4 strip k until round 5;
+//                          unit_px / unit_py in tile_common.hpp), one pixel per lane (same geometry as the
 //                          forward renderer).  The tile list is walked BACK TO FRONT in rounds of 256 entries; per
 //                          round a wave lists the entries the forward BLENDED in its strip and walks that list four
 //                          entries at a time with no data-dependent branch: six per-pixel terms per entry (the sums'
@@ -243,8 +244,8 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
         return;
     }
     const uint32_t tile = ty * cp.grid_x + tx;
-    const uint32_t px = tx * kBlockX + (lane & 15u);
-    const uint32_t py = ty * kBlockY + 4u * wave + (lane >> 4);
+    const uint32_t px = unit_px(tx, wave, lane);
+    const uint32_t py = unit_py(ty, wave, lane);
     const float    pxf = (float)px, pyf = (float)py;
     const bool     inside = (px < cp.width) && (py < cp.height);
     const size_t   hw  = (size_t)cp.width * cp.height;
@@ -310,7 +311,7 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
             }
             if (!KNOWN) {
                 const float rx0 = (float)(tx * kBlockX), ry0 = (float)(ty * kBlockY), rx1 = rx0 + (float)(kBlockX - 1);
-                kmask = splat_strip_mask(a.x, a.y, a.z, a.w, b.x, t, rx0, ry0, rx1);
+                kmask = splat_unit_mask(a.x, a.y, a.z, a.w, b.x, t, rx0, ry0, rx1);
             }
         }
         __syncthreads(); // previous round fully flushed

@@ -2,8 +2,9 @@
 // (m_forward_render_shader, lcgs/src/gs_tile_splatter/shader.cpp:171-288).
 //
 // CDNA4 shape (not the reference's 256-thread block in which every thread walks every entry):
-//   * k_render_forward_b (the renderer in use): one workgroup of four wave64s per 16x16 tile, wave k owns the 16x4
-//     pixel strip k, one pixel per lane.  A round stages 256 list entries: lane l gathers entry l's 36-byte record
+//   * k_render_forward_b (the renderer in use): one workgroup of four wave64s per 16x16 tile, wave k owns the 8x8
+//     pixel quadrant k, one pixel per lane (rounds 1-5a: the 16x4 strip k -- "strip" in names and comments below means a
+//     wave's 64 pixels; a compact unit meets ~10 % fewer splats: tile_common.hpp, profiles/r05_unit_quads_ab.txt).  A round stages 256 list entries: lane l gathers entry l's 36-byte record
 //     with wide loads, tests it against the four strips (exact "can this splat reach the strip" test) and parks it
 //     in three 16-byte-pitch LDS slabs; the per-strip ballots go to LDS and wave k then walks only the set bits of
 //     "its" masks with scalar bit scans, reading each entry back as wave-uniform (broadcast, conflict-free) LDS
@@ -59,7 +60,7 @@ struct FetchRec {
 using namespace tile;
 
 // ---------------------------------------------------------------------------------------------
-// One workgroup (4 wave64s) per tile, wave k owns the 16x4 strip k, one pixel per lane.
+// One workgroup (4 wave64s) per tile, wave k owns "strip" k = the tile's 8x8 quadrant k (unit_px / unit_py), one pixel per lane.
 // The heaviest tiles set the kernel's critical path; splitting a tile over four waves shortens it 4x and gives
 // the dispatcher four times as many independent wave-sized work items to balance.  A round stages 256 list
 // entries: every lane fetches one entry, tests it against the four strips, and the per-strip ballots (one
@@ -144,8 +145,8 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         return;
     }
     const uint32_t tile = ty * cp.grid_x + tx;
-    const uint32_t px = tx * kBlockX + (lane & 15u);
-    const uint32_t py = ty * kBlockY + 4u * wave + (lane >> 4);
+    const uint32_t px = unit_px(tx, wave, lane);
+    const uint32_t py = unit_py(ty, wave, lane);
     const float rx0 = (float)(tx * kBlockX), ry0 = (float)(ty * kBlockY), rx1 = rx0 + (float)(kBlockX - 1);
     const bool  inside = (px < cp.width) && (py < cp.height);
     // A finished pixel (saturated, or outside the image) gets a NaN y coordinate: its power is NaN, fails
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         const float4   a = na, b = nb;
         const float    c = nc;
         const float    t = have ? (2.0f * __logf(255.0f * b.y)) * 1.0001f + 2e-4f : -1.0f;
-        const uint32_t kmask = have ? splat_strip_mask(a.x, a.y, a.z, a.w, b.x, t, rx0, ry0, rx1) : 0u;
+        const uint32_t kmask = have ? splat_unit_mask(a.x, a.y, a.z, a.w, b.x, t, rx0, ry0, rx1) : 0u;
         __syncthreads(); // previous round's readers are done with the slab and the masks
         if (KEEP && lane < 4u) s_blend[wave][lane] = 0ull; // (strips that are finished, or finish mid-round, blend nothing)
 #pragma unroll

@@ -106,6 +106,68 @@ __device__ __forceinline__ uint32_t splat_strip_mask(float mx, float my, float c
     return mask;
 }
 
+// The same for the four 8x8 QUADRANTS of a tile (bit k: columns x0 + 8 (k & 1) .. + 7, rows y0 + 8 (k >> 1) .. + 7): per quadrant
+// one facing vertical and one facing horizontal edge, the vertical edge's terms shared by the two quadrants of a column pair.
+__device__ __forceinline__ uint32_t splat_quad_mask(float mx, float my, float ca, float cb, float cc, float t, float x0, float y0)
+{
+    if (!(t > 0.0f)) return 0u; // opacity <= 1/255: alpha < 1/255 everywhere
+    const float det = ca * cc - cb * cb;
+    if (!(ca > 0.0f) || !(cc > 0.0f) || !(det > 1e-5f * (ca * cc))) return 0xFu; // degenerate / indefinite / NaN conic: keep
+    const float nb_cc = -cb * __builtin_amdgcn_rcpf(cc), nb_ca = -cb * __builtin_amdgcn_rcpf(ca);
+    uint32_t    mask = 0u;
+#pragma unroll
+    for (int jx = 0; jx < 2; ++jx) {
+        const float ex0 = (x0 + 8.0f * jx) - mx, ex1 = (x0 + 8.0f * jx + 7.0f) - mx;
+        const bool  in_x = ex0 <= 0.0f && ex1 >= 0.0f;
+        const float dxv   = ex0 > 0.0f ? ex0 : ex1; // the vertical edge that faces the mean (either, if the mean's x is inside)
+        const float dyv_f = nb_cc * dxv;            // its free minimiser
+        const float v1 = ca * dxv * dxv, cb2dx = 2.0f * cb * dxv;
+#pragma unroll
+        for (int jy = 0; jy < 2; ++jy) {
+            const float ey0 = (y0 + 8.0f * jy) - my, ey1 = (y0 + 8.0f * jy + 7.0f) - my;
+            const float dyv = fmin_(fmax_(dyv_f, ey0), ey1);
+            const float v2 = cb2dx * dyv, v3 = cc * dyv * dyv;
+            const float qv = v1 + v2 + v3, sv = fabsf(v1) + fabsf(v2) + fabsf(v3);
+            const float dyh = ey0 > 0.0f ? ey0 : ey1;
+            const float dxh = fmin_(fmax_(nb_ca * dyh, ex0), ex1);
+            const float h1 = ca * dxh * dxh, h2 = 2.0f * cb * dxh * dyh, h3 = cc * dyh * dyh;
+            const float qh = h1 + h2 + h3, sh = fabsf(h1) + fabsf(h2) + fabsf(h3);
+            const bool  hv   = qh < qv;
+            const float best = hv ? qh : qv, slack = hv ? sh : sv;
+            const bool  inside = in_x && ey0 <= 0.0f && ey1 >= 0.0f;
+            const bool  reach  = inside || !(best == best) || best - 1e-5f * slack <= t; // (NaN: keep)
+            mask |= reach ? (1u << (2 * jy + jx)) : 0u;
+        }
+    }
+    return mask;
+}
+
+// Which 64 pixels of a 16x16 tile wave k of a renderer workgroup owns ("strip k" in the renderers' names), and the reach test
+// that goes with it.
+//   LCGS_UNIT_QUADS = 1 (default since round 5): the 8x8 quadrant k (lane = 8 row + column)
+//   LCGS_UNIT_QUADS = 0 (rounds 1-5a; A/B builds): the 16x4 strip k (lane = 16 row + column)
+// A compact unit meets fewer splats: a footprint of d x d pixels reaches (d/16 + 1)(d/4 + 1) strips but (d/8 + 1)^2 quadrants,
+// ~10 % fewer (entry, wave) pairs for both renderers -- forward 1 400 -> 1 432 frames/s, render-backward 0.440 -> 0.415 ms,
+// forward+backward +3.6 % in same-box A/B (profiles/r05_unit_quads_ab.txt).  Per-pixel arithmetic is untouched: same images bit
+// for bit.  The backward's reduction needs nothing new: lanes l, l + 16, l + 32, l + 48 still share their column, so dx stays a
+// lane constant through the two permlane folds, and the DPP step sums a 16-lane group = two pixel rows of eight columns.
+#ifndef LCGS_UNIT_QUADS
+#define LCGS_UNIT_QUADS 1
+#endif
+__device__ __forceinline__ uint32_t unit_px(uint32_t tx, uint32_t wave, uint32_t lane)
+{
+    return LCGS_UNIT_QUADS ? tx * kBlockX + 8u * (wave & 1u) + (lane & 7u) : tx * kBlockX + (lane & 15u);
+}
+__device__ __forceinline__ uint32_t unit_py(uint32_t ty, uint32_t wave, uint32_t lane)
+{
+    return LCGS_UNIT_QUADS ? ty * kBlockY + 8u * (wave >> 1) + (lane >> 3) : ty * kBlockY + 4u * wave + (lane >> 4);
+}
+__device__ __forceinline__ uint32_t splat_unit_mask(float mx, float my, float ca, float cb, float cc, float t, float x0, float y0,
+                                                    float x1)
+{
+    return LCGS_UNIT_QUADS ? splat_quad_mask(mx, my, ca, cb, cc, t, x0, y0) : splat_strip_mask(mx, my, ca, cb, cc, t, x0, y0, x1);
+}
+
 // Workgroup -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b lands on XCD b % 8,
 // and is that XCD's (b / 8)-th workgroup).  Tiles are grouped into blocks of 8 x 4 tiles (128 x 64 px: most
 // splats live inside one block, so its tiles share their records in one XCD's L2) and the blocks are dealt
