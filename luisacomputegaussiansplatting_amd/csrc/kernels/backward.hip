@@ -411,7 +411,8 @@ __global__ void __launch_bounds__(256, LCGS_BWD_WAVES) k_render_backward(CamPara
                 const bool  valid = cand & !(alpha < 1.0f / 255.0f);
                 LCGS_STAT(2, (unsigned)__popcll(__builtin_amdgcn_ballot_w64(valid)));
 #ifdef LCGS_BWD_STATS
-                {   // which sub-blocks of the 16x4 strip does this entry blend into? (lane = 16 * row + column)
+                {   // which sub-blocks of the wave's unit does this entry blend into?  (Lane groups as named for the 16x4 strip of
+                    // rounds 1-5a, lane = 16 * row + column; on the 8x8 quadrant the same lane groups are other pixel blocks.)
                     const unsigned long long vb = __builtin_amdgcn_ballot_w64(valid);
                     sub_[0] += (vb & 0x00FF00FF00FF00FFull) != 0, sub_[1] += (vb & 0xFF00FF00FF00FF00ull) != 0; // 8x4 halves
                     sub_[2] += (vb & 0x00000000FFFFFFFFull) != 0, sub_[3] += (vb & 0xFFFFFFFF00000000ull) != 0; // 16x2 halves
