@@ -187,10 +187,10 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
 
     // stable partition by tile id: only ceil(log2 G) key bits are live.  The kernel that writes the pairs also leaves
     // the partition's first per-chunk digit counts in the sort workspace (the depth sort is done with it by then).
-    const int tile_bits = std::max(1, ceil_log2_u32(cp.grid_x * cp.grid_y));
+    const int tile_bits = std::max(1, ceil_log2_u32(list_grid_x(cp) * list_grid_y(cp)));
     const PairSortFirstPass first = pair_sort_first_pass(ctx->pair_capacity, hint_L, 0, tile_bits, ctx->sort_ws.ptr);
     const bool counted =
-        launch_expand(P, hint_V, hint_L, d_counts, cp.grid_x, order, ctx->rects.as<uint2>(), ctx->rects_sorted.as<uint2>(),
+        launch_expand(P, hint_V, hint_L, d_counts, list_grid_x(cp), order, ctx->rects.as<uint2>(), ctx->rects_sorted.as<uint2>(),
                       ctx->pairk[0].as<uint32_t>(), ctx->pairv[0].as<uint32_t>(), ctx->pair_capacity,
                       ctx->expand_ws.as<uint32_t>(), st, &first, id_mask);
     LCGS_TRY(mark(ctx, "expand"));
@@ -210,7 +210,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
     } else {
         const int ob = deferred ? (ctx->order_cur ^ 1) : 0;
         order_now    = ctx->tile_order[ob].as<uint32_t>();
-        launch_tile_order(ctx->ranges, G, order_now, st);
+        launch_tile_order(ctx->ranges, G, order_now, st, cp.grid_x, cp.list_shift);
         if (deferred) {
             ctx->order_cur = ob;
             ctx->order_G   = G;
@@ -222,7 +222,7 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
         // frame's schedule, and the next frame's zeroed copy
         const int ob = ctx->order_cur ^ 1, znext = (zb + 2) % 3; // the copy of the frame after the next
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_ranges, 0)); // (carried by the ranges dispatch)
-        launch_tile_order(ctx->ranges, G, ctx->tile_order[ob].as<uint32_t>(), ctx->aux_stream);
+        launch_tile_order(ctx->ranges, G, ctx->tile_order[ob].as<uint32_t>(), ctx->aux_stream, cp.grid_x, cp.list_shift);
         LCGS_HIP_CHECK(hipMemsetAsync(ctx->zero_ws[znext].ptr, 0, ctx->zero_bytes, ctx->aux_stream));
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_aux_done, ctx->aux_stream));
         ctx->aux_pending       = true;
@@ -286,6 +286,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
     LCGS_REQUIRE(ctx->pos != nullptr, "no scene bound (call lcgs_scene_bind / lcgs_scene_upload first)");
     CamParams cp      = make_cam_params(*camera);
     cp.lod_min_radius = ctx->lod_min_radius;
+    cp.list_shift     = (!keep_state && ctx->coarse_lists) ? 1u : 0u; // (gs_math.hpp CamParams::list_shift)
     ctx->owner_recs   = nullptr; // (an ordinary frame: its backward is lcgs_render_backward again)
     uint32_t        earlier_truncated = 0; // asynchronous frames before this one that overflowed the pair workspace
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -441,6 +442,7 @@ lcgs_status prepare_twin(lcgs_context* ctx)
             LCGS_TRY(lcgs_scene_bind(t, ctx->P, ctx->sh_deg, ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity));
         t->use_half_sh    = false;
         t->lod_min_radius = ctx->lod_min_radius;
+        t->coarse_lists   = ctx->coarse_lists;
         t->cull_bound     = ctx->cull_bound; // (borrowed, like the permutation: built on ctx->stream before the fork below)
         t->cull_key       = ctx->cull_key;
         // the sibling renders the same (possibly re-ordered) arrays: it borrows their permutation for the order of equal depths

@@ -175,6 +175,7 @@ struct lcgs_context {
     int stage_mode = 0; // LCGS_STAGES_EXACT
     uint32_t stage_serial = 0;   // lcgs_tile_splat_forward's per-frame mark of the "unwritten pair slots" word
     bool stage_side_copy = true; // the unsorted pair buffers' copy beside the depth sort (A/B hook LCGS_STAGE_SIDE_COPY=0)
+    bool coarse_lists    = true; // frames that keep no backward state list their pairs per 32 x 32 pixels (A/B hook LCGS_COARSE_LISTS=0)
     bool bwd_use_masks   = true; // the render-backward walks the forward's kept strip bits (test hook LCGS_BWD_USE_MASKS=0: it repeats the strip tests)
     bool stage_mailbox   = true; // the splatter's scalars posted to pinned memory and polled (A/B hook LCGS_STAGE_MAILBOX=0: copy + sync)
     int stage_sort = 0; // lcgs_tile_splat_forward's sort route: 0 = by frame size, 1 = literal six passes, 2 = sort-before-duplicate

@@ -125,6 +125,7 @@ CamParams make_cam_params(const lcgs_camera& cam)
     cp.grid_x   = (cp.width + kBlockX - 1u) / kBlockX; // gs_tile_splatter/impl.cpp:76-79
     cp.grid_y   = (cp.height + kBlockY - 1u) / kBlockY;
     cp.lod_min_radius = 0;
+    cp.list_shift     = 0;
     return cp;
 }
 

@@ -60,7 +60,8 @@ struct Projected {
     int32_t  radius;    // reference radius (0 if near-culled)
     uint32_t ref_tiles; // reference tiles_touched
     float    pix_x, pix_y, depth, conic[3];
-    uint32_t rmin[2], rw, rh; // pruned rect: origin + size in tiles
+    uint32_t rmin[2], rw, rh; // pruned rect: origin + size in LIST BLOCKS (= tiles unless CamParams::list_shift)
+    uint32_t trect_xy, trect_wh; // the same rect in tiles, packed like SplatRecord::rect_xy / rect_wh
 };
 
 // One splat's inputs, loaded before any of the arithmetic so that all of a lane's loads are in flight together.
@@ -94,6 +95,7 @@ __device__ __forceinline__ Projected project_splat(const CamParams& cp, float sc
     r.pix_x = r.pix_y = r.depth = 0.0f;
     r.conic[0] = r.conic[1] = r.conic[2] = 0.0f;
     r.rmin[0] = r.rmin[1] = r.rw = r.rh = 0;
+    r.trect_xy = r.trect_wh = 0;
     float v[3], ndc[2];
     view_transform(cp, px, py, pz, v);
     if (v[2] < 0.2f) return r; // gs_projector/shader.cpp:121
@@ -118,6 +120,15 @@ __device__ __forceinline__ Projected project_splat(const CamParams& cp, float sc
     if (r.radius <= 0) r.ref_tiles = 0; // radius <= 0 never emits pairs (gs_tile_splatter/shader.cpp:41-42)
     if (r.ref_tiles == 0) return r;
     tight_rect(r.pix_x, r.pix_y, filt[0], filt[1], filt[2], opac, fmin, fmax, tmin, tmax);
+    r.trect_xy = tmin[0] | (tmin[1] << 16);
+    r.trect_wh = (tmax[0] - tmin[0]) | ((tmax[1] - tmin[1]) << 16);
+    if (cp.list_shift != 0u && tmax[0] > tmin[0] && tmax[1] > tmin[1]) { // the same rect in list blocks (half-open)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            tmax[a] = ((tmax[a] - 1u) >> cp.list_shift) + 1u;
+            tmin[a] >>= cp.list_shift;
+        }
+    }
     r.rmin[0] = tmin[0];
     r.rmin[1] = tmin[1];
     r.rw      = tmax[0] - tmin[0];
@@ -551,8 +562,7 @@ k_build_records(int sh_deg, CamParams cp, float scale_modifier, const FrameParam
     float4* out = reinterpret_cast<float4*>(recs + vid);
     out[0]      = make_float4(pr.pix_x, pr.pix_y, pr.conic[0], pr.conic[1]);
     out[1]      = make_float4(pr.conic[2], opacity[idx], clamp_(raw[0], 0.0f, 1.0f), clamp_(raw[1], 0.0f, 1.0f));
-    out[2]      = make_float4(clamp_(raw[2], 0.0f, 1.0f), pr.depth, __uint_as_float(pr.rmin[0] | (pr.rmin[1] << 16)),
-                              __uint_as_float(pr.rw | (pr.rh << 16)));
+    out[2]      = make_float4(clamp_(raw[2], 0.0f, 1.0f), pr.depth, __uint_as_float(pr.trect_xy), __uint_as_float(pr.trect_wh));
     if (JAC) {
         // last, with the record gone from the registers; the coefficients are read from the LDS row once more
         asm volatile("" ::: "memory");

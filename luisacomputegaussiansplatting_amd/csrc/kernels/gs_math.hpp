@@ -53,7 +53,19 @@ struct CamParams {
     // opt-in footprint cull of the fused frame (lcgs_set_lod; 0 = off = the reference's behaviour): a splat whose reference
     // radius (pixels, gs_tile_splatter/shader.cpp:148) is below this is treated as if it touched no tile
     int32_t lod_min_radius;
+    // The granularity of the fused frame's pair lists: lists are kept per block of (1 << list_shift)^2 tiles (0: per tile, like the
+    // reference; 1: per 32 x 32 pixels).  A splat's footprint meets fewer coarse blocks than tiles (7.53 M -> 4.47 M pairs on the
+    // bench frame), and duplication, the tile partition and the range pass scale with the pairs; the renderer's workgroups still
+    // own one 16 x 16 tile each and walk their block's list -- the reach masks of their staging drop what belongs to the block's
+    // other tiles.  Frames that keep backward state use 0 (the backward walks per-tile lists).
+    uint32_t list_shift;
 };
+LCGS_HD uint32_t list_grid_x(const CamParams& cp) { return (cp.grid_x + (1u << cp.list_shift) - 1u) >> cp.list_shift; }
+LCGS_HD uint32_t list_grid_y(const CamParams& cp) { return (cp.grid_y + (1u << cp.list_shift) - 1u) >> cp.list_shift; }
+LCGS_HD uint32_t list_block_of_tile(const CamParams& cp, uint32_t tx, uint32_t ty)
+{
+    return (ty >> cp.list_shift) * list_grid_x(cp) + (tx >> cp.list_shift);
+}
 
 // Per-call parameters of the fused frame, kept in DEVICE memory so that a captured hipGraph of the frame stays
 // valid when the camera moves: one tiny eager kernel refreshes this block, then the whole frame replays.

@@ -217,7 +217,8 @@ void launch_pos_moments(int64_t P, const float* pos, double* partial, hipStream_
 void launch_morton_keys(int64_t P, const float* pos, const float lo[3], const float cells_per_unit[3], uint32_t* keys,
                         uint32_t* vals, hipStream_t stream);
 void launch_gather_rows(int64_t rows, int row_floats, const uint32_t* perm, const float* src, float* dst, hipStream_t stream);
-void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream);
+void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream, uint32_t grid_x = 0,
+                       uint32_t list_shift = 0);
 void launch_blend_exp(const float* x, float* out, int64_t n, hipStream_t stream);
 void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uint32_t* ranges,
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,

@@ -44,6 +44,7 @@ struct FetchAoS {
         b = make_float4(conic[3 * (size_t)id + 2], opacity[id], color[3 * (size_t)id], color[3 * (size_t)id + 1]);
         c = color[3 * (size_t)id + 2];
     }
+    __device__ __forceinline__ uint2 rect(uint32_t) const { return make_uint2(0u, 0xFFFFFFFFu); } // (no list blocks on this path)
 };
 
 struct FetchRec {
@@ -55,6 +56,8 @@ struct FetchRec {
         b               = p[1];
         c               = reinterpret_cast<const float*>(recs + id)[8];
     }
+    // the splat's pruned rect in tiles (origin, size): what its per-tile lists would hold it for
+    __device__ __forceinline__ uint2 rect(uint32_t id) const { return make_uint2(recs[id].rect_xy, recs[id].rect_wh); }
 };
 
 using namespace tile;
@@ -164,12 +167,18 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
     __syncthreads();
     if (lane == 0 && alive) atomicAdd(&s_live_waves, 1u);
 
-    const uint32_t range_start = ranges[2 * (size_t)tile + 0];
-    const uint32_t range_end   = ranges[2 * (size_t)tile + 1];
+    const uint32_t lblock      = cp.list_shift ? list_block_of_tile(cp, tx, ty) : tile; // whose list this tile walks
+    const uint32_t range_start = ranges[2 * (size_t)lblock + 0];
+    const uint32_t range_end   = ranges[2 * (size_t)lblock + 1];
 
     float4 na = make_float4(0, 0, 0, 0), nb = make_float4(0, 0, 0, 0);
     float  nc = 0.0f;
-    if (range_start + tid < range_end) fetch(point_list[range_start + tid], na, nb, nc);
+    uint2  nrect = make_uint2(0u, 0xFFFFFFFFu); // (coarse lists only)
+    if (range_start + tid < range_end) {
+        const uint32_t id = point_list[range_start + tid];
+        fetch(id, na, nb, nc);
+        if (cp.list_shift) nrect = fetch.rect(id);
+    }
     __syncthreads();
 
     for (uint32_t base = range_start; base < range_end; base += 256u) {
@@ -180,7 +189,13 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         const float4   a = na, b = nb;
         const float    c = nc;
         const float    t = have ? (2.0f * __logf(255.0f * b.y)) * 1.0001f + 2e-4f : -1.0f;
-        const uint32_t kmask = have ? splat_unit_mask(a.x, a.y, a.z, a.w, b.x, t, rx0, ry0, rx1) : 0u;
+        uint32_t       kmask = have ? splat_unit_mask(a.x, a.y, a.z, a.w, b.x, t, rx0, ry0, rx1) : 0u;
+        if (cp.list_shift) {
+            // a block's list holds every splat that reaches ANY of its tiles: this tile takes those whose pruned rect covers it --
+            // exactly the entries of its own list (the reference's 3-sigma rect cuts footprints the alpha test alone would keep)
+            const uint32_t dx_ = tx - (nrect.x & 0xFFFFu), dy_ = ty - (nrect.x >> 16);
+            if (!(dx_ < (nrect.y & 0xFFFFu) && dy_ < (nrect.y >> 16))) kmask = 0u;
+        }
         __syncthreads(); // previous round's readers are done with the slab and the masks
         if (KEEP && lane < 4u) s_blend[wave][lane] = 0ull; // (strips that are finished, or finish mid-round, blend nothing)
 #pragma unroll
@@ -194,7 +209,11 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
             s_rows[2][tid] = make_float4(b.y, b.z, b.w, c);
         }
         const uint32_t en = e + 256u;
-        if (en < range_end) fetch(point_list[en], na, nb, nc);
+        if (en < range_end) {
+            const uint32_t id = point_list[en];
+            fetch(id, na, nb, nc);
+            if (cp.list_shift) nrect = fetch.rect(id);
+        }
         __syncthreads();
 
         if (alive) {
@@ -339,16 +358,20 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
 // which a few late heavy tiles keep the kernel alive (measured: -16 % renderer time on the bicycle stand-in).
 // One workgroup: counting sort of the tiles into 1024 length buckets (descending); order inside a bucket is
 // whatever the LDS atomics produce.
+// (grid_x, shift: the tiles' lists are their blocks' -- CamParams::list_shift; shift 0: ranges are per tile)
 __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ ranges, uint32_t G,
-                                                       uint32_t* __restrict__ order)
+                                                       uint32_t* __restrict__ order, uint32_t grid_x, uint32_t shift)
 {
+    const uint32_t lgx = (grid_x + (1u << shift) - 1u) >> shift;
+    auto           list_of = [&](uint32_t t) { return shift ? ((t / grid_x) >> shift) * lgx + ((t % grid_x) >> shift) : t; };
     __shared__ uint32_t s_bucket[1024];
     __shared__ uint32_t s_wave[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     s_bucket[tid] = 0;
     __syncthreads();
     for (uint32_t t = tid; t < G; t += 1024u) {
-        const uint32_t len = ranges[2 * (size_t)t + 1] - ranges[2 * (size_t)t];
+        const uint32_t lb  = list_of(t);
+        const uint32_t len = ranges[2 * (size_t)lb + 1] - ranges[2 * (size_t)lb];
         const uint32_t b   = 1023u - ((len >> 3) < 1023u ? (len >> 3) : 1023u);
         atomicAdd(&s_bucket[b], 1u);
     }
@@ -368,7 +391,8 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
     s_bucket[tid] = carry + inc - own; // exclusive start of the bucket
     __syncthreads();
     for (uint32_t t = tid; t < G; t += 1024u) {
-        const uint32_t len = ranges[2 * (size_t)t + 1] - ranges[2 * (size_t)t];
+        const uint32_t lb  = list_of(t);
+        const uint32_t len = ranges[2 * (size_t)lb + 1] - ranges[2 * (size_t)lb];
         const uint32_t b   = 1023u - ((len >> 3) < 1023u ? (len >> 3) : 1023u);
         order[atomicAdd(&s_bucket[b], 1u)] = t;
     }
@@ -415,10 +439,10 @@ void launch_blend_exp(const float* x, float* out, int64_t n, hipStream_t stream)
     hipLaunchKernelGGL(k_blend_exp, dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, x, out, n);
 }
 
-void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream)
+void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream, uint32_t grid_x, uint32_t list_shift)
 {
     if (G == 0) return;
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, ranges, G, order);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, ranges, G, order, grid_x ? grid_x : 1u, grid_x ? list_shift : 0u);
 }
 
 void launch_render_forward_aos(const CamParams& cp, const float bg[3], const uint32_t* ranges,

@@ -32,6 +32,13 @@ def _render_both(lcgs, oracle, scene, W, H, bg=(0.1, 0.2, 0.3), pose=POSE, scale
     st = r.frame_stats()
     assert st["num_rendered"] == n and 0 < st["num_pairs"] <= n
     if check_lists:
+        # Frames that keep no backward state list their pairs per block of 2 x 2 tiles (CamParams::list_shift); the per-tile lists
+        # inspected below are those of a frame that keeps it -- the same view again, which must also give the same image bit for bit.
+        img_k = torch.full((3, H, W), -1.0, device=DEV)
+        assert r.forward(cam, img_k, bg=bg, scale_modifier=scale_modifier, keep_state=True, sync=True) == n
+        assert torch.equal(img_k, img), "per-tile lists and per-block lists render different images"
+        assert r.frame_stats()["num_pairs"] >= st["num_pairs"]
+        st = r.frame_stats()
         # Per tile, the fused list is the reference list (stable sort on (tile<<32|depth), index-order ties) with
         # only never-contributing entries pruned: same relative order, and every pruned (tile, splat) pair has
         # alpha < 1/255 (or power > 0) at every pixel of the tile.
@@ -318,12 +325,15 @@ def test_stream_switch_with_frames_in_flight(lcgs, oracle):
         assert torch.equal(img, ref), k
 
 
-def test_asynchronous_overflow_is_reported_at_the_next_sync(lcgs, oracle):
+def test_asynchronous_overflow_is_reported_at_the_next_sync(lcgs, oracle, monkeypatch):
     """A frame enqueued without synchronisation that needs more pairs than the workspace holds: its lists are
     truncated, the next synchronising call says so (LCGS_ERR_CAPACITY) and grows the workspace; rendering the frame
     again gives the full image."""
     rng = np.random.default_rng(13)
     scene = make_scene(rng, 6000, log_scale=(-1.0, 0.2))  # big splats: L >> max(4 * P, 2^22)
+    # (per-tile lists: with the per-block lists of frames that keep no backward state these 6000 splats fit the initial
+    #  workspace; the two tests below overflow it in that mode too, with four times the splats and no CPU oracle to wait for)
+    monkeypatch.setenv("LCGS_COARSE_LISTS", "0")
     r = lcgs.Renderer(lcgs.Context(0))
     d = upload_scene(scene)
     r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
@@ -340,12 +350,14 @@ def test_asynchronous_overflow_is_reported_at_the_next_sync(lcgs, oracle):
 
 
 @pytest.mark.parametrize("second_sync", [False, True])
-def test_asynchronous_overflow_is_not_forgotten_when_a_later_frame_fits(lcgs, second_sync):
+@pytest.mark.parametrize("coarse", [False, True], ids=["tile-lists", "block-lists"])
+def test_asynchronous_overflow_is_not_forgotten_when_a_later_frame_fits(lcgs, second_sync, coarse, monkeypatch):
     """The overflow record is sticky on the device: an asynchronous frame that was truncated is still reported after a
     later frame (here a small one that fits) has rewritten the per-frame counters -- by lcgs_synchronize, and by a later
     synchronising lcgs_render_forward."""
     rng = np.random.default_rng(13)
-    scene = make_scene(rng, 6000, log_scale=(-1.0, 0.2))  # big splats: L >> max(4 * P, 2^22) at 1080p
+    monkeypatch.setenv("LCGS_COARSE_LISTS", "1" if coarse else "0")
+    scene = make_scene(rng, 24000 if coarse else 6000, log_scale=(-1.0, 0.2))  # big splats: L >> max(4 * P, 2^22) at 1080p
     r = lcgs.Renderer(lcgs.Context(0))
     d = upload_scene(scene)
     r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
@@ -376,7 +388,7 @@ def test_asynchronous_overflow_is_not_forgotten_when_a_later_frame_fits(lcgs, se
 def test_asynchronous_overflow_inside_a_camera_batch(lcgs):
     """Same through lcgs_render_forward_batch: both workspaces (the context's and its sibling's) report and grow."""
     rng = np.random.default_rng(13)
-    scene = make_scene(rng, 6000, log_scale=(-1.0, 0.2))
+    scene = make_scene(rng, 24000, log_scale=(-1.0, 0.2))  # (per-block lists: a quarter of the pairs per big splat)
     d = upload_scene(scene)
     cam = lcgs.get_lookat_cam(*POSE, width=1920, height=1080)
     good = lcgs.Renderer(lcgs.Context(0))

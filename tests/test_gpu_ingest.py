@@ -209,7 +209,7 @@ def test_spatial_reorder_keeps_the_image_and_permutes_the_outputs(lcgs, oracle):
         b = torch.full((3, res[1], res[0]), -1.0, device=DEV)
         fresh = lcgs.Renderer(lcgs.Context(0))
         fresh.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])  # file order, no bounds
-        na = fresh.forward(cam2, a, sync=True)
+        na = fresh.forward(cam2, a, keep_state=True, sync=True)  # (both per tile: num_pairs depends on the list granularity)
         nb = r.forward(cam2, b, keep_state=True, sync=True)
         sa, sb_ = fresh.frame_stats(), r.frame_stats()
         assert na == nb and float((a - b).abs().max()) <= 1e-6
