@@ -309,6 +309,25 @@ def leg_lod(r, cam, img, args, world, timed):
     return lod
 
 
+def renderer_entries(torch, r, stats, W, H, dev):
+    """List entries the renderer's workgroups stage in the frame just rendered.  A frame that keeps no backward state lists its
+    pairs per block of 2 x 2 tiles (fewer pairs through duplication / partition / ranges) and every tile's workgroup walks its
+    block's list: the renderer then reads each block's list once per tile of the block."""
+    if os.environ.get("LCGS_COARSE_LISTS", "1") == "0":
+        return int(stats["num_pairs"])
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    rng = torch.zeros(2 * gx * gy, dtype=torch.int32, device=dev)
+    r.last_lists(None, rng)
+    bx, by = (gx + 1) // 2, (gy + 1) // 2
+    rr = rng[:2 * bx * by].view(by, bx, 2).long()
+    lens = rr[..., 1] - rr[..., 0]
+    tx = torch.full((bx,), 2, device=dev, dtype=torch.long)
+    ty = torch.full((by,), 2, device=dev, dtype=torch.long)
+    if gx % 2: tx[-1] = 1
+    if gy % 2: ty[-1] = 1
+    return int((lens * ty[:, None] * tx[None, :]).sum().item())
+
+
 def rooflines(r, stats, acc, data, P, W, H, ms_per_step):
     """the dominant kernel's roofline (HBM figures + the measured VALU issue fraction) and the whole frame three ways"""
     V, Lref, Lp, G = stats["num_visible"], stats["num_rendered"], stats["num_pairs"], stats["num_tiles"]
@@ -324,7 +343,10 @@ def rooflines(r, stats, acc, data, P, W, H, ms_per_step):
         "expand": 12 * V + 8 * V + 8 * Lp,
         "tile_sort": (16 + 20) * Lp,  # the first pass's counts come from the emitter
         "ranges": 4 * Lp + 8 * G,
-        "render": 40 * Lp + 12 * W * H,
+        # 4-byte id + 36 of the 48-byte record (+ its 8-byte tile rect when lists are per block) per list entry, each counted ONCE:
+        # with per-block lists the (up to) four tiles of a block each stage the block's list -- `renderer_entries` -- and the
+        # re-reads are served by L2 for the most part (PMC traffic ~1.85 x these bytes, profiles/r05_pmc_traffic.txt)
+        "render": (48 if stats.get("renderer_entries", Lp) != Lp else 40) * Lp + 12 * W * H,
     }
     stage_kernel = {"render": "k_render_forward_b", "build_records": "k_build_records", "cull_compact": "k_cull_compact"}
     dominant = max(acc, key=acc.get) if acc else "render"
@@ -404,6 +426,11 @@ def rooflines(r, stats, acc, data, P, W, H, ms_per_step):
                 "valu_issue": valu, "kernel_sources_sha256": src_hash, "library_sha256": lib_hash,
                 "note": "the dominant kernel (per-tile compositing) is VALU-issue bound, not HBM bound: `frac` is its HBM "
                         "fraction (the contract's figure), valu_issue.frac the roof it is at; see DESIGN.md 4"}
+    if dominant == "render" and stats.get("renderer_entries", Lp) != Lp:
+        roofline["list_entries"] = Lp
+        roofline["entries_staged_by_tile_workgroups"] = stats["renderer_entries"]
+        roofline["note"] += ("; pair lists are per block of 2 x 2 tiles: the bytes count every list entry once, the (up to) four tile "
+                             "workgroups of a block each stage it (re-reads mostly served by L2)")
     if profile_errors:
         roofline["profile_errors"] = profile_errors
     # Whole frame, three ways, side by side (none of them is `roofline`, which is the dominant kernel's):
@@ -844,6 +871,7 @@ def main():
     # first frame synchronises: sizes the pair buffers for this view
     n_rendered = r.forward(cam, img, sync=True)
     stats = r.frame_stats()
+    stats["renderer_entries"] = renderer_entries(torch, r, stats, W, H, dev)
 
     def barrier():
         torch.cuda.synchronize(dev)
