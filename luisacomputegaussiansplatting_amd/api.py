@@ -701,6 +701,9 @@ class Renderer:
         return {k: int(getattr(s, k)) for k, _ in _FrameStats._fields_}
 
     def last_lists(self, d_list, d_ranges):
+        """lcgs_debug_last_lists: the last fused frame's sorted lists (original splat indices) and ranges.  Per TILE after a frame
+        with keep_state=True; a frame without it lists its pairs per block of 2 x 2 tiles (the first ceil(gx / 2) * ceil(gy / 2)
+        ranges, row-major; the rest zero).  Either argument may be None."""
         _check(load_library().lcgs_debug_last_lists(self.ctx._h, _ptr(d_list), _ptr(d_ranges)))
 
     def adam_step(self, grads: dict, raw: dict, m: dict, v: dict, activated: dict, step: int, lr: dict,
