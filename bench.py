@@ -313,7 +313,7 @@ def renderer_entries(torch, r, stats, W, H, dev):
     """List entries the renderer's workgroups stage in the frame just rendered.  A frame that keeps no backward state lists its
     pairs per block of 2 x 2 tiles (fewer pairs through duplication / partition / ranges) and every tile's workgroup walks its
     block's list: the renderer then reads each block's list once per tile of the block."""
-    if os.environ.get("LCGS_COARSE_LISTS", "1") == "0":
+    if os.environ.get("LCGS_COARSE_LISTS", "auto") == "0":
         return int(stats["num_pairs"])
     gx, gy = (W + 15) // 16, (H + 15) // 16
     rng = torch.zeros(2 * gx * gy, dtype=torch.int32, device=dev)
@@ -321,6 +321,10 @@ def renderer_entries(torch, r, stats, W, H, dev):
     bx, by = (gx + 1) // 2, (gy + 1) // 2
     rr = rng[:2 * bx * by].view(by, bx, 2).long()
     lens = rr[..., 1] - rr[..., 0]
+    # (the library decides per context from the pair count; per-block ranges fill the first bx * by slots and leave the rest zero)
+    per_block = bx * by < gx * gy and int(lens.sum().item()) == int(stats["num_pairs"]) and not bool(rng[2 * bx * by:].any().item())
+    if not per_block:
+        return int(stats["num_pairs"])
     tx = torch.full((bx,), 2, device=dev, dtype=torch.long)
     ty = torch.full((by,), 2, device=dev, dtype=torch.long)
     if gx % 2: tx[-1] = 1
@@ -869,6 +873,9 @@ def main():
     img = torch.zeros(3, H, W, device=dev)
 
     # first frame synchronises: sizes the pair buffers for this view
+    n_rendered = r.forward(cam, img, sync=True)
+    # (a context's first frame lists its pairs per tile; from the second on the library may switch to per-block lists for frames
+    #  without backward state, by the pair count: the counters reported are those of the frames that are timed)
     n_rendered = r.forward(cam, img, sync=True)
     stats = r.frame_stats()
     stats["renderer_entries"] = renderer_entries(torch, r, stats, W, H, dev)

@@ -301,8 +301,8 @@ LCGS_API lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* o
 /* Diagnostics: the sorted per-tile lists of the last fused frame expressed in ORIGINAL splat indices
  * (what the reference's accel.point_list holds after GSTileSplatter::forward, proxy.h:62) and the tile
  * ranges (proxy.h:63).  d_list: num_pairs entries; d_ranges: 2 * tiles.  Either may be NULL.  Synchronises.
- * Per TILE after a frame with keep_state != 0.  A frame that keeps no backward state lists its pairs per block of
- * 2 x 2 tiles (fewer pairs to duplicate and partition; every tile's workgroup walks its block's list and takes the
+ * Per TILE after a frame with keep_state != 0.  A frame that keeps no backward state may list its pairs per block of
+ * 2 x 2 tiles (the context switches to it once a synchronised frame has shown >= 3 M per-tile pairs: fewer pairs to duplicate and partition; every tile's workgroup walks its block's list and takes the
  * entries whose pruned rect covers it -- the same per-pixel sequence, the same image bit for bit): then the first
  * ceil(grid_x / 2) * ceil(grid_y / 2) ranges are the blocks', row-major, and the rest are zero. */
 LCGS_API lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t* d_ranges);

@@ -201,7 +201,7 @@ lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx)
     if (const char* e = getenv("LCGS_GRAPH")) ctx->use_graph = (e[0] == '1'); // tuning hook
     if (const char* e = getenv("LCGS_STAGE_SIDE_COPY")) ctx->stage_side_copy = e[0] != '0'; // A/B hook
     if (const char* e = getenv("LCGS_STAGE_MAILBOX")) ctx->stage_mailbox = e[0] != '0';      // A/B hook
-    if (const char* e = getenv("LCGS_COARSE_LISTS")) ctx->coarse_lists = e[0] != '0';        // A/B hook
+    if (const char* e = getenv("LCGS_COARSE_LISTS")) ctx->coarse_mode = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2); // A/B / test hook
     if (const char* e = getenv("LCGS_BWD_USE_MASKS")) ctx->bwd_use_masks = e[0] != '0';      // test hook: the launcher's mask-less form
     if (const char* e = getenv("LCGS_STAGE_SORT")) ctx->stage_sort = e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0); // test hook
     // The auxiliary stream has the LOWEST dispatch priority: its bandwidth-bound workgroups fill the gaps the main

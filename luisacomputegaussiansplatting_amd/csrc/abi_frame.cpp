@@ -286,7 +286,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
     LCGS_REQUIRE(ctx->pos != nullptr, "no scene bound (call lcgs_scene_bind / lcgs_scene_upload first)");
     CamParams cp      = make_cam_params(*camera);
     cp.lod_min_radius = ctx->lod_min_radius;
-    cp.list_shift     = (!keep_state && ctx->coarse_lists) ? 1u : 0u; // (gs_math.hpp CamParams::list_shift)
+    cp.list_shift     = (!keep_state && (ctx->coarse_mode == 1 || (ctx->coarse_mode == 2 && ctx->coarse_on))) ? 1u : 0u;
     ctx->owner_recs   = nullptr; // (an ordinary frame: its backward is lcgs_render_backward again)
     uint32_t        earlier_truncated = 0; // asynchronous frames before this one that overflowed the pair workspace
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -305,6 +305,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
             key.cull_bound = ctx->cull_rows(); // (selects the cull kernel)
             key.img = d_img; key.radii = d_radii; key.P = ctx->P; key.sh_deg = ctx->sh_deg;
             key.width = camera->width; key.height = camera->height; key.keep_state = keep_state != 0;
+            key.list_shift = (int)cp.list_shift;
             key.hint_V = ctx->hint_V; key.hint_L = ctx->hint_L; key.capacity = ctx->pair_capacity; key.stream = ctx->stream;
             if (!ctx->graph_exec || !(key == ctx->graph_key)) {
                 if (ctx->graph_exec) {
@@ -352,6 +353,12 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
             ctx->hint_V = (int64_t)ctx->h_counts[0] + ctx->h_counts[0] / 4 + 4096;
         if ((int64_t)ctx->h_counts[4] > ctx->hint_L || (int64_t)ctx->h_counts[4] * 2 < ctx->hint_L)
             ctx->hint_L = (int64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4 + 4096;
+        {   // per-block lists for the following frames without backward state?  (context.hpp coarse_mode; a per-block count is
+            // ~0.45-0.7 of the per-tile one: taken as 0.6)
+            const int64_t per_tile = cp.list_shift ? (int64_t)ctx->h_counts[4] * 5 / 3 : (int64_t)ctx->h_counts[4];
+            if (per_tile >= 3000000) ctx->coarse_on = true;
+            else if (per_tile < 2400000) ctx->coarse_on = false;
+        }
         // overflow bookkeeping: [3] this frame, [6] / [7] every frame since the last read-back (sticky on the device)
         const bool     own    = ctx->h_counts[3] != 0;
         const uint32_t sticky = ctx->h_counts[6], sticky_want = ctx->h_counts[7];
@@ -442,7 +449,8 @@ lcgs_status prepare_twin(lcgs_context* ctx)
             LCGS_TRY(lcgs_scene_bind(t, ctx->P, ctx->sh_deg, ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity));
         t->use_half_sh    = false;
         t->lod_min_radius = ctx->lod_min_radius;
-        t->coarse_lists   = ctx->coarse_lists;
+        t->coarse_mode    = ctx->coarse_mode;
+        t->coarse_on      = ctx->coarse_on;
         t->cull_bound     = ctx->cull_bound; // (borrowed, like the permutation: built on ctx->stream before the fork below)
         t->cull_key       = ctx->cull_key;
         // the sibling renders the same (possibly re-ordered) arrays: it borrows their permutation for the order of equal depths

@@ -84,7 +84,7 @@ struct lcgs_context {
     struct GraphKey {
         const void *pos = nullptr, *scale = nullptr, *rotq = nullptr, *sh = nullptr, *opacity = nullptr, *sh_half = nullptr,
                    *img = nullptr, *radii = nullptr, *cull_bound = nullptr;
-        int         P = -1, sh_deg = -1, width = 0, height = 0, keep_state = -1;
+        int         P = -1, sh_deg = -1, width = 0, height = 0, keep_state = -1, list_shift = -1;
         int64_t     hint_V = -1, hint_L = -1;
         uint32_t    capacity = 0;
         hipStream_t stream = nullptr;
@@ -92,7 +92,7 @@ struct lcgs_context {
         {
             return pos == o.pos && scale == o.scale && rotq == o.rotq && sh == o.sh && opacity == o.opacity &&
                    sh_half == o.sh_half && img == o.img && radii == o.radii && cull_bound == o.cull_bound && P == o.P && sh_deg == o.sh_deg && width == o.width &&
-                   height == o.height && keep_state == o.keep_state && hint_V == o.hint_V && hint_L == o.hint_L &&
+                   height == o.height && keep_state == o.keep_state && list_shift == o.list_shift && hint_V == o.hint_V && hint_L == o.hint_L &&
                    capacity == o.capacity && stream == o.stream;
         }
     } graph_key;
@@ -175,7 +175,12 @@ struct lcgs_context {
     int stage_mode = 0; // LCGS_STAGES_EXACT
     uint32_t stage_serial = 0;   // lcgs_tile_splat_forward's per-frame mark of the "unwritten pair slots" word
     bool stage_side_copy = true; // the unsorted pair buffers' copy beside the depth sort (A/B hook LCGS_STAGE_SIDE_COPY=0)
-    bool coarse_lists    = true; // frames that keep no backward state list their pairs per 32 x 32 pixels (A/B hook LCGS_COARSE_LISTS=0)
+    // Frames that keep no backward state may list their pairs per block of 2 x 2 tiles (CamParams::list_shift).  It pays from
+    // ~3 M per-tile pairs up (-2 % at 0.2-0.9 M, 0 at 2.5 M, +2.5 % at 4-8 M, +6 % at 10 M, +15 % at 17 M: profiles/
+    // r05_coarse_lists_ab.txt), so the default decides per context from the last synchronised frame's pair count, with hysteresis;
+    // LCGS_COARSE_LISTS=0 / 1 force it off / on (A/B and test hook).
+    int  coarse_mode     = 2;     // 0 never, 1 always, 2 by the pair count
+    bool coarse_on       = false; // (mode 2) the current decision
     bool bwd_use_masks   = true; // the render-backward walks the forward's kept strip bits (test hook LCGS_BWD_USE_MASKS=0: it repeats the strip tests)
     bool stage_mailbox   = true; // the splatter's scalars posted to pinned memory and polled (A/B hook LCGS_STAGE_MAILBOX=0: copy + sync)
     int stage_sort = 0; // lcgs_tile_splat_forward's sort route: 0 = by frame size, 1 = literal six passes, 2 = sort-before-duplicate

@@ -49,3 +49,16 @@ def test_backward_suite_without_kept_masks():
                           "tests/test_gpu_backward.py", "tests/test_gpu_random_sweep.py"], cwd=ROOT, env=env, capture_output=True,
                          text=True, timeout=1200)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+# Per-block pair lists (frames without backward state; by default only from ~3 M pairs up, which no small test scene reaches)
+# forced on: the fused-frame, ingest and random-sweep suites -- every frame against the oracle bit for bit, camera batches, LOD,
+# half-precision coefficients, overflow handling -- and forced off.
+@pytest.mark.parametrize("mode", ["1", "0"], ids=["block-lists", "tile-lists"])
+def test_parity_suites_under_forced_list_granularity(mode):
+    env = dict(os.environ, LCGS_COARSE_LISTS=mode)
+    res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          "tests/test_gpu_fused.py", "tests/test_gpu_ingest.py", "tests/test_gpu_random_sweep.py",
+                          "tests/test_gpu_lod.py", "tests/test_gpu_sh_degrees.py"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
