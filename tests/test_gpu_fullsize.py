@@ -93,6 +93,31 @@ def test_c3_bicycle_properties(lcgs, oracle, bicycle):
     assert int((rng[:, 1] - rng[:, 0]).sum()) == lst.size
 
 
+def test_c3_bicycle_per_block_lists_render_the_same_frames(lcgs, bicycle, monkeypatch):
+    """C3 at size through both list granularities (CamParams::list_shift): a context forced to per-tile lists and one forced to
+    lists per block of 2 x 2 tiles render three views of the bicycle scene to the same images bit for bit, with the same
+    num_rendered and 35-60 % fewer sorted pairs; and the default decides for the per-block lists on this scene after its first
+    synchronised frame (>= 3 M per-tile pairs)."""
+    scene, _, d = bicycle
+    frames = {}
+    for mode in ("0", "1", "auto"):
+        monkeypatch.setenv("LCGS_COARSE_LISTS", mode)
+        r = lcgs.Renderer(lcgs.Context(0))
+        r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])
+        out = []
+        for pose in (BICYCLE_POSE, ([2.5, 1.0, 1.8], [0, 0, 0.4], [0, 0, 1]), ([-1.0, -3.0, 1.2], [0, 0.5, 0.5], [0, -1, 0])):
+            cam = lcgs.get_lookat_cam(*pose, width=W, height=H)
+            img = torch.full((3, H, W), -1.0, device=DEV)
+            n = r.forward(cam, img, sync=True)
+            out.append((n, r.frame_stats()["num_pairs"], img))
+        frames[mode] = out
+    for (n0, p0, i0), (n1, p1, i1), (na, pa, ia) in zip(frames["0"], frames["1"], frames["auto"]):
+        assert n0 == n1 == na and torch.equal(i0, i1) and torch.equal(i0, ia)
+        assert 0.4 * p0 < p1 < 0.65 * p0, (p0, p1)
+    # the default: per tile for a context's first frame, per block from the second on (this scene: 7.5 M per-tile pairs)
+    assert frames["auto"][0][1] == frames["0"][0][1] and frames["auto"][1][1] == frames["1"][1][1]
+
+
 def test_c4_garden_forward_backward_gradients(lcgs, oracle):
     scene, _ = baseline_scene(lcgs, "garden")
     P = scene["pos"].shape[0]
