@@ -520,6 +520,23 @@ def leg_cpu_baseline_and_parity(out, scene, r, cam, img, P, W, H):
         "pixels_over_1e-4": int(over.sum()), "max_abs_diff": float(dl.max()),
         "all_flagged": bool((~over | amb).all()), "ambiguous_pixels": int(amb.sum()),
         "max_abs_diff_unflagged": float(dl[~amb].max()) if (~amb).any() else 0.0, "pixels": int(dl.size)}
+    # ... and to the reference's LIKELY numerics (round 6): the same frame against the oracle built with FMA contraction
+    # (what a CUDA JIT does by default), with reciprocal-multiply division, rsqrt forms, right-to-left sums -- samples of
+    # such a compiler's choices, not replicas (oracle/numerics.py).  `classes` says how many pixels of the frame carry a
+    # decision inside its rounding window (threshold / depth order / rect-radius) and how many may move beyond 1e-4 at
+    # all; per variant: how many do, how far, and whether EVERY pixel of the frame stays inside its bound.
+    try:
+        from oracle import numerics
+
+        rep, _ = numerics.report(scene, ocam, img=gi)
+        vs = rep["variants"]
+        out["parity"]["vs_contracted"] = dict(vs["contracted"], classes=rep["classes"])
+        out["parity"]["vs_other_numerics"] = {
+            k: {q: v[q] for q in ("pixels_over_1e-4", "max_abs_diff", "unexplained_pixels", "all_explained",
+                                  "worst_ratio_diff_to_bound", "radii_differ")}
+            for k, v in vs.items() if k != "contracted"}
+    except Exception as e:  # a reporting leg: never costs the line
+        out["parity"]["vs_contracted"] = {"error": repr(e)}
 
 
 def leg_gradients(S):

@@ -15,19 +15,19 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = ("liblcgs_oracle_f32.so", "liblcgs_oracle_f64.so", "liblcgs_oracle_f32_contract.so")
+# numerics variants (comparison runs only; lcgs_oracle.h) and the classes of rounding-sensitive pixels
+NUM_RCP_DIV, NUM_RSQRT, NUM_REASSOC = 1, 2, 4
+CLS_THRESHOLD, CLS_DEPTH, CLS_RECT = 1, 2, 4
 
 
 def build(force: bool = False) -> None:
     """Compile the C restatement (and oracle/_ref when /root/reference is present)."""
-    need = force or not all(
-        os.path.exists(os.path.join(_HERE, f)) for f in ("liblcgs_oracle_f32.so", "liblcgs_oracle_f64.so")
-    )
+    need = force or not all(os.path.exists(os.path.join(_HERE, f)) for f in _LIBS)
     if not need:
         srcs = [os.path.join(_HERE, f) for f in ("lcgs_oracle.c", "lcgs_oracle_bwd.c", "lcgs_oracle.h")]
         newest = max(os.path.getmtime(s) for s in srcs)
-        oldest = min(
-            os.path.getmtime(os.path.join(_HERE, f)) for f in ("liblcgs_oracle_f32.so", "liblcgs_oracle_f64.so")
-        )
+        oldest = min(os.path.getmtime(os.path.join(_HERE, f)) for f in _LIBS)
         need = newest > oldest
     if need:
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
@@ -40,14 +40,18 @@ def _ptr(a, ctype):
 
 
 class Oracle:
-    def __init__(self, precision: str = "f32"):
-        assert precision in ("f32", "f64")
+    def __init__(self, precision: str = "f32", contracted: bool = False):
+        """contracted=True loads the numerics VARIANT built with -ffp-contract=fast (f32 only; comparison runs)."""
+        assert precision in ("f32", "f64") and not (contracted and precision != "f32")
         build()
         self.precision = precision
+        self.contracted = contracted
         self.dtype = np.float32 if precision == "f32" else np.float64
         self.creal = C.c_float if precision == "f32" else C.c_double
-        self.lib = C.CDLL(os.path.join(_HERE, f"liblcgs_oracle_{precision}.so"))
+        self.lib = C.CDLL(os.path.join(_HERE, f"liblcgs_oracle_{precision}{'_contract' if contracted else ''}.so"))
         assert self.lib.orc_sizeof_real() == np.dtype(self.dtype).itemsize
+        assert bool(self.lib.orc_build_contracted()) == contracted
+        self.lib.orc_mark_rect_uncertain.restype = C.c_int64
         creal = self.creal
 
         class Camera(C.Structure):
@@ -79,6 +83,11 @@ class Oracle:
     def rp(self, a):
         return _ptr(a, self.creal)
 
+    def convert_camera(self, cam):
+        """the same camera (e.g. another Oracle's) in this library's struct: the host-side camera is common to every
+        numerics variant, and the f64 twin gets the f32 camera's values widened"""
+        return self.camera_from_dict(self.camera_to_dict(cam))
+
     def set_threads(self, n: int) -> None:
         self.lib.orc_set_threads(C.c_int(n))
 
@@ -88,6 +97,11 @@ class Oracle:
     def set_blend_exp(self, use_libm: bool) -> None:
         """False (default): the build-defined blend exp the HIP kernels repeat bit for bit; True: libm's expf"""
         self.lib.orc_set_blend_exp(C.c_int(1 if use_libm else 0))
+
+    def set_numerics(self, flags: int) -> None:
+        """NUM_RCP_DIV | NUM_RSQRT: device-side divisions / square roots the way a fast-math JIT may form them; 0 = the
+        parity oracle.  Comparison runs only."""
+        self.lib.orc_set_numerics(C.c_int(flags))
 
     def blend_exp(self, x):
         """orc_blend_exp over an array of binary32 values (f32 build only)"""
@@ -256,6 +270,49 @@ class Oracle:
                                     self.rp(color), self.rp(img), self.rp(final_T), _ptr(n_contrib, C.c_uint32),
                                     _ptr(ambig, C.c_uint8), self.creal(ambig_eps))
         return img, final_T, n_contrib, ambig
+
+    def render_forward_ex(self, width, height, bg, ranges, point_list, means_pix, conic, opacity, color, ambig_eps,
+                          depth=None, depth_tol=None, drec=None, dcolor=None, eval_eps=0.0, mean_eps=0.0, window_factor=0.0,
+                          impact_floor=0.0):
+        """orc_render_forward_ex: the image plus, per pixel, the classes of rounding-sensitive decisions (cls) and the
+        first-order bound of what the per-splat uncertainties can do to it (sens)."""
+        ranges = np.ascontiguousarray(ranges, dtype=np.uint32)
+        point_list = np.ascontiguousarray(point_list, dtype=np.uint32)
+        a = lambda x: None if x is None else self.arr(x)
+        means, conic, opacity, color, bg = (self.arr(x) for x in (means_pix, conic, opacity, color, bg))
+        depth, depth_tol, drec, dcolor = a(depth), a(depth_tol), a(drec), a(dcolor)
+        n_var = 0 if drec is None else drec.shape[1]
+        assert drec is None or drec.shape == (opacity.shape[0], n_var, 5)
+        img = np.zeros((3, height, width), dtype=self.dtype)
+        final_T = np.zeros((height, width), dtype=self.dtype)
+        n_contrib = np.zeros((height, width), dtype=np.uint32)
+        cls = np.zeros((height, width), dtype=np.uint8)
+        sens = np.zeros((height, width), dtype=self.dtype)
+        flip = np.zeros((height, width), dtype=self.dtype)
+        rss = np.zeros((height, width), dtype=self.dtype)
+        self.lib.orc_render_forward_ex(C.c_int(width), C.c_int(height), self.rp(bg), _ptr(ranges, C.c_uint32),
+                                       _ptr(point_list, C.c_uint32), self.rp(means), self.rp(conic), self.rp(opacity),
+                                       self.rp(color), self.rp(img), self.rp(final_T), _ptr(n_contrib, C.c_uint32),
+                                       _ptr(cls, C.c_uint8), self.creal(ambig_eps), self.rp(depth), self.rp(depth_tol),
+                                       C.c_int(n_var), self.rp(drec), self.rp(dcolor), self.creal(eval_eps), self.creal(mean_eps),
+                                       self.creal(window_factor),
+                                       self.creal(impact_floor), self.rp(sens), self.rp(rss), self.rp(flip))
+        return img, final_T, n_contrib, cls, sens, rss, flip
+
+    def mark_rect_uncertain(self, width, height, means_pix, conic, opacity, r_lo, r_hi, dmean, eps, impact_floor, cls,
+                            flip):
+        """orc_mark_rect_uncertain: ORs CLS_RECT into cls, adds the reach to flip (both in place); returns the number of
+        splats with an uncertain tile"""
+        means, conic, opacity, dmean = (self.arr(x) for x in (means_pix, conic, opacity, dmean))
+        r_lo = np.ascontiguousarray(r_lo, dtype=np.int32)
+        r_hi = np.ascontiguousarray(r_hi, dtype=np.int32)
+        assert cls.dtype == np.uint8 and cls.flags.c_contiguous and cls.shape == (height, width)
+        assert flip.dtype == self.dtype and flip.flags.c_contiguous and flip.shape == (height, width)
+        return int(self.lib.orc_mark_rect_uncertain(C.c_int(opacity.shape[0]), C.c_int(width), C.c_int(height),
+                                                    self.rp(means), self.rp(conic), self.rp(opacity),
+                                                    _ptr(r_lo, C.c_int32), _ptr(r_hi, C.c_int32), self.rp(dmean),
+                                                    self.creal(eps), self.creal(impact_floor), _ptr(cls, C.c_uint8),
+                                                    self.rp(flip)))
 
     def render(self, scene, cam, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_deg=3, ambig_eps=0.0):
         """Whole forward pipeline (app/main.cpp:266-308).  scene = dict(pos, scale, rotq, sh, opacity)."""

@@ -83,6 +83,32 @@ void  orc_blend_exp_array(int64_t n, const float* x, float* out)
 void orc_set_blend_exp(int use_libm) { (void)use_libm; }
 #endif
 
+/* ---- numerics VARIANTS (comparison runs only; the parity oracle is the default: everything off, -ffp-contract=off) ----
+ * The reference's kernels are JIT-compiled by LuisaCompute for its backend; on CUDA that means NVRTC, which contracts
+ * a*b+c into FMAs by default and, under fast-math, turns a/b into a*rcp(b) and sqrt / normalize into rsqrt forms.  None of
+ * that is knowable offline (LuisaCompute is absent), so the restatement is ALSO built and run under those perturbations --
+ * samples of what such a compiler may do, not replicas -- to measure how far the frame moves and to check that every
+ * moved pixel is attributable to a rounding-sensitive decision the oracle itself can name (oracle/numerics.py):
+ *   - contraction: this file compiled with -ffp-contract=fast (Makefile target liblcgs_oracle_f32_contract.so, macro
+ *     ORC_CONTRACTED); the HOST-side camera code (util/camera.h, gs_projector/impl.cpp:34-42 run in C++ on the host, not
+ *     in the JIT) stays uncontracted in every build: the `#pragma GCC optimize` region below.
+ *   - ORC_NUM_RCP_DIV: every device-side a / b becomes a * (1 / b);
+ *   - ORC_NUM_RSQRT:  normalize(v) = v * rsqrt(dot) with a single-rounding rsqrt, sqrt(x) = x * rsqrt(x);
+ *   - ORC_NUM_REASSOC: dot products and matrix-vector sums added right to left (LuisaCompute's own order is assumed, not
+ *     known: header above) -- kept OUT of the ensemble that measures the uncertainties, as the independent check of them.
+ * The blend's exp stays the defined sequence (explicit fmaf builtins) unless orc_set_blend_exp(1) asks for libm's. */
+static int g_num = 0;
+void orc_set_numerics(int flags) { g_num = flags; }
+int  orc_get_numerics(void) { return g_num; }
+int  orc_build_contracted(void)
+{
+#ifdef ORC_CONTRACTED
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 static int g_threads = 0;
 /* FD-validation aid: when non-zero the two hard blend thresholds (alpha < 1/255 skip, T < 1e-4 stop) are disabled in
  * the forward AND the backward, which makes the image a smooth function of the parameters so that central
@@ -119,16 +145,28 @@ int orc_get_threads(void)
 static inline real r_min(real a, real b) { return a < b ? a : b; }
 static inline real r_max(real a, real b) { return a > b ? a : b; }
 static inline real r_clamp(real v, real lo, real hi) { return r_min(r_max(v, lo), hi); }
-static inline real dot3(const real a[3], const real b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline real dot3(const real a[3], const real b[3])
+{
+    if (g_num & ORC_NUM_REASSOC) return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]);
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
 static inline void cross3(const real a[3], const real b[3], real o[3])
 {
     o[0] = a[1] * b[2] - a[2] * b[1];
     o[1] = a[2] * b[0] - a[0] * b[2];
     o[2] = a[0] * b[1] - a[1] * b[0];
 }
+/* device-side division / square root / normalize: the reference's expressions unless a numerics variant is switched on */
+static inline real d_div(real a, real b) { return (g_num & ORC_NUM_RCP_DIV) ? a * (RC(1.0f) / b) : a / b; }
+static inline real d_rsqrt1(real x) { return (real)(1.0 / sqrt((double)x)); } /* one rounding, like a hardware rsqrt */
+static inline real d_sqrt(real x)
+{
+    if ((g_num & ORC_NUM_RSQRT) && x > RC(0.0f) && x < (real)INFINITY) return x * d_rsqrt1(x);
+    return R_SQRT(x);
+}
 static inline void normalize3(const real v[3], real o[3])
 {
-    real inv = RC(1.0f) / R_SQRT(dot3(v, v));
+    real inv = (g_num & ORC_NUM_RSQRT) ? d_rsqrt1(dot3(v, v)) : RC(1.0f) / R_SQRT(dot3(v, v));
     o[0] = v[0] * inv;
     o[1] = v[1] * inv;
     o[2] = v[2] * inv;
@@ -151,6 +189,10 @@ static inline int32_t f2i_sat(real x)
 /* column-major 3x3: m[c*3+r].  LC order: out = m[0]*v.x + m[1]*v.y + m[2]*v.z */
 static inline void m3_mul_v3(const real m[9], const real v[3], real o[3])
 {
+    if (g_num & ORC_NUM_REASSOC) {
+        for (int r = 0; r < 3; ++r) o[r] = m[0 * 3 + r] * v[0] + (m[1 * 3 + r] * v[1] + m[2 * 3 + r] * v[2]);
+        return;
+    }
     for (int r = 0; r < 3; ++r) o[r] = m[0 * 3 + r] * v[0] + m[1 * 3 + r] * v[1] + m[2 * 3 + r] * v[2];
 }
 static inline void m3_mul(const real a[9], const real b[9], real o[9])
@@ -169,22 +211,46 @@ static inline void m3_transpose(const real a[9], real o[9])
 
 void orc_mat4_mul_vec4(const real m[16], const real v[4], real out[4])
 {
+    if (g_num & ORC_NUM_REASSOC) {
+        for (int r = 0; r < 4; ++r)
+            out[r] = m[0 * 4 + r] * v[0] + (m[1 * 4 + r] * v[1] + (m[2 * 4 + r] * v[2] + m[3 * 4 + r] * v[3]));
+        return;
+    }
     for (int r = 0; r < 4; ++r)
         out[r] = m[0 * 4 + r] * v[0] + m[1 * 4 + r] * v[1] + m[2 * 4 + r] * v[2] + m[3 * 4 + r] * v[3];
 }
 
 /* ------------------------------------------------------------------ camera */
+/* HOST-side code of the reference (plain C++ in util/camera.h and gs_projector/impl.cpp, never seen by the JIT): compiled
+ * without contraction in every build, with its own copies of the small vector helpers so that nothing is inlined across
+ * the boundary. */
+#pragma GCC push_options
+#pragma GCC optimize("fp-contract=off")
+static real h_dot3(const real a[3], const real b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void h_cross3(const real a[3], const real b[3], real o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static void h_normalize3(const real v[3], real o[3])
+{
+    real inv = RC(1.0f) / R_SQRT(h_dot3(v, v));
+    o[0] = v[0] * inv;
+    o[1] = v[1] * inv;
+    o[2] = v[2] * inv;
+}
 /* lcgs/include/lcgs/util/camera.h:74-82 */
 void orc_get_lookat_cam(const real pos[3], const real target[3], const real world_up[3], orc_camera* cam)
 {
     real d[3] = { target[0] - pos[0], target[1] - pos[1], target[2] - pos[2] };
     real c[3];
     memcpy(cam->position, pos, 3 * sizeof(real));
-    normalize3(d, cam->front);
-    cross3(cam->front, world_up, c);
-    normalize3(c, cam->right);
-    cross3(cam->right, cam->front, c);
-    normalize3(c, cam->up);
+    h_normalize3(d, cam->front);
+    h_cross3(cam->front, world_up, c);
+    h_normalize3(c, cam->right);
+    h_cross3(cam->right, cam->front, c);
+    h_normalize3(c, cam->up);
     /* defaults, camera.h:21-24 */
     cam->fov          = RC(60.0f);
     cam->aspect_ratio = RC(1.0f);
@@ -208,9 +274,9 @@ void orc_local_to_world_matrix(const orc_camera* cam, real m[16])
 /* camera.h:38-51 */
 void orc_world_to_local_matrix(const orc_camera* cam, real m[16])
 {
-    real tx = -dot3(cam->position, cam->right);
-    real ty = -dot3(cam->position, cam->up);
-    real tz = -dot3(cam->position, cam->front);
+    real tx = -h_dot3(cam->position, cam->right);
+    real ty = -h_dot3(cam->position, cam->up);
+    real tz = -h_dot3(cam->position, cam->front);
     for (int c = 0; c < 3; ++c) {
         m[c * 4 + 0] = cam->right[c];
         m[c * 4 + 1] = cam->up[c];
@@ -256,6 +322,7 @@ static void make_cam_params(const orc_camera* cam, cam_params* cp)
     cp->focalx = (real)cam->width / (RC(2.0f) * cp->tanfovx);
     cp->focaly = (real)cam->height / (RC(2.0f) * cp->tanfovy);
 }
+#pragma GCC pop_options
 
 /* ------------------------------------------------------------------ SH */
 /* lcgs/include/lcgs/util/sh.hpp:12-28 */
@@ -381,15 +448,15 @@ static void ewasplat_cov(const real cov3d[9], const real t[3], const real view[1
     real J[9], W[9], T[9], Tt[9], A[9];
     memset(J, 0, sizeof(J));
     if (focal) {
-        J[0 * 3 + 0] = focalx / t[2];
-        J[1 * 3 + 1] = focaly / t[2];
-        J[0 * 3 + 2] = (-focalx * t[0]) / (t[2] * t[2]);
-        J[1 * 3 + 2] = (-focaly * t[1]) / (t[2] * t[2]);
+        J[0 * 3 + 0] = d_div(focalx, t[2]);
+        J[1 * 3 + 1] = d_div(focaly, t[2]);
+        J[0 * 3 + 2] = d_div(-focalx * t[0], t[2] * t[2]);
+        J[1 * 3 + 2] = d_div(-focaly * t[1], t[2] * t[2]);
     } else {
         J[0 * 3 + 0] = RC(1.0f) / t[2];
         J[1 * 3 + 1] = RC(1.0f) / t[2];
-        J[0 * 3 + 2] = (-t[0]) / (t[2] * t[2]);
-        J[1 * 3 + 2] = (-t[1]) / (t[2] * t[2]);
+        J[0 * 3 + 2] = d_div(-t[0], t[2] * t[2]);
+        J[1 * 3 + 2] = d_div(-t[1], t[2] * t[2]);
     }
     for (int c = 0; c < 3; ++c)
         for (int r = 0; r < 3; ++r) W[c * 3 + r] = view[c * 4 + r];
@@ -405,8 +472,8 @@ static void cam_clamp(const real p[3], real tanfovx, real tanfovy, real t[3])
 {
     real limx = RC(1.3f) * tanfovx;
     real limy = RC(1.3f) * tanfovy;
-    real txtz = p[0] / p[2];
-    real tytz = p[1] / p[2];
+    real txtz = d_div(p[0], p[2]);
+    real tytz = d_div(p[1], p[2]);
     t[0] = r_clamp(txtz, -limx, limx) * p[2];
     t[1] = r_clamp(tytz, -limy, limy) * p[2];
     t[2] = p[2];
@@ -440,9 +507,9 @@ static void project_one(const cam_params* cp, const real mean[3], const real s[3
     cov2d[1] = cov[0 * 3 + 1];
     cov2d[2] = cov[1 * 3 + 1];
     if (!use_focal) { /* :73-76 */
-        cov2d[0] = cov2d[0] * RC(1.0f) / (cp->tanfovx * cp->tanfovx);
-        cov2d[1] = cov2d[1] * RC(1.0f) / (cp->tanfovx * cp->tanfovy);
-        cov2d[2] = cov2d[2] * RC(1.0f) / (cp->tanfovy * cp->tanfovy);
+        cov2d[0] = d_div(cov2d[0] * RC(1.0f), cp->tanfovx * cp->tanfovx);
+        cov2d[1] = d_div(cov2d[1] * RC(1.0f), cp->tanfovx * cp->tanfovy);
+        cov2d[2] = d_div(cov2d[2] * RC(1.0f), cp->tanfovy * cp->tanfovy);
     }
 }
 
@@ -522,9 +589,9 @@ void orc_allocate_tiles(int P, int width, int height, const real* depth, real* m
         real inv_det = RC(1.0f) / (det + RC(1e-6f));
         real conic[3] = { inv_det * cz, inv_det * (-cy), inv_det * cx };
         real mid     = RC(0.5f) * (cx + cz);
-        real lambda1 = mid + R_SQRT(r_max(RC(0.1f), mid * mid - det));
-        real lambda2 = mid - R_SQRT(r_max(RC(0.1f), mid * mid - det));
-        int32_t my_radius = f2i_sat(R_CEIL(RC(3.0f) * R_SQRT(r_max(lambda1, lambda2))));
+        real lambda1 = mid + d_sqrt(r_max(RC(0.1f), mid * mid - det));
+        real lambda2 = mid - d_sqrt(r_max(RC(0.1f), mid * mid - det));
+        int32_t my_radius = f2i_sat(R_CEIL(RC(3.0f) * d_sqrt(r_max(lambda1, lambda2))));
         real     pix[2] = { ndc2pix(ndc[0], res[0]), ndc2pix(ndc[1], res[1]) };
         uint32_t rmin[2], rmax[2];
         get_rect(pix, my_radius, rmin, rmax, grids);
@@ -651,16 +718,39 @@ static inline int near_rel(real a, real b, real eps)
 
 /* gs_tile_splatter/shader.cpp:171-288.  The reference stages entries through shared memory in
  * rounds of 256; that only changes where the values are read from, not their values or order,
- * so the restatement walks the tile list directly. */
-void orc_render_forward(int width, int height, const real bg[3], const uint32_t* ranges,
-                        const uint32_t* point_list, const real* means_2d, const real* conic,
-                        const real* opacity, const real* color, real* img, real* final_T,
-                        uint32_t* n_contrib, uint8_t* ambig, real ambig_eps)
+ * so the restatement walks the tile list directly.
+ *
+ * The optional outputs beyond the reference's image name what makes a pixel sensitive to rounding (oracle/numerics.py):
+ *   cls[H*W]   ORC_CLS_THRESHOLD  some `power > 0`, `alpha < 1/255` or `T < 1e-4` decision of the pixel was within
+ *                                 ambig_eps (relative) of flipping (the `ambig` flag of rounds 1-5) -- the window widened
+ *                                 by window_factor x what the entry's own uncertainty does to its alpha, and, for T, by
+ *                                 the accumulated uncertainty of the factors in front;
+ *              ORC_CLS_DEPTH      two entries that BOTH contribute to the pixel lie closer in depth than the sum of their
+ *                                 depth uncertainties (depth_tol[], absolute): the stable sort may order them either way
+ *                                 (equal depth bits included: a perturbed evaluation separates them);
+ *              (ORC_CLS_RECT is set by orc_mark_rect_uncertain below);
+ *              a bit is set when the flip could move the pixel by more than impact_floor;
+ *   flip[H*W]  the sum of what each ambiguous decision could move the pixel by if it went the other way: an alpha skip
+ *              T alpha, a `T < 1e-4` stop T, a swap of two adjacent contributors T_i alpha_i alpha_j;
+ *   sens[H*W]  first-order bound of what the per-splat uncertainties drec[P][n_var][5] (signed distances of n_var other
+ *              evaluations of the splat's record; |d power| = the largest any of them gives at the pixel) / dcolor[P] can do
+ *              to the pixel: sum over contributing entries of T alpha (|d power| + |d colour|) -- a perturbed alpha_k
+ *              moves the pixel by at most T_k |d alpha_k| (colours lie in [0, 1], the entries behind scale with
+ *              1 / (1 - alpha_k));
+ *   sens_rss[H*W]  the same terms combined as independent errors: sqrt(sum of squares). */
+static void render_forward_impl(int width, int height, const real bg[3], const uint32_t* ranges,
+                                const uint32_t* point_list, const real* means_2d, const real* conic,
+                                const real* opacity, const real* color, real* img, real* final_T,
+                                uint32_t* n_contrib, uint8_t* ambig, real ambig_eps, const real* depth,
+                                const real* depth_tol, int n_var, const real* drec, const real* dcolor,
+                                real eval_eps, real mean_eps, real window_factor, real impact_floor, real* sens, real* sens_rss, real* flip)
 {
     uint32_t grids[2];
     make_grids(width, height, grids);
     const size_t hw      = (size_t)width * (size_t)height;
     const int    n_tiles = (int)(grids[0] * grids[1]);
+    const int    want_depth = ambig && depth && depth_tol;
+    const int    want_sens  = n_var > 0 && drec;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile_id = 0; tile_id < n_tiles; ++tile_id) {
         uint32_t tx = (uint32_t)tile_id % grids[0], ty = (uint32_t)tile_id / grids[0];
@@ -676,6 +766,15 @@ void orc_render_forward(int width, int height, const real bg[3], const uint32_t*
                 uint32_t contributor      = 0u;
                 uint32_t last_contributor = 0u;
                 uint8_t  amb              = 0;
+                real     last_depth = RC(0.0f), last_tol = RC(0.0f), sn = RC(0.0f), sq = RC(0.0f), T_unc = RC(0.0f), T_jump = RC(0.0f), fl = RC(0.0f);
+                real     last_w     = RC(0.0f); /* T alpha of the previous contributor */
+                int      have_last  = 0;
+/* an ambiguous decision: its class bit (when the flip could move the pixel by more than impact_floor) and its impact */
+#define ORC_AMBIGUOUS(bit, impact)                       \
+    do {                                                 \
+        if ((impact) > impact_floor) amb |= (bit);       \
+        fl = fl + (impact);                              \
+    } while (0)
                 for (uint32_t e = range_start; e < range_end; ++e) {
                     contributor    = contributor + 1u;
                     uint32_t id    = point_list[e];
@@ -686,14 +785,61 @@ void orc_render_forward(int width, int height, const real bg[3], const uint32_t*
                     real     cz    = conic[3 * (size_t)id + 2];
                     real     o     = opacity[id];
                     real     power = RC(-0.5f) * (cx * dx * dx + cz * dy * dy) - cy * dx * dy; /* :256 */
-                    if (ambig && R_FABS(power) <= ambig_eps) amb = 1;
+                    /* what the splat's own uncertainty does to `power` at this pixel (first order); it widens the windows
+                     * of the entry's threshold decisions and feeds the continuous bound */
+                    real dpow = RC(0.0f);
+                    if (want_sens) {
+                        /* the pixel's own evaluation of :256: each product and sum rounds at the size of the TERMS, which
+                         * for a needle-shaped splat are far larger than the power they cancel to */
+                        dpow = eval_eps * (RC(0.5f) * (R_FABS(cx) * dx * dx + R_FABS(cz) * dy * dy) + R_FABS(cy * dx * dy) +
+                                           RC(2.0f)); /* + the exp itself: implementations differ by a few ulp (relative in alpha) */
+                        /* the pixel mean ((ndc + 1) S - 1) / 2 is good to about an ulp of itself and of S / 2 -- 1e-4 px
+                         * at x = 1500 -- whichever way it is evaluated; the spread over a handful of evaluations below
+                         * is a sample of that (often exactly 0), so it gets this floor */
+                        dpow = dpow + mean_eps * (R_FABS(cx * dx + cy * dy) * (R_FABS(means_2d[2 * (size_t)id + 0]) + RC(0.5f) * (real)width) +
+                                                  R_FABS(cz * dy + cy * dx) * (R_FABS(means_2d[2 * (size_t)id + 1]) + RC(0.5f) * (real)height));
+                        real dvar = RC(0.0f);
+                        /* drec[id][v] = (d mean.x, d mean.y, d conic.x, d conic.y, d conic.z): the SIGNED distance of
+                         * evaluation v's record from this one -- signed, because an ill-conditioned splat's conic terms
+                         * are each far larger than the power they sum to, and their errors are as correlated */
+                        const real* r = drec + (size_t)id * 5 * (size_t)n_var;
+                        for (int v = 0; v < n_var; ++v, r += 5) {
+                            real d = RC(-0.5f) * (r[2] * dx * dx + r[4] * dy * dy) - r[3] * dx * dy -
+                                     (cx * dx + cy * dy) * r[0] - (cz * dy + cy * dx) * r[1];
+                            dvar = r_max(dvar, R_FABS(d));
+                        }
+                        dpow = dpow + dvar;
+                    }
+                    const real w_a = ambig_eps + window_factor * dpow; /* relative window of alpha = o exp(power) */
+                    if (ambig && R_FABS(power) <= w_a) ORC_AMBIGUOUS(ORC_CLS_THRESHOLD, T * r_min(RC(0.99f), o));
                     if (power > RC(0.0f)) continue;
                     real alpha = r_min(RC(0.99f), o * R_EXP(power));
-                    if (ambig && near_rel(alpha, RC(1.0f) / RC(255.0f), ambig_eps)) amb = 1;
+                    if (ambig && near_rel(alpha, RC(1.0f) / RC(255.0f), w_a)) {
+                        ORC_AMBIGUOUS(ORC_CLS_THRESHOLD, T * alpha);
+                        T_jump = T_jump + alpha / (RC(1.0f) - alpha); /* blended or not: every later T is that uncertain */
+                    }
                     if (!orc_g_smooth && alpha < RC(1.0f) / RC(255.0f)) continue;
                     real test_T = T * (RC(1.0f) - alpha);
-                    if (ambig && near_rel(test_T, RC(0.0001f), ambig_eps)) amb = 1;
+                    /* T carries the relative uncertainty of every (1 - alpha_j) in front: alpha_j dpow_j / (1 - alpha_j) */
+                    const real t_unc = alpha < RC(0.99f) ? alpha * dpow / (RC(1.0f) - alpha) : RC(0.0f);
+                    if (ambig && near_rel(test_T, RC(0.0001f), ambig_eps + window_factor * (T_unc + t_unc) + T_jump))
+                        ORC_AMBIGUOUS(ORC_CLS_THRESHOLD, T); /* this entry's T alpha and everything behind it: <= T */
                     if (!orc_g_smooth && test_T < RC(0.0001f)) break; /* done = true; loop exits at next iteration, :261-265 */
+                    if (want_depth) {
+                        /* swapping two adjacent contributors i, j moves the pixel by T_i alpha_i alpha_j |c_i - c_j| */
+                        if (have_last && depth[id] - last_depth <= depth_tol[id] + last_tol)
+                            ORC_AMBIGUOUS(ORC_CLS_DEPTH, last_w * alpha);
+                        last_w     = T * alpha;
+                        last_depth = depth[id];
+                        last_tol   = depth_tol[id];
+                        have_last  = 1;
+                    }
+                    if (want_sens) {
+                        const real term = T * (alpha < RC(0.99f) ? alpha * dpow : RC(0.0f)) + (dcolor ? T * alpha * dcolor[id] : RC(0.0f));
+                        sn    = sn + term;
+                        sq    = sq + term * term;
+                        T_unc = T_unc + t_unc;
+                    }
                     for (int ch = 0; ch < 3; ++ch) C[ch] = C[ch] + T * alpha * color[3 * (size_t)id + ch];
                     T                = test_T;
                     last_contributor = contributor;
@@ -703,9 +849,93 @@ void orc_render_forward(int width, int height, const real bg[3], const uint32_t*
                 if (final_T) final_T[pix_id] = T;
                 if (n_contrib) n_contrib[pix_id] = last_contributor;
                 if (ambig) ambig[pix_id] = amb;
+                if (sens) sens[pix_id] = sn;
+                if (sens_rss) sens_rss[pix_id] = R_SQRT(sq);
+                if (flip) flip[pix_id] = fl;
+#undef ORC_AMBIGUOUS
             }
         }
     }
+}
+
+void orc_render_forward(int width, int height, const real bg[3], const uint32_t* ranges,
+                        const uint32_t* point_list, const real* means_2d, const real* conic,
+                        const real* opacity, const real* color, real* img, real* final_T,
+                        uint32_t* n_contrib, uint8_t* ambig, real ambig_eps)
+{
+    render_forward_impl(width, height, bg, ranges, point_list, means_2d, conic, opacity, color, img, final_T, n_contrib,
+                        ambig, ambig_eps, NULL, NULL, 0, NULL, NULL, RC(0.0f), RC(0.0f), RC(0.0f), RC(0.0f), NULL, NULL, NULL);
+}
+
+void orc_render_forward_ex(int width, int height, const real bg[3], const uint32_t* ranges,
+                           const uint32_t* point_list, const real* means_2d, const real* conic,
+                           const real* opacity, const real* color, real* img, real* final_T,
+                           uint32_t* n_contrib, uint8_t* cls, real ambig_eps, const real* depth,
+                           const real* depth_tol, int n_var, const real* drec, const real* dcolor,
+                           real eval_eps, real mean_eps, real window_factor, real impact_floor, real* sens, real* sens_rss, real* flip)
+{
+    render_forward_impl(width, height, bg, ranges, point_list, means_2d, conic, opacity, color, img, final_T, n_contrib,
+                        cls, ambig_eps, depth, depth_tol, n_var, drec, dcolor, eval_eps, mean_eps, window_factor, impact_floor, sens, sens_rss, flip);
+}
+
+/* ORC_CLS_RECT: which tiles a splat is listed in is decided by ceil(3 sqrt(lambda)) (shader.cpp:145-148) and by four
+ * float -> uint conversions of (pix -+ radius) / 16 (module.cpp:30-35).  Given, per splat, the radii the rounding window
+ * allows (r_lo <= radius <= r_hi, from oracle/numerics.py) and the uncertainty of its pixel mean (dmean), a tile is
+ * UNCERTAIN for the splat when it lies in the widest rect those allow but not in the narrowest; every pixel of such a
+ * tile that the splat would reach with alpha >= (1 - eps) / 255 gets the flag -- whether or not this run listed it there --
+ * and alpha added to its flip bound.  (Conservative: the transmittance in front of the splat is ignored.)  Returns the number of splats with an uncertain tile. */
+int64_t orc_mark_rect_uncertain(int P, int width, int height, const real* means_pix, const real* conic,
+                                const real* opacity, const int32_t* r_lo, const int32_t* r_hi, const real* dmean,
+                                real eps, real impact_floor, uint8_t* cls, real* flip)
+{
+    uint32_t grids[2];
+    make_grids(width, height, grids);
+    int64_t n_uncertain = 0;
+#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : n_uncertain)
+    for (int idx = 0; idx < P; ++idx) {
+        if (r_hi[idx] <= 0) continue;
+        const real p[2]  = { means_pix[2 * (size_t)idx], means_pix[2 * (size_t)idx + 1] };
+        const real d[2]  = { dmean[2 * (size_t)idx], dmean[2 * (size_t)idx + 1] };
+        const real pm[2] = { p[0] - d[0], p[1] - d[1] }, pp[2] = { p[0] + d[0], p[1] + d[1] };
+        uint32_t a[2], b[2], wmin[2], wmax[2], nmin[2], nmax[2];
+        get_rect(pm, r_hi[idx], wmin, b, grids); /* widest: lowest min edge ... */
+        get_rect(pp, r_hi[idx], a, wmax, grids); /* ... highest max edge */
+        if (r_lo[idx] > 0) {
+            get_rect(pp, r_lo[idx], nmin, b, grids);
+            get_rect(pm, r_lo[idx], a, nmax, grids);
+        } else {
+            nmin[0] = nmin[1] = nmax[0] = nmax[1] = 0u; /* the splat may not be listed at all */
+        }
+        if (wmin[0] == nmin[0] && wmin[1] == nmin[1] && wmax[0] == nmax[0] && wmax[1] == nmax[1]) continue;
+        n_uncertain += 1;
+        const real cx = conic[3 * (size_t)idx], cy = conic[3 * (size_t)idx + 1], cz = conic[3 * (size_t)idx + 2];
+        const real o = opacity[idx];
+        for (uint32_t j = wmin[1]; j < wmax[1]; ++j)
+            for (uint32_t i = wmin[0]; i < wmax[0]; ++i) {
+                if (i >= nmin[0] && i < nmax[0] && j >= nmin[1] && j < nmax[1]) continue; /* certain */
+                for (uint32_t ly = 0; ly < BLOCK_Y; ++ly)
+                    for (uint32_t lx = 0; lx < BLOCK_X; ++lx) {
+                        uint32_t x = i * BLOCK_X + lx, y = j * BLOCK_Y + ly;
+                        if (!(x < (uint32_t)width && y < (uint32_t)height)) continue;
+                        real dx = p[0] - (real)x, dy = p[1] - (real)y;
+                        real power = RC(-0.5f) * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+                        if (power > eps) continue;
+                        real alpha = r_min(RC(0.99f), o * R_EXP(r_min(power, RC(0.0f))));
+                        if (alpha < (RC(1.0f) - eps) * (RC(1.0f) / RC(255.0f))) continue;
+                        uint8_t* c = &cls[(size_t)x + (size_t)width * (size_t)y];
+                        if (alpha > impact_floor) {
+#pragma omp atomic update
+                            *c |= ORC_CLS_RECT;
+                        }
+                        if (flip) {
+                            real* f = &flip[(size_t)x + (size_t)width * (size_t)y];
+#pragma omp atomic update
+                            *f += alpha;
+                        }
+                    }
+            }
+    }
+    return n_uncertain;
 }
 
 /* gs_tile_splatter/impl.cpp:63-180 */

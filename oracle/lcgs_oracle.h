@@ -23,7 +23,7 @@
  *     sequence of binary32 operations (orc_blend_exp, <= 2.73 ulp from the true value
  *     on the blend's range), which the HIP kernels repeat bit for bit.  PARITY
  *     UNPINNED against the reference below that band, like every other exp of it.
- *   - the two reference-held output images (doc/*_cuda.png): pin the unrasterised
+ *   - the two reference-held output images (the two doc/..._cuda.png): pin the unrasterised
  *     last tile row / column and the row flip (tests/test_reference_png.py).
  *   - scan / sort: lcpp is absent; semantics = inclusive sum / stable ascending
  *     sort.  PARITY UNPINNED.
@@ -67,6 +67,13 @@ void orc_set_smooth(int on);
 /* The blend's exp (gs_tile_splatter/shader.cpp:258): a build-DEFINED sequence of binary32 operations, see lcgs_oracle.c.
  * orc_set_blend_exp(1) switches the f32 build to libm's expf (comparison runs only); no-op in the f64 build. */
 void  orc_set_blend_exp(int use_libm);
+/* Numerics VARIANTS for comparison runs (lcgs_oracle.c): never set for parity work. */
+#define ORC_NUM_RCP_DIV 1 /* device-side a / b  ->  a * (1 / b) */
+#define ORC_NUM_RSQRT   2 /* normalize through a single-rounding rsqrt, sqrt(x) = x * rsqrt(x) */
+#define ORC_NUM_REASSOC 4 /* dot products / matrix-vector sums added right to left */
+void orc_set_numerics(int flags);
+int  orc_get_numerics(void);
+int  orc_build_contracted(void); /* 1 in liblcgs_oracle_f32_contract.so (-ffp-contract=fast), else 0 */
 float orc_blend_exp(float x);
 float orc_blend_exp_sel(float x);
 void  orc_blend_exp_array(int64_t n, const float* x, float* out);
@@ -123,6 +130,28 @@ void orc_render_forward(int width, int height, const real bg[3],
                         const real* means_2d, const real* conic, const real* opacity, const real* color,
                         real* img, real* final_T, uint32_t* n_contrib,
                         uint8_t* ambig, real ambig_eps);
+
+/* The same walk with what makes each pixel rounding-sensitive named beside the image (see lcgs_oracle.c; driver:
+ * oracle/numerics.py).  cls bits: */
+#define ORC_CLS_THRESHOLD 1u /* a power / alpha / T decision within ambig_eps of flipping (= `ambig` above) */
+#define ORC_CLS_DEPTH     2u /* two contributing entries closer in depth than their depth uncertainties */
+#define ORC_CLS_RECT      4u /* a splat reaches the pixel through a tile its rounding window may or may not list */
+void orc_render_forward_ex(int width, int height, const real bg[3],
+                           const uint32_t* ranges, const uint32_t* point_list,
+                           const real* means_2d, const real* conic, const real* opacity, const real* color,
+                           real* img, real* final_T, uint32_t* n_contrib,
+                           uint8_t* cls, real ambig_eps,
+                           const real* depth, const real* depth_tol, /* [P], nullable: no ORC_CLS_DEPTH */
+                           int n_var, const real* drec,              /* [P][n_var][5] signed (d mean.xy, d conic.xyz), nullable: no sens */
+                           const real* dcolor,                       /* [P] absolute, nullable */
+                           real eval_eps,                            /* rounding of the pixel's own power evaluation, x the sum of |terms| */
+                           real mean_eps,                            /* floor of the pixel mean's uncertainty, x (|mean| + S / 2) */
+                           real window_factor,                       /* threshold windows += factor x the entry's own uncertainty */
+                           real impact_floor,                        /* a class bit needs a possible move beyond this */
+                           real* sens, real* sens_rss, real* flip);  /* [H*W] continuous terms: sum, root of squares; flip impacts */
+int64_t orc_mark_rect_uncertain(int P, int width, int height, const real* means_pix, const real* conic,
+                                const real* opacity, const int32_t* r_lo, const int32_t* r_hi, const real* dmean,
+                                real eps, real impact_floor, uint8_t* cls, real* flip);
 
 /* gs_tile_splatter/impl.cpp:63-180: allocate_tiles -> scan -> keys -> sort -> ranges -> render.
  * Buffers sized L_cap for keys/lists.  Returns num_rendered, or -1 if L_cap is too small. */

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from conftest import make_scene
-from gpu_util import DEV, assert_image_parity, assert_parity_vs_libm_expf, dev, upload_scene
+from gpu_util import DEV, assert_image_parity, assert_parity_vs_libm_expf, assert_parity_vs_numerics_variants, dev, upload_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -170,8 +170,12 @@ def test_synth_stand_in_scenes(lcgs, oracle):
     from conftest import baseline_scene
 
     scene, data = baseline_scene(lcgs, "chair")
-    _, orc, stats = _render_both(lcgs, oracle, scene, 800, 800, bg=(0, 0, 0), check_lists=True, vs_libm=True)
+    r, orc, stats = _render_both(lcgs, oracle, scene, 800, 800, bg=(0, 0, 0), check_lists=True, vs_libm=True)
     assert orc["num_rendered"] > (1_000_000 if data == "synthetic" else 100_000)
+    # the same frame against the reference's LIKELY numerics (oracle/numerics.py): every pixel inside its bound
+    img = torch.zeros(3, 800, 800, device=DEV)
+    r.forward(lcgs.get_lookat_cam(*POSE, width=800, height=800), img, sync=True)
+    assert_parity_vs_numerics_variants(img.cpu().numpy(), scene, oracle.lookat(*POSE, width=800, height=800))
 
 
 @pytest.mark.parametrize("P,spread", [(5000, 0.05), (30000, 0.04), (70000, 0.03)])

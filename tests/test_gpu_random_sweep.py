@@ -6,7 +6,8 @@ import pytest
 import torch
 
 from conftest import make_scene
-from gpu_util import DEV, assert_image_parity, assert_parity_vs_libm_expf, check_gradients, dev, upload_scene
+from gpu_util import (DEV, assert_image_parity, assert_parity_vs_libm_expf, assert_parity_vs_numerics_variants, check_gradients, dev,
+                      upload_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -46,6 +47,11 @@ def test_random_forward_frames(lcgs, oracle, seed):
     if n:
         assert_image_parity(img.cpu().numpy(), ref)
         assert_parity_vs_libm_expf(img.cpu().numpy(), oracle, scene, ocam, bg=bg, scale_modifier=sm)
+        if seed % 4 == 0:  # (every draw runs on the CPU in tests/test_oracle_numerics.py; here the HIP frame is the one held)
+            from oracle import numerics
+
+            rep, _ = numerics.report(scene, ocam, bg=bg, scale_modifier=sm, img=img.cpu().numpy())
+            assert all(v["all_explained"] for v in rep["variants"].values()), rep
 
 
 @pytest.mark.parametrize("seed", range(5))
