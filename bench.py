@@ -430,6 +430,9 @@ def rooflines(r, stats, acc, data, P, W, H, ms_per_step):
                 "valu_issue": valu, "kernel_sources_sha256": src_hash, "library_sha256": lib_hash,
                 "note": "the dominant kernel (per-tile compositing) is VALU-issue bound, not HBM bound: `frac` is its HBM "
                         "fraction (the contract's figure), valu_issue.frac the roof it is at; see DESIGN.md 4"}
+    # PMC bytes over algorithmic bytes: how much the kernel re-reads (1 = every byte once)
+    roofline["traffic_ratio"] = (round((traffic["fetch_bytes_x2_corrected"] + traffic["write_bytes"]) / stage_bytes[dominant], 3)
+                                 if traffic and stage_bytes.get(dominant) else None)
     if dominant == "render" and stats.get("renderer_entries", Lp) != Lp:
         roofline["list_entries"] = Lp
         roofline["entries_staged_by_tile_workgroups"] = stats["renderer_entries"]
@@ -592,6 +595,7 @@ def leg_gradients(S):
             el_compact = timed_steps(False, compact=True) if dist is None else None
             r.set_profiling(True)
             r.forward(cam, img, keep_state=True, sync=True)
+            Lk = r.frame_stats()["num_pairs"]  # the keep-state frame's own PER-TILE lists: what k_render_backward walks
             r.backward(dL, *[views[k] for k in KEYS])
             bwd_stages = r.stage_times()
             r.set_profiling(False)
@@ -602,12 +606,14 @@ def leg_gradients(S):
                               "collective": coll.name if coll is not None else None,
                               "backward_stages_ms": {k: round(v, 4) for k, v in bwd_stages.items()}}
             # ---- the metric's second half has a dominant kernel of its own: k_render_backward.  Algorithmic bytes per launch
-            # (render half of the backward): 40 L (list entry + 36-byte record re-gathered) + 20 W H (final_T,
+            # (render half of the backward): 40 L -- L = the pairs of the frame that KEPT the backward's state, per
+            # tile (7.53 M on the stand-in), not the forward-only frame's per-block pairs (4.47 M) that rounds up to 5 priced it
+            # with -- (list entry + 36-byte record re-gathered) + 20 W H (final_T,
             # n_contrib, dL/dimg) + 40 V (2-D gradient rows, read-modify-write); time = HIP events around the kernel on the
             # context's stream (profiling mode: alone, not beside the zero-fill); traffic and the VALU issue fraction from the
             # committed rocprofv3 passes of this workload, refused when measured on other sources.
             rb_ms = bwd_stages.get("render_backward", 0.0)
-            rb_bytes = 40 * Lp + 20 * W * H + 40 * V
+            rb_bytes = 40 * Lk + 20 * W * H + 40 * V
             if rb_ms > 0:
                 rb_gbs = rb_bytes / (rb_ms * 1e-3) / 1e9
                 rb_traffic = None
@@ -621,8 +627,10 @@ def leg_gradients(S):
                 out["fwd_bwd"]["roofline"] = {
                     "kernel": "k_render_backward", "bound": "valu", "achieved": round(rb_gbs, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(rb_gbs / HBM_PEAK_GBS, 4), "traffic": rb_traffic,
-                    "algorithmic_bytes_per_launch": rb_bytes, "avg_launch_ms": round(rb_ms, 4), "valu_issue": rb_valu,
-                    "kernel_sources_sha256": src_hash,
+                    "algorithmic_bytes_per_launch": rb_bytes, "list_entries": Lk, "avg_launch_ms": round(rb_ms, 4),
+                    "traffic_ratio": (round((rb_traffic["fetch_bytes_x2_corrected"] + rb_traffic["write_bytes"]) / rb_bytes, 3)
+                                      if rb_traffic else None),
+                    "valu_issue": rb_valu, "kernel_sources_sha256": src_hash,
                     "note": "the step's dominant kernel: VALU-issue-bound (per-pixel terms and nine 64-lane sums per list entry and strip); "
                             "`frac` is its HBM fraction, valu_issue.frac the measured share of SIMD cycles issuing VALU work"}
             if dist is not None:

@@ -58,7 +58,7 @@ lcgs_status lcgs_render_backward_adam(lcgs_context* ctx, const float* d_dL_dimg,
     auto aligned16 = [](const lcgs_params* p) {
         return ((reinterpret_cast<uintptr_t>(p->rotq) | reinterpret_cast<uintptr_t>(p->sh)) & 15) == 0;
     };
-    const bool fusable = ctx->sh_deg == 3 && ctx->last.valid && ctx->last.has_state && ctx->last_has_jac && aligned16(raw) &&
+    const bool fusable = ctx->sh_deg == 3 && ctx->frame_state_valid() && ctx->last.has_state && ctx->last_has_jac && aligned16(raw) &&
                          aligned16(m) && aligned16(v) && aligned16(activated);
     if (!fusable) {
         // other SH degrees, frames without the kept colour Jacobian, unaligned rows: the same step as two calls on
@@ -89,7 +89,7 @@ lcgs_status lcgs_render_backward_adam(lcgs_context* ctx, const float* d_dL_dimg,
 lcgs_status lcgs_visible_rows(lcgs_context* ctx, const uint32_t** d_rows, const uint32_t** d_count)
 {
     LCGS_REQUIRE(ctx && d_rows && d_count, "NULL argument");
-    LCGS_REQUIRE(ctx->last.valid, "no frame rendered yet");
+    LCGS_REQUIRE(ctx->frame_state_valid(), "no frame rendered yet");
     *d_rows  = ctx->vis_index.as<uint32_t>();
     *d_count = ctx->counts.as<uint32_t>(); // [0] = on-screen splats of the last frame
     return LCGS_OK;
@@ -107,7 +107,7 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
     LCGS_REQUIRE(fused || (grads->d_dL_dpos && grads->d_dL_dscale && grads->d_dL_drotq && grads->d_dL_dsh &&
                            grads->d_dL_dopacity),
                  "NULL gradient buffer");
-    if (!ctx->last.valid || !ctx->last.has_state) {
+    if (!ctx->frame_state_valid() || !ctx->last.has_state) {
         set_last_error("lcgs_render_backward needs a preceding lcgs_render_forward(..., keep_state = 1)");
         return LCGS_ERR_STATE;
     }

@@ -358,7 +358,7 @@ lcgs_status lcgs_get_stage_times(lcgs_context* ctx, lcgs_stage_times* out)
 lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* out)
 {
     LCGS_REQUIRE(ctx && out, "NULL argument");
-    LCGS_REQUIRE(ctx->last.valid, "no frame rendered yet");
+    LCGS_REQUIRE(ctx->frame_state_valid(), "no frame rendered yet");
     LCGS_TRY(sync_frame(ctx));
     ctx->stats.num_gaussians = ctx->P;
     ctx->stats.num_visible   = ctx->h_counts[0];
@@ -374,7 +374,7 @@ lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* out)
 // reference's point_list holds) and the tile ranges.  d_list must hold num_pairs entries, d_ranges 2*G.
 lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t* d_ranges)
 {
-    LCGS_REQUIRE(ctx && ctx->last.valid, "no frame rendered yet");
+    LCGS_REQUIRE(ctx && ctx->frame_state_valid(), "no frame rendered yet");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
     LCGS_TRY(sync_frame(ctx));
     const uint32_t L = ctx->h_counts[2];

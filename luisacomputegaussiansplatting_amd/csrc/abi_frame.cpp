@@ -278,6 +278,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
 {
     LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device)); // multi-GPU processes: every entry point selects its device
+    ctx->note_foreign_writes();
     LCGS_TRY(check_camera(camera));
     LCGS_REQUIRE(bg_color != nullptr, "bg_color is NULL");
     LCGS_REQUIRE(d_img != nullptr, "d_img is NULL");
@@ -402,6 +403,7 @@ lcgs_status lcgs_render_forward_batch(lcgs_context* ctx, int num_views, const lc
     if (num_views == 0) return LCGS_OK;
     LCGS_REQUIRE(cameras != nullptr && d_imgs != nullptr && bg_color != nullptr, "NULL argument");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->note_foreign_writes();
     const bool two = num_views > 1 && !ctx->profiling && !ctx->use_graph && ctx->P > 0;
     // frames in flight: 2 (measured best through round 3); LCGS_BATCH_IN_FLIGHT = 3 / 4 is a tuning hook (a chain of siblings)
     static const int want = [] {
@@ -451,8 +453,14 @@ lcgs_status prepare_twin(lcgs_context* ctx)
         t->lod_min_radius = ctx->lod_min_radius;
         t->coarse_mode    = ctx->coarse_mode;
         t->coarse_on      = ctx->coarse_on;
-        t->cull_bound     = ctx->cull_bound; // (borrowed, like the permutation: built on ctx->stream before the fork below)
-        t->cull_key       = ctx->cull_key;
+        // (borrowed, like the permutation: built on ctx->stream before the fork below; rows another thread's writer has
+        // declared stale -- context.hpp foreign_writes -- are not handed on)
+        const bool rows_ok = ctx->cull_rows() != nullptr || !(ctx->foreign_writes.load(std::memory_order_acquire) & lcgs_context::kRowsStale);
+        t->cull_bound      = rows_ok ? ctx->cull_bound : nullptr;
+        t->cull_key        = ctx->cull_key;
+        if (!rows_ok) t->cull_key = {};
+        t->foreign_writes.fetch_and(~lcgs_context::kRowsStale, std::memory_order_acq_rel);
+        registry_publish(t);
         // the sibling renders the same (possibly re-ordered) arrays: it borrows their permutation for the order of equal depths
         t->scene_perm.ptr   = ctx->scene_perm.ptr;
         t->scene_perm.bytes = 0;

@@ -49,6 +49,9 @@ void scene_arrays_written(lcgs_context* ctx, const float* pos, const float* scal
 // the process's live contexts (lcgs_create / lcgs_destroy), for scene_arrays_written
 void registry_add(lcgs_context* ctx);
 void registry_remove(lcgs_context* ctx);
+// the owning thread publishes the arrays its derived rows were built from and the arrays it has bound (threading:
+// context.hpp foreign_writes)
+void registry_publish(lcgs_context* ctx);
 // abi_frame.cpp
 lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool keep_state);
 lcgs_status prepare_twin(lcgs_context* ctx); // the sibling context of camera / view batches: created on first use, same scene

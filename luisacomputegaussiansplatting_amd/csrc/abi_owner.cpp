@@ -221,7 +221,7 @@ lcgs_status lcgs_owner_render_backward(lcgs_context* ctx, const float* d_dL_dimg
     LCGS_REQUIRE(ctx && d_dL_dimg && d_grads2d, "NULL argument");
     LCGS_REQUIRE((reinterpret_cast<uintptr_t>(d_grads2d) & 15) == 0, "d_grads2d must be 16-byte aligned (rows are float4 x 3)");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
-    if (!ctx->last.valid || !ctx->last.has_state || !ctx->owner_recs) {
+    if (!ctx->frame_state_valid() || !ctx->last.has_state || !ctx->owner_recs) {
         set_last_error("lcgs_owner_render_backward needs a preceding lcgs_owner_render(..., keep_state = 1)");
         return LCGS_ERR_STATE;
     }

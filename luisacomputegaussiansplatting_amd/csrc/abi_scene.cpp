@@ -33,7 +33,10 @@ lcgs_status refresh_cull_bound(lcgs_context* ctx)
 {
     const bool own = ctx->P > 0 && ctx->pos == ctx->owned[0].as<float>() && ctx->scale == ctx->owned[1].as<float>() &&
                      ctx->rotq == ctx->owned[2].as<float>();
-    if (!own) return LCGS_OK; // (rows of other arrays -- declared static -- stay: a frame uses them only for THOSE arrays)
+    if (!own) { // (rows of other arrays -- declared static -- stay: a frame uses them only for THOSE arrays)
+        registry_publish(ctx); // (the bound arrays changed)
+        return LCGS_OK;
+    }
     return build_cull_bound(ctx, ctx->P, ctx->pos, ctx->scale, ctx->rotq);
 }
 
@@ -46,47 +49,134 @@ lcgs_status build_cull_bound(lcgs_context* ctx, int P, const float* pos, const f
     }();
     ctx->cull_bound = nullptr;
     ctx->cull_key   = {};
-    if (!enabled || P <= 0 || !pos || !scale || !rotq) return LCGS_OK;
-    LCGS_TRY(ctx->cull_bound_buf.ensure((size_t)P * sizeof(float4)));
-    launch_cull_bound(P, pos, scale, rotq, ctx->cull_bound_buf.as<float4>(), ctx->stream);
-    LCGS_HIP_CHECK(hipGetLastError());
-    ctx->cull_bound = ctx->cull_bound_buf.as<float4>();
-    ctx->cull_key   = { pos, scale, rotq, P };
-    return LCGS_OK;
+    // (whatever another thread posted about the OLD rows is settled: a write it makes from here on posts again)
+    ctx->foreign_writes.fetch_and(~lcgs_context::kRowsStale, std::memory_order_acq_rel);
+    lcgs_status s = LCGS_OK;
+    if (enabled && P > 0 && pos && scale && rotq) {
+        s = ctx->cull_bound_buf.ensure((size_t)P * sizeof(float4));
+        if (s == LCGS_OK) {
+            launch_cull_bound(P, pos, scale, rotq, ctx->cull_bound_buf.as<float4>(), ctx->stream);
+            if (hipGetLastError() != hipSuccess) s = LCGS_ERR_HIP;
+        }
+        if (s == LCGS_OK) {
+            ctx->cull_bound = ctx->cull_bound_buf.as<float4>();
+            ctx->cull_key   = { pos, scale, rotq, P };
+        }
+    }
+    registry_publish(ctx);
+    return s;
 }
 
 namespace
 {
-std::mutex                 g_registry_mutex;
-std::vector<lcgs_context*> g_registry;
+// What a context PUBLISHES for other threads' writers (under g_registry_mutex): the arrays its derived rows were built from
+// and the arrays it has bound.  Writers compare against these copies, never against the context's own fields.
+struct Published {
+    lcgs_context* ctx = nullptr;
+    const float * key_pos = nullptr, *key_scale = nullptr, *key_rotq = nullptr; // cull_key
+    int           key_P = 0;
+    const float * arr[5] = { nullptr, nullptr, nullptr, nullptr, nullptr }; // bound pos / scale / rotq / sh / opacity
+    size_t        arr_floats[5] = { 0, 0, 0, 0, 0 };
+};
+std::mutex             g_registry_mutex;
+std::vector<Published> g_registry;
+
+Published* find_published(lcgs_context* ctx) // (mutex held)
+{
+    for (Published& e : g_registry)
+        if (e.ctx == ctx) return &e;
+    return nullptr;
+}
+bool same_thread_family(const lcgs_context* a, const lcgs_context* b) // b is a (or a's batch sibling, or a is b's)
+{
+    if (a == b) return true;
+    for (const lcgs_context* t = a->twin; t; t = t->twin)
+        if (t == b) return true;
+    for (const lcgs_context* t = b->twin; t; t = t->twin)
+        if (t == a) return true;
+    return false;
+}
 } // namespace
 void registry_add(lcgs_context* ctx)
 {
     std::lock_guard<std::mutex> lock(g_registry_mutex);
-    g_registry.push_back(ctx);
+    Published e;
+    e.ctx = ctx;
+    g_registry.push_back(e);
 }
 void registry_remove(lcgs_context* ctx)
 {
     std::lock_guard<std::mutex> lock(g_registry_mutex);
-    g_registry.erase(std::remove(g_registry.begin(), g_registry.end(), ctx), g_registry.end());
+    g_registry.erase(std::remove_if(g_registry.begin(), g_registry.end(), [&](const Published& e) { return e.ctx == ctx; }),
+                     g_registry.end());
+}
+// the owning thread, whenever its cull_key or its bound arrays change
+void registry_publish(lcgs_context* ctx)
+{
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    Published* e = find_published(ctx);
+    if (!e) return;
+    e->key_pos   = ctx->cull_bound ? ctx->cull_key.pos : nullptr;
+    e->key_scale = ctx->cull_bound ? ctx->cull_key.scale : nullptr;
+    e->key_rotq  = ctx->cull_bound ? ctx->cull_key.rotq : nullptr;
+    e->key_P     = ctx->cull_bound ? ctx->cull_key.P : 0;
+    const size_t feat = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3;
+    const float* arr[5]    = { ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity };
+    const size_t floats[5] = { 3, 3, 4, feat, 1 };
+    for (int i = 0; i < 5; ++i) {
+        e->arr[i]        = arr[i];
+        e->arr_floats[i] = floats[i] * (size_t)std::max(ctx->P, 0);
+    }
 }
 
 // The library is about to write (or has let someone write) position / scale / rotation rows inside the given arrays: every
 // context whose derived rows were built from arrays that overlap them drops the rows -- this context, its batch siblings AND
 // any other context of the process that renders the same arrays (an optimiser step issued through context A on arrays
 // context B owns).  Frames fall back to reading the arrays themselves until the rows are rebuilt (bind / lcgs_scene_modified).
-void scene_arrays_written(lcgs_context* /*ctx*/, const float* pos, const float* scale, const float* rotq)
+// Contexts of OTHER host threads are never touched: the comparison runs on what they published, and they get a bit posted
+// (lcgs_context::foreign_writes) that their own thread honours at its next use of the rows.
+void scene_arrays_written(lcgs_context* ctx, const float* pos, const float* scale, const float* rotq)
 {
     std::lock_guard<std::mutex> lock(g_registry_mutex);
-    for (lcgs_context* c : g_registry) {
-        if (!c->cull_bound || c->cull_key.P <= 0) continue;
+    for (Published& e : g_registry) {
+        if (e.key_P <= 0) continue;
         auto inside = [&](const float* p, const float* base, size_t floats) {
-            return p != nullptr && base != nullptr && p >= base && p < base + floats * (size_t)c->cull_key.P;
+            return p != nullptr && base != nullptr && p >= base && p < base + floats * (size_t)e.key_P;
         };
-        if (inside(pos, c->cull_key.pos, 3) || inside(scale, c->cull_key.scale, 3) || inside(rotq, c->cull_key.rotq, 4)) {
-            c->cull_bound = nullptr;
-            c->cull_key   = {};
+        if (!(inside(pos, e.key_pos, 3) || inside(scale, e.key_scale, 3) || inside(rotq, e.key_rotq, 4))) continue;
+        e.key_pos = e.key_scale = e.key_rotq = nullptr;
+        e.key_P                               = 0;
+        if (ctx && same_thread_family(ctx, e.ctx)) { // the caller's own: dropped in place
+            e.ctx->cull_bound = nullptr;
+            e.ctx->cull_key   = {};
+        } else {
+            e.ctx->foreign_writes.fetch_or(lcgs_context::kRowsStale, std::memory_order_acq_rel);
         }
+    }
+}
+
+// lcgs_scene_modified: the arrays ctx has bound were written behind the library's back.  Every OTHER context that has any of
+// them bound gets told (its f16 coefficient copy and the kept state of its last frame are stale too); ctx itself and its
+// siblings are handled by the caller.
+void scene_modified_elsewhere(lcgs_context* ctx)
+{
+    const size_t feat       = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3;
+    const float* arr[5]     = { ctx->pos, ctx->scale, ctx->rotq, ctx->sh, ctx->opacity };
+    const size_t floats[5]  = { 3, 3, 4, feat, 1 };
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    for (Published& e : g_registry) {
+        if (same_thread_family(ctx, e.ctx)) continue;
+        bool overlap = false;
+        for (int i = 0; i < 5 && !overlap; ++i) {
+            const float* a0 = arr[i];
+            const float* a1 = a0 ? a0 + floats[i] * (size_t)std::max(ctx->P, 0) : nullptr;
+            for (int j = 0; j < 5 && !overlap; ++j) {
+                const float* b0 = e.arr[j];
+                const float* b1 = b0 ? b0 + e.arr_floats[j] : nullptr;
+                overlap = a0 && b0 && a0 < b1 && b0 < a1;
+            }
+        }
+        if (overlap) e.ctx->foreign_writes.fetch_or(lcgs_context::kSceneModified, std::memory_order_acq_rel);
     }
 }
 } // namespace abi
@@ -128,6 +218,7 @@ lcgs_status lcgs_scene_declare_static(lcgs_context* ctx, int num_gaussians, cons
     if (num_gaussians == 0 || !d_pos) { // withdraw the declaration
         ctx->cull_bound = nullptr;
         ctx->cull_key   = {};
+        registry_publish(ctx);
         return refresh_cull_bound(ctx); // (a context-owned scene that is bound keeps its own rows)
     }
     LCGS_REQUIRE(d_scale && d_rotq, "NULL device pointer");
@@ -143,8 +234,11 @@ lcgs_status lcgs_scene_modified(lcgs_context* ctx)
     // drops them; this context builds its own again (context-owned arrays only, ordered on its stream behind the
     // caller's writes as far as the caller ordered those before this call)
     scene_arrays_written(ctx, ctx->pos, ctx->scale, ctx->rotq);
-    ctx->use_half_sh = false; // the f16 copy of the coefficients (if any) is stale as well
-    ctx->last.valid  = false; // ... and so is the kept state of the last frame
+    scene_modified_elsewhere(ctx); // other threads' contexts on these arrays: told, they act at their next frame / backward
+    for (lcgs_context* c = ctx; c; c = c->twin) {
+        c->use_half_sh = false; // the f16 copy of the coefficients (if any) is stale as well
+        c->last.valid  = false; // ... and so is the kept state of the last frame
+    }
     return refresh_cull_bound(ctx);
 }
 

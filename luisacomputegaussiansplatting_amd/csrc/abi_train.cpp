@@ -39,7 +39,7 @@ lcgs_status lcgs_adam_step(lcgs_context* ctx, int num_gaussians, int sh_degree, 
     const uint32_t* d_rows   = nullptr;
     int64_t         hint     = num_gaussians;
     if (cfg->visible_only) {
-        LCGS_REQUIRE(ctx->last.valid && ctx->P == num_gaussians,
+        LCGS_REQUIRE(ctx->frame_state_valid() && ctx->P == num_gaussians,
                      "visible_only needs a forward frame of this scene in this context");
         row_list = ctx->vis_index.as<uint32_t>();
         d_rows   = ctx->counts.as<uint32_t>(); // [0] = survivors of the last frame

@@ -2,6 +2,8 @@
 // (abi_*.cpp: frames, scene, optimiser -- see abi_internal.hpp; host/comm.cpp: the RCCL gradient collectives).
 #pragma once
 
+#include <atomic>
+
 #include "common.hpp"
 #include "kernels/launch.hpp"
 
@@ -57,11 +59,34 @@ struct lcgs_context {
         const float *pos = nullptr, *scale = nullptr, *rotq = nullptr;
         int          P = 0;
     } cull_key;
+    // THREADING: a context (with its batch sibling) is used by one host thread at a time; the only cross-thread traffic is
+    // this word.  Another thread's writer (an optimiser step through ITS context on arrays this one renders, or its
+    // lcgs_scene_modified) never touches this context's fields: it compares against the copy of the keys this context
+    // PUBLISHED under the registry mutex (abi_scene.cpp) and posts bits here; the owning thread honours them at its next
+    // use -- kRowsStale at once (cull_rows() below; cleared when the rows are rebuilt), kSceneModified in
+    // frame_state_valid() / note_foreign_writes().
+    static constexpr uint32_t kRowsStale = 1u, kSceneModified = 2u;
+    std::atomic<uint32_t>     foreign_writes{ 0 };
     const float4* cull_rows() const
     {
+        if (foreign_writes.load(std::memory_order_acquire) & kRowsStale) return nullptr;
         return (cull_bound && pos == cull_key.pos && scale == cull_key.scale && rotq == cull_key.rotq && P == cull_key.P)
                    ? cull_bound
                    : nullptr;
+    }
+    // another thread declared the bound arrays modified: the f16 coefficient copy and the last frame's kept state are stale
+    void note_foreign_writes()
+    {
+        if (foreign_writes.load(std::memory_order_acquire) & kSceneModified) {
+            foreign_writes.fetch_and(~kSceneModified, std::memory_order_acq_rel);
+            use_half_sh = false;
+            last.valid  = false;
+        }
+    }
+    bool frame_state_valid()
+    {
+        note_foreign_writes();
+        return last.valid;
     }
 
     // workspace of the fused frame

@@ -88,7 +88,7 @@ def assert_parity_vs_numerics_variants(gpu_img, scene, ocam, **render_kw):
     from the parity oracle's in a few hundred of two million pixels by up to 3e-3 -- threshold, depth-order and rect flips, and
     ill-conditioned splats.  Asserted, per variant: EVERY pixel of the frame lies within the per-pixel bound the checker
     derives from its own evaluations (the continuous first-order term from the measured per-splat uncertainties + what each
-    decision inside its rounding window could move the pixel by); the pixels beyond 1e-4 are at most 2e-4 of the frame; and
+    decision inside its rounding window could move the pixel by); the pixels beyond 1e-4 are at most 5e-4 of the frame; and
     the bound is not vacuous: at most 6 % of the frame may move beyond 1e-4 by it.  Three of the variants take no part in
     measuring the uncertainties (numerics.ENSEMBLE): the independent check.  Returns numerics.report's dict."""
     from oracle import numerics
@@ -99,7 +99,7 @@ def assert_parity_vs_numerics_variants(gpu_img, scene, ocam, **render_kw):
     assert c["pixels_that_may_move_over_1e_4"] <= 0.06 * n, c
     for name, v in rep["variants"].items():
         assert v["all_explained"], (name, v)
-        assert v["pixels_over_1e-4"] <= max(3, int(np.ceil(2e-4 * n))), (name, v)
+        assert v["pixels_over_1e-4"] <= max(3, int(np.ceil(5e-4 * n))), (name, v)
     vs = rep["variants"]
     print(f"[parity vs numerics variants] {gpu_img.shape[2]}x{gpu_img.shape[1]}: may move > 1e-4: "
           f"{c['pixels_that_may_move_over_1e_4']} of {n} px (flagged: threshold {c['threshold_pixels']}, depth order "
@@ -113,7 +113,7 @@ GRAD_F32_FACTOR = 3.0   # see check_gradients
 GRAD_GIANT_BAR = 5e-3
 
 
-def check_gradients(g, ref32, ref64, P, radii, tag, report=None):
+def check_gradients(g, ref32, ref64, P, radii, tag, report=None, flat_bar=None):
     """The kernels' gradients against the f64 oracle -- the ONLY yardstick (the f32 oracle shares the kernels' exp and
     threshold decisions, so agreement with it alone proves nothing about precision).  Bar per attribute, over ALL rows
     (screen-filling giants included since round 4): BASELINE's 1e-3 relative, or -- on ill-conditioned draws, where f32
@@ -131,6 +131,8 @@ def check_gradients(g, ref32, ref64, P, radii, tag, report=None):
     the shared part; the soak additionally asserts the DISTRIBUTION (median, 90th percentile).
     Rows of giants (radius > 64 px) are held to max(GRAD_GIANT_BAR, 3 x the f32 oracle on those rows) on their own, so
     that they cannot hide inside a large norm either.
+    flat_bar: additionally hold every attribute to this figure outright, whatever the f32 oracle does (BASELINE C4 at size:
+    5e-4 -- every attribute lands below 3e-4 there, so the f32-relative slack is not needed and not granted).
     report: a list -> nothing is asserted, the figures are appended (soak's survey mode)."""
     rel = lambda x, y: float(np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-30))
     giant = radii > 64
@@ -148,5 +150,6 @@ def check_gradients(g, ref32, ref64, P, radii, tag, report=None):
         print(f"[gradients vs f64] {tag} {k}: kernels {e:.2e}, f32 oracle {e32:.2e}; {int(giant.sum())} giants: {eg:.2e} / {eg32:.2e}")
         assert e <= max(1e-3, GRAD_F32_FACTOR * e32), (
             f"{tag} {k}: {e:.2e} vs the f64 oracle (f32 oracle vs f64: {e32:.2e}; giants alone {eg:.2e} / {eg32:.2e})")
+        assert flat_bar is None or e <= flat_bar, f"{tag} {k}: {e:.2e} vs the f64 oracle, beyond the flat bar {flat_bar:.0e}"
         assert eg <= max(GRAD_GIANT_BAR, GRAD_F32_FACTOR * eg32), (
             f"{tag} {k}: rows of the {int(giant.sum())} giants {eg:.2e} vs f64 (f32 oracle on them: {eg32:.2e})")

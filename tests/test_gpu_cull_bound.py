@@ -332,6 +332,82 @@ def test_optimiser_step_through_another_context_drops_the_rows(lcgs):
     assert torch.equal(a, b) and not torch.equal(a, before)
 
 
+def test_writers_on_another_host_thread_post_to_the_owner_instead_of_touching_it(lcgs):
+    """The threading contract (context.hpp foreign_writes; round-5 advisor): a context is used by one host thread, and a writer
+    on ANOTHER thread -- an optimiser step through its own context B on arrays context A renders, or B's lcgs_scene_modified
+    -- never mutates A: it compares with what A published and posts a flag that A's thread honours at its next use.  Thread B
+    steps the arrays 20 times while thread A keeps rendering them (those frames read arrays in flux: no result is asserted,
+    only that nothing faults); afterwards A, untouched by any call of its own, renders the final arrays' frame -- its rows
+    were declared stale, not left in use -- and after B's scene_modified A's kept frame state is gone."""
+    import threading
+
+    rng = np.random.default_rng(47)
+    P = 50_001
+    scene = _edge_scene(rng, P)
+    W, H = 480, 272
+    cam = lcgs.get_lookat_cam([-4.0, 0.3, 1.0], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+    keys = ("pos", "scale", "rotq", "sh", "opacity")
+    A = lcgs.Renderer(lcgs.Context(0))
+    A.upload_scene(scene, order="file")
+    act = A.scene_tensors()
+    B = lcgs.Renderer(lcgs.Context(0))
+    B.bind_scene(*[act[k] for k in keys])
+    grads = {k: torch.from_numpy(rng.normal(size=tuple(act[k].shape)).astype(np.float32)).to(DEV) for k in keys}
+    lr = {"pos": 0.01, "sh_dc": 0.0, "sh_rest": 0.0, "opacity": 0.0, "scale": 0.02, "rot": 0.01}
+    raw = {"pos": act["pos"], "scale": torch.log(act["scale"].abs() + 1e-12), "rotq": act["rotq"].clone(), "sh": act["sh"],
+           "opacity": torch.log(act["opacity"] / (1 - act["opacity"]).clamp_min(1e-6))}
+    m = {k: torch.zeros_like(raw[k]) for k in keys}
+    v = {k: torch.zeros_like(raw[k]) for k in keys}
+    errors = []
+    go = threading.Barrier(2)
+
+    def writer():
+        try:
+            go.wait()
+            for step in range(1, 21):
+                B.adam_step(grads, raw, m, v, act, step, lr)
+            B.ctx.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def viewer():
+        try:
+            img = torch.zeros(3, H, W, device=DEV)
+            go.wait()
+            for _ in range(40):
+                A.forward(cam, img, sync=True)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=writer), threading.Thread(target=viewer)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    assert A.verify_derived() == 0      # A uses no derived rows any more: they were declared stale by B's first step
+    ref = lcgs.Renderer(lcgs.Context(0))
+    d = {k: act[k].clone() for k in act}
+    ref.bind_scene(*[d[k] for k in keys])
+    a, b = torch.zeros(3, H, W, device=DEV), torch.zeros(3, H, W, device=DEV)
+    assert A.forward(cam, a, keep_state=True, sync=True) == ref.forward(cam, b, sync=True) > 0
+    assert torch.equal(a, b)
+    # binding the own arrays again rebuilds the rows (and settles the flag); same frame
+    A.bind_scene(*[act[k] for k in keys])
+    A.forward(cam, a, keep_state=True, sync=True)
+    assert torch.equal(a, b) and A.verify_derived() == 0
+    # B writes behind the library's back and says so: A's kept frame state must not survive (a backward would mix frames)
+    th = threading.Thread(target=lambda: (act["pos"].add_(0.01), torch.cuda.synchronize(), B.scene_modified()))
+    th.start()
+    th.join()
+    g = {k: torch.zeros_like(act[k]) for k in keys}
+    with pytest.raises(lcgs.LcgsError):
+        A.backward(torch.zeros(3, H, W, device=DEV), *[g[k] for k in keys])
+    ref.bind_scene(*[act[k].clone() for k in keys])
+    assert A.forward(cam, a, sync=True) == ref.forward(cam, b, sync=True) and torch.equal(a, b)
+
+
 def test_destroy_returns_every_byte(lcgs):
     """create / upload / frame (forward + backward state) / destroy in a loop: free device memory comes back each time
     (round 4 leaked the 16-byte cull rows of every context that owned a scene)."""
