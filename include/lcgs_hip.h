@@ -546,6 +546,19 @@ LCGS_API void        lcgs_comm_owner_rows(int64_t num_gaussians, int world_size,
 LCGS_API lcgs_status lcgs_owner_step_forward(lcgs_context* ctx, lcgs_comm* comm, const lcgs_camera* cameras /* [world_size] */,
                                              const float bg_color[3], float scale_modifier, float* d_img);
 LCGS_API lcgs_status lcgs_owner_step_backward(lcgs_context* ctx, lcgs_comm* comm, const float* d_dL_dimg, const lcgs_grads* grads);
+/* The step WITHOUT a host read-back (round 6; opt-in per communicator, every rank alike).  Once a step's count table is known,
+ * the next step sizes its messages from it -- n + n / 4 + 1024 rows, clipped to the owner's range: every rank derives the
+ * same sizes from the same all-gathered table -- the true counts stay on the device (the view's frame is built from padded
+ * per-owner segments), the frame's pair-buffer check is not read back either, and no call between lcgs_owner_step_forward
+ * and the end of lcgs_owner_step_backward waits for the device.  A message that was clipped or a frame whose pairs were
+ * truncated raises a flag that is max-reduced over the ranks behind the forward half; lcgs_owner_step_finish -- REQUIRED
+ * after the backward call of such a step, before the gradients are used -- waits for that flag only (the device is in the
+ * backward by then), adopts the step's table for the next one and reports *redo = 1 on EVERY rank if ANY rank's step was
+ * short: forward and backward are then called again (that repetition reads its sizes back and grows what was too small).
+ * The first step of a communicator, and any step whose padded segments would not fit the workspace the scene sizes, read
+ * back as before (finish then reports 0 at once).  Bytes on the wire: <= 1.25 x the exact step's + 1024 rows a message. */
+LCGS_API lcgs_status lcgs_owner_step_set_async(lcgs_comm* comm, int enable);
+LCGS_API lcgs_status lcgs_owner_step_finish(lcgs_context* ctx, lcgs_comm* comm, int* redo);
 typedef struct lcgs_loopback_group lcgs_loopback_group;
 LCGS_API lcgs_status lcgs_loopback_group_create(int world_size, lcgs_loopback_group** out);
 LCGS_API lcgs_status lcgs_loopback_group_destroy(lcgs_loopback_group* group); /* after its communicators */

@@ -144,7 +144,8 @@ EXPORTED_SYMBOLS = [
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png", "lcgs_l2_loss_backward",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh", "lcgs_scene_modified", "lcgs_debug_verify_derived",
-    "lcgs_comm_owner_rows", "lcgs_owner_step_forward", "lcgs_owner_step_backward", "lcgs_loopback_group_create",
+    "lcgs_comm_owner_rows", "lcgs_owner_step_forward", "lcgs_owner_step_backward", "lcgs_owner_step_set_async",
+    "lcgs_owner_step_finish", "lcgs_loopback_group_create",
     "lcgs_loopback_group_destroy", "lcgs_comm_create_loopback",
     "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_set_lod", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_set_transport", "lcgs_comm_shard_rows",
     "lcgs_grads_allreduce", "lcgs_adam_step_sharded", "lcgs_comm_track_touched_rows", "lcgs_comm_get_stats",
@@ -830,6 +831,27 @@ class Comm:
         """lcgs_owner_step_backward: the view's 2-D gradients back to the owners, parameter gradients at this rank's own rows"""
         g = _Grads(*[_ptr(grads[k]) for k in _KEYS])
         _check(load_library().lcgs_owner_step_backward(self.ctx._h, self._h, _ptr(dL_dimg), C.byref(g)))
+
+    def owner_step_set_async(self, enable: bool = True):
+        """lcgs_owner_step_set_async: steps size their messages from the previous step's counts and read nothing back; every
+        such step must be closed with owner_step_finish()"""
+        _check(load_library().lcgs_owner_step_set_async(self._h, C.c_int(1 if enable else 0)))
+
+    def owner_step_finish(self) -> bool:
+        """lcgs_owner_step_finish: True = some rank's step was short (a clipped message, truncated pairs): EVERY rank calls
+        forward + backward again"""
+        redo = C.c_int(0)
+        _check(load_library().lcgs_owner_step_finish(self.ctx._h, self._h, C.byref(redo)))
+        return bool(redo.value)
+
+    def owner_step(self, cams, img, dL_dimg, grads: dict, bg=(0.0, 0.0, 0.0), scale_modifier: float = 1.0) -> int:
+        """forward + backward + finish, repeated while the step was short; returns the number of repetitions (0 normally)"""
+        for attempt in range(3):
+            self.owner_step_forward(cams, img, bg, scale_modifier)
+            self.owner_step_backward(dL_dimg, grads)
+            if not self.owner_step_finish():
+                return attempt
+        raise LcgsError("the ownership step did not settle after two repetitions")
 
     def set_transport(self, transport: str):
         """lcgs_comm_set_transport: "f32" (default, exact) or "f16" (opt-in: half the bytes, ~sqrt(N) x 5e-4 relative)"""

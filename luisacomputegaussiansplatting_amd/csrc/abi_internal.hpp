@@ -46,6 +46,17 @@ lcgs_status build_cull_bound(lcgs_context* ctx, int P, const float* pos, const f
 // fall back to reading position + scale + rotation until the arrays are bound again
 // (EVERY live context of the process is looked at -- a second context that renders the same arrays keeps rows of its own)
 void scene_arrays_written(lcgs_context* ctx, const float* pos, const float* scale, const float* rotq);
+// abi_owner.cpp: lcgs_owner_render, and its variant for the ownership step that reads nothing back (comm.cpp)
+struct OwnerAsyncFrame {
+    OwnerSegs       segs;            // padded per-owner segments of the received rows / records
+    const uint32_t* table = nullptr; // device: the all-gathered counts, [o * N + view] = owner o's rows on `view`'s screen
+    uint32_t        view  = 0;
+    uint32_t*       overflow = nullptr; // device word: bit 0 a segment was clipped, bit 1 the pair buffers were too small
+};
+lcgs_status owner_render_frame(lcgs_context* ctx, const lcgs_camera* camera, const float bg_color[3], int num_rows,
+                               const uint32_t* d_rows, const float* d_records, float* d_img, int keep_state,
+                               const OwnerAsyncFrame* af);
+void owner_frame_settle(lcgs_context* ctx); // hints / pair capacity from the pinned counters of such a frame
 // the process's live contexts (lcgs_create / lcgs_destroy), for scene_arrays_written
 void registry_add(lcgs_context* ctx);
 void registry_remove(lcgs_context* ctx);

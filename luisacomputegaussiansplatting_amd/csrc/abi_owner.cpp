@@ -115,6 +115,19 @@ lcgs_status lcgs_owner_counts(lcgs_context* ctx, int first_slot, int num_slots, 
 lcgs_status lcgs_owner_render(lcgs_context* ctx, const lcgs_camera* camera, const float bg_color[3], int num_rows,
                               const uint32_t* d_rows, const float* d_records, float* d_img, int keep_state)
 {
+    return lcgs::abi::owner_render_frame(ctx, camera, bg_color, num_rows, d_rows, d_records, d_img, keep_state, nullptr);
+}
+
+} // extern "C"
+
+// lcgs_owner_render; with `af` the variant of the ownership step that reads nothing back (comm.cpp): the rows sit in padded
+// per-owner segments whose true counts are on the device, num_rows is the segments' total CAPACITY (every launch is sized by
+// it, every count is read on the device), there is one attempt and no synchronisation -- the pair-buffer verdict is OR-ed
+// into *af->overflow and the frame's counters are copied to the pinned block for whoever waits on the step later.
+lcgs_status lcgs::abi::owner_render_frame(lcgs_context* ctx, const lcgs_camera* camera, const float bg_color[3], int num_rows,
+                                          const uint32_t* d_rows, const float* d_records, float* d_img, int keep_state,
+                                          const OwnerAsyncFrame* af)
+{
     LCGS_REQUIRE(ctx && bg_color && d_img, "NULL argument");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     LCGS_TRY(check_camera(camera));
@@ -153,9 +166,15 @@ lcgs_status lcgs_owner_render(lcgs_context* ctx, const lcgs_camera* camera, cons
             id_mask        = (1u << tie.id_bits) - 1u;
             tie.scratch_k1 = ctx->tie_ws.as<uint32_t>();
         }
-        launch_unpack_records(num_rows, recs, d_rows, tied ? tie.perm : nullptr, tie.id_bits, tie.tag_shift,
-                              ctx->sortk[0].as<uint32_t>(), ctx->sortv[0].as<uint32_t>(), ctx->rects.as<uint2>(),
-                              ctx->vis_index.as<uint32_t>(), dc, (uint32_t)ctx->P, cp.grid_x, cp.grid_y, st);
+        if (af)
+            launch_unpack_records_seg(af->segs, af->table, af->view, recs, d_rows, tied ? tie.perm : nullptr, tie.id_bits,
+                                      tie.tag_shift, ctx->sortk[0].as<uint32_t>(), ctx->sortv[0].as<uint32_t>(),
+                                      ctx->rects.as<uint2>(), ctx->vis_index.as<uint32_t>(), dc, af->overflow, (uint32_t)ctx->P,
+                                      cp.grid_x, cp.grid_y, st);
+        else
+            launch_unpack_records(num_rows, recs, d_rows, tied ? tie.perm : nullptr, tie.id_bits, tie.tag_shift,
+                                  ctx->sortk[0].as<uint32_t>(), ctx->sortv[0].as<uint32_t>(), ctx->rects.as<uint2>(),
+                                  ctx->vis_index.as<uint32_t>(), dc, (uint32_t)ctx->P, cp.grid_x, cp.grid_y, st);
         const int w = launch_pair_sort_u32(ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
                                            ctx->sortv[0].as<uint32_t>(), ctx->sortv[1].as<uint32_t>(), dc, ctx->P, num_rows, 0, 32,
                                            ctx->sort_ws.ptr, st);
@@ -183,6 +202,22 @@ lcgs_status lcgs_owner_render(lcgs_context* ctx, const lcgs_camera* camera, cons
                                   keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, dc, nullptr, order_now, st,
                                   keep_state ? ctx->strip_masks.as<uint8_t>() : nullptr, nullptr);
         LCGS_HIP_CHECK(hipGetLastError());
+        if (af) { // no read-back: the verdict travels with the step's flag, the counters to the pinned block
+            launch_owner_pair_verdict(dc, af->overflow, st);
+            LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, dc, 40, hipMemcpyDeviceToHost, st));
+            ctx->counts_pending      = false;
+            ctx->last.valid          = true;
+            ctx->last.has_state      = keep_state != 0;
+            ctx->last.cp             = cp;
+            ctx->last.scale_modifier = 1.0f;
+            ctx->last.list_buf       = where2;
+            memcpy(ctx->last.bg, bg_color, sizeof(float) * 3);
+            ctx->last_tile_order = order_now;
+            ctx->owner_recs      = recs;
+            ctx->owner_rows      = num_rows;
+            ctx->g2d_zeroed      = false;
+            return LCGS_OK;
+        }
         LCGS_HIP_CHECK(hipMemcpyAsync(ctx->h_counts, dc, 40, hipMemcpyDeviceToHost, st));
         LCGS_HIP_CHECK(hipStreamSynchronize(st));
         ctx->counts_pending = false;
@@ -216,6 +251,23 @@ lcgs_status lcgs_owner_render(lcgs_context* ctx, const lcgs_camera* camera, cons
     return LCGS_ERR_CAPACITY;
 }
 
+// what a step that read nothing back learns later from the pinned counters (comm.cpp lcgs_owner_step_finish): the launch
+// hints follow the frame, a frame that overflowed its pair buffers grows them for the redo
+void lcgs::abi::owner_frame_settle(lcgs_context* ctx)
+{
+    if (!ctx->h_counts) return;
+    if ((int64_t)ctx->h_counts[4] > ctx->hint_L || (int64_t)ctx->h_counts[4] * 2 < ctx->hint_L)
+        ctx->hint_L = (int64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4 + 4096;
+    if (ctx->h_counts[3] != 0 || ctx->h_counts[6] != 0) {
+        const uint64_t want = (uint64_t)ctx->h_counts[7] + ctx->h_counts[7] / 4;
+        if (want <= 0x7FFFFFFFull) ctx->pair_capacity = std::max(ctx->pair_capacity, (uint32_t)want);
+        ctx->h_counts[3] = ctx->h_counts[6] = ctx->h_counts[7] = 0;
+        (void)hipMemsetAsync(ctx->counts.as<uint32_t>() + 6, 0, 8, ctx->stream); // (the sticky record: reported here)
+    }
+}
+
+extern "C" {
+
 lcgs_status lcgs_owner_render_backward(lcgs_context* ctx, const float* d_dL_dimg, float* d_grads2d)
 {
     LCGS_REQUIRE(ctx && d_dL_dimg && d_grads2d, "NULL argument");
@@ -228,6 +280,8 @@ lcgs_status lcgs_owner_render_backward(lcgs_context* ctx, const float* d_dL_dimg
     hipStream_t st = ctx->stream;
     LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)ctx->P)));
     launch_zero_grads2d(ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(), st, ctx->bwd_counter.as<uint32_t>());
+    // (rows are addressed by POSITION; a frame from padded segments has positions beyond its row count: clear those too)
+    LCGS_HIP_CHECK(hipMemsetAsync(ctx->grads2d.ptr, 0, (size_t)ctx->owner_rows * LCGS_OWNER_GRAD_FLOATS * 4, st));
     launch_render_backward(ctx->last.cp, ctx->last.bg, ctx->ranges, ctx->pairv[ctx->last.list_buf].as<uint32_t>(), ctx->owner_recs,
                            ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(), d_dL_dimg, ctx->grads2d.as<float>(),
                            ctx->last_tile_order, st, ctx->strip_masks.as<uint8_t>(), ctx->counts.as<uint32_t>());

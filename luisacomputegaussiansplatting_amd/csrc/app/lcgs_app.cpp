@@ -460,9 +460,12 @@ int main(int argc, char** argv)
                 for (int a = 0; a < 5; ++a) // rows of other owners stay zero: the verification sum below needs that
                     if (hipMemsetAsync(gp[a], 0, (size_t)P * widths[a] * 4, nullptr) != hipSuccess) die("memset failed");
                 if (hipDeviceSynchronize() != hipSuccess) die("sync failed");
-                comm->owner_step_forward(cams.data(), bg, d_img.data());
+                // (from the second round on without a host read-back: sizes from the previous round's counts, one verdict
+                // behind the step, repeated by every rank if any rank's was short)
+                comm->owner_step_set_async(true);
+                const int redone = comm->owner_step(cams.data(), bg, d_img.data(), d_ones.data(), grads);
+                if (redone && root) printf("round %zu: the ownership step was repeated %d time(s)\n", round, redone);
                 save_view(d_img.data(), round * (size_t)gpus + (size_t)rank);
-                comm->owner_step_backward(d_ones.data(), grads);
                 device.synchronize();
                 const lcgs_comm_stats st = comm->stats();
                 comm->allreduce(P, grads); // VERIFICATION only (the step itself never sums dense rows): norms as --backward prints them

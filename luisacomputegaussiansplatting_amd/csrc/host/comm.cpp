@@ -33,9 +33,7 @@
 
 #include <rccl/rccl.h> // types and enums only: every entry point is resolved with dlsym
 
-#include "../common.hpp"
-#include "../context.hpp"
-#include "../kernels/launch.hpp"
+#include "../abi_internal.hpp"
 
 using namespace lcgs;
 
@@ -224,8 +222,25 @@ struct lcgs_comm {
         size_t       count; // all-reduce: elements; the others: elements per rank
     };
     std::vector<LoopOp> loop_ops; // loopback: the collectives of the open group, executed at its end
+    // ... without a read-back (lcgs_owner_step_set_async): message sizes come from the PREVIOUS step's all-gathered counts
+    // (x 1.25 + 1024: every rank derives the same table), the true counts stay on the device, a clipped message or a
+    // truncated frame raises a flag that is max-reduced over the ranks and read by lcgs_owner_step_finish -- the redo is
+    // everybody's or nobody's
+    bool         owner_async = false, force_sync_once = false;
+    struct {
+        bool                  have = false;
+        int                   world = 0;
+        int64_t               P = 0;
+        std::vector<uint32_t> table; // [o * N + v]: rows of owner o on view v's screen, last step
+    } prev;
+    uint32_t*    h_next = nullptr;   // pinned: the table of the step in flight [N x N] + the reduced flag [1]
+    DeviceBuffer flag_dev;           // u32: bit 0 a message was clipped, bit 1 a frame's pairs were truncated (any rank)
+    hipEvent_t   ev_checked = nullptr; // behind the flag's reduction and the copies to h_next
     struct {
         bool     valid = false;
+        bool     async = false;                 // the step in flight used padded messages (sizes below)
+        int64_t  cap_in[LCGS_MAX_RANKS]{};      // rows owner o's message to me holds (>= its true count, else clipped)
+        int64_t  cap_out[LCGS_MAX_RANKS]{};     // rows my message to view v holds
         int64_t  n_all = 0;                     // rows on my view's screen (all owners)
         int64_t  in_off[LCGS_MAX_RANKS + 1]{};  // owner o's rows start here in in_rows / in_recs / g2d_all
         uint32_t out[LCGS_MAX_RANKS]{};         // my rows on view v's screen (= table[me][v])
@@ -337,6 +352,28 @@ struct Wire {
         }
         LCGS_HIP_CHECK(hipMemcpy(d_recv, all.data(), all.size() * 4, hipMemcpyHostToDevice));
         if (!g->barrier()) return loop_failed(); // nobody overwrites the table before everybody has read it
+        return LCGS_OK;
+    }
+    // a few words max-reduced in place, outside any group (the ownership step's redo flag)
+    lcgs_status allreduce_max_u32(uint32_t* d_buf, size_t count)
+    {
+        if (!c->loop) {
+            LCGS_RCCL_CHECK(rccl().AllReduce(d_buf, d_buf, count, ncclUint32, ncclMax, c->comm, c->stream));
+            return LCGS_OK;
+        }
+        LCGS_REQUIRE(count <= 8, "loopback: the flag reduction carries a few words");
+        const int N = c->loop->world;
+        DeviceBuffer all;
+        LCGS_TRY(all.ensure((size_t)N * count * 4));
+        lcgs_status s = allgather_u32(d_buf, all.as<uint32_t>(), count); // (the loopback's rendezvous is host-side anyway)
+        uint32_t    h[8 * LCGS_MAX_RANKS], m[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (s == LCGS_OK && hipMemcpy(h, all.ptr, (size_t)N * count * 4, hipMemcpyDeviceToHost) != hipSuccess) s = LCGS_ERR_HIP;
+        all.release();
+        LCGS_TRY(s);
+        for (int r = 0; r < N; ++r)
+            for (size_t k = 0; k < count; ++k) m[k] = std::max(m[k], h[(size_t)r * count + k]);
+        LCGS_HIP_CHECK(hipMemcpyAsync(d_buf, m, count * 4, hipMemcpyHostToDevice, c->stream));
+        LCGS_HIP_CHECK(hipStreamSynchronize(c->stream)); // (m lives on this stack)
         return LCGS_OK;
     }
     lcgs_status group_end()
@@ -605,6 +642,9 @@ lcgs_status lcgs_comm_destroy(lcgs_comm* c)
                              &c->own_recs, &c->in_rows, &c->in_recs, &c->g2d_all, &c->g_in, &c->loop_scratch })
         b->release();
     if (c->h_matrix) (void)hipHostFree(c->h_matrix);
+    if (c->h_next) (void)hipHostFree(c->h_next);
+    c->flag_dev.release();
+    if (c->ev_checked) (void)hipEventDestroy(c->ev_checked);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_out) (void)hipEventDestroy(c->ev_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1053,6 +1093,17 @@ lcgs_status lcgs_comm_create_loopback(lcgs_context* ctx, lcgs_loopback_group* gr
     return LCGS_OK;
 }
 
+static_assert(LCGS_MAX_OWNER_VIEWS <= lcgs::kMaxOwnerSegs, "OwnerSegs holds one segment per view slot");
+// rows a padded message from an owner of `owner_count` rows holds when it carried n rows in the last step
+static int64_t padded_rows(int64_t n, int64_t owner_count) { return std::min(owner_count, n + n / 4 + 1024); }
+
+lcgs_status lcgs_owner_step_set_async(lcgs_comm* c, int enable)
+{
+    LCGS_REQUIRE(c != nullptr, "comm is NULL");
+    c->owner_async = enable != 0;
+    return LCGS_OK;
+}
+
 lcgs_status lcgs_owner_step_forward(lcgs_context* ctx, lcgs_comm* c, const lcgs_camera* cameras, const float bg_color[3],
                                     float scale_modifier, float* d_img)
 {
@@ -1065,6 +1116,7 @@ lcgs_status lcgs_owner_step_forward(lcgs_context* ctx, lcgs_comm* c, const lcgs_
     int64_t   first = 0, count = 0;
     lcgs_comm_owner_rows(ctx->P, N, me, &first, &count);
     c->own.valid = false;
+    c->own.async = false;
     c->stats     = lcgs_comm_stats{};
     Wire      wire{ c };
     LoopGuard guard{ c };
@@ -1084,6 +1136,103 @@ lcgs_status lcgs_owner_step_forward(lcgs_context* ctx, lcgs_comm* c, const lcgs_
     for (int v = 0; v < N; ++v)
         if (ctx->owner[v].valid && ctx->owner[v].row_count > 0)
             LCGS_HIP_CHECK(hipMemcpyAsync(c->bounds.as<uint32_t>() + v, ctx->owner[v].counts.ptr, 4, hipMemcpyDeviceToDevice, ctx->stream));
+
+    // The step WITHOUT a read-back (lcgs_owner_step_set_async): possible once a previous step's table is known, for the
+    // same scene and world, and while the padded segments of my view fit the workspace the scene sizes
+    bool    async = c->owner_async && !c->force_sync_once && c->prev.have && c->prev.world == N && c->prev.P == ctx->P;
+    int64_t cap_total = 0;
+    if (async) {
+        for (int o = 0; o < N; ++o) {
+            int64_t of = 0, oc = 0;
+            lcgs_comm_owner_rows(ctx->P, N, o, &of, &oc);
+            c->own.cap_in[o]  = padded_rows(c->prev.table[(size_t)o * N + me], oc);
+            c->own.in_off[o]  = cap_total;
+            cap_total += c->own.cap_in[o];
+            c->own.cap_out[o] = padded_rows(c->prev.table[(size_t)me * N + o], count);
+        }
+        c->own.in_off[N] = cap_total;
+        if (cap_total > ctx->P || cap_total >= (int64_t)0x7FFFFFFF) async = false;
+    }
+    c->force_sync_once = false;
+
+    if (async) {
+        if (!c->h_next) LCGS_HIP_CHECK(hipHostMalloc((void**)&c->h_next, ((size_t)LCGS_MAX_RANKS * LCGS_MAX_RANKS + 4) * 4, 0));
+        if (!c->ev_checked) LCGS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_checked, hipEventDisableTiming));
+        LCGS_TRY(c->flag_dev.ensure(16));
+        LCGS_HIP_CHECK(hipMemsetAsync(c->flag_dev.ptr, 0, 16, ctx->stream));
+        LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+        LCGS_TRY(wire.allgather_u32(c->bounds.as<uint32_t>(), c->matrix.as<uint32_t>(), (size_t)N));
+        // (for lcgs_owner_step_finish and the next step's sizes: nobody waits for this copy here)
+        LCGS_HIP_CHECK(hipMemcpyAsync(c->h_next, c->matrix.ptr, (size_t)N * N * 4, hipMemcpyDeviceToHost, c->stream));
+        // ---- 3'. padded messages: sizes from the last step's table, true counts on the device
+        const bool alias = N == 1 && !c->self_p2p; // one rank: my view reads my own projection where it lies
+        if (!alias) {
+            LCGS_TRY(c->in_rows.ensure((size_t)cap_total * 4 + 16));
+            LCGS_TRY(c->in_recs.ensure((size_t)cap_total * kRecBytes + 16));
+        }
+        int64_t sent = 0, received = 0;
+        if (!alias && !c->self_p2p && c->own.cap_in[me] > 0) { // my own share stays on the device (cap_in[me] == cap_out[me])
+            LCGS_HIP_CHECK(hipMemcpyAsync(c->in_rows.as<uint32_t>() + c->own.in_off[me], c->own_rows.as<uint32_t>() + (size_t)me * count,
+                                          (size_t)c->own.cap_in[me] * 4, hipMemcpyDeviceToDevice, c->stream));
+            LCGS_HIP_CHECK(hipMemcpyAsync(c->in_recs.as<float>() + (size_t)c->own.in_off[me] * LCGS_OWNER_RECORD_FLOATS,
+                                          c->own_recs.as<float>() + (size_t)me * count * LCGS_OWNER_RECORD_FLOATS,
+                                          (size_t)c->own.cap_in[me] * kRecBytes, hipMemcpyDeviceToDevice, c->stream));
+        }
+        LCGS_TRY(wire.group_begin());
+        for (int o = 0; o < N && !alias; ++o) {
+            const int64_t   n_out = c->own.cap_out[o], n_in = c->own.cap_in[o];
+            const uint32_t* rows_out = c->own_rows.as<uint32_t>() + (size_t)o * count;
+            const float*    recs_out = c->own_recs.as<float>() + (size_t)o * count * LCGS_OWNER_RECORD_FLOATS;
+            uint32_t*       rows_in  = c->in_rows.as<uint32_t>() + c->own.in_off[o];
+            float*          recs_in  = c->in_recs.as<float>() + (size_t)c->own.in_off[o] * LCGS_OWNER_RECORD_FLOATS;
+            if (o == me && !c->self_p2p) continue;
+            if (n_out > 0) {
+                LCGS_TRY(wire.send(rows_out, (size_t)n_out * 4, o));
+                LCGS_TRY(wire.send(recs_out, (size_t)n_out * kRecBytes, o));
+                sent += n_out * (int64_t)(4 + kRecBytes);
+            }
+            if (n_in > 0) {
+                LCGS_TRY(wire.recv(rows_in, (size_t)n_in * 4, o));
+                LCGS_TRY(wire.recv(recs_in, (size_t)n_in * kRecBytes, o));
+                received += n_in * (int64_t)(4 + kRecBytes);
+            }
+        }
+        LCGS_TRY(wire.group_end());
+        LCGS_HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_out, 0));
+        c->stats.bytes_sent        = sent + (int64_t)(N - 1) * N * 4;
+        c->stats.bytes_received    = received + (int64_t)(N - 1) * N * 4;
+        c->stats.touched_rows      = cap_total; // (the capacity: the row count itself is on the device)
+        c->stats.collective_groups = 3;         // the counts, the records, the flag
+        c->own.n_all               = cap_total;
+        for (int v = 0; v < N; ++v) {
+            c->own.out[v] = (uint32_t)c->own.cap_out[v];
+            if (ctx->owner[v].valid && ctx->owner[v].row_count > 0) ctx->owner[v].num = (int)c->own.cap_out[v]; // (a launch bound)
+        }
+        // ---- 4'. my view from everybody's rows: no read-back, the verdicts go into the flag word
+        abi::OwnerAsyncFrame af;
+        af.segs.n = (uint32_t)N;
+        for (int o = 0; o <= N; ++o) af.segs.off[o] = (uint32_t)c->own.in_off[o];
+        af.table    = c->matrix.as<uint32_t>();
+        af.view     = (uint32_t)me;
+        af.overflow = c->flag_dev.as<uint32_t>();
+        const uint32_t* rows_v = alias ? c->own_rows.as<uint32_t>() : c->in_rows.as<uint32_t>();
+        const float*    recs_v = alias ? c->own_recs.as<float>() : c->in_recs.as<float>();
+        if (cap_total > 0)
+            LCGS_TRY(abi::owner_render_frame(ctx, &cameras[me], bg_color, (int)cap_total, rows_v, recs_v, d_img, /*keep_state=*/1, &af));
+        // ---- 5'. one verdict for everybody: the flag, max-reduced; with the table it reaches pinned memory behind ev_checked
+        LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+        LCGS_TRY(wire.allreduce_max_u32(c->flag_dev.as<uint32_t>(), 1));
+        LCGS_HIP_CHECK(hipMemcpyAsync(c->h_next + (size_t)N * N, c->flag_dev.ptr, 4, hipMemcpyDeviceToHost, c->stream));
+        LCGS_HIP_CHECK(hipEventRecord(c->ev_checked, c->stream));
+        c->own.valid = true;
+        c->own.async = true;
+        guard.ok     = true;
+        return LCGS_OK;
+    }
+
     LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
     LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
     LCGS_TRY(wire.allgather_u32(c->bounds.as<uint32_t>(), c->matrix.as<uint32_t>(), (size_t)N));
@@ -1103,10 +1252,21 @@ lcgs_status lcgs_owner_step_forward(lcgs_context* ctx, lcgs_comm* c, const lcgs_
         c->own.out[v] = (uint32_t)table(me, v);
         if (ctx->owner[v].valid && ctx->owner[v].row_count > 0) ctx->owner[v].num = (int)table(me, v);
     }
+    // (what the next step sizes its padded messages from, if it runs without a read-back)
+    c->prev.table.assign(c->h_matrix, c->h_matrix + (size_t)N * N);
+    c->prev.have = true, c->prev.world = N, c->prev.P = ctx->P;
     // ---- 3. the records travel: mine to every view's rank, every owner's to me (owner order = ascending rows)
     LCGS_TRY(c->in_rows.ensure((size_t)n_all * 4 + 16));
     LCGS_TRY(c->in_recs.ensure((size_t)n_all * kRecBytes + 16));
     int64_t sent = 0, received = 0;
+    // (my own share stays on the device: copied in front of the group, so that nothing but RCCL calls sits inside it)
+    if (!c->self_p2p && table(me, me) > 0) {
+        LCGS_HIP_CHECK(hipMemcpyAsync(c->in_rows.as<uint32_t>() + c->own.in_off[me], c->own_rows.as<uint32_t>() + (size_t)me * count,
+                                      (size_t)table(me, me) * 4, hipMemcpyDeviceToDevice, c->stream));
+        LCGS_HIP_CHECK(hipMemcpyAsync(c->in_recs.as<float>() + (size_t)c->own.in_off[me] * LCGS_OWNER_RECORD_FLOATS,
+                                      c->own_recs.as<float>() + (size_t)me * count * LCGS_OWNER_RECORD_FLOATS,
+                                      (size_t)table(me, me) * kRecBytes, hipMemcpyDeviceToDevice, c->stream));
+    }
     LCGS_TRY(wire.group_begin());
     for (int o = 0; o < N; ++o) {
         const int64_t n_out = table(me, o), n_in = table(o, me);
@@ -1114,13 +1274,7 @@ lcgs_status lcgs_owner_step_forward(lcgs_context* ctx, lcgs_comm* c, const lcgs_
         const float*    recs_out = c->own_recs.as<float>() + (size_t)o * count * LCGS_OWNER_RECORD_FLOATS;
         uint32_t*       rows_in  = c->in_rows.as<uint32_t>() + c->own.in_off[o];
         float*          recs_in  = c->in_recs.as<float>() + (size_t)c->own.in_off[o] * LCGS_OWNER_RECORD_FLOATS;
-        if (o == me && !c->self_p2p) { // my own share stays on the device
-            if (n_in > 0) {
-                LCGS_HIP_CHECK(hipMemcpyAsync(rows_in, rows_out, (size_t)n_in * 4, hipMemcpyDeviceToDevice, c->stream));
-                LCGS_HIP_CHECK(hipMemcpyAsync(recs_in, recs_out, (size_t)n_in * kRecBytes, hipMemcpyDeviceToDevice, c->stream));
-            }
-            continue;
-        }
+        if (o == me && !c->self_p2p) continue;
         if (n_out > 0) {
             LCGS_TRY(wire.send(rows_out, (size_t)n_out * 4, o));
             LCGS_TRY(wire.send(recs_out, (size_t)n_out * kRecBytes, o));
@@ -1158,33 +1312,41 @@ lcgs_status lcgs_owner_step_backward(lcgs_context* ctx, lcgs_comm* c, const floa
     }
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     const int     N = c->world, me = c->rank;
-    const int64_t n_all = c->own.n_all;
+    const int64_t n_all = c->own.n_all; // (a step without read-back: the padded segments' total capacity)
+    const bool    alias = c->own.async && N == 1 && !c->self_p2p;
     c->own.valid        = false;
     Wire      wire{ c };
     LoopGuard guard{ c };
-    // ---- 1. my view's 2-D gradients, one 48-byte row per received row (owner order)
-    LCGS_TRY(c->g2d_all.ensure((size_t)n_all * kG2dBytes + 16));
+    // ---- 1. my view's 2-D gradients, one 48-byte row per received row (owner order; padded segments keep their positions)
+    int64_t first = 0, count = 0;
+    lcgs_comm_owner_rows(ctx->P, N, me, &first, &count);
+    // (a step without read-back: the per-splat kernel of step 3 walks a view's TRUE row count, which a clipped message falls
+    // short of -- the step is then repeated, but until the verdict is read nothing may be read out of bounds: every view's
+    // rows get room for my whole range)
+    LCGS_TRY(c->g2d_all.ensure((size_t)std::max(n_all, alias ? count : (int64_t)0) * kG2dBytes + 16));
     if (n_all > 0) LCGS_TRY(lcgs_owner_render_backward(ctx, d_dL_dimg, c->g2d_all.as<float>()));
     // ---- 2. every owner gets its rows' share back; I get my rows' share of every view
     int64_t gin_off[LCGS_MAX_RANKS + 1], total_in = 0;
     for (int v = 0; v < N; ++v) {
         gin_off[v] = total_in;
-        total_in += c->own.out[v];
+        total_in += c->own.async ? count : (int64_t)c->own.out[v];
     }
-    LCGS_TRY(c->g_in.ensure((size_t)total_in * kG2dBytes + 16));
+    if (!alias) LCGS_TRY(c->g_in.ensure((size_t)total_in * kG2dBytes + 16));
+    const float* g_in = alias ? c->g2d_all.as<float>() : c->g_in.as<float>();
     LCGS_HIP_CHECK(hipEventRecord(c->ev_in, ctx->stream));
     LCGS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
     int64_t sent = 0, received = 0;
+    if (!alias && !c->self_p2p && c->own.out[me] > 0) // (my own share: a device copy in front of the group)
+        LCGS_HIP_CHECK(hipMemcpyAsync(c->g_in.as<float>() + (size_t)gin_off[me] * LCGS_OWNER_GRAD_FLOATS,
+                                      c->g2d_all.as<float>() + (size_t)c->own.in_off[me] * LCGS_OWNER_GRAD_FLOATS,
+                                      (size_t)c->own.out[me] * kG2dBytes, hipMemcpyDeviceToDevice, c->stream));
     LCGS_TRY(wire.group_begin());
-    for (int o = 0; o < N; ++o) {
+    for (int o = 0; o < N && !alias; ++o) {
         const int64_t n_out = c->own.in_off[o + 1] - c->own.in_off[o]; // owner o's rows on my screen: their gradients go back
         const int64_t n_in  = c->own.out[o];                           // my rows on view o's screen: their gradients come in
         const float*  out   = c->g2d_all.as<float>() + (size_t)c->own.in_off[o] * LCGS_OWNER_GRAD_FLOATS;
         float*        in    = c->g_in.as<float>() + (size_t)gin_off[o] * LCGS_OWNER_GRAD_FLOATS;
-        if (o == me && !c->self_p2p) {
-            if (n_in > 0) LCGS_HIP_CHECK(hipMemcpyAsync(in, out, (size_t)n_in * kG2dBytes, hipMemcpyDeviceToDevice, c->stream));
-            continue;
-        }
+        if (o == me && !c->self_p2p) continue;
         if (n_out > 0) {
             LCGS_TRY(wire.send(out, (size_t)n_out * kG2dBytes, o));
             sent += n_out * (int64_t)kG2dBytes;
@@ -1202,8 +1364,33 @@ lcgs_status lcgs_owner_step_backward(lcgs_context* ctx, lcgs_comm* c, const floa
     c->stats.collective_groups += 1;
     // ---- 3. my rows: the 2-D gradients of every view -> parameter gradients, summed in view order
     for (int v = 0; v < N; ++v)
-        LCGS_TRY(lcgs_owner_backward(ctx, v, c->g_in.as<float>() + (size_t)gin_off[v] * LCGS_OWNER_GRAD_FLOATS, grads, v > 0));
+        LCGS_TRY(lcgs_owner_backward(ctx, v, g_in + (size_t)gin_off[v] * LCGS_OWNER_GRAD_FLOATS, grads, v > 0));
     guard.ok = true;
+    return LCGS_OK;
+}
+
+lcgs_status lcgs_owner_step_finish(lcgs_context* ctx, lcgs_comm* c, int* redo)
+{
+    LCGS_REQUIRE(ctx && c && redo, "NULL argument");
+    LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another (or a destroyed) context");
+    *redo = 0;
+    if (!c->own.async) return LCGS_OK; // a step that read its sizes back has nothing left to report
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    c->own.async = false;
+    // waits for the FORWARD half of the step at most (the flag's reduction sits behind every rank's frame, in front of the
+    // backward's messages on the communicator's stream): by now the device is normally far into the backward
+    LCGS_HIP_CHECK(hipEventSynchronize(c->ev_checked));
+    const int N = c->world, me = c->rank;
+    c->prev.table.assign(c->h_next, c->h_next + (size_t)N * N);
+    c->prev.have = true, c->prev.world = N, c->prev.P = ctx->P;
+    abi::owner_frame_settle(ctx);
+    int64_t rows = 0;
+    for (int o = 0; o < N; ++o) rows += std::min<int64_t>(c->h_next[(size_t)o * N + me], c->own.cap_in[o]);
+    c->stats.touched_rows = rows; // rows on this rank's screen
+    if (c->h_next[(size_t)N * N] != 0u) { // somebody's message was clipped, or somebody's frame truncated: everybody redoes
+        *redo              = 1;
+        c->force_sync_once = true; // (the redo reads its sizes back: exact, and the frame grows its own buffers)
+    }
     return LCGS_OK;
 }
 

@@ -1018,6 +1018,57 @@ __global__ void __launch_bounds__(256) k_unpack_records(uint32_t n, const SplatR
         vis_index[i] = row;
     }
 }
+// The same from PADDED segments (the ownership step without a host read-back, comm.cpp): owner o's rows occupy positions
+// [segs.off[o], segs.off[o] + count_o) of recs / rows, count_o = table[o * N + view] -- the all-gathered counts, read on the
+// device -- clipped to the segment's capacity (a clipped segment raises *overflow: the step is redone).  The sort's input is
+// dense (entry d = the d-th valid row in owner order = ascending global rows), its values are POSITIONS: rects, vis_index,
+// the records and later the 2-D gradient rows are addressed by position, so nothing is ever compacted or copied.
+__global__ void __launch_bounds__(256) k_unpack_records_seg(OwnerSegs segs, const uint32_t* __restrict__ table, uint32_t view,
+                                                            const SplatRecord* __restrict__ recs, const uint32_t* __restrict__ rows,
+                                                            const uint32_t* __restrict__ perm, uint32_t id_bits, uint32_t tag_shift,
+                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                            uint2* __restrict__ rects, uint32_t* __restrict__ vis_index,
+                                                            uint32_t* __restrict__ d_counts, uint32_t* __restrict__ overflow,
+                                                            uint32_t P, uint32_t grid_x, uint32_t grid_y)
+{
+    __shared__ uint32_t s_cnt[kMaxOwnerSegs], s_dense[kMaxOwnerSegs + 1];
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0u;
+        bool     over = false;
+        for (uint32_t o = 0; o < segs.n; ++o) {
+            const uint32_t want = table[o * segs.n + view], cap = segs.off[o + 1] - segs.off[o];
+            over |= want > cap;
+            s_cnt[o]   = want < cap ? want : cap;
+            s_dense[o] = acc;
+            acc += s_cnt[o];
+        }
+        s_dense[segs.n] = acc;
+        if (blockIdx.x == 0) {
+            d_counts[0] = acc;
+            d_counts[1] = acc; // (non-zero iff anything can be drawn)
+            d_counts[kCountTieUnresolved] = 0u;
+            if (over) atomicOr(overflow, 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t total = segs.off[segs.n];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        uint32_t o = 0u;
+        while (o + 1u < segs.n && i >= segs.off[o + 1]) ++o;
+        const uint32_t j = i - segs.off[o];
+        if (j >= s_cnt[o]) continue;
+        const uint32_t    d = s_dense[o] + j;
+        const SplatRecord r = recs[i];
+        uint32_t          row = rows[i];
+        const uint32_t x0 = r.rect_xy & 0xFFFFu, y0 = r.rect_xy >> 16, w = r.rect_wh & 0xFFFFu, h = r.rect_wh >> 16;
+        const bool     ok = row < P && x0 + w <= grid_x && y0 + h <= grid_y; // (as k_unpack_records: nothing indexes past the scene / grid)
+        if (!ok) row = 0u;
+        keys[d]      = __float_as_uint(r.depth);
+        vals[d]      = perm ? (i | ((perm[row] >> tag_shift) << id_bits)) : i;
+        rects[i]     = ok ? make_uint2(r.rect_xy, r.rect_wh) : make_uint2(0u, 0u);
+        vis_index[i] = row;
+    }
+}
 } // namespace
 
 void launch_rows_global(const uint32_t* vis, const uint32_t* d_count, uint32_t row_first, uint32_t* rows_out, int64_t hint,
@@ -1036,6 +1087,29 @@ void launch_unpack_records(int64_t n, const SplatRecord* recs, const uint32_t* r
     b         = b < 1 ? 1 : (b > 8192 ? 8192 : b);
     hipLaunchKernelGGL(k_unpack_records, dim3((unsigned)b), dim3(256), 0, stream, (uint32_t)n, recs, rows, perm, id_bits,
                        tag_shift, keys, vals, rects, vis_index, d_counts, P, grid_x, grid_y);
+}
+
+void launch_unpack_records_seg(const OwnerSegs& segs, const uint32_t* table, uint32_t view, const SplatRecord* recs,
+                               const uint32_t* rows, const uint32_t* perm, uint32_t id_bits, uint32_t tag_shift, uint32_t* keys,
+                               uint32_t* vals, uint2* rects, uint32_t* vis_index, uint32_t* d_counts, uint32_t* overflow, uint32_t P,
+                               uint32_t grid_x, uint32_t grid_y, hipStream_t stream)
+{
+    int64_t b = ((int64_t)segs.off[segs.n] + 255) / 256;
+    b         = b < 1 ? 1 : (b > 8192 ? 8192 : b);
+    hipLaunchKernelGGL(k_unpack_records_seg, dim3((unsigned)b), dim3(256), 0, stream, segs, table, view, recs, rows, perm,
+                       id_bits, tag_shift, keys, vals, rects, vis_index, d_counts, overflow, P, grid_x, grid_y);
+}
+
+namespace
+{
+__global__ void k_owner_pair_verdict(const uint32_t* __restrict__ d_counts, uint32_t* __restrict__ overflow)
+{
+    if (d_counts[3] != 0u) atomicOr(overflow, 2u); // this frame needed more pairs than the workspace holds (truncated)
+}
+} // namespace
+void launch_owner_pair_verdict(const uint32_t* d_counts, uint32_t* overflow, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_owner_pair_verdict, dim3(1), dim3(1), 0, stream, d_counts, overflow);
 }
 
 size_t expand_ws_bytes(int P_cap) { return (size_t)((P_cap + kExpandChunk - 1) / kExpandChunk + 8) * sizeof(uint32_t); }

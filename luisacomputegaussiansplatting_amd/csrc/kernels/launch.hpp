@@ -122,6 +122,18 @@ void launch_rows_global(const uint32_t* vis, const uint32_t* d_count, uint32_t r
 void launch_unpack_records(int64_t n, const SplatRecord* recs, const uint32_t* rows, const uint32_t* perm, uint32_t id_bits,
                            uint32_t tag_shift, uint32_t* keys, uint32_t* vals, uint2* rects, uint32_t* vis_index,
                            uint32_t* d_counts, uint32_t P, uint32_t grid_x, uint32_t grid_y, hipStream_t stream);
+// ... the same from PADDED per-owner segments whose true counts are on the device (fused_forward.hip k_unpack_records_seg)
+constexpr int kMaxOwnerSegs = 16; // = LCGS_MAX_OWNER_VIEWS (one view slot per rank of an ownership step)
+struct OwnerSegs {
+    uint32_t n = 0;                      // owners
+    uint32_t off[kMaxOwnerSegs + 1] = {}; // owner o's segment = positions [off[o], off[o + 1])
+};
+void launch_unpack_records_seg(const OwnerSegs& segs, const uint32_t* table, uint32_t view, const SplatRecord* recs,
+                               const uint32_t* rows, const uint32_t* perm, uint32_t id_bits, uint32_t tag_shift, uint32_t* keys,
+                               uint32_t* vals, uint2* rects, uint32_t* vis_index, uint32_t* d_counts, uint32_t* overflow, uint32_t P,
+                               uint32_t grid_x, uint32_t grid_y, hipStream_t stream);
+// *overflow |= 2 when the frame's pair buffers were too small (d_counts[3])
+void launch_owner_pair_verdict(const uint32_t* d_counts, uint32_t* overflow, hipStream_t stream);
 struct PairSortFirstPass;
 size_t expand_ws_bytes(int P_cap);
 // v_hint: expected survivor count (bounds the launch; larger live counts are handled by chunk striding)

@@ -313,6 +313,26 @@ public:
     {
         check(lcgs_owner_step_backward(m_dev->ctx(), m_comm, d_dL_dimg, &grads));
     }
+    // The step without a host read-back (lcgs_owner_step_set_async): message sizes from the previous step's counts.  Every
+    // such step is closed with owner_step_finish(); true = some rank's step was short, EVERY rank repeats forward + backward.
+    void owner_step_set_async(bool enable = true) { check(lcgs_owner_step_set_async(m_comm, enable ? 1 : 0)); }
+    bool owner_step_finish()
+    {
+        int redo = 0;
+        check(lcgs_owner_step_finish(m_dev->ctx(), m_comm, &redo));
+        return redo != 0;
+    }
+    // forward + backward + finish, repeated while the step was short; returns the repetitions (0 normally)
+    int owner_step(const lcgs_camera* cameras, const float bg_color[3], float* d_img, const float* d_dL_dimg,
+                   const lcgs_grads& grads, float scale_modifier = 1.0f)
+    {
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            owner_step_forward(cameras, bg_color, d_img, scale_modifier);
+            owner_step_backward(d_dL_dimg, grads);
+            if (!owner_step_finish()) return attempt;
+        }
+        throw Error(LCGS_ERR_STATE, "the ownership step did not settle after two repetitions");
+    }
     lcgs_comm_stats stats() const
     {
         lcgs_comm_stats st;

@@ -73,6 +73,8 @@ class RcclCollective:
         self.comm = api.Comm(ctx, rank, world_size, exchange, loopback=loopback)
         self.rank, self.world_size = rank, world_size
         self._img = None
+        self._owner_async = False
+        self.owner_redos = 0  # ownership steps that had to be repeated (a clipped message / truncated pairs on some rank)
 
     def allreduce_grads(self, grads: dict):
         self.comm.allreduce_grads(grads)
@@ -96,8 +98,10 @@ class RcclCollective:
         cam = cams[self.rank]
         if self._img is None or tuple(self._img.shape) != (3, cam.height, cam.width):
             self._img = torch.zeros(3, cam.height, cam.width, device=grads["pos"].device, dtype=torch.float32)
-        self.comm.owner_step_forward(cams, self._img)
-        self.comm.owner_step_backward(dL_dimg, grads)
+        if not self._owner_async:  # no read-back from the second step on (lcgs_owner_step_set_async / _finish)
+            self.comm.owner_step_set_async(True)
+            self._owner_async = True
+        self.owner_redos += self.comm.owner_step(cams, self._img, dL_dimg, grads)
         if optimise:
             engine.adam(grads, step, rows=api.owner_rows(int(grads["pos"].shape[0]), self.world_size, self.rank))
         st = self.comm.stats()

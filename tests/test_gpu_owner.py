@@ -265,10 +265,16 @@ def _reference_views(lcgs, scene, cams, dLs, bg):
     return imgs, g, vis
 
 
-@pytest.mark.parametrize("self_p2p", [False, True])
-def test_owner_step_through_rccl_at_world_size_one(lcgs, monkeypatch, self_p2p):
+def _padded(n):
+    return n + n // 4 + 1024  # comm.cpp padded_rows (before the clip to the owner's range)
+
+
+@pytest.mark.parametrize("self_p2p,async_steps", [(False, False), (True, False), (False, True), (True, True)])
+def test_owner_step_through_rccl_at_world_size_one(lcgs, monkeypatch, self_p2p, async_steps):
     """One rank owns everything: the step is the fused frame + its backward.  With LCGS_OWNER_SELF_P2P=1 the rank's own share
-    travels through ncclSend / ncclRecv to itself -- RCCL's point-to-point path, the one N > 1 ranks use."""
+    travels through ncclSend / ncclRecv to itself -- RCCL's point-to-point path, the one N > 1 ranks use.  async_steps: from the
+    second step on nothing is read back (lcgs_owner_step_set_async): padded messages sized from the previous step's counts,
+    the true counts on the device, one verdict behind the step (lcgs_owner_step_finish)."""
     if self_p2p:
         monkeypatch.setenv("LCGS_OWNER_SELF_P2P", "1")
     rng = np.random.default_rng(71)
@@ -284,28 +290,36 @@ def test_owner_step_through_rccl_at_world_size_one(lcgs, monkeypatch, self_p2p):
     comm = lcgs.Comm(r.ctx, 0, 1)
     try:
         g = {k: torch.full_like(act[k], 9.0) for k in KEYS}
-        for _ in range(2):  # twice: buffers re-used, slots re-used
+        if async_steps:
+            comm.owner_step_set_async(True)
+        for step in range(3):  # repeatedly: buffers re-used, slots re-used; async: the first step reads back, the others do not
             img = torch.full((3, H, W), -1.0, device=DEV)
-            comm.owner_step_forward(cams, img, bg=bg)
-            comm.owner_step_backward(dLs[0], g)
+            if async_steps:
+                assert comm.owner_step(cams, img, dLs[0], g, bg=bg) == 0
+            else:
+                comm.owner_step_forward(cams, img, bg=bg)
+                comm.owner_step_backward(dLs[0], g)
             r.ctx.synchronize()
             assert torch.equal(img, imgs[0])
             for k in KEYS:
                 assert _rel(g[k], g_ref[k]) <= 1e-4, k
         st = comm.stats()
         assert st["touched_rows"] == vis[0]
-        want = vis[0] * (4 + 48 + 48) if self_p2p else 0
+        rows = min(P, _padded(vis[0])) if async_steps else vis[0]
+        want = rows * (4 + 48 + 48) if self_p2p else 0
         assert st["bytes_sent"] == want and st["bytes_received"] == want, (st, want)
     finally:
         comm.close()
 
 
-@pytest.mark.parametrize("world,reordered", [(2, False), (3, True), (8, False)])
-def test_owner_step_with_n_ranks_in_process(lcgs, world, reordered):
+@pytest.mark.parametrize("world,reordered,async_steps", [(2, False, False), (3, True, False), (8, False, False),
+                                                         (2, True, True), (3, False, True), (8, False, True)])
+def test_owner_step_with_n_ranks_in_process(lcgs, world, reordered, async_steps):
     """N contexts on the one GPU, one host thread each, joined by the in-process loopback transport: the SAME C code path as
     the RCCL step (message table, offsets, slot state, stream ordering) with N > 1 participants.  Every rank's image is its
     view's fused frame bit for bit; every rank's rows hold the gradients of all N views summed; the byte counts are the
-    design's (4 + 48) out as an owner, 48 back as a renderer."""
+    design's (4 + 48) out as an owner, 48 back as a renderer.  async_steps: the steps behind the first read nothing back --
+    padded per-owner segments, true counts on the device, positions instead of compacted rows -- and give the same."""
     import threading
 
     rng = np.random.default_rng(80 + world)
@@ -336,9 +350,14 @@ def test_owner_step_with_n_ranks_in_process(lcgs, world, reordered):
                 comm = lcgs.Comm(r.ctx, me, world, loopback=group)
                 g = {k: torch.full_like(act[k], 9.0) for k in KEYS}
                 img = torch.full((3, H, W), -1.0, device=DEV)
-                for _ in range(2):
-                    comm.owner_step_forward(cams, img, bg=bg)
-                    comm.owner_step_backward(dLs[me], g)
+                if async_steps:
+                    comm.owner_step_set_async(True)
+                for _ in range(3 if async_steps else 2):
+                    if async_steps:
+                        assert comm.owner_step(cams, img, dLs[me], g, bg=bg) == 0
+                    else:
+                        comm.owner_step_forward(cams, img, bg=bg)
+                        comm.owner_step_backward(dLs[me], g)
                 r.ctx.synchronize()
                 side.synchronize()
                 out[me] = (img, g, comm.stats(), perm)
@@ -372,5 +391,69 @@ def test_owner_step_with_n_ranks_in_process(lcgs, world, reordered):
     assert sent == received
     # every on-screen row of every view travels once as (4 + 48) bytes and its gradient once as 48, except an owner's own view
     table_bytes = world * (world - 1) * world * 4
-    assert (sent - table_bytes) % 4 == 0 and sent - table_bytes <= sum(vis) * 100
+    slack = (sum(vis) // 4 + 1024 * world * world) * 100 if async_steps else 0  # padded messages: <= 1.25 x + 1024 rows each
+    assert (sent - table_bytes) % 4 == 0 and sent - table_bytes <= sum(vis) * 100 + slack
     assert sent - table_bytes >= (sum(vis) * 100) * (world - 1) // world // 2  # (views see the ranges unevenly; not an exact law)
+
+
+def test_owner_step_without_read_back_is_repeated_by_every_rank_when_a_message_was_clipped(lcgs):
+    """Three in-process ranks, steps without read-back.  Step 1 (reads back) looks AWAY from the scene: its table is all but
+    empty.  Step 2 turns to the scene: every message is sized for step 1's counts and clipped -- the flag is raised on the
+    device, max-reduced, and lcgs_owner_step_finish tells EVERY rank to repeat the step (that repetition reads its sizes
+    back); the result is the ordinary one.  Step 3 runs without read-back again, sized by step 2's table."""
+    import threading
+
+    world = 3
+    rng = np.random.default_rng(91)
+    P = 45_001
+    scene = make_scene(rng, P, log_scale=(-4.0, 0.8))
+    cams = [lcgs.get_lookat_cam([-3 * np.cos(a), -0.5 + 3 * np.sin(a), 2.3], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+            for a in np.linspace(0.0, 1.0, world)]
+    away = [lcgs.get_lookat_cam([-3 * np.cos(a), -0.5 + 3 * np.sin(a), 2.3], [-9 * np.cos(a), 6 * np.sin(a), 8.0], [0, 0, 1],
+                                width=W, height=H) for a in np.linspace(0.0, 1.0, world)]
+    dLs = [torch.from_numpy(rng.normal(size=(3, H, W)).astype(np.float32)).to(DEV) for _ in cams]
+    bg = (0.1, 0.2, 0.3)
+    imgs_ref, g_ref, vis = _reference_views(lcgs, scene, cams, dLs, bg)
+    group = lcgs.api.LoopbackGroup(world)
+    out, errors = [None] * world, []
+
+    def rank_main(me):
+        try:
+            side = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(side):
+                r = lcgs.Renderer(lcgs.Context(0, side.cuda_stream))
+                act = upload_scene(scene)
+                r.bind_scene(*[act[k] for k in KEYS])
+                comm = lcgs.Comm(r.ctx, me, world, loopback=group)
+                comm.owner_step_set_async(True)
+                g = {k: torch.full_like(act[k], 9.0) for k in KEYS}
+                img = torch.full((3, H, W), -1.0, device=DEV)
+                redos = [comm.owner_step(away, img, dLs[me], g, bg=bg),   # reads back (first step): nearly nothing on screen
+                         comm.owner_step(cams, img, dLs[me], g, bg=bg)]   # sized by that: clipped, repeated
+                r.ctx.synchronize()
+                first = (img.clone(), {k: g[k].clone() for k in KEYS})
+                redos.append(comm.owner_step(cams, img, dLs[me], g, bg=bg))  # sized by step 2's table: fits
+                r.ctx.synchronize()
+                side.synchronize()
+                out[me] = (first, img, g, redos)
+                comm.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((me, repr(e)))
+
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=rank_main, args=(me,)) for me in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank hangs"
+    group.close()
+    for me in range(world):
+        (img2, g2), img3, g3, redos = out[me]
+        assert redos == [0, 1, 0], (me, redos)
+        first, count = lcgs.api.owner_rows(P, world, me)
+        for img, g in ((img2, g2), (img3, g3)):
+            assert torch.equal(img, imgs_ref[me]), me
+            for k in KEYS:
+                assert _rel(g[k][first:first + count], g_ref[k][first:first + count]) <= 1e-4, (me, k)
