@@ -56,6 +56,8 @@ struct OwnerAsyncFrame {
 lcgs_status owner_render_frame(lcgs_context* ctx, const lcgs_camera* camera, const float bg_color[3], int num_rows,
                                const uint32_t* d_rows, const float* d_records, float* d_img, int keep_state,
                                const OwnerAsyncFrame* af);
+lcgs_status owner_render_backward_into(lcgs_context* ctx, const float* d_dL_dimg, float* d_grads2d, const DenseFill* fill);
+lcgs_status owner_backward_rows(lcgs_context* ctx, int slot, const float* d_grads2d, const lcgs_grads* grads, int mode);
 void owner_frame_settle(lcgs_context* ctx); // hints / pair capacity from the pinned counters of such a frame
 // the process's live contexts (lcgs_create / lcgs_destroy), for scene_arrays_written
 void registry_add(lcgs_context* ctx);

@@ -270,6 +270,16 @@ extern "C" {
 
 lcgs_status lcgs_owner_render_backward(lcgs_context* ctx, const float* d_dL_dimg, float* d_grads2d)
 {
+    return lcgs::abi::owner_render_backward_into(ctx, d_dL_dimg, d_grads2d, nullptr);
+}
+
+} // extern "C"
+
+// lcgs_owner_render_backward.  The 2-D gradient rows are formed where the caller wants them (one 48-byte row per received
+// row, by position: no staging copy); `fill`: dense gradient arrays (the caller's own rows) cleared as a side job of the
+// VALU-bound kernel, like the fused backward's (abi_backward.cpp), instead of 0.3 ms of memsets behind it.
+lcgs_status lcgs::abi::owner_render_backward_into(lcgs_context* ctx, const float* d_dL_dimg, float* d_grads2d, const DenseFill* fill)
+{
     LCGS_REQUIRE(ctx && d_dL_dimg && d_grads2d, "NULL argument");
     LCGS_REQUIRE((reinterpret_cast<uintptr_t>(d_grads2d) & 15) == 0, "d_grads2d must be 16-byte aligned (rows are float4 x 3)");
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
@@ -278,20 +288,29 @@ lcgs_status lcgs_owner_render_backward(lcgs_context* ctx, const float* d_dL_dimg
         return LCGS_ERR_STATE;
     }
     hipStream_t st = ctx->stream;
-    LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)ctx->P)));
-    launch_zero_grads2d(ctx->counts.as<uint32_t>(), ctx->grads2d.as<float>(), st, ctx->bwd_counter.as<uint32_t>());
-    // (rows are addressed by POSITION; a frame from padded segments has positions beyond its row count: clear those too)
-    LCGS_HIP_CHECK(hipMemsetAsync(ctx->grads2d.ptr, 0, (size_t)ctx->owner_rows * LCGS_OWNER_GRAD_FLOATS * 4, st));
+    // (rows are addressed by POSITION; a frame from padded segments has positions beyond its row count: all of them are cleared)
+    LCGS_HIP_CHECK(hipMemsetAsync(d_grads2d, 0, (size_t)ctx->owner_rows * LCGS_OWNER_GRAD_FLOATS * 4, st));
+    LCGS_HIP_CHECK(hipMemsetAsync(ctx->bwd_counter.ptr, 0, 4, st)); // the persistent render-backward's tile counter
     launch_render_backward(ctx->last.cp, ctx->last.bg, ctx->ranges, ctx->pairv[ctx->last.list_buf].as<uint32_t>(), ctx->owner_recs,
-                           ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(), d_dL_dimg, ctx->grads2d.as<float>(),
-                           ctx->last_tile_order, st, ctx->strip_masks.as<uint8_t>(), ctx->counts.as<uint32_t>());
+                           ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(), d_dL_dimg, d_grads2d, ctx->last_tile_order, st,
+                           ctx->strip_masks.as<uint8_t>(), ctx->counts.as<uint32_t>(), nullptr, 0, fill);
     LCGS_HIP_CHECK(hipGetLastError());
-    LCGS_HIP_CHECK(hipMemcpyAsync(d_grads2d, ctx->grads2d.ptr, (size_t)ctx->owner_rows * LCGS_OWNER_GRAD_FLOATS * 4,
-                                  hipMemcpyDeviceToDevice, st));
     return LCGS_OK;
 }
 
+extern "C" {
+
 lcgs_status lcgs_owner_backward(lcgs_context* ctx, int slot, const float* d_grads2d, const lcgs_grads* grads, int accumulate)
+{
+    return lcgs::abi::owner_backward_rows(ctx, slot, d_grads2d, grads, accumulate ? 1 : 0);
+}
+
+} // extern "C"
+
+// lcgs_owner_backward.  mode 0: the range is cleared, the view's rows are written; 1: the view's rows are ADDED to what the
+// range holds; 2: the range has been cleared already (the render-backward's side job, comm.cpp), the view's rows are written
+// -- plain stores instead of a read-modify-write of 236 bytes a row.
+lcgs_status lcgs::abi::owner_backward_rows(lcgs_context* ctx, int slot, const float* d_grads2d, const lcgs_grads* grads, int mode)
 {
     LCGS_REQUIRE(ctx && grads, "NULL argument");
     LCGS_REQUIRE(slot >= 0 && slot < LCGS_MAX_OWNER_VIEWS, "slot out of range");
@@ -310,7 +329,7 @@ lcgs_status lcgs_owner_backward(lcgs_context* ctx, int slot, const float* d_grad
     const size_t feat = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3, f = (size_t)s.row_first, c = (size_t)s.row_count;
     float *gp = grads->d_dL_dpos + 3 * f, *gs = grads->d_dL_dscale + 3 * f, *gq = grads->d_dL_drotq + 4 * f,
           *gsh = grads->d_dL_dsh + feat * f, *go = grads->d_dL_dopacity + f;
-    if (!accumulate) { // the first view of the step: every row of the range that is not on its screen is an exact zero
+    if (mode == 0) { // the first view of the step: every row of the range that is not on its screen is an exact zero
         LCGS_HIP_CHECK(hipMemsetAsync(gp, 0, c * 3 * 4, st));
         LCGS_HIP_CHECK(hipMemsetAsync(gs, 0, c * 3 * 4, st));
         LCGS_HIP_CHECK(hipMemsetAsync(gq, 0, c * 4 * 4, st));
@@ -326,9 +345,12 @@ lcgs_status lcgs_owner_backward(lcgs_context* ctx, int slot, const float* d_grad
     const RowRange r = shard_of(ctx, s.row_first);
     launch_preprocess_backward(s.num, ctx->sh_deg, s.cp, s.scale_modifier, r.pos, r.scale, r.rotq, r.sh, s.vis.as<uint32_t>(),
                                s.counts.as<uint32_t>(), d_grads2d, gp, gs, gq, gsh, go, st,
-                               s.has_jac ? s.shjac.as<float4>() : nullptr, /*compact=*/false, nullptr, 0, 1, /*accumulate=*/true);
+                               s.has_jac ? s.shjac.as<float4>() : nullptr, /*compact=*/false, nullptr, 0, 1, /*accumulate=*/mode == 1);
     LCGS_HIP_CHECK(hipGetLastError());
     return LCGS_OK;
 }
+
+
+extern "C" {
 
 } // extern "C"

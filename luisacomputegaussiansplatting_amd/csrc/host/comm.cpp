@@ -1324,7 +1324,19 @@ lcgs_status lcgs_owner_step_backward(lcgs_context* ctx, lcgs_comm* c, const floa
     // short of -- the step is then repeated, but until the verdict is read nothing may be read out of bounds: every view's
     // rows get room for my whole range)
     LCGS_TRY(c->g2d_all.ensure((size_t)std::max(n_all, alias ? count : (int64_t)0) * kG2dBytes + 16));
-    if (n_all > 0) LCGS_TRY(lcgs_owner_render_backward(ctx, d_dL_dimg, c->g2d_all.as<float>()));
+    // (the own rows of the dense gradient arrays are cleared as a side job of the render-backward: view 0 then ADDS like the rest)
+    const size_t feat = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3;
+    const bool   filled = n_all > 0 && count > 0 && (size_t)count * feat < ((size_t)1 << 32) && grads->d_dL_dpos && grads->d_dL_dscale &&
+                        grads->d_dL_drotq && grads->d_dL_dsh && grads->d_dL_dopacity;
+    DenseFill fill;
+    if (filled) {
+        fill.b0 = grads->d_dL_dpos + 3 * (size_t)first, fill.b1 = grads->d_dL_dscale + 3 * (size_t)first;
+        fill.b2 = grads->d_dL_drotq + 4 * (size_t)first, fill.b3 = grads->d_dL_dsh + feat * (size_t)first;
+        fill.b4 = grads->d_dL_dopacity + (size_t)first;
+        const size_t n[5] = { (size_t)count * 3, (size_t)count * 3, (size_t)count * 4, (size_t)count * feat, (size_t)count };
+        for (int a = 0; a < 5; ++a) fill.n[a] = (uint32_t)n[a];
+    }
+    if (n_all > 0) LCGS_TRY(abi::owner_render_backward_into(ctx, d_dL_dimg, c->g2d_all.as<float>(), filled ? &fill : nullptr));
     // ---- 2. every owner gets its rows' share back; I get my rows' share of every view
     int64_t gin_off[LCGS_MAX_RANKS + 1], total_in = 0;
     for (int v = 0; v < N; ++v) {
@@ -1364,7 +1376,7 @@ lcgs_status lcgs_owner_step_backward(lcgs_context* ctx, lcgs_comm* c, const floa
     c->stats.collective_groups += 1;
     // ---- 3. my rows: the 2-D gradients of every view -> parameter gradients, summed in view order
     for (int v = 0; v < N; ++v)
-        LCGS_TRY(lcgs_owner_backward(ctx, v, g_in + (size_t)gin_off[v] * LCGS_OWNER_GRAD_FLOATS, grads, v > 0));
+        LCGS_TRY(abi::owner_backward_rows(ctx, v, g_in + (size_t)gin_off[v] * LCGS_OWNER_GRAD_FLOATS, grads, v > 0 ? 1 : (filled ? 2 : 0)));
     guard.ok = true;
     return LCGS_OK;
 }
