@@ -571,6 +571,19 @@ def leg_gradients(S):
                         dist.broadcast(t, 0)
                         return t.cpu().numpy().tobytes()
                     coll = mg.RcclCollective(ctx, rank, world, exchange)
+                    # ---- before anything distributed is timed: what the communicator says about ITSELF (lcgs_comm_selftest: a
+                    # 1 KB all-reduce, zero- and one-byte messages to every peer in one group, an ownership step on a 10 000-splat
+                    # scratch scene with and without read-back; 30 s per phase).  In the line whatever it says; when it fails the
+                    # gradient legs are not attempted (a transport that cannot pass this would hang them)
+                    st_self = coll.comm.selftest(timeout_s=30.0, check=False)
+                    oks = torch.tensor([1 if st_self["ok"] else 0], device=dev, dtype=torch.int32)
+                    if world > 1:
+                        dist.all_reduce(oks, op=dist.ReduceOp.MIN)
+                    st_self["every_rank_ok"] = bool(int(oks.item()) == 1)
+                    out["comm_selftest"] = st_self
+                    r.bind_scene(d["pos"], d["scale"], d["rotq"], d["sh"], d["opacity"])  # (the self-test put the binding back; the rows too)
+                    if not st_self["every_rank_ok"]:
+                        raise RuntimeError(f"communicator self-test failed: {st_self['message']}")
                     if args.grad_transport != "f32":
                         coll.comm.set_transport(args.grad_transport)
                 else:

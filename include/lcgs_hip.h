@@ -559,6 +559,29 @@ LCGS_API lcgs_status lcgs_owner_step_backward(lcgs_context* ctx, lcgs_comm* comm
  * back as before (finish then reports 0 at once).  Bytes on the wire: <= 1.25 x the exact step's + 1024 rows a message. */
 LCGS_API lcgs_status lcgs_owner_step_set_async(lcgs_comm* comm, int enable);
 LCGS_API lcgs_status lcgs_owner_step_finish(lcgs_context* ctx, lcgs_comm* comm, int* redo);
+/* What a communicator says about ITSELF before anything is timed (round 6): a collective -- every rank calls it -- of three
+ * phases, each watched against timeout_s from the calling thread (a phase that never returns is reported in `timed_out`, the
+ * call returns LCGS_ERR_STATE and the process should exit: the worker thread is left behind):
+ *   1. a 1 KB all-reduce (rank r contributes r + 1 in 256 floats; every element must come back as N (N + 1) / 2);
+ *   2. one group of point-to-point messages: to every peer (to itself at N = 1) a zero-byte and a one-byte message, and back;
+ *   3. an ownership step on a 10 000-splat scene the call generates, with and without read-back: the rank's image must be its
+ *      fused frame of that scene bit for bit, its own rows' gradients the sum of the N views' ordinary backward passes (1e-4).
+ *      (N > LCGS_MAX_OWNER_VIEWS: not run, owner_step_ok = -1.)
+ * The context's scene binding is put back afterwards (lcgs_scene_bind of what was bound: frame state and the opt-in f16
+ * coefficient copy are reset).  Returns LCGS_OK only when every phase ran and was right. */
+typedef struct lcgs_comm_selftest_report {
+    int    world_size, rank;
+    int    allreduce_ok;
+    double allreduce_ms;
+    int    p2p_ok;
+    double p2p_ms;
+    int    owner_step_ok; /* 1 right, 0 wrong, -1 not run */
+    double owner_step_ms;
+    double owner_max_grad_err; /* worst relative L2 error of an attribute over the own rows, over the three steps */
+    int    timed_out;          /* 0, or the phase (1..3) that did not finish within timeout_s */
+    char   message[256];
+} lcgs_comm_selftest_report;
+LCGS_API lcgs_status lcgs_comm_selftest(lcgs_context* ctx, lcgs_comm* comm, double timeout_s, lcgs_comm_selftest_report* out);
 typedef struct lcgs_loopback_group lcgs_loopback_group;
 LCGS_API lcgs_status lcgs_loopback_group_create(int world_size, lcgs_loopback_group** out);
 LCGS_API lcgs_status lcgs_loopback_group_destroy(lcgs_loopback_group* group); /* after its communicators */

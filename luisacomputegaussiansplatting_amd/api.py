@@ -44,6 +44,14 @@ def build_library(force: bool = False) -> str:
     return library_path()
 
 
+class _SelftestReport(C.Structure):
+    """lcgs_comm_selftest_report"""
+
+    _fields_ = [("world_size", C.c_int), ("rank", C.c_int), ("allreduce_ok", C.c_int), ("allreduce_ms", C.c_double),
+                ("p2p_ok", C.c_int), ("p2p_ms", C.c_double), ("owner_step_ok", C.c_int), ("owner_step_ms", C.c_double),
+                ("owner_max_grad_err", C.c_double), ("timed_out", C.c_int), ("message", C.c_char * 256)]
+
+
 class Camera(C.Structure):
     """struct Camera, lcgs/include/lcgs/util/camera.h:15-25"""
 
@@ -145,7 +153,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
     "lcgs_render_forward_batch", "lcgs_scene_use_half_sh", "lcgs_scene_modified", "lcgs_debug_verify_derived",
     "lcgs_comm_owner_rows", "lcgs_owner_step_forward", "lcgs_owner_step_backward", "lcgs_owner_step_set_async",
-    "lcgs_owner_step_finish", "lcgs_loopback_group_create",
+    "lcgs_owner_step_finish", "lcgs_comm_selftest", "lcgs_loopback_group_create",
     "lcgs_loopback_group_destroy", "lcgs_comm_create_loopback",
     "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_set_lod", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_set_transport", "lcgs_comm_shard_rows",
     "lcgs_grads_allreduce", "lcgs_adam_step_sharded", "lcgs_comm_track_touched_rows", "lcgs_comm_get_stats",
@@ -831,6 +839,22 @@ class Comm:
         """lcgs_owner_step_backward: the view's 2-D gradients back to the owners, parameter gradients at this rank's own rows"""
         g = _Grads(*[_ptr(grads[k]) for k in _KEYS])
         _check(load_library().lcgs_owner_step_backward(self.ctx._h, self._h, _ptr(dL_dimg), C.byref(g)))
+
+    def selftest(self, timeout_s: float = 30.0, check: bool = True) -> dict:
+        """lcgs_comm_selftest (a collective: every rank calls it): a 1 KB all-reduce, zero- and one-byte messages to every peer
+        in one group, an ownership step on a 10 000-splat scene with and without read-back -- each phase against timeout_s.
+        Returns the report as a dict (`ok`, per-phase `*_ok` / `*_ms`, `timed_out`, `message`); check=True raises on failure."""
+        rep = _SelftestReport()
+        status = load_library().lcgs_comm_selftest(self.ctx._h, self._h, C.c_double(timeout_s), C.byref(rep))
+        out = {"ok": status == 0, "world_size": int(rep.world_size), "rank": int(rep.rank),
+               "allreduce_ok": int(rep.allreduce_ok), "allreduce_ms": round(float(rep.allreduce_ms), 3),
+               "p2p_ok": int(rep.p2p_ok), "p2p_ms": round(float(rep.p2p_ms), 3),
+               "owner_step_ok": int(rep.owner_step_ok), "owner_step_ms": round(float(rep.owner_step_ms), 3),
+               "owner_max_grad_err": float(rep.owner_max_grad_err), "timed_out": int(rep.timed_out),
+               "message": rep.message.decode(errors="replace")}
+        if check:
+            _check(status)
+        return out
 
     def owner_step_set_async(self, enable: bool = True):
         """lcgs_owner_step_set_async: steps size their messages from the previous step's counts and read nothing back; every

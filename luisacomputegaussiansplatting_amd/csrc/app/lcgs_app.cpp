@@ -1,7 +1,7 @@
 // lcgs-app -- CLI work-alike of the reference's app/main.cpp on the MI355X library.
 //   lcgs-app --ply <path> [--res WxH] [--out dir] [--world colmap|blender] [--exp_N N] [--backend hip]
 //            [--path fused|stage|deferred] [--synth kind:count:seed] [--ingest device|host] [--cameras file]
-//            [--order file|spatial] [--pose garden|lego] [--gpus N] [--backward [--owner]] [--fit K]
+//            [--order file|spatial] [--pose garden|lego] [--gpus N] [--backward [--owner] [--comm-selftest]] [--fit K]
 // Same flags (app/main.cpp:52-124; `--key=value` and `--key value`, app/command_parser.hpp:5-79), the same
 // hard-coded look-at camera (app/main.cpp:191-207), the same frame loop (:266-308), the same output:
 // <out>/<ply stem>_<backend>.png, CHW float -> vertically flipped RGB8 with a truncating *255 (:323-339).
@@ -63,6 +63,9 @@ void usage(const char* argv0)
     printf("  --owner                  With --backward: the splat-ownership step instead (every GPU owns P / N rows; 48-byte\n"
            "                           records and 2-D gradients of on-screen rows travel by RCCL send / recv, no dense sum).\n"
            "                           The printed norms come from a verification all-reduce outside the step\n");
+    printf("  --comm-selftest          With --backward: before anything else, the communicator's self-test on every rank (1 KB\n"
+           "                           all-reduce, zero- and one-byte messages to every peer, an ownership step on a scratch\n"
+           "                           scene; 30 s per phase).  A failure is printed and ends the run with a non-zero status\n");
     printf("  --fit <K>                Training without a Python binding (doc/roadmap.md:4), as a demonstration: the loaded scene's\n"
            "                           frame is the target, opacities and base colours are perturbed, K optimiser steps\n"
            "                           (forward, L2 loss, backward, Adam) pull them back; prints the loss per step.  With\n"
@@ -87,7 +90,7 @@ int main(int argc, char** argv)
     std::string ply_path = "gsplat.ply", backend = "hip", out_dir = "out", world = "colmap", path = "fused", synth;
     std::string ingest = "device", cameras_file, order = "auto", pose = "garden";
     int         exp_N = 1, gpus = 1, fit_steps = 0;
-    bool        backward = false, fused_adam = false, owner = false;
+    bool        backward = false, fused_adam = false, owner = false, comm_selftest = false;
     // parse_command (app/command_parser.hpp:5-79): strip leading dashes, `key=value` or `key value`
     for (int i = 1; i < argc; ++i) {
         std::string arg = argv[i];
@@ -142,6 +145,7 @@ int main(int argc, char** argv)
             if (gpus < 1 || gpus > 64) die("--gpus out of range");
         } else if (key == "backward") backward = true;
         else if (key == "owner") owner = true;
+        else if (key == "comm-selftest" || key == "comm_selftest") comm_selftest = true;
         else if (key == "fit") {
             if (value.empty()) die("--fit requires a value");
             fit_steps = std::stoi(value);
@@ -432,6 +436,19 @@ int main(int argc, char** argv)
                 } else if (read(token_read, id.bytes, sizeof(id.bytes)) != (ssize_t)sizeof(id.bytes))
                     die("cannot receive the communicator token");
                 comm.reset(new lcgs::Comm(device, id, rank, gpus));
+                if (comm_selftest) { // what the communicator says about itself, before it carries anything that matters
+                    const lcgs_comm_selftest_report t = comm->selftest(30.0, /*throw_on_failure=*/false);
+                    printf("rank %d / %d communicator self-test: all-reduce %s (%.2f ms), point-to-point %s (%.2f ms), ownership step %s "
+                           "(%.1f ms, worst gradient error %.1e)%s%s\n",
+                           t.rank, t.world_size, t.allreduce_ok == 1 ? "ok" : "WRONG", t.allreduce_ms, t.p2p_ok == 1 ? "ok" : "WRONG",
+                           t.p2p_ms, t.owner_step_ok == 1 ? "ok" : (t.owner_step_ok < 0 ? "not run" : "WRONG"), t.owner_step_ms,
+                           t.owner_max_grad_err, t.timed_out ? " -- TIMED OUT: " : "", t.timed_out ? t.message : "");
+                    fflush(stdout);
+                    if (t.timed_out || t.allreduce_ok != 1 || t.p2p_ok != 1 || t.owner_step_ok == 0) {
+                        fprintf(stderr, "communicator self-test failed on rank %d: %s\n", rank, t.message);
+                        _exit(3); // (a phase may be stuck inside RCCL: no destructors, no second attempt from this process)
+                    }
+                }
             }
             lcgs::Scene         scene(device);
             lcgs::Buffer<float> g_pos, g_scale, g_rotq, g_sh, g_op, d_ones;

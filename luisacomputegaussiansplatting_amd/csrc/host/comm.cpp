@@ -1407,3 +1407,289 @@ lcgs_status lcgs_owner_step_finish(lcgs_context* ctx, lcgs_comm* c, int* redo)
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// lcgs_comm_selftest: what the first N > 1 run on hardware should say about ITSELF before anything is timed.  Every rank of
+// the communicator calls it (a collective).  Three phases, each run by a worker thread and watched against timeout_s from
+// the calling thread (an RCCL call that never returns, a kernel that never finishes: the phase is reported, not waited for):
+//   1. a 1 KB all-reduce (256 floats, rank r contributes r + 1: every element must come back as N (N + 1) / 2);
+//   2. point-to-point inside ONE group: to every peer (to itself at N = 1) a zero-byte and a one-byte message, and the same
+//      back -- the two message shapes the ownership step's tables can produce at their edge;
+//   3. one ownership step on a 10 000-splat scene the call generates (the context's own binding is put back afterwards):
+//      with and without read-back, the rank's image against its fused frame of the same scene (bit for bit), its own rows'
+//      gradients against the sum of the N views' ordinary backward passes.
+// ---------------------------------------------------------------------------------------------------------------------
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <memory>
+#include <thread>
+
+namespace
+{
+struct SelftestShared {
+    std::atomic<int>    phase{ 0 }; // 1..3 while running, 4 when done
+    std::atomic<double> phase_start{ 0.0 };
+    std::atomic<bool>   done{ false };
+    lcgs_status                status = LCGS_OK;
+    lcgs_comm_selftest_report  rep{};
+    std::string                error;
+};
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct DevArr {
+    void* p = nullptr;
+    ~DevArr()
+    {
+        if (p) (void)hipFree(p);
+    }
+    lcgs_status alloc(size_t bytes)
+    {
+        LCGS_HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+        return LCGS_OK;
+    }
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+lcgs_status selftest_allreduce(lcgs_comm* c, lcgs_comm_selftest_report* rep)
+{
+    const int N = c->world;
+    DevArr    buf;
+    LCGS_TRY(buf.alloc(1024));
+    std::vector<float> h(256, (float)(c->rank + 1));
+    LCGS_HIP_CHECK(hipMemcpyAsync(buf.p, h.data(), 1024, hipMemcpyHostToDevice, c->stream));
+    Wire         wire{ c };
+    const double t0 = now_s();
+    LCGS_TRY(wire.group_begin());
+    LCGS_TRY(wire.allreduce_sum(buf.as<float>(), 256));
+    LCGS_TRY(wire.group_end());
+    LCGS_HIP_CHECK(hipMemcpyAsync(h.data(), buf.p, 1024, hipMemcpyDeviceToHost, c->stream));
+    LCGS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    rep->allreduce_ms = (now_s() - t0) * 1e3;
+    const float want = 0.5f * (float)N * (float)(N + 1);
+    rep->allreduce_ok = 1;
+    for (float x : h)
+        if (x != want) rep->allreduce_ok = 0;
+    return LCGS_OK;
+}
+
+lcgs_status selftest_p2p(lcgs_comm* c, lcgs_comm_selftest_report* rep)
+{
+    const int N = c->world, me = c->rank;
+    DevArr    out, in;
+    LCGS_TRY(out.alloc(16));
+    LCGS_TRY(in.alloc((size_t)N + 16));
+    const unsigned char mine = (unsigned char)(me + 1);
+    LCGS_HIP_CHECK(hipMemcpyAsync(out.p, &mine, 1, hipMemcpyHostToDevice, c->stream));
+    LCGS_HIP_CHECK(hipMemsetAsync(in.p, 0, (size_t)N + 16, c->stream));
+    Wire         wire{ c };
+    const double t0 = now_s();
+    LCGS_TRY(wire.group_begin());
+    for (int p = 0; p < N; ++p) {
+        if (N > 1 && p == me) continue; // (one rank: the messages go to itself)
+        LCGS_TRY(wire.send(out.p, 0, p));
+        LCGS_TRY(wire.send(out.p, 1, p));
+        LCGS_TRY(wire.recv(in.as<unsigned char>() + p, 0, p));
+        LCGS_TRY(wire.recv(in.as<unsigned char>() + p, 1, p));
+    }
+    LCGS_TRY(wire.group_end());
+    std::vector<unsigned char> h((size_t)N);
+    LCGS_HIP_CHECK(hipMemcpyAsync(h.data(), in.p, (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    LCGS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    rep->p2p_ms = (now_s() - t0) * 1e3;
+    rep->p2p_ok = 1;
+    for (int p = 0; p < N; ++p)
+        if ((N == 1 || p != me) && h[(size_t)p] != (unsigned char)(p + 1)) rep->p2p_ok = 0;
+    return LCGS_OK;
+}
+
+lcgs_status selftest_owner_step(lcgs_context* ctx, lcgs_comm* c, lcgs_comm_selftest_report* rep)
+{
+    const int N = c->world, me = c->rank;
+    rep->owner_step_ok = -1; // not run
+    if (N > LCGS_MAX_OWNER_VIEWS) return LCGS_OK;
+    constexpr int P = 10000, W = 320, H = 240, feat = 48;
+    // ---- the scene (the same on every rank: a counter-based generator) and the N views
+    std::vector<float> h_pos((size_t)P * 3), h_sh((size_t)P * feat), h_op((size_t)P), h_scale((size_t)P * 3), h_rotq((size_t)P * 4);
+    LCGS_TRY(lcgs_synth_scene(0, 4242u, 0, P, h_pos.data(), h_sh.data(), h_op.data(), h_scale.data(), h_rotq.data()));
+    const size_t widths[5] = { 3, 3, 4, (size_t)feat, 1 };
+    const float* host[5]   = { h_pos.data(), h_scale.data(), h_rotq.data(), h_sh.data(), h_op.data() };
+    DevArr       act[5], g_ref[5], g_own[5], img_ref, img_own, dL;
+    for (int a = 0; a < 5; ++a) {
+        LCGS_TRY(act[a].alloc((size_t)P * widths[a] * 4));
+        LCGS_TRY(g_ref[a].alloc((size_t)P * widths[a] * 4));
+        LCGS_TRY(g_own[a].alloc((size_t)P * widths[a] * 4));
+        LCGS_HIP_CHECK(hipMemcpy(act[a].p, host[a], (size_t)P * widths[a] * 4, hipMemcpyHostToDevice));
+    }
+    const size_t img_bytes = (size_t)3 * W * H * 4;
+    LCGS_TRY(img_ref.alloc(img_bytes));
+    LCGS_TRY(img_own.alloc(img_bytes));
+    LCGS_TRY(dL.alloc(img_bytes));
+    {
+        std::vector<float> h((size_t)3 * W * H);
+        uint32_t           x = 12345u + (uint32_t)me * 977u; // (every rank differentiates its own view with its own loss gradient)
+        for (float& v : h) {
+            x = x * 1664525u + 1013904223u;
+            v = ((float)(x >> 8) / 16777216.0f) - 0.5f;
+        }
+        LCGS_HIP_CHECK(hipMemcpy(dL.p, h.data(), img_bytes, hipMemcpyHostToDevice));
+    }
+    std::vector<lcgs_camera> cams((size_t)N);
+    for (int v = 0; v < N; ++v) {
+        const float a = 0.35f * (float)v, pos[3] = { -3.0f * std::cos(a), -0.5f + 3.0f * std::sin(a), 2.3f }, tgt[3] = { 0, 0, 0.5f },
+                    up[3] = { 0, 0, 1 };
+        lcgs_get_lookat_cam(pos, tgt, up, &cams[(size_t)v]);
+        cams[(size_t)v].width = W, cams[(size_t)v].height = H, cams[(size_t)v].aspect_ratio = (float)W / (float)H;
+    }
+    // ---- the context's own binding is put back whatever happens below
+    struct Binding {
+        lcgs_context* ctx;
+        int           P = 0, deg = 3;
+        const float * pos = nullptr, *scale = nullptr, *rotq = nullptr, *sh = nullptr, *op = nullptr;
+        ~Binding()
+        {
+            (void)lcgs_synchronize(ctx);
+            (void)lcgs_scene_bind(ctx, pos ? P : 0, deg, pos, scale, rotq, sh, op);
+        }
+    } keep{ ctx };
+    LCGS_TRY(lcgs_scene_pointers(ctx, &keep.P, &keep.deg, &keep.pos, &keep.scale, &keep.rotq, &keep.sh, &keep.op));
+    LCGS_TRY(lcgs_scene_bind(ctx, P, 3, act[0].as<float>(), act[1].as<float>(), act[2].as<float>(), act[3].as<float>(), act[4].as<float>()));
+    const float bg[3] = { 0.1f, 0.2f, 0.3f };
+    // ---- what the step must reproduce: my view's fused frame; my rows' gradients = the sum of every view's ordinary backward
+    // (every view differentiated with ITS rank's loss gradient: regenerate those)
+    lcgs_grads gr = { g_ref[0].as<float>(), g_ref[1].as<float>(), g_ref[2].as<float>(), g_ref[3].as<float>(), g_ref[4].as<float>() };
+    DevArr     dLv, scratch;
+    LCGS_TRY(dLv.alloc(img_bytes));
+    LCGS_TRY(scratch.alloc(img_bytes));
+    for (int v = 0; v < N; ++v) {
+        std::vector<float> h((size_t)3 * W * H);
+        uint32_t           x = 12345u + (uint32_t)v * 977u;
+        for (float& q : h) {
+            x = x * 1664525u + 1013904223u;
+            q = ((float)(x >> 8) / 16777216.0f) - 0.5f;
+        }
+        LCGS_HIP_CHECK(hipMemcpy(dLv.p, h.data(), img_bytes, hipMemcpyHostToDevice));
+        int n = 0;
+        LCGS_TRY(lcgs_render_forward(ctx, &cams[(size_t)v], bg, 1.0f, v == me ? img_ref.as<float>() : scratch.as<float>(), nullptr, 1, &n));
+        if (n > 0) LCGS_TRY(v == 0 ? lcgs_render_backward(ctx, dLv.as<float>(), &gr) : lcgs_render_backward_accumulate(ctx, dLv.as<float>(), &gr));
+        else if (v == 0)
+            for (int a = 0; a < 5; ++a) LCGS_HIP_CHECK(hipMemsetAsync(g_ref[a].p, 0, (size_t)P * widths[a] * 4, ctx->stream));
+        LCGS_TRY(lcgs_synchronize(ctx)); // (dLv is rewritten by a blocking copy at the top of the loop: the backward must be through)
+    }
+    // ---- the step: once reading its sizes back, then twice without (the second of those is sized by the first's table)
+    lcgs_grads   go = { g_own[0].as<float>(), g_own[1].as<float>(), g_own[2].as<float>(), g_own[3].as<float>(), g_own[4].as<float>() };
+    int64_t      first = 0, count = 0;
+    lcgs_comm_owner_rows(P, N, me, &first, &count);
+    const bool   was_async = c->owner_async;
+    const double t0 = now_s();
+    double       worst = 0.0;
+    bool         image_ok = true;
+    lcgs_status  st = LCGS_OK;
+    for (int round = 0; round < 3 && st == LCGS_OK; ++round) {
+        c->owner_async = round > 0;
+        LCGS_HIP_CHECK(hipMemsetAsync(img_own.p, 0, img_bytes, ctx->stream));
+        for (int attempt = 0; attempt < 3 && st == LCGS_OK; ++attempt) {
+            st = lcgs_owner_step_forward(ctx, c, cams.data(), bg, 1.0f, img_own.as<float>());
+            if (st == LCGS_OK) st = lcgs_owner_step_backward(ctx, c, dL.as<float>(), &go);
+            int redo = 0;
+            if (st == LCGS_OK) st = lcgs_owner_step_finish(ctx, c, &redo);
+            if (!redo) break;
+        }
+        if (st != LCGS_OK) break;
+        if (lcgs_synchronize(ctx) != LCGS_OK) st = LCGS_ERR_HIP;
+        std::vector<float> a((size_t)3 * W * H), b((size_t)3 * W * H);
+        LCGS_HIP_CHECK(hipMemcpy(a.data(), img_own.p, img_bytes, hipMemcpyDeviceToHost));
+        LCGS_HIP_CHECK(hipMemcpy(b.data(), img_ref.p, img_bytes, hipMemcpyDeviceToHost));
+        if (memcmp(a.data(), b.data(), img_bytes) != 0) image_ok = false;
+        for (int k = 0; k < 5; ++k) {
+            const size_t       n = (size_t)count * widths[k];
+            std::vector<float> x(n), y(n);
+            if (n == 0) continue;
+            LCGS_HIP_CHECK(hipMemcpy(x.data(), g_own[k].as<float>() + (size_t)first * widths[k], n * 4, hipMemcpyDeviceToHost));
+            LCGS_HIP_CHECK(hipMemcpy(y.data(), g_ref[k].as<float>() + (size_t)first * widths[k], n * 4, hipMemcpyDeviceToHost));
+            double num = 0.0, den = 0.0;
+            for (size_t i = 0; i < n; ++i) {
+                num += ((double)x[i] - y[i]) * ((double)x[i] - y[i]);
+                den += (double)y[i] * y[i];
+            }
+            worst = std::max(worst, std::sqrt(num / std::max(den, 1e-30)));
+            if (getenv("LCGS_SELFTEST_DEBUG")) fprintf(stderr, "[selftest] rank %d round %d attr %d: err %.3e (|ref| %.3e), image_ok %d\n", me, round, k, std::sqrt(num / std::max(den, 1e-30)), std::sqrt(den), (int)image_ok);
+        }
+    }
+    c->owner_async = was_async;
+    c->prev.have   = false; // (the table belongs to the scratch scene)
+    LCGS_TRY(st);
+    rep->owner_step_ms      = (now_s() - t0) * 1e3;
+    rep->owner_max_grad_err = worst;
+    rep->owner_step_ok      = (image_ok && worst <= 1e-4) ? 1 : 0;
+    return LCGS_OK;
+}
+} // namespace
+
+extern "C" {
+
+lcgs_status lcgs_comm_selftest(lcgs_context* ctx, lcgs_comm* c, double timeout_s, lcgs_comm_selftest_report* out)
+{
+    LCGS_REQUIRE(ctx && c && out, "NULL argument");
+    LCGS_REQUIRE(c->ctx == ctx, "the communicator belongs to another (or a destroyed) context");
+    LCGS_REQUIRE(timeout_s > 0.0, "timeout_s must be positive");
+    *out            = lcgs_comm_selftest_report{};
+    out->world_size = c->world;
+    out->rank       = c->rank;
+    auto sh = std::make_shared<SelftestShared>(); // (outlives this call if a phase never returns: the worker is then detached)
+    sh->rep = *out;
+    std::thread worker([sh, ctx, c] {
+        lcgs_status s = hipSetDevice(ctx->device) == hipSuccess ? LCGS_OK : LCGS_ERR_HIP;
+        auto        enter = [&](int p) {
+            sh->phase_start.store(now_s());
+            sh->phase.store(p);
+        };
+        if (s == LCGS_OK) {
+            enter(1);
+            s = selftest_allreduce(c, &sh->rep);
+        }
+        if (s == LCGS_OK) {
+            enter(2);
+            s = selftest_p2p(c, &sh->rep);
+        }
+        if (s == LCGS_OK) {
+            enter(3);
+            s = selftest_owner_step(ctx, c, &sh->rep);
+        }
+        if (s != LCGS_OK) sh->error = lcgs_last_error(); // (thread-local in the worker: carried over)
+        sh->status = s;
+        sh->phase.store(4);
+        sh->done.store(true);
+    });
+    sh->phase_start.store(now_s());
+    while (!sh->done.load()) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        if (now_s() - sh->phase_start.load() > timeout_s && !sh->done.load()) {
+            const int p = sh->phase.load();
+            worker.detach(); // it may never return; the process is expected to report and exit
+            *out           = sh->rep;
+            out->timed_out = p > 0 ? p : 1;
+            snprintf(out->message, sizeof(out->message), "phase %d (%s) did not finish within %.1f s", out->timed_out,
+                     out->timed_out == 1 ? "all-reduce" : (out->timed_out == 2 ? "point-to-point" : "ownership step"), timeout_s);
+            set_last_error(out->message);
+            return LCGS_ERR_STATE;
+        }
+    }
+    worker.join();
+    *out = sh->rep;
+    if (sh->status != LCGS_OK) {
+        snprintf(out->message, sizeof(out->message), "%s", sh->error.c_str());
+        set_last_error(sh->error);
+        return sh->status;
+    }
+    const bool ok = out->allreduce_ok == 1 && out->p2p_ok == 1 && out->owner_step_ok != 0;
+    snprintf(out->message, sizeof(out->message), ok ? "ok" : "a phase gave wrong results (see the *_ok fields)");
+    if (!ok) {
+        set_last_error("lcgs_comm_selftest: a phase gave wrong results");
+        return LCGS_ERR_STATE;
+    }
+    return LCGS_OK;
+}
+
+} // extern "C"

@@ -333,6 +333,15 @@ public:
         }
         throw Error(LCGS_ERR_STATE, "the ownership step did not settle after two repetitions");
     }
+    // lcgs_comm_selftest (a collective): 1 KB all-reduce, zero- and one-byte messages to every peer, an ownership step on a
+    // scratch scene -- each against timeout_s.  Throws when a phase failed or never returned (the report says which).
+    lcgs_comm_selftest_report selftest(double timeout_s = 30.0, bool throw_on_failure = true)
+    {
+        lcgs_comm_selftest_report rep;
+        const lcgs_status         s = lcgs_comm_selftest(m_dev->ctx(), m_comm, timeout_s, &rep);
+        if (s != LCGS_OK && throw_on_failure) throw Error(s, std::string("communicator self-test: ") + rep.message);
+        return rep;
+    }
     lcgs_comm_stats stats() const
     {
         lcgs_comm_stats st;

@@ -130,11 +130,14 @@ def test_lcgs_app_ownership_step_prints_the_same_norms(lcgs, tmp_path):
         for p, t, u in views:
             f.write(" ".join(str(x) for x in p + t + u) + "\n")
     got = {}
-    for tag, extra in (("dense", []), ("owner", ["--owner"])):
+    for tag, extra in (("dense", []), ("owner", ["--owner", "--comm-selftest"])):
         out = str(tmp_path / tag)
         res = subprocess.run([app, "--synth", f"0:{P}:1001", f"--res={W}x{H}", "--out", out, "--cameras", cams, "--gpus", "1",
                               "--backward"] + extra, capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stderr
+        if "--comm-selftest" in extra:  # the communicator's self-test ran first and said so
+            assert re.search(r"rank 0 / 1 communicator self-test: all-reduce ok \([^)]*\), point-to-point ok \([^)]*\), "
+                             r"ownership step ok", res.stdout), res.stdout
         got[tag] = re.findall(r"round (\d+) \(1 view[^)]*\): grad_l2 pos (\S+) scale (\S+) rotq (\S+) sh (\S+) opacity (\S+)", res.stdout)
         assert len(got[tag]) == len(views), res.stdout
         for k in range(len(views)):

@@ -622,3 +622,65 @@ def test_view_parallel_trainer_with_three_ranks_in_process(lcgs):
                     da = (act[k] - act_ref[k]).abs()
                     scale = max(float(act_ref[k].abs().max()), 1e-6)
                     assert float((da > 1e-3 * scale).float().mean()) < 0.01, (mode, me, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# lcgs_comm_selftest: what a communicator says about itself before anything is timed (round 6)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_comm_selftest_through_rccl_at_world_size_one(lcgs):
+    """all three phases through RCCL's own code path (the point-to-point phase sends to itself), on a context that has a
+    scene of its own bound: the binding -- and the frame it renders -- are the same afterwards"""
+    from conftest import make_scene
+
+    rng = np.random.default_rng(5)
+    scene = make_scene(rng, 30_000)
+    r = lcgs.Renderer(lcgs.Context(0))
+    r.upload_scene(scene)
+    cam = lcgs.get_lookat_cam([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1], width=320, height=240)
+    before = torch.zeros(3, 240, 320, device=DEV)
+    n0 = r.forward(cam, before, sync=True)
+    comm = lcgs.Comm(r.ctx, 0, 1)
+    try:
+        rep = comm.selftest(timeout_s=60.0)
+        assert rep["ok"] and rep["allreduce_ok"] == 1 and rep["p2p_ok"] == 1 and rep["owner_step_ok"] == 1, rep
+        assert rep["timed_out"] == 0 and rep["owner_max_grad_err"] <= 1e-4 and rep["world_size"] == 1, rep
+        after = torch.zeros(3, 240, 320, device=DEV)
+        assert r.forward(cam, after, sync=True) == n0 and torch.equal(before, after)
+        assert r.verify_derived() == 0
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_comm_selftest_with_n_ranks_in_process(lcgs, world):
+    """the same C code with N participants over the in-process loopback: every rank's three phases pass"""
+    import threading
+
+    group = lcgs.api.LoopbackGroup(world)
+    out, errors = [None] * world, []
+
+    def rank_main(me):
+        try:
+            side = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(side):
+                r = lcgs.Renderer(lcgs.Context(0, side.cuda_stream))
+                comm = lcgs.Comm(r.ctx, me, world, loopback=group)
+                out[me] = comm.selftest(timeout_s=120.0, check=False)
+                comm.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((me, repr(e)))
+
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=rank_main, args=(me,)) for me in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank hangs"
+    group.close()
+    for me in range(world):
+        rep = out[me]
+        assert rep["ok"] and rep["rank"] == me and rep["world_size"] == world, rep
+        assert rep["allreduce_ok"] == 1 and rep["p2p_ok"] == 1 and rep["owner_step_ok"] == 1 and rep["timed_out"] == 0, rep
+        assert rep["owner_max_grad_err"] <= 1e-4, rep
