@@ -153,6 +153,12 @@ def parse_args():
                          "about sqrt(N) x 5e-4 relative error; never the default)")
     ap.add_argument("--leg-timeout", type=float, default=600.0,
                     help="N > 1: seconds the legs after the forward measurement may take before the line is printed without them")
+    ap.add_argument("--sweep", action="store_true",
+                    help="instead of the bench line: the workload sweep (tools/workload_sweep.py) -- scale_modifier x scene x "
+                         "resolution, counts / frames/s / forward+backward per point, a fitted time model and what sits off it; "
+                         "writes profiles/r06_workload_sweep.json (--sweep-out)")
+    ap.add_argument("--sweep-out", type=str, default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                                                  "r06_workload_sweep.json"))
     ap.add_argument("--collective", choices=("rccl", "torch"), default="rccl",
                     help="N > 1 gradient collective: the library's own RCCL path (lcgs_comm C ABI, default) or "
                          "torch.distributed's (cross-check)")
@@ -313,7 +319,7 @@ def renderer_entries(torch, r, stats, W, H, dev):
     """List entries the renderer's workgroups stage in the frame just rendered.  A frame that keeps no backward state lists its
     pairs per block of 2 x 2 tiles (fewer pairs through duplication / partition / ranges) and every tile's workgroup walks its
     block's list: the renderer then reads each block's list once per tile of the block."""
-    if os.environ.get("LCGS_COARSE_LISTS", "auto") == "0":
+    if os.environ.get("LCGS_COARSE_LISTS", "auto") == "0" or stats.get("list_shift", 1) == 0:
         return int(stats["num_pairs"])
     gx, gy = (W + 15) // 16, (H + 15) // 16
     rng = torch.zeros(2 * gx * gy, dtype=torch.int32, device=dev)
@@ -833,6 +839,11 @@ def leg_gradients(S):
 
 def main():
     args = parse_args()
+    if args.sweep:  # a tool of its own output: never the bench line
+        from tools import workload_sweep
+
+        workload_sweep.run(args.sweep_out, quick=os.environ.get("LCGS_SWEEP_QUICK") == "1")
+        return
 
     # The contract is ONE JSON line on stdout.  Libraries below print there too (RCCL's version banner at communicator
     # creation, gloo's "connected to N peer ranks"): from here on file descriptor 1 points at stderr, and the line is

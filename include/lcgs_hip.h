@@ -295,6 +295,9 @@ typedef struct lcgs_frame_stats {
     int64_t equal_depth_unresolved; /* always 0 since round 3: runs of EXACTLY equal depths of any length are blended in file
                                      * order in a re-ordered scene too (runs beyond 4096 members are sorted through global
                                      * scratch; see lcgs_scene_reorder_spatial).  Kept for ABI stability. */
+    int64_t list_shift; /* granularity of the last frame's pair lists (num_pairs, lcgs_debug_last_lists): 0 per 16 x 16 tile,
+                         * 1 per block of 2 x 2 tiles (frames without backward state of a context whose frames exceed ~3 M
+                         * per-tile pairs); round 6 */
 } lcgs_frame_stats;
 LCGS_API lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* out);
 
@@ -306,6 +309,10 @@ LCGS_API lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* o
  * entries whose pruned rect covers it -- the same per-pixel sequence, the same image bit for bit): then the first
  * ceil(grid_x / 2) * ceil(grid_y / 2) ranges are the blocks', row-major, and the rest are zero. */
 LCGS_API lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t* d_ranges);
+/* Diagnostics: what the last frame with keep_state != 0 kept per pixel -- the final transmittance and the 1-based position,
+ * within the pixel's tile list, of its last contributor (the values the reference computes and drops,
+ * gs_tile_splatter/shader.cpp:219-220,252,273).  width * height entries each; either may be NULL.  Synchronises. */
+LCGS_API lcgs_status lcgs_debug_last_state(lcgs_context* ctx, float* d_final_T, uint32_t* d_n_contrib);
 
 /* Diagnostics: the compositing loop's exp (`exp(power)`, gs_tile_splatter/shader.cpp:258) evaluated on the device for n
  * values.  The reference's exp is whatever LuisaCompute's JIT maps it to (unpinned); this library defines it as a fixed

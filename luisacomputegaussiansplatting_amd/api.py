@@ -115,7 +115,8 @@ class _StageTimes(C.Structure):
 
 class _FrameStats(C.Structure):
     _fields_ = [("num_gaussians", C.c_int64), ("num_visible", C.c_int64), ("num_rendered", C.c_int64),
-                ("num_pairs", C.c_int64), ("num_tiles", C.c_int64), ("equal_depth_unresolved", C.c_int64)]
+                ("num_pairs", C.c_int64), ("num_tiles", C.c_int64), ("equal_depth_unresolved", C.c_int64),
+                ("list_shift", C.c_int64)]
 
 
 class _Grads(C.Structure):
@@ -147,7 +148,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_sh_process", "lcgs_project_forward", "lcgs_tile_splat_forward", "lcgs_set_stage_mode", "lcgs_stage_flush",
     "lcgs_inclusive_sum_u32",
     "lcgs_sort_pairs_u64_u32", "lcgs_scene_bind", "lcgs_scene_upload", "lcgs_render_forward",
-    "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists", "lcgs_debug_blend_exp",
+    "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists", "lcgs_debug_last_state", "lcgs_debug_blend_exp",
     "lcgs_render_backward", "lcgs_render_backward_adam", "lcgs_fit_views", "lcgs_render_backward_accumulate", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png", "lcgs_l2_loss_backward",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
@@ -714,6 +715,11 @@ class Renderer:
         with keep_state=True; a frame without it lists its pairs per block of 2 x 2 tiles (the first ceil(gx / 2) * ceil(gy / 2)
         ranges, row-major; the rest zero).  Either argument may be None."""
         _check(load_library().lcgs_debug_last_lists(self.ctx._h, _ptr(d_list), _ptr(d_ranges)))
+
+    def last_state(self, d_final_T, d_n_contrib):
+        """lcgs_debug_last_state: per pixel, what the last keep_state frame kept for its backward (final transmittance; 1-based
+        list position of the last contributor).  Either argument may be None."""
+        _check(load_library().lcgs_debug_last_state(self.ctx._h, _ptr(d_final_T), _ptr(d_n_contrib)))
 
     def adam_step(self, grads: dict, raw: dict, m: dict, v: dict, activated: dict, step: int, lr: dict,
                   betas=(0.9, 0.999), eps: float = 1e-15, visible_only: bool = False, sh_degree: int = 3,

@@ -366,6 +366,7 @@ lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* out)
     ctx->stats.num_pairs     = ctx->h_counts[2];
     ctx->stats.num_tiles     = (int64_t)ctx->last.cp.grid_x * ctx->last.cp.grid_y;
     ctx->stats.equal_depth_unresolved = ctx->perm_valid ? ctx->h_counts[9] : 0;
+    ctx->stats.list_shift             = ctx->last.cp.list_shift;
     *out                     = ctx->stats;
     return LCGS_OK;
 }
@@ -385,6 +386,20 @@ lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t*
         LCGS_HIP_CHECK(hipMemcpyAsync(d_ranges, ctx->ranges,
                                       (size_t)ctx->last.cp.grid_x * ctx->last.cp.grid_y * 8, hipMemcpyDeviceToDevice,
                                       ctx->stream));
+    LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return LCGS_OK;
+}
+
+// Debug/parity hook: what the last keep_state frame stored for its backward -- the values the reference computes and drops
+// (gs_tile_splatter/shader.cpp:219-220,252,273): per pixel the final transmittance and the 1-based list position of the
+// last contributor.
+lcgs_status lcgs_debug_last_state(lcgs_context* ctx, float* d_final_T, uint32_t* d_n_contrib)
+{
+    LCGS_REQUIRE(ctx && ctx->frame_state_valid() && ctx->last.has_state, "no keep_state frame rendered yet");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->last.cp.width * ctx->last.cp.height;
+    if (d_final_T) LCGS_HIP_CHECK(hipMemcpyAsync(d_final_T, ctx->final_T.ptr, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_n_contrib) LCGS_HIP_CHECK(hipMemcpyAsync(d_n_contrib, ctx->n_contrib.ptr, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
     LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return LCGS_OK;
 }

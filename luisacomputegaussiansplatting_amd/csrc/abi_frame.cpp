@@ -140,7 +140,10 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
                         ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(), dfirst, st, ctx->cull_rows());
     LCGS_TRY(mark(ctx, "cull_compact"));
     const int64_t hint_V = ctx->hint_V > 0 ? ctx->hint_V : P;
-    const int64_t hint_L = ctx->hint_L > 0 ? ctx->hint_L : ctx->pair_capacity;
+    // (per-tile and per-block frames of one context keep a launch-size hint each: their pair counts differ by up to 3 x, and a
+    // context that alternates between them -- a viewer beside a trainer -- would size every forward-only frame for the other's)
+    const int64_t hint_own = cp.list_shift ? (ctx->hint_Lb > 0 ? ctx->hint_Lb : ctx->hint_L) : ctx->hint_L;
+    const int64_t hint_L   = hint_own > 0 ? hint_own : ctx->pair_capacity;
     // survivors by depth bits (the low 32 bits of the reference key), sorted before duplication.  The first pass reads
     // the cull pass's chunk slabs, hands out the dense ids and writes vis_index / rects; its completion is the fork
     // point of the record builder.
@@ -307,7 +310,7 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
             key.img = d_img; key.radii = d_radii; key.P = ctx->P; key.sh_deg = ctx->sh_deg;
             key.width = camera->width; key.height = camera->height; key.keep_state = keep_state != 0;
             key.list_shift = (int)cp.list_shift;
-            key.hint_V = ctx->hint_V; key.hint_L = ctx->hint_L; key.capacity = ctx->pair_capacity; key.stream = ctx->stream;
+            key.hint_V = ctx->hint_V; key.hint_L = cp.list_shift ? (ctx->hint_Lb > 0 ? ctx->hint_Lb : ctx->hint_L) : ctx->hint_L; key.capacity = ctx->pair_capacity; key.stream = ctx->stream;
             if (!ctx->graph_exec || !(key == ctx->graph_key)) {
                 if (ctx->graph_exec) {
                     LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -352,14 +355,28 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
         // (kept unless the live counts leave the [hint/2, hint] band, so a captured graph stays valid)
         if ((int64_t)ctx->h_counts[0] > ctx->hint_V || (int64_t)ctx->h_counts[0] * 2 < ctx->hint_V)
             ctx->hint_V = (int64_t)ctx->h_counts[0] + ctx->h_counts[0] / 4 + 4096;
-        if ((int64_t)ctx->h_counts[4] > ctx->hint_L || (int64_t)ctx->h_counts[4] * 2 < ctx->hint_L)
-            ctx->hint_L = (int64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4 + 4096;
-        {   // per-block lists for the following frames without backward state?  (context.hpp coarse_mode; a per-block count is
-            // ~0.45-0.7 of the per-tile one: taken as 0.6)
-            const int64_t per_tile = cp.list_shift ? (int64_t)ctx->h_counts[4] * 5 / 3 : (int64_t)ctx->h_counts[4];
-            if (per_tile >= 3000000) ctx->coarse_on = true;
-            else if (per_tile < 2400000) ctx->coarse_on = false;
+        {
+            int64_t& hl = cp.list_shift ? ctx->hint_Lb : ctx->hint_L;
+            if ((int64_t)ctx->h_counts[4] > hl || (int64_t)ctx->h_counts[4] * 2 < hl) hl = (int64_t)ctx->h_counts[4] + ctx->h_counts[4] / 4 + 4096;
         }
+        {   // per-block lists for the following frames without backward state?  (context.hpp coarse_mode)  The decision is
+            // made in PER-TILE pairs whichever granularity this frame used: a per-tile frame has the count itself and notes
+            // its share of the reference's num_rendered (the pruning's yield: a property of the scene, 0.58 on the bicycle
+            // stand-in); a per-block frame multiplies its num_rendered -- which does not depend on the granularity -- by
+            // that share.  (Until round 6 the per-block count was scaled by 5/3, a ratio that really varies from 0.45 to 0.7:
+            // near the thresholds successive frames could flip the decision back and forth.)
+            if (!cp.list_shift && ctx->h_counts[1] > 0)
+                ctx->coarse_yield = std::min(1.0, std::max(0.05, (double)ctx->h_counts[4] / (double)ctx->h_counts[1]));
+            // Round 6's workload sweep (profiles/r06_workload_sweep.json) added the second condition: what per-block lists save
+            // is the duplication of footprints that span several tiles of a block, and a frame of SMALL footprints (scale
+            // modifier 0.5: 1.6-1.9 tiles per on-screen splat) has little of it -- its per-block lists are 0.8 of the per-tile
+            // ones and the 2.4 x stagings cost 4-10 % of the frame; from ~2.2 tiles per splat up they win.
+            const int64_t per_tile = cp.list_shift ? (int64_t)((double)ctx->h_counts[1] * ctx->coarse_yield) : (int64_t)ctx->h_counts[4];
+            const int64_t V_now    = (int64_t)ctx->h_counts[0];
+            if (per_tile >= 3000000 && per_tile * 10 >= V_now * 22) ctx->coarse_on = true;
+            else if (per_tile < 2400000 || per_tile * 10 < V_now * 19) ctx->coarse_on = false;
+        }
+        ctx->stats.list_shift = cp.list_shift;
         // overflow bookkeeping: [3] this frame, [6] / [7] every frame since the last read-back (sticky on the device)
         const bool     own    = ctx->h_counts[3] != 0;
         const uint32_t sticky = ctx->h_counts[6], sticky_want = ctx->h_counts[7];
@@ -453,6 +470,7 @@ lcgs_status prepare_twin(lcgs_context* ctx)
         t->lod_min_radius = ctx->lod_min_radius;
         t->coarse_mode    = ctx->coarse_mode;
         t->coarse_on      = ctx->coarse_on;
+        t->coarse_yield   = ctx->coarse_yield;
         // (borrowed, like the permutation: built on ctx->stream before the fork below; rows another thread's writer has
         // declared stale -- context.hpp foreign_writes -- are not handed on)
         const bool rows_ok = ctx->cull_rows() != nullptr || !(ctx->foreign_writes.load(std::memory_order_acquire) & lcgs_context::kRowsStale);
@@ -473,6 +491,7 @@ lcgs_status prepare_twin(lcgs_context* ctx)
         // launch sizes and pair capacity learnt by the synchronised frames of this context serve the sibling too
         t->hint_V        = std::max(t->hint_V, ctx->hint_V);
         t->hint_L        = std::max(t->hint_L, ctx->hint_L);
+        t->hint_Lb       = std::max(t->hint_Lb, ctx->hint_Lb);
         t->pair_capacity = std::max(t->pair_capacity, ctx->pair_capacity);
         LCGS_HIP_CHECK(hipEventRecord(ctx->ev_batch_fork, ctx->stream));
         LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->twin_stream, ctx->ev_batch_fork, 0));

@@ -163,7 +163,7 @@ struct lcgs_context {
     hipEvent_t   ev_fit_bwd = nullptr;
     // launch-size hints from the last synchronised frame (live counts stay on the device; larger counts are
     // still handled correctly by chunk striding)
-    int64_t hint_V = 0, hint_L = 0;
+    int64_t hint_V = 0, hint_L = 0, hint_Lb = 0; // (hint_L: frames with per-tile lists; hint_Lb: per 2 x 2-tile block)
     // workspace of the stage-level path / primitives
     DeviceBuffer st_keys_tmp, st_vals_tmp, st_sort_temp, st_scan_temp, st_scalar;
     DeviceBuffer st_flags, st_u32[8], st_keys_exp, st_vals_exp; // the splatter's sort-before-duplicate (lcgs_tile_splat_forward)
@@ -206,6 +206,7 @@ struct lcgs_context {
     // LCGS_COARSE_LISTS=0 / 1 force it off / on (A/B and test hook).
     int  coarse_mode     = 2;     // 0 never, 1 always, 2 by the pair count
     bool coarse_on       = false; // (mode 2) the current decision
+    double coarse_yield  = 0.6;   // pruned per-tile pairs / reference num_rendered, from this context's last per-tile frame
     bool bwd_use_masks   = true; // the render-backward walks the forward's kept strip bits (test hook LCGS_BWD_USE_MASKS=0: it repeats the strip tests)
     bool stage_mailbox   = true; // the splatter's scalars posted to pinned memory and polled (A/B hook LCGS_STAGE_MAILBOX=0: copy + sync)
     int stage_sort = 0; // lcgs_tile_splat_forward's sort route: 0 = by frame size, 1 = literal six passes, 2 = sort-before-duplicate

@@ -62,3 +62,25 @@ def test_parity_suites_under_forced_list_granularity(mode):
                           "tests/test_gpu_lod.py", "tests/test_gpu_sh_degrees.py"], cwd=ROOT, env=env, capture_output=True,
                          text=True, timeout=1500)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+def test_workload_sweep_tool_runs_and_its_oracle_points_are_bit_identical(lcgs, tmp_path):
+    """`bench.py --sweep` (tools/workload_sweep.py) on scenes cut to a twentieth: every point is measured, the fitted model and
+    the findings are written, the two oracle points are bit-identical, and the default list granularity never loses more than
+    a few per cent to a forced one (the rule of abi_frame.cpp came out of this sweep at full size)."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    out = str(tmp_path / "sweep.json")
+    env = dict(os.environ, LCGS_SWEEP_QUICK="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sweep", "--sweep-out", out], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.load(open(out))
+    assert len(d["points"]) == 30 and d["quick"]
+    assert all(c["bit_identical"] and c["num_rendered_equal"] for c in d["oracle_checks"]) and len(d["oracle_checks"]) == 2
+    assert not d["findings"]["pair_workspace_grew_inside_a_timed_loop"]
+    assert all(p["forward_fps"]["default"] > 0 and p["fwd_bwd_msplats"] > 0 and p["examined"] > 0 for p in d["points"])
