@@ -304,11 +304,20 @@ LCGS_API lcgs_status lcgs_get_frame_stats(lcgs_context* ctx, lcgs_frame_stats* o
 /* Diagnostics: the sorted per-tile lists of the last fused frame expressed in ORIGINAL splat indices
  * (what the reference's accel.point_list holds after GSTileSplatter::forward, proxy.h:62) and the tile
  * ranges (proxy.h:63).  d_list: num_pairs entries; d_ranges: 2 * tiles.  Either may be NULL.  Synchronises.
- * Per TILE after a frame with keep_state != 0.  A frame that keeps no backward state may list its pairs per block of
- * 2 x 2 tiles (the context switches to it once a synchronised frame has shown >= 3 M per-tile pairs: fewer pairs to duplicate and partition; every tile's workgroup walks its block's list and takes the
- * entries whose pruned rect covers it -- the same per-pixel sequence, the same image bit for bit): then the first
- * ceil(grid_x / 2) * ceil(grid_y / 2) ranges are the blocks', row-major, and the rest are zero. */
+ * At the granularity the frame used (lcgs_set_list_policy below, lcgs_frame_stats.list_shift): per tile, or per block of
+ * 2 x 2 tiles -- then the first ceil(grid_x / 2) * ceil(grid_y / 2) ranges are the blocks', row-major, and the rest are zero. */
 LCGS_API lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t* d_ranges);
+/* The granularity of the fused frame's sorted pair lists.  LCGS_LISTS_PER_TILE: one list per 16 x 16 tile, the reference's
+ * (gs_tile_splatter/impl.cpp:135-149).  LCGS_LISTS_PER_BLOCK: one per block of 2 x 2 tiles -- fewer pairs to duplicate and
+ * partition; every tile's workgroup walks its block's list and takes the entries whose pruned rect covers it, the same
+ * per-pixel sequence and the same image bit for bit; frames with keep_state != 0 stay per tile (the backward walks per-tile
+ * lists).  LCGS_LISTS_AUTO (default): per block while the last synchronised frame had >= 3 M per-tile pairs
+ * and >= 2.2 tiles per on-screen splat, per tile otherwise (and for a context's first frame).  lcgs_frame_stats.list_shift
+ * says what the last frame used; lcgs_debug_last_lists returns the lists at that granularity. */
+#define LCGS_LISTS_PER_TILE 0
+#define LCGS_LISTS_PER_BLOCK 1
+#define LCGS_LISTS_AUTO 2
+LCGS_API lcgs_status lcgs_set_list_policy(lcgs_context* ctx, int policy);
 /* Diagnostics: what the last frame with keep_state != 0 kept per pixel -- the final transmittance and the 1-based position,
  * within the pixel's tile list, of its last contributor (the values the reference computes and drops,
  * gs_tile_splatter/shader.cpp:219-220,252,273).  width * height entries each; either may be NULL.  Synchronises. */

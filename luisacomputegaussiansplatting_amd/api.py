@@ -148,7 +148,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_sh_process", "lcgs_project_forward", "lcgs_tile_splat_forward", "lcgs_set_stage_mode", "lcgs_stage_flush",
     "lcgs_inclusive_sum_u32",
     "lcgs_sort_pairs_u64_u32", "lcgs_scene_bind", "lcgs_scene_upload", "lcgs_render_forward",
-    "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists", "lcgs_debug_last_state", "lcgs_debug_blend_exp",
+    "lcgs_set_profiling", "lcgs_get_stage_times", "lcgs_get_frame_stats", "lcgs_debug_last_lists", "lcgs_debug_last_state", "lcgs_set_list_policy", "lcgs_debug_blend_exp",
     "lcgs_render_backward", "lcgs_render_backward_adam", "lcgs_fit_views", "lcgs_render_backward_accumulate", "lcgs_render_backward_compact", "lcgs_visible_rows", "lcgs_ply_read", "lcgs_ply_write_raw", "lcgs_scene_host_free", "lcgs_synth_scene",
     "lcgs_image_to_rgb8", "lcgs_image_to_rgb8_device", "lcgs_write_png", "lcgs_l2_loss_backward",
     "lcgs_scene_load_ply", "lcgs_scene_pointers", "lcgs_scene_download", "lcgs_scene_reorder_spatial", "lcgs_adam_step",
@@ -715,6 +715,10 @@ class Renderer:
         with keep_state=True; a frame without it lists its pairs per block of 2 x 2 tiles (the first ceil(gx / 2) * ceil(gy / 2)
         ranges, row-major; the rest zero).  Either argument may be None."""
         _check(load_library().lcgs_debug_last_lists(self.ctx._h, _ptr(d_list), _ptr(d_ranges)))
+
+    def set_list_policy(self, policy: str):
+        """lcgs_set_list_policy: "tile" (the reference's per-tile lists), "block" (per 2 x 2 tiles), "auto" (default)"""
+        _check(load_library().lcgs_set_list_policy(self.ctx._h, C.c_int({"tile": 0, "block": 1, "auto": 2}[policy])))
 
     def last_state(self, d_final_T, d_n_contrib):
         """lcgs_debug_last_state: per pixel, what the last keep_state frame kept for its backward (final transmittance; 1-based

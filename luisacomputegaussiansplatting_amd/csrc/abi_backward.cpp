@@ -176,7 +176,13 @@ lcgs_status render_backward(lcgs_context* ctx, const float* d_dL_dimg, const lcg
     const int      k_bwd = ctx->persist_bwd_forced >= 0 ? ctx->persist_bwd_forced
                                                         : (ctx->frames_in_flight ? ctx->persist_bwd_in_flight : 0);
     const uint32_t bwd_wgs = (!ctx->profiling && k_bwd > 0) ? (uint32_t)(k_bwd * std::max(ctx->num_cus, 1)) : 0u;
-    launch_render_backward(ctx->last.cp, ctx->last.bg, ctx->ranges, ctx->pairv[ctx->last.list_buf].as<uint32_t>(),
+    // (a frame on per-block lists left every tile a list of its own for this walk: render.hip COMPACT)
+    const bool      own_lists = ctx->last.cp.list_shift != 0u;
+    const uint32_t* bw_ranges = own_lists ? ctx->keep_ranges.as<uint32_t>() : ctx->ranges;
+    const uint32_t* bw_list   = own_lists ? ctx->keep_list.as<uint32_t>() : ctx->pairv[ctx->last.list_buf].as<uint32_t>();
+    CamParams       bw_cp     = ctx->last.cp;
+    bw_cp.list_shift          = 0u;
+    launch_render_backward(bw_cp, ctx->last.bg, bw_ranges, bw_list,
                            ctx->recs.as<SplatRecord>(), ctx->final_T.as<float>(), ctx->n_contrib.as<uint32_t>(),
                            d_dL_dimg, ctx->grads2d.as<float>(), ctx->last_tile_order, st,
                            render_forward_writes_strip_masks() && ctx->bwd_use_masks ? ctx->strip_masks.as<uint8_t>() : nullptr,

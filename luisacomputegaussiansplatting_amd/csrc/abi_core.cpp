@@ -202,6 +202,7 @@ lcgs_status lcgs_create(int device_id, void* stream, lcgs_context** out_ctx)
     if (const char* e = getenv("LCGS_STAGE_SIDE_COPY")) ctx->stage_side_copy = e[0] != '0'; // A/B hook
     if (const char* e = getenv("LCGS_STAGE_MAILBOX")) ctx->stage_mailbox = e[0] != '0';      // A/B hook
     if (const char* e = getenv("LCGS_COARSE_LISTS")) ctx->coarse_mode = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2); // A/B / test hook
+    if (const char* e = getenv("LCGS_COARSE_KEEP")) ctx->coarse_keep = e[0] != '0';                               // A/B / test hook
     if (const char* e = getenv("LCGS_BWD_USE_MASKS")) ctx->bwd_use_masks = e[0] != '0';      // test hook: the launcher's mask-less form
     if (const char* e = getenv("LCGS_STAGE_SORT")) ctx->stage_sort = e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0); // test hook
     // The auxiliary stream has the LOWEST dispatch priority: its bandwidth-bound workgroups fill the gaps the main
@@ -279,7 +280,7 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
                              &ctx->rects, &ctx->rects_sorted, &ctx->cull_slab, &ctx->chunk_info, &ctx->chunk_base, &ctx->pairk[0], &ctx->pairk[1], &ctx->pairv[0],
                              &ctx->pairv[1], &ctx->zero_ws[0], &ctx->zero_ws[1], &ctx->zero_ws[2], &ctx->counts, &ctx->sort_ws,
                              &ctx->expand_ws, &ctx->final_T, &ctx->n_contrib, &ctx->list_idx, &ctx->grads2d, &ctx->tile_order[0], &ctx->tile_order[1], &ctx->st_keys_tmp,
-                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->shjac, &ctx->tie_ws, &ctx->fused_grads, &ctx->bwd_counter, &ctx->st_flags, &ctx->st_keys_exp, &ctx->st_vals_exp,
+                             &ctx->st_vals_tmp, &ctx->st_sort_temp, &ctx->st_scan_temp, &ctx->st_scalar, &ctx->sh_half, &ctx->strip_masks, &ctx->keep_list, &ctx->keep_ranges, &ctx->shjac, &ctx->tie_ws, &ctx->fused_grads, &ctx->bwd_counter, &ctx->st_flags, &ctx->st_keys_exp, &ctx->st_vals_exp,
                              &ctx->st_u32[0], &ctx->st_u32[1], &ctx->st_u32[2], &ctx->st_u32[3], &ctx->st_u32[4], &ctx->st_u32[5], &ctx->st_u32[6], &ctx->st_u32[7],
                              &ctx->cull_bound_buf, &ctx->verify_ws, &ctx->st_win, &ctx->st_win2, &ctx->st_offs };
     for (DeviceBuffer* b : bufs) b->release();
@@ -387,6 +388,16 @@ lcgs_status lcgs_debug_last_lists(lcgs_context* ctx, uint32_t* d_list, uint32_t*
                                       (size_t)ctx->last.cp.grid_x * ctx->last.cp.grid_y * 8, hipMemcpyDeviceToDevice,
                                       ctx->stream));
     LCGS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return LCGS_OK;
+}
+
+// The granularity of the fused frame's pair lists (context.hpp coarse_mode): per tile like the reference, per 2 x 2-tile block,
+// or the library's decision from the last synchronised frame's counts (the default).
+lcgs_status lcgs_set_list_policy(lcgs_context* ctx, int policy)
+{
+    LCGS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    LCGS_REQUIRE(policy == LCGS_LISTS_PER_TILE || policy == LCGS_LISTS_PER_BLOCK || policy == LCGS_LISTS_AUTO, "unknown list policy");
+    for (lcgs_context* c = ctx; c; c = c->twin) c->coarse_mode = policy;
     return LCGS_OK;
 }
 

@@ -76,7 +76,13 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
     if (keep_state) {
         LCGS_TRY(ctx->final_T.ensure((size_t)cp.width * cp.height * 4));
         LCGS_TRY(ctx->n_contrib.ensure((size_t)cp.width * cp.height * 4));
-        LCGS_TRY(ctx->strip_masks.ensure((size_t)ctx->pair_capacity));
+        // (per-block lists: every tile owns a segment that could hold its whole block's list -- 4 x the pairs, render.hip COMPACT)
+        const size_t list_slots = (size_t)ctx->pair_capacity * (cp.list_shift ? 4u : 1u);
+        LCGS_TRY(ctx->strip_masks.ensure(list_slots));
+        if (cp.list_shift) {
+            LCGS_TRY(ctx->keep_list.ensure(list_slots * 4));
+            LCGS_TRY(ctx->keep_ranges.ensure(G * 8));
+        }
         LCGS_TRY(ctx->grads2d.ensure(grads2d_bytes((int64_t)P)));
         LCGS_TRY(ctx->shjac.ensure(P * 48));
         if (!ctx->bwd_counter.ptr) { // (allocated once; starts at zero whatever runs first)
@@ -248,7 +254,9 @@ lcgs_status enqueue_forward(lcgs_context* ctx, const CamParams& cp, const float 
                               keep_state ? ctx->n_contrib.as<uint32_t>() : nullptr, d_counts, d_fp, order_now, part ? rst : st,
                               keep_state ? ctx->strip_masks.as<uint8_t>() : nullptr, deferred ? ctx->ev_render : nullptr,
                               ctx->work_counters, persist_wgs, g2d_in_render ? ctx->grads2d.as<float>() : nullptr,
-                              g2d_in_render ? ctx->bwd_counter.as<uint32_t>() : nullptr);
+                              g2d_in_render ? ctx->bwd_counter.as<uint32_t>() : nullptr,
+                              keep_state && cp.list_shift ? ctx->keep_list.as<uint32_t>() : nullptr,
+                              keep_state && cp.list_shift ? ctx->keep_ranges.as<uint32_t>() : nullptr);
     ctx->g2d_zeroed = g2d_in_render; // (consumed by the first backward of this frame; same stream: no event)
     ctx->last_tile_order = order_now;
     LCGS_TRY(mark(ctx, "render"));
@@ -290,7 +298,11 @@ lcgs_status lcgs_render_forward(lcgs_context* ctx, const lcgs_camera* camera, co
     LCGS_REQUIRE(ctx->pos != nullptr, "no scene bound (call lcgs_scene_bind / lcgs_scene_upload first)");
     CamParams cp      = make_cam_params(*camera);
     cp.lod_min_radius = ctx->lod_min_radius;
-    cp.list_shift     = (!keep_state && (ctx->coarse_mode == 1 || (ctx->coarse_mode == 2 && ctx->coarse_on))) ? 1u : 0u;
+    // (frames that keep backward state stay per tile: letting them follow -- their renderer then writes per-tile lists for the
+    // backward while it stages, render.hip COMPACT -- was built in round 6 and lost 1.1 %: REJECTED.md; LCGS_COARSE_KEEP=1 is
+    // the A/B hook; the segments need 4 x the pair capacity in 32-bit positions)
+    cp.list_shift     = ((!keep_state || (ctx->coarse_keep && ctx->pair_capacity < (1u << 30))) &&
+                     (ctx->coarse_mode == 1 || (ctx->coarse_mode == 2 && ctx->coarse_on))) ? 1u : 0u;
     ctx->owner_recs   = nullptr; // (an ordinary frame: its backward is lcgs_render_backward again)
     uint32_t        earlier_truncated = 0; // asynchronous frames before this one that overflowed the pair workspace
     for (int attempt = 0; attempt < 4; ++attempt) {

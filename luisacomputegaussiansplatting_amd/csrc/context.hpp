@@ -92,7 +92,8 @@ struct lcgs_context {
     // workspace of the fused frame
     DeviceBuffer cull_slab, chunk_info, chunk_base; // the cull pass's per-chunk output (fused_forward.hip k_cull_compact)
     DeviceBuffer recs, sortk[2], sortv[2], vis_index, rects, rects_sorted, pairk[2], pairv[2], zero_ws[3], counts, sort_ws,
-        expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks, shjac, tie_ws, fused_grads, bwd_counter;
+        expand_ws, final_T, n_contrib, list_idx, grads2d, strip_masks, shjac, tie_ws, fused_grads, bwd_counter, keep_list,
+        keep_ranges; // (the last two: per-tile lists a keep-state frame on per-block lists writes for its backward)
     bool         last_has_jac = false; // the last keep_state frame stored the colour Jacobian (degree 3)
     // zero_ws holds what a frame needs zeroed: the tile ranges.  Three
     // copies rotate: while frame N runs, the auxiliary stream clears the copy of frame N + 2.  Two frames ahead, not
@@ -206,6 +207,8 @@ struct lcgs_context {
     // LCGS_COARSE_LISTS=0 / 1 force it off / on (A/B and test hook).
     int  coarse_mode     = 2;     // 0 never, 1 always, 2 by the pair count
     bool coarse_on       = false; // (mode 2) the current decision
+    bool coarse_keep     = false; // frames that keep backward state follow the decision too (render.hip COMPACT): built and
+                                  // measured in round 6, -1.1 % on forward+backward (REJECTED.md) -- off; LCGS_COARSE_KEEP=1: A/B hook
     double coarse_yield  = 0.6;   // pruned per-tile pairs / reference num_rendered, from this context's last per-tile frame
     bool bwd_use_masks   = true; // the render-backward walks the forward's kept strip bits (test hook LCGS_BWD_USE_MASKS=0: it repeats the strip tests)
     bool stage_mailbox   = true; // the splatter's scalars posted to pinned memory and polled (A/B hook LCGS_STAGE_MAILBOX=0: copy + sync)

@@ -239,7 +239,11 @@ void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uin
                                hipEvent_t done = nullptr, uint32_t* work_counter = nullptr, uint32_t persistent_wgs = 0,
                                // frames that keep backward state: the renderer also clears the 2-D gradient rows
                                // (12 floats x d_counts[0]) and the backward's counter block as a side job
-                               float* g2d_zero = nullptr, uint32_t* bwd_counters = nullptr);
+                               float* g2d_zero = nullptr, uint32_t* bwd_counters = nullptr,
+                               // frames that keep backward state on PER-BLOCK lists (cp.list_shift): every tile's own list
+                               // (entries that reach one of its units, in order; 4 x the pair capacity), with strip_masks
+                               // at the same positions, and its range -- what the backward then walks (render.hip COMPACT)
+                               uint32_t* keep_list = nullptr, uint32_t* keep_ranges = nullptr);
 // work_counter + persistent_wgs: a bounded grid of persistent_wgs workgroups that pull tiles from *work_counter (which
 // must be zero when the kernel starts) instead of one workgroup per tile -- caps the wave slots the renderer holds
 // strip_masks[list position] = the four per-strip reach bits of that entry (written when final_T / n_contrib are

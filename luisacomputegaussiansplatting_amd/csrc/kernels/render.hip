@@ -77,7 +77,13 @@ typedef float v2f __attribute__((ext_vector_type(2))); // arithmetic on it lower
 // workgroup renders which tile never mattered); what it buys is a cap on the wave slots the renderer holds per CU, so that
 // ANOTHER frame's short sort-chain kernels find free slots on every CU the moment they are dispatched instead of queueing
 // behind 8160 resident-or-pending tile workgroups (camera batches, lcgs_fit_views: DESIGN.md 9).
-template <typename Fetch, bool KEEP, bool PERSIST>
+// COMPACT (frames that keep backward state on PER-BLOCK lists, round 6): a tile's workgroup walks its block's list and, while
+// it stages, writes the entries that can reach one of its four units -- in list order -- to a segment of its own (keep_list;
+// tile q of a block whose list is [s, e) owns [4 s + q (e - s), ...): room for the whole block list, no allocation), with the
+// kept masks beside them and its range in keep_ranges; the last-contributor positions are positions in THAT list.  The
+// backward then walks a per-tile list exactly as before -- a denser one than the reference's (only entries that reach a
+// unit) -- while duplication, tile partition and range pass ran on 0.6 x the pairs.
+template <typename Fetch, bool KEEP, bool PERSIST, bool COMPACT>
 __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg0, float bg1, float bg2,
                                                             const FrameParams* __restrict__ fpp,
                                                             const uint32_t* __restrict__ ranges,
@@ -89,7 +95,9 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                                                             uint8_t* __restrict__ strip_masks,
                                                             uint32_t* __restrict__ work_counter,
                                                             float4* __restrict__ g2d_zero,
-                                                            uint32_t* __restrict__ bwd_counters)
+                                                            uint32_t* __restrict__ bwd_counters,
+                                                            uint32_t* __restrict__ keep_list,
+                                                            uint32_t* __restrict__ keep_ranges)
 {
     // one 16-byte row per entry in each of three slabs: a single address register serves all three reads
     // s_rows[0]: mean.x, mean.y, -conic.x / 2, -conic.z / 2;  [1]: conic.y, power floor (-t/2), -, - (with [0], all the cull
@@ -102,6 +110,7 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
     __shared__ unsigned long long s_blend[4][4];
     __shared__ uint32_t           s_live_waves;
     __shared__ uint32_t           s_slot;
+    __shared__ uint32_t           s_cnt[4]; // COMPACT: entries of the round each staging wave keeps
 
     if (fpp) { // graph replay: per-call parameters come from device memory
         cp  = fpp->cp;
@@ -174,11 +183,16 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
     float4 na = make_float4(0, 0, 0, 0), nb = make_float4(0, 0, 0, 0);
     float  nc = 0.0f;
     uint2  nrect = make_uint2(0u, 0xFFFFFFFFu); // (coarse lists only)
+    uint32_t nid = 0u;                           // (COMPACT: the staged entry's dense id goes into the tile's own list)
     if (range_start + tid < range_end) {
         const uint32_t id = point_list[range_start + tid];
         fetch(id, na, nb, nc);
         if (cp.list_shift) nrect = fetch.rect(id);
+        nid = id;
     }
+    // COMPACT: this tile's segment of keep_list / strip_masks and how much of it is filled
+    const uint32_t seg        = COMPACT ? 4u * range_start + ((tx & 1u) | ((ty & 1u) << 1)) * (range_end - range_start) : 0u;
+    uint32_t       round_base = 0u;
     __syncthreads();
 
     for (uint32_t base = range_start; base < range_end; base += 256u) {
@@ -203,18 +217,34 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
             const unsigned long long m = __ballot((kmask >> k) & 1u);
             if (lane == 0) s_mask[wave][k] = m;
         }
+        uint32_t rank = 0u; // COMPACT: the entry's place among its staging wave's kept entries
+        if (COMPACT) {
+            const unsigned long long km = __ballot(kmask != 0u);
+            rank = (uint32_t)__popcll(km & (lane_bit - 1ull));
+            if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(km);
+        }
         if (kmask) {
             s_rows[0][tid] = make_float4(a.x, a.y, -0.5f * a.z, -0.5f * b.x);
-            *reinterpret_cast<float2*>(&s_rows[1][tid]) = make_float2(a.w, fmax_(-0.5f * t, kBlendExpMin));
+            if (COMPACT) s_rows[1][tid] = make_float4(a.w, fmax_(-0.5f * t, kBlendExpMin), __uint_as_float(rank), 0.0f);
+            else *reinterpret_cast<float2*>(&s_rows[1][tid]) = make_float2(a.w, fmax_(-0.5f * t, kBlendExpMin));
             s_rows[2][tid] = make_float4(b.y, b.z, b.w, c);
         }
+        const uint32_t id_now = nid;
         const uint32_t en = e + 256u;
         if (en < range_end) {
             const uint32_t id = point_list[en];
             fetch(id, na, nb, nc);
             if (cp.list_shift) nrect = fetch.rect(id);
+            nid = id;
         }
         __syncthreads();
+        uint32_t my_pos = 0u, kept = 0u; // COMPACT: where this lane's entry goes in the tile's list; the round's total
+        if (COMPACT) {
+            const uint32_t c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3];
+            kept   = c0 + c1 + c2 + c3;
+            my_pos = seg + round_base + (wave > 0u ? c0 : 0u) + (wave > 1u ? c1 : 0u) + (wave > 2u ? c2 : 0u) + rank;
+            if (kmask) keep_list[my_pos] = id_now;
+        }
 
         if (alive) {
             for (uint32_t w = 0; w < 4u && alive; ++w) {
@@ -228,6 +258,13 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                 // cost (the backward only needs a superset).  (On the passing path only: an instruction on the `continue` path
                 // makes the compiler merge the two paths through seven register copies per entry.)
                 unsigned long long bm = 0ull;
+                // COMPACT: list position (1-based, within the tile's own list) of staging wave w's first kept entry
+                uint32_t wbase = 0u;
+                if (COMPACT) {
+                    wbase = round_base + 1u;
+                    for (uint32_t q = 0; q < w; ++q) wbase += s_cnt[q];
+                    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+                }
                 while (m != 0ull) { // scalar loop control
                     const uint32_t l   = (uint32_t)__ffsll((long long)m) - 1u;
                     asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(l)); // one scalar op instead of add/addc/and
@@ -286,7 +323,10 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
                         // exec region serves the sums and the position (two regions cost 6 us of the 0.24 ms)
                         float              t0, t1, t2;
                         unsigned long long sv;
-                        const uint32_t     lc = base - range_start + idx + 1u;
+                        // (COMPACT: the entry's rank among its staging wave's kept entries lies in its second slab row)
+                        const uint32_t     lc = COMPACT ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(
+                                                              wbase + __float_as_uint(*reinterpret_cast<const float*>(rows + 4096 + 8))))
+                                                        : base - range_start + idx + 1u;
                         asm volatile("s_and_saveexec_b64 %[sv], %[lv]\n\t"
                                      "v_mul_f32 %[t0], %[w], %[cr]\n\t"
                                      "v_mul_f32 %[t1], %[w], %[cg]\n\t"
@@ -326,7 +366,15 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
             if (!alive && lane == 0) atomicSub(&s_live_waves, 1u);
         }
         __syncthreads();
-        if (KEEP && strip_masks && have) {
+        if (COMPACT) {
+            if (kmask) {
+                uint32_t kref = 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) kref |= (uint32_t)((s_blend[k][wave] >> lane) & 1ull) << k;
+                strip_masks[my_pos] = (uint8_t)kref;
+            }
+            round_base += kept;
+        } else if (KEEP && strip_masks && have) {
             // The backward walks the same list positions through these masks (it need not repeat the strip tests) -- and only
             // the entries a strip's pixels could blend when it walked them: bit k = the entry passed strip k's candidate test.  Entries
             // that merely could reach a strip contribute exact zeros to every gradient; a quarter of the backward's walks were those.
@@ -337,6 +385,10 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
         }
     }
 
+    if (COMPACT && tid == 0) {
+        keep_ranges[2 * (size_t)tile + 0] = seg;
+        keep_ranges[2 * (size_t)tile + 1] = seg + round_base;
+    }
     if (inside) {
         const size_t hw  = (size_t)cp.width * cp.height;
         const float  Tk  = T;
@@ -409,23 +461,29 @@ void launch_render(const CamParams& cp, const float bg[3], const uint32_t* range
                    Fetch fetch, float* img, float* final_T, uint32_t* n_contrib, const uint32_t* d_counts,
                    const FrameParams* d_fp, const uint32_t* tile_order, hipStream_t stream,
                    uint8_t* strip_masks = nullptr, hipEvent_t done = nullptr, uint32_t* work_counter = nullptr,
-                   uint32_t persistent_wgs = 0, float* g2d_zero = nullptr, uint32_t* bwd_counters = nullptr)
+                   uint32_t persistent_wgs = 0, float* g2d_zero = nullptr, uint32_t* bwd_counters = nullptr,
+                   uint32_t* keep_list = nullptr, uint32_t* keep_ranges = nullptr)
 {
     if (cp.grid_x * cp.grid_y == 0) return;
     const uint32_t full = render_grid_size(cp.grid_x, cp.grid_y);
     const bool     keep = final_T || n_contrib;
+    // a keep-state frame on per-block lists writes every tile's own list while it stages (COMPACT)
+    const bool     compact = keep && cp.list_shift != 0u && keep_list && keep_ranges && strip_masks;
     // (`done`, when given, is carried by the dispatch packet: no separate event-record packet behind the kernel)
-#define LCGS_LAUNCH_RENDER(KEEP_, PERSIST_, GRID_)                                                                          \
-    hipExtLaunchKernelGGL((k_render_forward_b<Fetch, KEEP_, PERSIST_>), dim3(GRID_), dim3(256), 0, stream, nullptr, done, 0, cp, \
+#define LCGS_LAUNCH_RENDER(KEEP_, PERSIST_, COMPACT_, GRID_)                                                                \
+    hipExtLaunchKernelGGL((k_render_forward_b<Fetch, KEEP_, PERSIST_, COMPACT_>), dim3(GRID_), dim3(256), 0, stream, nullptr, done, 0, cp, \
                           bg[0], bg[1], bg[2], d_fp, ranges, point_list, fetch, img, final_T, n_contrib, d_counts, tile_order, \
-                          KEEP_ ? strip_masks : (uint8_t*)nullptr, work_counter, reinterpret_cast<float4*>(g2d_zero), bwd_counters)
+                          KEEP_ ? strip_masks : (uint8_t*)nullptr, work_counter, reinterpret_cast<float4*>(g2d_zero), bwd_counters, \
+                          keep_list, keep_ranges)
     if (work_counter && persistent_wgs > 0 && persistent_wgs < full) { // a bounded grid that pulls tiles from the counter
-        if (keep) LCGS_LAUNCH_RENDER(true, true, persistent_wgs);
-        else LCGS_LAUNCH_RENDER(false, true, persistent_wgs);
+        if (compact) LCGS_LAUNCH_RENDER(true, true, true, persistent_wgs);
+        else if (keep) LCGS_LAUNCH_RENDER(true, true, false, persistent_wgs);
+        else LCGS_LAUNCH_RENDER(false, true, false, persistent_wgs);
     } else {
         work_counter = nullptr;
-        if (keep) LCGS_LAUNCH_RENDER(true, false, full);
-        else LCGS_LAUNCH_RENDER(false, false, full); // forward only: the last-contributor bookkeeping is compiled out
+        if (compact) LCGS_LAUNCH_RENDER(true, false, true, full);
+        else if (keep) LCGS_LAUNCH_RENDER(true, false, false, full);
+        else LCGS_LAUNCH_RENDER(false, false, false, full); // forward only: the last-contributor bookkeeping is compiled out
     }
 #undef LCGS_LAUNCH_RENDER
 }
@@ -458,10 +516,11 @@ void launch_render_forward_rec(const CamParams& cp, const float bg[3], const uin
                                const uint32_t* point_list, const SplatRecord* recs, float* img, float* final_T,
                                uint32_t* n_contrib, const uint32_t* d_counts, const FrameParams* d_fp,
                                const uint32_t* tile_order, hipStream_t stream, uint8_t* strip_masks, hipEvent_t done,
-                               uint32_t* work_counter, uint32_t persistent_wgs, float* g2d_zero, uint32_t* bwd_counters)
+                               uint32_t* work_counter, uint32_t persistent_wgs, float* g2d_zero, uint32_t* bwd_counters,
+                               uint32_t* keep_list, uint32_t* keep_ranges)
 {
     launch_render(cp, bg, ranges, point_list, FetchRec{ recs }, img, final_T, n_contrib, d_counts, d_fp, tile_order,
-                  stream, strip_masks, done, work_counter, persistent_wgs, g2d_zero, bwd_counters);
+                  stream, strip_masks, done, work_counter, persistent_wgs, g2d_zero, bwd_counters, keep_list, keep_ranges);
 }
 
 // the forward renderer fills strip_masks whenever it keeps backward state

@@ -34,8 +34,12 @@ def _render_both(lcgs, oracle, scene, W, H, bg=(0.1, 0.2, 0.3), pose=POSE, scale
     if check_lists:
         # Frames that keep no backward state list their pairs per block of 2 x 2 tiles (CamParams::list_shift); the per-tile lists
         # inspected below are those of a frame that keeps it -- the same view again, which must also give the same image bit for bit.
+        # (round 6: a keep-state frame may use per-block lists too -- its renderer then writes the backward per-tile lists of
+        # its own --, so the inspection frame ASKS for the reference's granularity)
         img_k = torch.full((3, H, W), -1.0, device=DEV)
+        r.set_list_policy("tile")
         assert r.forward(cam, img_k, bg=bg, scale_modifier=scale_modifier, keep_state=True, sync=True) == n
+        assert r.frame_stats()["list_shift"] == 0
         assert torch.equal(img_k, img), "per-tile lists and per-block lists render different images"
         assert r.frame_stats()["num_pairs"] >= st["num_pairs"]
         st = r.frame_stats()

@@ -54,13 +54,19 @@ def test_backward_suite_without_kept_masks():
 # Per-block pair lists (frames without backward state; by default only from ~3 M pairs up, which no small test scene reaches)
 # forced on: the fused-frame, ingest and random-sweep suites -- every frame against the oracle bit for bit, camera batches, LOD,
 # half-precision coefficients, overflow handling -- and forced off.
-@pytest.mark.parametrize("mode", ["1", "0"], ids=["block-lists", "tile-lists"])
+# Round 6: frames that KEEP backward state can follow the same decision -- their renderer writes every tile's own list while it
+# stages its block's (render.hip COMPACT) and the backward walks those.  Built, correct, 1.1 % slower (REJECTED.md): not the
+# default, kept behind LCGS_COARSE_KEEP=1 as the A/B hook -- the backward, training and ownership suites run through it here.
+@pytest.mark.parametrize("mode", [{"LCGS_COARSE_LISTS": "1"}, {"LCGS_COARSE_LISTS": "0"},
+                                  {"LCGS_COARSE_LISTS": "1", "LCGS_COARSE_KEEP": "1"}],
+                         ids=["block-lists", "tile-lists", "block-lists-also-for-keep-state-frames"])
 def test_parity_suites_under_forced_list_granularity(mode):
-    env = dict(os.environ, LCGS_COARSE_LISTS=mode)
+    env = dict(os.environ, **mode)
     res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                           "tests/test_gpu_fused.py", "tests/test_gpu_ingest.py", "tests/test_gpu_random_sweep.py",
-                          "tests/test_gpu_lod.py", "tests/test_gpu_sh_degrees.py"], cwd=ROOT, env=env, capture_output=True,
-                         text=True, timeout=1500)
+                          "tests/test_gpu_lod.py", "tests/test_gpu_sh_degrees.py", "tests/test_gpu_backward.py",
+                          "tests/test_gpu_train.py", "tests/test_gpu_owner.py"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=1800)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
 
 
