@@ -14,6 +14,7 @@
 #include "abi_internal.hpp"
 #include <atomic>
 #include <chrono>
+#include <thread>
 
 using namespace lcgs;
 using namespace lcgs::abi;
@@ -241,7 +242,9 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
     // host's next launches overlap the scatter launch still running behind the scan.  (Round 4: one 12-byte copy + a
     // synchronisation; before that three 4-byte copies into pageable words, ~80 us of idle GPU per frame.)
     if (!ctx->h_stage) {
-        LCGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), 16, hipHostMallocDefault));
+        // (coherent + mapped, asked for explicitly: the host polls this block while the stream that posts to it is still
+        // running -- the hand-off must not depend on what HIP_HOST_COHERENT makes of a default allocation)
+        LCGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), 16, hipHostMallocCoherent | hipHostMallocMapped));
         memset(ctx->h_stage, 0, 16);
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->h_stage_dev), ctx->h_stage, 0) != hipSuccess) {
             (void)hipGetLastError();
@@ -263,7 +266,11 @@ lcgs_status lcgs_tile_splat_forward(lcgs_context* ctx, const lcgs_tile_accel* ac
                 posted = true;
                 break;
             }
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
             if ((spins & 0xFFFFu) == 0xFFFFu) {
                 if (hipStreamQuery(st) != hipErrorNotReady) break; // finished (posted by now, re-checked below) or failed
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;

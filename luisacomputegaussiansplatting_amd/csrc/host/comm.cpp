@@ -162,6 +162,17 @@ struct lcgs_loopback_group {
     std::vector<std::deque<Msg>> box;  // box[dst * world + src]: the sends posted in the open group, in order
     std::vector<hipEvent_t>      done; // per rank: behind the copies of its receives of the last group
     int                          members = 0;
+    int                          device  = -1;  // every member's device (one GPU: that is the point)
+    std::vector<char>            taken;         // ranks that have a communicator
+    // messages nobody received (a member gave up mid-group): their events are not leaked
+    void drop_unconsumed()
+    {
+        for (auto& q : box) {
+            for (Msg& m : q)
+                if (m.ready) (void)hipEventDestroy(m.ready);
+            q.clear();
+        }
+    }
     // collectives of the open group (all-reduce / reduce-scatter / all-gather): what every rank passed, op by op
     struct CollArgs {
         const float* send;
@@ -189,6 +200,7 @@ struct lcgs_loopback_group {
     {
         std::lock_guard<std::mutex> lock(mu);
         failed = true;
+        drop_unconsumed();
         cv.notify_all();
     }
 };
@@ -635,6 +647,7 @@ lcgs_status lcgs_comm_destroy(lcgs_comm* c)
     if (c->loop) {
         std::lock_guard<std::mutex> lock(c->loop->mu);
         --c->loop->members;
+        if (c->rank >= 0 && (size_t)c->rank < c->loop->taken.size()) c->loop->taken[(size_t)c->rank] = 0;
     }
     c->packed.release();
     c->scales.release();
@@ -1046,6 +1059,7 @@ lcgs_status lcgs_loopback_group_create(int world_size, lcgs_loopback_group** out
     g->ready.assign(world_size, nullptr);
     g->reduced.assign(world_size, nullptr);
     g->scratch.assign(world_size, nullptr);
+    g->taken.assign(world_size, 0);
     *out = g;
     return LCGS_OK;
 }
@@ -1054,6 +1068,7 @@ lcgs_status lcgs_loopback_group_destroy(lcgs_loopback_group* g)
 {
     if (!g) return LCGS_OK;
     LCGS_REQUIRE(g->members == 0, "communicators of this group are still alive");
+    g->drop_unconsumed();
     for (auto* evs : { &g->done, &g->ready, &g->reduced })
         for (hipEvent_t e : *evs)
             if (e) (void)hipEventDestroy(e);
@@ -1067,6 +1082,13 @@ lcgs_status lcgs_comm_create_loopback(lcgs_context* ctx, lcgs_loopback_group* gr
     *out = nullptr;
     LCGS_REQUIRE(rank >= 0 && rank < group->world, "rank out of range");
     LCGS_REQUIRE(ctx->comm == nullptr, "the context already has a communicator attached");
+    {
+        std::lock_guard<std::mutex> lock(group->mu);
+        LCGS_REQUIRE(!group->taken[(size_t)rank], "this rank of the loopback group already has a communicator");
+        LCGS_REQUIRE(group->device < 0 || group->device == ctx->device, "the members of a loopback group share ONE device");
+        group->taken[(size_t)rank] = 1;
+        group->device              = ctx->device;
+    }
     LCGS_HIP_CHECK(hipSetDevice(ctx->device));
     lcgs_comm* c = new (std::nothrow) lcgs_comm();
     if (!c) return LCGS_ERR_OUT_OF_MEMORY;
@@ -1081,6 +1103,10 @@ lcgs_status lcgs_comm_create_loopback(lcgs_context* ctx, lcgs_loopback_group* gr
         if (e == hipSuccess) ++group->members;
     }
     if (e != hipSuccess) {
+        {
+            std::lock_guard<std::mutex> lock(group->mu);
+            group->taken[(size_t)rank] = 0;
+        }
         c->loop = nullptr;
         (void)lcgs_comm_destroy(c);
         LCGS_HIP_CHECK(e);

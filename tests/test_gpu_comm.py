@@ -684,3 +684,17 @@ def test_comm_selftest_with_n_ranks_in_process(lcgs, world):
         assert rep["ok"] and rep["rank"] == me and rep["world_size"] == world, rep
         assert rep["allreduce_ok"] == 1 and rep["p2p_ok"] == 1 and rep["owner_step_ok"] == 1 and rep["timed_out"] == 0, rep
         assert rep["owner_max_grad_err"] <= 1e-4, rep
+
+
+def test_loopback_group_rejects_a_rank_taken_twice(lcgs):
+    """(round-5 advisor) two communicators for one rank of a loopback group would share a mailbox; the rank is free again once
+    its communicator is gone"""
+    group = lcgs.api.LoopbackGroup(2)
+    a, b = lcgs.Renderer(lcgs.Context(0)), lcgs.Renderer(lcgs.Context(0))
+    c0 = lcgs.Comm(a.ctx, 0, 2, loopback=group)
+    with pytest.raises(lcgs.LcgsError):
+        lcgs.Comm(b.ctx, 0, 2, loopback=group)
+    c0.close()
+    c0 = lcgs.Comm(b.ctx, 0, 2, loopback=group)
+    c0.close()
+    group.close()
