@@ -17,7 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = ("liblcgs_oracle_f32.so", "liblcgs_oracle_f64.so", "liblcgs_oracle_f32_contract.so")
 # numerics variants (comparison runs only; lcgs_oracle.h) and the classes of rounding-sensitive pixels
-NUM_RCP_DIV, NUM_RSQRT, NUM_REASSOC = 1, 2, 4
+NUM_RCP_DIV, NUM_RSQRT, NUM_REASSOC, NUM_REASSOC2 = 1, 2, 4, 8
 CLS_THRESHOLD, CLS_DEPTH, CLS_RECT = 1, 2, 4
 
 

@@ -95,7 +95,9 @@ void orc_set_blend_exp(int use_libm) { (void)use_libm; }
  *   - ORC_NUM_RCP_DIV: every device-side a / b becomes a * (1 / b);
  *   - ORC_NUM_RSQRT:  normalize(v) = v * rsqrt(dot) with a single-rounding rsqrt, sqrt(x) = x * rsqrt(x);
  *   - ORC_NUM_REASSOC: dot products and matrix-vector sums added right to left (LuisaCompute's own order is assumed, not
- *     known: header above) -- kept OUT of the ensemble that measures the uncertainties, as the independent check of them.
+ *     known: header above);
+ *   - ORC_NUM_REASSOC2: the third grouping, (a + c) + b -- kept OUT of the ensemble that measures the uncertainties
+ *     (oracle/numerics.py ENSEMBLE), as the independent check of them.
  * The blend's exp stays the defined sequence (explicit fmaf builtins) unless orc_set_blend_exp(1) asks for libm's. */
 static int g_num = 0;
 void orc_set_numerics(int flags) { g_num = flags; }
@@ -148,6 +150,7 @@ static inline real r_clamp(real v, real lo, real hi) { return r_min(r_max(v, lo)
 static inline real dot3(const real a[3], const real b[3])
 {
     if (g_num & ORC_NUM_REASSOC) return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]);
+    if (g_num & ORC_NUM_REASSOC2) return (a[0] * b[0] + a[2] * b[2]) + a[1] * b[1];
     return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
 }
 static inline void cross3(const real a[3], const real b[3], real o[3])
@@ -193,6 +196,10 @@ static inline void m3_mul_v3(const real m[9], const real v[3], real o[3])
         for (int r = 0; r < 3; ++r) o[r] = m[0 * 3 + r] * v[0] + (m[1 * 3 + r] * v[1] + m[2 * 3 + r] * v[2]);
         return;
     }
+    if (g_num & ORC_NUM_REASSOC2) {
+        for (int r = 0; r < 3; ++r) o[r] = (m[0 * 3 + r] * v[0] + m[2 * 3 + r] * v[2]) + m[1 * 3 + r] * v[1];
+        return;
+    }
     for (int r = 0; r < 3; ++r) o[r] = m[0 * 3 + r] * v[0] + m[1 * 3 + r] * v[1] + m[2 * 3 + r] * v[2];
 }
 static inline void m3_mul(const real a[9], const real b[9], real o[9])
@@ -214,6 +221,11 @@ void orc_mat4_mul_vec4(const real m[16], const real v[4], real out[4])
     if (g_num & ORC_NUM_REASSOC) {
         for (int r = 0; r < 4; ++r)
             out[r] = m[0 * 4 + r] * v[0] + (m[1 * 4 + r] * v[1] + (m[2 * 4 + r] * v[2] + m[3 * 4 + r] * v[3]));
+        return;
+    }
+    if (g_num & ORC_NUM_REASSOC2) {
+        for (int r = 0; r < 4; ++r)
+            out[r] = (m[0 * 4 + r] * v[0] + m[2 * 4 + r] * v[2]) + (m[1 * 4 + r] * v[1] + m[3 * 4 + r] * v[3]);
         return;
     }
     for (int r = 0; r < 4; ++r)
@@ -768,6 +780,7 @@ static void render_forward_impl(int width, int height, const real bg[3], const u
                 uint8_t  amb              = 0;
                 real     last_depth = RC(0.0f), last_tol = RC(0.0f), sn = RC(0.0f), sq = RC(0.0f), T_unc = RC(0.0f), T_jump = RC(0.0f), fl = RC(0.0f);
                 real     last_w     = RC(0.0f); /* T alpha of the previous contributor */
+                real     last_Tb    = RC(0.0f); /* T in front of the previous contributor */
                 int      have_last  = 0;
 /* an ambiguous decision: its class bit (when the flip could move the pixel by more than impact_floor) and its impact */
 #define ORC_AMBIGUOUS(bit, impact)                       \
@@ -824,12 +837,19 @@ static void render_forward_impl(int width, int height, const real bg[3], const u
                     const real t_unc = alpha < RC(0.99f) ? alpha * dpow / (RC(1.0f) - alpha) : RC(0.0f);
                     if (ambig && near_rel(test_T, RC(0.0001f), ambig_eps + window_factor * (T_unc + t_unc) + T_jump))
                         ORC_AMBIGUOUS(ORC_CLS_THRESHOLD, T); /* this entry's T alpha and everything behind it: <= T */
-                    if (!orc_g_smooth && test_T < RC(0.0001f)) break; /* done = true; loop exits at next iteration, :261-265 */
+                    if (!orc_g_smooth && test_T < RC(0.0001f)) { /* done = true; loop exits at next iteration, :261-265 */
+                        /* ... unless the entry that stops the pixel and the last contributor may trade places: the other order
+                         * can blend THIS entry (T_last alpha) and stop on that one instead */
+                        if (want_depth && have_last && depth[id] - last_depth <= depth_tol[id] + last_tol)
+                            ORC_AMBIGUOUS(ORC_CLS_DEPTH, last_Tb);
+                        break;
+                    }
                     if (want_depth) {
                         /* swapping two adjacent contributors i, j moves the pixel by T_i alpha_i alpha_j |c_i - c_j| */
                         if (have_last && depth[id] - last_depth <= depth_tol[id] + last_tol)
                             ORC_AMBIGUOUS(ORC_CLS_DEPTH, last_w * alpha);
                         last_w     = T * alpha;
+                        last_Tb    = T;
                         last_depth = depth[id];
                         last_tol   = depth_tol[id];
                         have_last  = 1;

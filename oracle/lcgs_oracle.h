@@ -71,6 +71,7 @@ void  orc_set_blend_exp(int use_libm);
 #define ORC_NUM_RCP_DIV 1 /* device-side a / b  ->  a * (1 / b) */
 #define ORC_NUM_RSQRT   2 /* normalize through a single-rounding rsqrt, sqrt(x) = x * rsqrt(x) */
 #define ORC_NUM_REASSOC 4 /* dot products / matrix-vector sums added right to left */
+#define ORC_NUM_REASSOC2 8 /* ... in the third grouping, (a + c) + b: the hold-out of oracle/numerics.py */
 void orc_set_numerics(int flags);
 int  orc_get_numerics(void);
 int  orc_build_contracted(void); /* 1 in liblcgs_oracle_f32_contract.so (-ffp-contract=fast), else 0 */

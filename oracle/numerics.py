@@ -14,7 +14,7 @@ of how far another valid f32 evaluation may land:
   rss   the continuous part, first order: every contributing entry k moves the pixel by at most T_k alpha_k |d power_k|
         (+ its colour's uncertainty); entries are independent, so the terms add as a root-sum-square.  |d power_k| is
         MEASURED, not assumed: the largest change of `power` at this pixel when the splat's record (pixel mean, conic) is
-        replaced by any of the ENSEMBLE's evaluations of it -- the f64 twin and four numerics variants, signed, because an
+        replaced by any of the ENSEMBLE's evaluations of it -- the f64 twin and five numerics variants, signed, because an
         ill-conditioned splat's conic terms are each far larger than the power they cancel to -- plus the rounding of the
         pixel's own evaluation of gs_tile_splatter/shader.cpp:256 and of the mean at the size of its terms;
   flip  the discontinuous part: the sum, over the pixel's decisions that lie inside their rounding window, of what the
@@ -29,20 +29,24 @@ of how far another valid f32 evaluation may land:
           CLS_RECT       a splat reaches the pixel through a tile that its radius `ceil(3 sqrt(lambda))` (shader.cpp:145-148)
                          or the rect's float -> uint edges (module.cpp:30-35) may or may not list: alpha.
 `explain(img, other, cl)` holds a second frame against the bound: EVERY pixel must be within it, and the pixels beyond
-1e-4 are attributed to the classes they carry.  Three of VARIANTS are not in the ensemble -- the independent check that the
-measured uncertainties generalise (right-to-left sums move 143 pixels of C3 beyond 1e-4; all inside their bounds).
+1e-4 are attributed to the classes they carry.  Four of VARIANTS are not in the ensemble -- the independent check that the
+measured uncertainties generalise: libm's expf, the THIRD grouping of every three- and four-term sum, and two combinations of
+everything at once.  (Right-to-left sums were a hold-out until a 400-draw soak, tools/numerics_soak.py, showed what holding a
+whole KIND of perturbation out costs: a screen-filling splat whose conic moves by 5e-4 under re-association and 1e-6 under
+everything else flips an alpha skip far outside its window.  Each kind is now sampled once in the ensemble.)
 """
 from __future__ import annotations
 
 import numpy as np
 
-from . import CLS_DEPTH, CLS_RECT, CLS_THRESHOLD, NUM_RCP_DIV, NUM_REASSOC, NUM_RSQRT, Oracle
+from . import CLS_DEPTH, CLS_RECT, CLS_THRESHOLD, NUM_RCP_DIV, NUM_REASSOC, NUM_REASSOC2, NUM_RSQRT, Oracle
 
 EPS32 = float(np.finfo(np.float32).eps)  # 2^-23
 AMBIG_EPS = 1e-5   # the threshold window of rounds 4-5 (tests/gpu_util.py::LIBM_AMBIG_EPS): T carries every earlier factor's error
 K_DEPTH = 2.0      # depth window per splat, in units of 2^-23 x the sum of |terms| of its dot product (the 4-term forward bound)
 K_RECT = 4.0       # rounding window of the radius argument and of the rect's pixel coordinates, same units
 K_EVAL = 2.0       # rounding of a pixel's own evaluation of `power` (shader.cpp:256), x 2^-23 x the sum of |terms|
+K_DET = 2.0        # the analytic member of the ensemble: common relative error of the conic, x 2^-23 x the determinant's cancellation
 K_MEAN = 0.5       # floor of a pixel mean's uncertainty, x 2^-23 x (|mean| + S / 2): about an ulp of the coordinate
 K_FLOOR = 0.5      # floor of the measured colour spread, in ulp
 SENS_FACTOR = 2.0  # an entry's threshold windows: its own uncertainty x this (the spread over five evaluations is a SAMPLE)
@@ -56,10 +60,13 @@ VARIANTS = {  # name -> (contracted build, orc_set_numerics flags, libm expf in 
     "rcp_div": (False, NUM_RCP_DIV, False),
     "rsqrt": (False, NUM_RSQRT, False),
     "fast_math": (True, NUM_RCP_DIV | NUM_RSQRT, False),
-    # not in the ensemble that measures the per-splat uncertainties: the independent checks of the bound
-    "libm_expf": (False, 0, True),
     "reassociated": (False, NUM_REASSOC, False),
+    # not in the ensemble that measures the per-splat uncertainties: the independent checks of the bound -- another exp, the
+    # third grouping of every three- and four-term sum, and everything at once in two combinations
+    "libm_expf": (False, 0, True),
+    "reassociated_other_grouping": (False, NUM_REASSOC2, False),
     "fast_math_reassociated_libm": (True, NUM_RCP_DIV | NUM_RSQRT | NUM_REASSOC, True),
+    "fast_math_other_grouping_libm": (True, NUM_RCP_DIV | NUM_RSQRT | NUM_REASSOC2, True),
 }
 
 _cache = {}
@@ -100,7 +107,7 @@ def _radius_arg(cov):
     return t(3.0) * np.sqrt(np.maximum(mid + s, mid - s))
 
 
-ENSEMBLE = ("f64", "contracted", "rcp_div", "rsqrt", "fast_math")
+ENSEMBLE = ("f64", "contracted", "rcp_div", "rsqrt", "fast_math", "reassociated")
 
 
 def _variant_oracle(name):
@@ -128,7 +135,7 @@ def uncertainties(scene, cam32, scale_modifier=1.0, sh_deg=3, st32=None, k_depth
     p32, c32, d32, col32, arg32 = f(a["pix"]), f(a["conic"]), f(a["depth"]), f(a["color"]), f(_radius_arg(a["cov"]))
     sp_depth, sp_arg, sp_col = np.zeros(P), np.zeros(P), np.zeros(P)
     sp_pix, sp_conic = np.zeros((P, 2)), np.zeros((P, 3))
-    drec = np.zeros((P, len(ensemble), 5), np.float32)
+    drec = np.zeros((P, len(ensemble) + 1, 5), np.float32)
     both = vis.copy()
     radii_differ = {}
     for k, name in enumerate(ensemble):
@@ -149,6 +156,17 @@ def uncertainties(scene, cam32, scale_modifier=1.0, sh_deg=3, st32=None, k_depth
         sp_col = np.maximum(sp_col, np.abs(col32 - b["color"]).max(axis=1))
         sp_arg = np.maximum(sp_arg, z(np.abs(arg32 - _radius_arg(b["cov"]))))
         radii_differ[name] = int((ok & (a["radii"] != b["radii"])).sum())
+    # ... and one ANALYTIC member: conic = (c, -b, a) / (a c - b^2) divides by a difference that cancels -- kappa = (a c + b^2) /
+    # |a c - b^2| is 5 for a round footprint and 1e3-1e5 for a needle or a screen-filling splat -- so ANY f32 evaluation carries
+    # a common relative error of about kappa ulp in all three components, whether or not one of the ensemble's six happens
+    # to show it for this splat (tools/numerics_soak.py: two of 3 600 frames had a splat whose samples agreed to 1e-6 while a
+    # seventh evaluation moved it by 3e-4 = 0.9 kappa eps).  A common factor moves `power` by that fraction of itself.
+    cov = f(a["cov"])
+    ca, cb, cc = cov[:, 0] + 0.3, cov[:, 1], cov[:, 2] + 0.3
+    with np.errstate(invalid="ignore", divide="ignore"):
+        kappa = np.where(vis, (ca * cc + cb * cb) / np.maximum(np.abs(ca * cc - cb * cb), 1e-300), 0.0)
+    kappa = np.where(np.isfinite(kappa), kappa, 0.0)
+    drec[:, len(ensemble), 2:5] = (c32 * (K_DET * EPS32 * kappa)[:, None]).astype(np.float32) * vis[:, None]
     # depth = front . p + tz (camera.h:38-51 as a matrix row): rounding scales with the TERMS, not with the result
     pos = f(scene["pos"])
     front = np.asarray(cam32.front, np.float64)
@@ -188,6 +206,14 @@ def classify(scene, cam32, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_deg=3, amb
     W, H = cam32.width, cam32.height
     st = _staged(o32, scene, cam32, scale_modifier, sh_deg)
     u = uncertainties(scene, cam32, scale_modifier, sh_deg, st32=st, **k)
+    if st["num_rendered"] == 0:  # nothing is drawn: the image is left untouched (gs_tile_splatter/impl.cpp:109), like orc_render
+        z = np.zeros((H, W), np.float32)
+        counts = {k: v for k, v in u.items() if isinstance(v, (int, dict))}
+        counts.update(rect_uncertain_splats=0, pixels=W * H, threshold_pixels=0, depth_pixels=0, rect_pixels=0, flagged_pixels=0,
+                      pixels_that_may_move_over_1e_4=0, of_them_by_conditioning_alone=0)
+        return {"img": np.zeros((3, H, W), np.float32), "num_rendered": 0, "radii": st["radii"], "final_T": z.copy(),
+                "n_contrib": np.zeros((H, W), np.uint32), "cls": np.zeros((H, W), np.uint8), "sens": z.copy(), "rss": z.copy(),
+                "flip": z.copy(), "bound": np.full((H, W), SENS_FLOOR), "counts": counts}
     img, final_T, n_contrib, cls, sens, rss, flip = o32.render_forward_ex(
         W, H, bg, st["ranges"], st["point_list"], st["pix"], st["conic"], scene["opacity"], st["color"], ambig_eps,
         depth=st["depth"], depth_tol=u["depth_tol"], drec=u["drec"], dcolor=u["dcolor"],

@@ -89,14 +89,14 @@ def assert_parity_vs_numerics_variants(gpu_img, scene, ocam, **render_kw):
     ill-conditioned splats.  Asserted, per variant: EVERY pixel of the frame lies within the per-pixel bound the checker
     derives from its own evaluations (the continuous first-order term from the measured per-splat uncertainties + what each
     decision inside its rounding window could move the pixel by); the pixels beyond 1e-4 are at most 5e-4 of the frame; and
-    the bound is not vacuous: at most 6 % of the frame may move beyond 1e-4 by it.  Three of the variants take no part in
+    the bound is not vacuous: at most 8 % of the frame may move beyond 1e-4 by it.  Four of the variants take no part in
     measuring the uncertainties (numerics.ENSEMBLE): the independent check.  Returns numerics.report's dict."""
     from oracle import numerics
 
     rep, cl = numerics.report(scene, ocam, img=gpu_img, **render_kw)
     n = gpu_img.shape[1] * gpu_img.shape[2]
     c = rep["classes"]
-    assert c["pixels_that_may_move_over_1e_4"] <= 0.06 * n, c
+    assert c["pixels_that_may_move_over_1e_4"] <= 0.08 * n, c
     for name, v in rep["variants"].items():
         assert v["all_explained"], (name, v)
         assert v["pixels_over_1e-4"] <= max(3, int(np.ceil(5e-4 * n))), (name, v)
