@@ -241,6 +241,23 @@ def test_bench_still_prints_its_line_when_a_multi_gpu_leg_fails():
     assert "fwd_bwd" not in out
 
 
+def test_bench_falls_back_to_torch_distributed_when_the_communicator_fails_its_selftest():
+    """the first N > 1 run's other insurance (round 6): a communicator that fails lcgs_comm_selftest is not given the timed
+    legs -- they run over torch.distributed's own communicator, and the line says so"""
+    env = dict(os.environ, LCGS_BENCH_FORCE_DIST="1", LCGS_BENCH_INJECT_SELFTEST_FAILURE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29536")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--splats", "100000", "--res", "320x240", "--steps",
+                          "2", "--warmup", "1", "--no-cpu-baseline", "--no-stage-path", "--no-batch", "--no-spatial"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([x for x in res.stdout.splitlines() if x.startswith("{")][-1])
+    st = out["comm_selftest"]
+    assert st["ok"] is False and st["every_rank_ok"] is False and "torch.distributed" in st["fallback"]
+    assert "injected" in out["leg_errors"]["comm_selftest"]
+    assert out["fwd_bwd"]["value"] > 0 and "rccl" not in out["fwd_bwd"]["collective"]
+    assert out["train_step"]["allreduce"]["value"] > 0
+
+
 def test_bench_with_two_ranks_on_one_gpu_through_the_torch_collective():
     """Same launch with --collective torch: the process group (gloo here) carries the gradients, so every N > 1 leg -- the
     view-parallel trainer's all-reduce and sharded steps, accumulated views, lcgs_fit_views + gradient sum -- runs end to
