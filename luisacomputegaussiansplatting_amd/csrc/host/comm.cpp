@@ -1177,7 +1177,17 @@ lcgs_status lcgs_owner_step_forward(lcgs_context* ctx, lcgs_comm* c, const lcgs_
             c->own.cap_out[o] = padded_rows(c->prev.table[(size_t)me * N + o], count);
         }
         c->own.in_off[N] = cap_total;
-        if (cap_total > ctx->P || cap_total >= (int64_t)0x7FFFFFFF) async = false;
+        // EVERY rank must take the same branch (the branches size their messages differently): the test runs over every
+        // view's padded segments, computed from the table all ranks share -- not over this rank's own column alone
+        for (int v = 0; v < N && async; ++v) {
+            int64_t total_v = 0;
+            for (int o = 0; o < N; ++o) {
+                int64_t of = 0, oc = 0;
+                lcgs_comm_owner_rows(ctx->P, N, o, &of, &oc);
+                total_v += padded_rows(c->prev.table[(size_t)o * N + v], oc);
+            }
+            if (total_v > ctx->P || total_v >= (int64_t)0x7FFFFFFF) async = false;
+        }
     }
     c->force_sync_once = false;
 
