@@ -60,7 +60,7 @@ lcgs_status ensure_fused_workspace(lcgs_context* ctx, const CamParams& cp, bool 
     }
     for (int i = 0; i < 2; ++i) {
         const void* before = ctx->tile_order[i].ptr;
-        LCGS_TRY(ctx->tile_order[i].ensure(G * 4));
+        LCGS_TRY(ctx->tile_order[i].ensure(G * 8)); // (G slots + the sorted blocks of a per-block schedule: render.hip k_tile_order)
         if (ctx->tile_order[i].ptr != before) ctx->order_G = 0;
     }
     ctx->zero_scan_bytes = b0;

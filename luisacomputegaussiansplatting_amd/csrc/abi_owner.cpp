@@ -195,7 +195,7 @@ lcgs_status lcgs::abi::owner_render_frame(lcgs_context* ctx, const lcgs_camera* 
                                                 ctx->pair_capacity, hint_L, 0, tile_bits, ctx->sort_ws.ptr, st, counted);
         launch_get_ranges_u32(hint_L, ctx->pair_capacity, dc, ctx->pairk[where2].as<uint32_t>(), ctx->ranges, nullptr, st, nullptr);
         uint32_t* order_now = ctx->tile_order[0].as<uint32_t>();
-        launch_tile_order(ctx->ranges, G, order_now, st);
+        launch_tile_order(ctx->ranges, G, order_now, st, cp.grid_x, 0u);
         ctx->order_G = 0; // (the pipelined frames' schedule buffers were used out of turn)
         launch_render_forward_rec(cp, bg_color, ctx->ranges, ctx->pairv[where2].as<uint32_t>(), recs, d_img,
                                   keep_state ? ctx->final_T.as<float>() : nullptr,

@@ -411,19 +411,50 @@ __global__ void __launch_bounds__(256) k_render_forward_b(CamParams cp, float bg
 // One workgroup: counting sort of the tiles into 1024 length buckets (descending); order inside a bucket is
 // whatever the LDS atomics produce.
 // (grid_x, shift: the tiles' lists are their blocks' -- CamParams::list_shift; shift 0: ranges are per tile)
+// Round 6, per-block lists: the BLOCKS of 2 x 2 tiles are sorted by their list's length, and the (up to) four
+// tiles of a block go to slots that are 8 apart -- workgroups are dealt round-robin over the 8 XCDs, so slots s, s + 8, s + 16,
+// s + 24 share an XCD and its L2: a block's list, which all four tile workgroups stage, is fetched into ONE L2 instead of four
+// (renderer FETCH_SIZE 204 -> 86 MB per launch), and neighbouring tiles' lists name the same splats (scratch: the sorted
+// blocks behind the G slots of `order`).
 __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ ranges, uint32_t G,
                                                        uint32_t* __restrict__ order, uint32_t grid_x, uint32_t shift)
 {
-    const uint32_t lgx = (grid_x + (1u << shift) - 1u) >> shift;
-    auto           list_of = [&](uint32_t t) { return shift ? ((t / grid_x) >> shift) * lgx + ((t % grid_x) >> shift) : t; };
+    // (A/B hook LCGS_TILE_ORDER_XCD=0: `shift` arrives with bit 8 set -> the tiles themselves are sorted, slots in sorted order)
+    // Per-TILE lists keep the plain longest-tile-first order: the block-interleaved one was measured on them too (round 6) and
+    // loses 2 % on forward+backward (5 % in file order) -- four neighbouring tiles that add to the same gradient rows at the
+    // same time, and a coarser longest-first.  (The weight() of that experiment stays below for the record.)
+    const uint32_t sh  = shift & 0xFFu;
+    const bool     by_block = !(shift & 0x100u) && grid_x > 1u && sh != 0u;
+    const uint32_t lgx = (grid_x + (1u << sh) - 1u) >> sh;
+    auto           list_of = [&](uint32_t t) { return sh ? ((t / grid_x) >> sh) * lgx + ((t % grid_x) >> sh) : t; };
     __shared__ uint32_t s_bucket[1024];
     __shared__ uint32_t s_wave[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t grid_y = G / grid_x;
+    const uint32_t bgx = (grid_x + 1u) >> 1, bgy = (grid_y + 1u) >> 1; // blocks of 2 x 2 tiles
+    const uint32_t n_items = by_block ? bgx * bgy : G;                 // what is sorted: blocks, or tiles
+    // a block's weight: its list's length (per-block lists), or the longest of its tiles' lists (per-tile lists)
+    auto weight = [&](uint32_t t) -> uint32_t {
+        if (!by_block) {
+            const uint32_t lb = list_of(t);
+            return ranges[2 * (size_t)lb + 1] - ranges[2 * (size_t)lb];
+        }
+        if (sh) return ranges[2 * (size_t)t + 1] - ranges[2 * (size_t)t]; // (block t IS list t: same 2 x 2 grid)
+        const uint32_t bx = t % bgx, by = t / bgx;
+        uint32_t       w = 0u;
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t tx = bx * 2u + (j & 1u), ty = by * 2u + (j >> 1);
+            if (tx < grid_x && ty < grid_y) {
+                const uint32_t l = ranges[2 * (size_t)(ty * grid_x + tx) + 1] - ranges[2 * (size_t)(ty * grid_x + tx)];
+                w = l > w ? l : w;
+            }
+        }
+        return w;
+    };
     s_bucket[tid] = 0;
     __syncthreads();
-    for (uint32_t t = tid; t < G; t += 1024u) {
-        const uint32_t lb  = list_of(t);
-        const uint32_t len = ranges[2 * (size_t)lb + 1] - ranges[2 * (size_t)lb];
+    for (uint32_t t = tid; t < n_items; t += 1024u) {
+        const uint32_t len = weight(t);
         const uint32_t b   = 1023u - ((len >> 3) < 1023u ? (len >> 3) : 1023u);
         atomicAdd(&s_bucket[b], 1u);
     }
@@ -442,11 +473,45 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
     __syncthreads();
     s_bucket[tid] = carry + inc - own; // exclusive start of the bucket
     __syncthreads();
-    for (uint32_t t = tid; t < G; t += 1024u) {
-        const uint32_t lb  = list_of(t);
-        const uint32_t len = ranges[2 * (size_t)lb + 1] - ranges[2 * (size_t)lb];
+    uint32_t* sorted = by_block ? order + G : order; // by block: the sorted BLOCKS go to the scratch behind the slots
+    for (uint32_t t = tid; t < n_items; t += 1024u) {
+        const uint32_t len = weight(t);
         const uint32_t b   = 1023u - ((len >> 3) < 1023u ? (len >> 3) : 1023u);
-        order[atomicAdd(&s_bucket[b], 1u)] = t;
+        sorted[atomicAdd(&s_bucket[b], 1u)] = t;
+    }
+    if (!by_block) return;
+    __threadfence_block();
+    __syncthreads();
+    // candidate slot c = 32 g + 8 j + k holds tile j (0..3: x + 2 y inside the block) of the (8 g + k)-th block; tiles that do
+    // not exist (odd grids) are squeezed out -- the four tiles of a block stay a multiple of 8 apart unless a hole falls
+    // between them (edge blocks only)
+    const uint32_t n_cand = ((n_items + 7u) / 8u) * 32u;
+    uint32_t       base = 0u;
+    for (uint32_t c0 = 0; c0 < n_cand; c0 += 1024u) {
+        const uint32_t c = c0 + tid;
+        uint32_t       tile = 0xFFFFFFFFu;
+        if (c < n_cand) {
+            const uint32_t g = c >> 5, j = (c >> 3) & 3u, k = c & 7u, bi = 8u * g + k;
+            if (bi < n_items) {
+                const uint32_t blk = sorted[bi];
+                const uint32_t tx = (blk % bgx) * 2u + (j & 1u), ty = (blk / bgx) * 2u + (j >> 1);
+                if (tx < grid_x && ty < grid_y) tile = ty * grid_x + tx;
+            }
+        }
+        const bool               valid = tile != 0xFFFFFFFFu;
+        const unsigned long long m     = __ballot(valid);
+        const uint32_t           rank  = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        __syncthreads(); // (s_wave of the previous chunk has been read)
+        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0u, total = 0u;
+        for (uint32_t w = 0; w < 16u; ++w) {
+            const uint32_t n = s_wave[w];
+            before += w < wave ? n : 0u;
+            total += n;
+        }
+        if (valid) order[base + before + rank] = tile;
+        base += total;
     }
 }
 
@@ -500,7 +565,10 @@ void launch_blend_exp(const float* x, float* out, int64_t n, hipStream_t stream)
 void launch_tile_order(const uint32_t* ranges, uint32_t G, uint32_t* order, hipStream_t stream, uint32_t grid_x, uint32_t list_shift)
 {
     if (G == 0) return;
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, ranges, G, order, grid_x ? grid_x : 1u, grid_x ? list_shift : 0u);
+    static const bool xcd_aware = [] { const char* e = getenv("LCGS_TILE_ORDER_XCD"); return !(e && e[0] == '0'); }(); // A/B hook
+    // (grid_x == 0: a caller that does not say how the tiles lie -- sorted as tiles)
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, ranges, G, order, grid_x ? grid_x : 1u,
+                       (grid_x ? list_shift : 0u) | ((!grid_x || !xcd_aware) ? 0x100u : 0u));
 }
 
 void launch_render_forward_aos(const CamParams& cp, const float bg[3], const uint32_t* ranges,
