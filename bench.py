@@ -599,6 +599,8 @@ def leg_gradients(S):
                             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                         if int(tm.item()) == 0:
                             coll.close()
+                        else:
+                            coll.comm.abandon()  # (its destructor would wait for the stuck stream at interpreter exit)
                         st_self["fallback"] = "gradient legs over torch.distributed (the library's communicator failed its self-test)"
                         out.setdefault("leg_errors", {})["comm_selftest"] = st_self["message"][:300]
                         coll = mg.TorchCollective(dist, rank, world)

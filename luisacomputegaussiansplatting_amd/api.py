@@ -833,6 +833,11 @@ class Comm:
         except Exception:
             pass
 
+    def abandon(self):
+        """forget the handle WITHOUT destroying the communicator: for one whose self-test left a phase stuck inside RCCL
+        (lcgs_comm_destroy would wait for its stream, i.e. for ever) -- the process is expected to report and exit"""
+        self._h = C.c_void_p(0)
+
     def info(self):
         """lcgs_comm_info: (rank, world_size) as the communicator itself -- i.e. RCCL -- sees them"""
         rk, ws = C.c_int(-1), C.c_int(-1)
