@@ -4,6 +4,8 @@ passes, as MI355X_MICROARCH.md prescribes).  usage: make_pmc_traffic.py <fetch_d
 import csv, glob, json, os, re, sys, collections
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import kernel_key
 from bench import kernel_sources_hash, library_hash  # what these counters were measured on (bench.py refuses a stale file)
 
 
@@ -13,8 +15,7 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
-            k = re.sub(r"^void ", "", k).split("(")[0].split("<")[0].split("::")[-1]
+            k = kernel_key(r["Kernel_Name"])
             acc[k] += float(r["Counter_Value"])
             n[k].add(r["Dispatch_Id"])
     return {k: (acc[k] / len(n[k]), len(n[k])) for k in acc}

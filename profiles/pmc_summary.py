@@ -3,7 +3,9 @@
 import csv, glob, os, re, sys, collections
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from bench import kernel_sources_hash, library_hash
+from kernel_names import kernel_key
 
 print("# kernel_sources_sha256", kernel_sources_hash())
 print("# library_sha256", library_hash())
@@ -11,8 +13,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(set)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
-        n = re.sub(r"^void ", "", n).split("(")[0].split("<")[0].split("::")[-1]
+        n = kernel_key(r["Kernel_Name"])
         acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[n].add(r["Dispatch_Id"])
 for n in acc:
