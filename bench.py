@@ -153,6 +153,9 @@ def parse_args():
                          "about sqrt(N) x 5e-4 relative error; never the default)")
     ap.add_argument("--leg-timeout", type=float, default=600.0,
                     help="N > 1: seconds the legs after the forward measurement may take before the line is printed without them")
+    ap.add_argument("--start-timeout", type=float, default=900.0,
+                    help="N > 1: seconds the process group's creation and the forward measurement (the first collectives this "
+                         "library ever issues on a new node) may take before rank 0 prints an error line instead of hanging")
     ap.add_argument("--sweep", action="store_true",
                     help="instead of the bench line: the workload sweep (tools/workload_sweep.py) -- scale_modifier x scene x "
                          "resolution, counts / frames/s / forward+backward per point, a fitted time model and what sits off it; "
@@ -576,7 +579,26 @@ def leg_gradients(S):
                             t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
                         dist.broadcast(t, 0)
                         return t.cpu().numpy().tobytes()
-                    coll = mg.RcclCollective(ctx, rank, world, exchange)
+                    # the library's own communicator (ncclCommInitRank under lcgs_comm_create): when ANY rank cannot create it
+                    # the gradient legs run over torch.distributed's instead -- a figure for the metric all the same, and the
+                    # line says why
+                    try:
+                        coll = mg.RcclCollective(ctx, rank, world, exchange)
+                        create_err = None
+                    except Exception as e:  # noqa: BLE001
+                        coll, create_err = None, f"{type(e).__name__}: {e}"
+                    made = torch.tensor([0 if coll is None else 1], device=dev, dtype=torch.int32)
+                    if world > 1:
+                        dist.all_reduce(made, op=dist.ReduceOp.MIN)
+                    if int(made.item()) == 0:
+                        if coll is not None:
+                            coll.close()
+                        out.setdefault("leg_errors", {})["comm_create"] = (create_err or "another rank could not create the communicator")[:300]
+                        out["comm_selftest"] = {"ok": False, "every_rank_ok": False, "message": "the communicator was not created",
+                                                "fallback": "gradient legs over torch.distributed"}
+                        coll = mg.TorchCollective(dist, rank, world)
+                        args.collective = "torch"
+                if dist is not None and args.collective == "rccl":  # (created on every rank)
                     # ---- before anything distributed is timed: what the communicator says about ITSELF (lcgs_comm_selftest: a
                     # 1 KB all-reduce, zero- and one-byte messages to every peer in one group, an ownership step on a 10 000-splat
                     # scratch scene with and without read-back; 30 s per phase).  In the line whatever it says; when it fails the
@@ -884,6 +906,20 @@ def main():
         sys.exit(subprocess.call(cmd, stdout=line_out))  # (the children's stdout is the real one)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: liblcgs_hip has no CPU path")
+    # N > 1: the process group's creation and the barriers around the forward measurement are the first collectives of a run
+    # -- on a new node, RCCL's first contact.  If they never return there is no measurement to print, but a line that says so
+    # beats a silent hang: rank 0 prints it and every rank exits non-zero (the leg watchdog below takes over afterwards).
+    early = None
+    if world > 1:
+        def never_started():
+            if rank == 0:
+                print(json.dumps({"metric": "forward fps @1080p, mip360_bicycle", "value": None, "unit": "frames/s", "n_gpus": world,
+                                  "error": f"no forward measurement within {args.start_timeout} s: the process group's creation "
+                                           "or the first barrier did not return (rank 0's view)"}), file=line_out, flush=True)
+            os._exit(3)
+        early = threading.Timer(args.start_timeout, never_started)
+        early.daemon = True
+        early.start()
     # a launcher that narrows each rank's visibility to one GPU leaves fewer devices than local ranks
     local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
@@ -979,6 +1015,8 @@ def main():
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if early is not None:
+        early.cancel()
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * args.steps / elapsed
 

@@ -288,13 +288,14 @@ def test_bench_with_two_ranks_on_one_gpu_through_the_torch_collective():
 def test_bench_with_two_ranks_on_one_gpu():
     """The driver's N > 1 launch, rehearsed with two ranks on the one GPU of the box (LCGS_BENCH_BACKEND=gloo; RCCL refuses
     two ranks on one device): torchrun, per-rank views, barriers, max-over-ranks timing, ONE line from rank 0 with the
-    whole-job rate -- and the gradient legs, which cannot build their communicator here, recorded as leg errors on every
-    rank instead of ending or hanging the run."""
+    whole-job rate -- and the gradient legs: the library's communicator cannot be created here (every rank is refused), which
+    is recorded in the line (`leg_errors.comm_create`) and the legs run over torch.distributed's communicator instead of
+    ending or hanging the run."""
     env = dict(os.environ, LCGS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--splats",
                           "200000", "--res", "640x480", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
-                          "--no-stage-path", "--no-spatial", "--leg-timeout", "120"],
+                          "--no-stage-path", "--no-spatial", "--leg-timeout", "300"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [x for x in res.stdout.splitlines() if x.startswith("{")]
@@ -303,8 +304,32 @@ def test_bench_with_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["config"]["parallelism"] == "view-parallel x2"
     assert out["camera_batch"]["value"] > 0 and out["moving_camera"]["value"] > 0
-    # the communicator of the gradient legs: refused on a shared device -> reported, or (a build that allows it) measured
-    assert ("leg_errors" in out) != ("fwd_bwd" in out and "value" in out["fwd_bwd"]), out.get("leg_errors")
+    # the communicator of the gradient legs: refused on a shared device -> reported, the legs measured over the process group's
+    # (or, a build that allows two ranks on a device: created, self-tested and used)
+    assert out["fwd_bwd"]["value"] > 0, out.get("leg_errors")
+    if "leg_errors" in out:
+        assert set(out["leg_errors"]) == {"comm_create"} and "ncclCommInitRank" in out["leg_errors"]["comm_create"]
+        assert out["comm_selftest"]["ok"] is False and "torch.distributed" in out["comm_selftest"]["fallback"]
+        assert "rccl" not in out["fwd_bwd"]["collective"] and out["train_step"]["allreduce"]["value"] > 0
+    else:
+        assert out["comm_selftest"]["every_rank_ok"] is True
+
+
+def test_bench_says_so_when_the_first_collectives_never_return():
+    """N > 1: the process group's creation and the barriers around the forward measurement are a new node's first contact with
+    RCCL.  If they do not return within --start-timeout there is nothing to report -- but rank 0 prints a line that says so
+    (`value` null, `error`) and the run ends non-zero instead of hanging (here: a timeout no start can meet)."""
+    env = dict(os.environ, LCGS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29545", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--splats",
+                          "200000", "--res", "640x480", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                          "--start-timeout", "0.02"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode != 0
+    lines = [x for x in res.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["value"] is None and out["n_gpus"] == 2 and "no forward measurement within" in out["error"]
 
 
 def test_allreduce_issues_the_same_collectives_whether_or_not_the_rank_ran_a_backward(lcgs):
