@@ -916,6 +916,8 @@ def main():
                 print(json.dumps({"metric": "forward fps @1080p, mip360_bicycle", "value": None, "unit": "frames/s", "n_gpus": world,
                                   "error": f"no forward measurement within {args.start_timeout} s: the process group's creation "
                                            "or the first barrier did not return (rank 0's view)"}), file=line_out, flush=True)
+            else:
+                time.sleep(20.0)  # (rank 0 prints the line: a launcher ends every rank as soon as the first one exits)
             os._exit(3)
         early = threading.Timer(args.start_timeout, never_started)
         early.daemon = True
