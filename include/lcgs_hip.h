@@ -314,6 +314,11 @@ LCGS_API lcgs_status lcgs_sparse_accumulate(lcgs_context* ctx, int sh_degree, co
 #define LCGS_OWNER_GRAD_FLOATS 12
 LCGS_API lcgs_status lcgs_owner_project(lcgs_context* ctx, int slot, const lcgs_camera* camera, float scale_modifier, int row_first,
                                         int row_count, int keep_state, uint32_t* d_rows, float* d_records, int* num_rows);
+/* The N views of a step over ONE row range in one call (view k -> slot first_slot + k; d_rows / d_records: host arrays of N
+ * device pointers): N independent pipelines run side by side and are joined on the context's stream; enqueue only. */
+LCGS_API lcgs_status lcgs_owner_project_views(lcgs_context* ctx, int first_slot, int num_views, const lcgs_camera* cameras,
+                                              float scale_modifier, int row_first, int row_count, int keep_state,
+                                              uint32_t* const* d_rows, float* const* d_records);
 LCGS_API lcgs_status lcgs_owner_counts(lcgs_context* ctx, int first_slot, int num_slots, int* num_rows);
 LCGS_API lcgs_status lcgs_owner_render(lcgs_context* ctx, const lcgs_camera* camera, const float bg_color[3], int num_rows,
                                        const uint32_t* d_rows, const float* d_records, float* d_img, int keep_state);

@@ -159,7 +159,7 @@ EXPORTED_SYMBOLS = [
     "lcgs_set_ingest_order", "lcgs_scene_permutation", "lcgs_set_lod", "lcgs_comm_unique_id", "lcgs_comm_create", "lcgs_comm_destroy", "lcgs_comm_info", "lcgs_comm_set_transport", "lcgs_comm_shard_rows",
     "lcgs_grads_allreduce", "lcgs_adam_step_sharded", "lcgs_comm_track_touched_rows", "lcgs_comm_get_stats",
     "lcgs_adam_step_sparse", "lcgs_sparse_touched_rows", "lcgs_sparse_message_words", "lcgs_sparse_pack",
-    "lcgs_sparse_accumulate", "lcgs_scene_declare_static", "lcgs_owner_project", "lcgs_owner_counts", "lcgs_owner_render", "lcgs_owner_render_backward", "lcgs_owner_backward",
+    "lcgs_sparse_accumulate", "lcgs_scene_declare_static", "lcgs_owner_project", "lcgs_owner_project_views", "lcgs_owner_counts", "lcgs_owner_render", "lcgs_owner_render_backward", "lcgs_owner_backward",
 ]
 
 
@@ -639,19 +639,19 @@ class Renderer:
         return out_rows, out_recs
 
     def owner_project_all(self, cams, row_first: int, row_count: int, keep_state: bool = True, scale_modifier: float = 1.0):
-        """The same for every view of a step -- view v into slot v -- with ONE synchronisation: N asynchronous
-        lcgs_owner_project calls (num_rows = NULL), then lcgs_owner_counts.  -> [(rows, records)] per view."""
+        """The same for every view of a step -- view v into slot v -- with ONE synchronisation: lcgs_owner_project_views (N
+        pipelines side by side), then lcgs_owner_counts.  -> [(rows, records)] per view."""
         import torch
 
         dev = torch.device("cuda", self.ctx.device_id)
-        lib, outs = load_library(), []
-        for v, cam in enumerate(cams):
-            out_rows = torch.empty(max(row_count, 1), dtype=torch.int32, device=dev)
-            out_recs = torch.empty(max(row_count, 1), self.OWNER_RECORD_FLOATS, dtype=torch.float32, device=dev)
-            _check(lib.lcgs_owner_project(self.ctx._h, C.c_int(v), C.byref(cam), C.c_float(scale_modifier), C.c_int(row_first),
-                                          C.c_int(row_count), C.c_int(1 if keep_state else 0), _ptr(out_rows), _ptr(out_recs),
-                                          None))
-            outs.append((out_rows, out_recs))
+        lib, N = load_library(), len(cams)
+        outs = [(torch.empty(max(row_count, 1), dtype=torch.int32, device=dev),
+                 torch.empty(max(row_count, 1), self.OWNER_RECORD_FLOATS, dtype=torch.float32, device=dev)) for _ in range(N)]
+        # lcgs_owner_project_views: the N pipelines side by side on the context's lanes, joined on its stream
+        rows_p = (C.c_void_p * N)(*[o[0].data_ptr() for o in outs])
+        recs_p = (C.c_void_p * N)(*[o[1].data_ptr() for o in outs])
+        _check(lib.lcgs_owner_project_views(self.ctx._h, C.c_int(0), C.c_int(N), (Camera * N)(*cams), C.c_float(scale_modifier),
+                                            C.c_int(row_first), C.c_int(row_count), C.c_int(1 if keep_state else 0), rows_p, recs_p))
         counts = (C.c_int * len(outs))()
         _check(lib.lcgs_owner_counts(self.ctx._h, C.c_int(0), C.c_int(len(outs)), counts))
         self._generation += 1

@@ -286,6 +286,17 @@ lcgs_status lcgs_destroy(lcgs_context* ctx)
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& s : ctx->owner)
         for (DeviceBuffer* b : { &s.vis, &s.shjac, &s.counts }) b->release();
+    for (auto& l : ctx->owner_lane) {
+        if (l.stream) {
+            (void)hipStreamSynchronize(l.stream);
+            (void)hipStreamDestroy(l.stream);
+        }
+        if (l.done) (void)hipEventDestroy(l.done);
+        for (DeviceBuffer* b : { &l.slab, &l.chunk_info, &l.chunk_base, &l.sortk[0], &l.sortk[1], &l.sortv[0], &l.sortv[1], &l.rects,
+                                 &l.sort_ws })
+            b->release();
+    }
+    if (ctx->ev_owner_fork) (void)hipEventDestroy(ctx->ev_owner_fork);
     for (auto& b : ctx->owned) b.release();
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->aux_stream) {

@@ -6,6 +6,7 @@
 // between the two halves is new.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -26,6 +27,49 @@ RowRange shard_of(lcgs_context* ctx, int row_first)
     const size_t feat = (size_t)(ctx->sh_deg + 1) * (ctx->sh_deg + 1) * 3;
     return { ctx->pos + 3 * (size_t)row_first, ctx->scale + 3 * (size_t)row_first, ctx->rotq + 4 * (size_t)row_first,
              ctx->sh + feat * (size_t)row_first, ctx->opacity + (size_t)row_first };
+}
+
+// The per-splat half of one view's frame on the slot's row range: the fused frame's first stages -- cull, compaction (the depth
+// sort's first pass only: the renderer of the view sorts what it receives), colour + packed records -- on the context's own
+// workspace and stream, or (lane != NULL) on a lane's scratch and stream beside other views of the same step.
+lcgs_status project_rows(lcgs_context* ctx, int slot, const CamParams& cp, float scale_modifier, bool keep_state, uint32_t* d_rows,
+                         float* d_records, lcgs_context::OwnerLane* lane)
+{
+    auto&        s = ctx->owner[slot];
+    const int    row_first = s.row_first, row_count = s.row_count;
+    const size_t n = (size_t)row_count;
+    LCGS_TRY(s.vis.ensure(n * 4 + 16));
+    LCGS_TRY(s.counts.ensure(64));
+    if (keep_state) LCGS_TRY(s.shjac.ensure(n * 48));
+    hipStream_t    st = lane ? lane->stream : ctx->stream;
+    const RowRange r  = shard_of(ctx, row_first);
+    uint32_t*      dc = s.counts.as<uint32_t>();
+    uint4*         slab       = lane ? lane->slab.as<uint4>() : ctx->cull_slab.as<uint4>();
+    uint2*         chunk_info = lane ? lane->chunk_info.as<uint2>() : ctx->chunk_info.as<uint2>();
+    uint32_t*      chunk_base = lane ? lane->chunk_base.as<uint32_t>() : ctx->chunk_base.as<uint32_t>();
+    uint32_t*      k0 = lane ? lane->sortk[0].as<uint32_t>() : ctx->sortk[0].as<uint32_t>();
+    uint32_t*      k1 = lane ? lane->sortk[1].as<uint32_t>() : ctx->sortk[1].as<uint32_t>();
+    uint32_t*      v0 = lane ? lane->sortv[0].as<uint32_t>() : ctx->sortv[0].as<uint32_t>();
+    uint32_t*      v1 = lane ? lane->sortv[1].as<uint32_t>() : ctx->sortv[1].as<uint32_t>();
+    uint2*         rects   = lane ? lane->rects.as<uint2>() : ctx->rects.as<uint2>();
+    void*          sort_ws = lane ? lane->sort_ws.ptr : ctx->sort_ws.ptr;
+    const DepthSortFirstPass dfirst = depth_sort_first_pass(row_count, sort_ws);
+    launch_cull_compact(row_count, cp, scale_modifier, nullptr, r.pos, r.scale, r.rotq, r.opacity, nullptr, slab, chunk_info, dfirst,
+                        st, ctx->cull_rows() ? ctx->cull_rows() + row_first : nullptr); // (the scene's bound rows, if it has them)
+    launch_depth_sort_from_chunks(row_count, row_count, slab, chunk_info, chunk_base, k0, k1, v0, v1, s.vis.as<uint32_t>(), rects, dc,
+                                  sort_ws, st, nullptr, nullptr, /*first_pass_only=*/true);
+    launch_build_records(row_count, ctx->sh_deg, cp, scale_modifier, nullptr, r.pos, r.scale, r.rotq, r.sh, r.opacity,
+                         s.vis.as<uint32_t>(), dc, reinterpret_cast<SplatRecord*>(d_records), st, nullptr,
+                         keep_state ? s.shjac.as<float4>() : nullptr);
+    s.has_jac = keep_state && build_records_writes_jacobian(ctx->sh_deg, r.sh, false);
+    launch_rows_global(s.vis.as<uint32_t>(), dc, (uint32_t)row_first, d_rows, row_count, st);
+    LCGS_HIP_CHECK(hipGetLastError());
+    s.valid          = true;
+    s.cp             = cp;
+    s.scale_modifier = scale_modifier;
+    s.num            = -1; // (on the device until read back)
+    ctx->last.valid  = false; // (the context's own frame state was overwritten)
+    return LCGS_OK;
 }
 } // namespace
 
@@ -51,40 +95,90 @@ lcgs_status lcgs_owner_project(lcgs_context* ctx, int slot, const lcgs_camera* c
     if (row_count == 0) return LCGS_OK;
     const CamParams cp = make_cam_params(*camera);
     LCGS_TRY(ensure_fused_workspace(ctx, cp, keep_state != 0));
-    const size_t n = (size_t)row_count;
-    LCGS_TRY(s.vis.ensure(n * 4 + 16));
-    LCGS_TRY(s.counts.ensure(64));
-    if (keep_state) LCGS_TRY(s.shjac.ensure(n * 48));
-    hipStream_t    st = ctx->stream;
-    const RowRange r  = shard_of(ctx, row_first);
-    uint32_t*      dc = s.counts.as<uint32_t>();
     if (ctx->aux_pending) { // a pipelined frame of this context may still be using the workspace through the auxiliary stream
-        LCGS_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_aux_done, 0));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_aux_done, 0));
         ctx->aux_pending = false;
     }
-    // the fused frame's first stages on the rows of the range: cull, compaction (the depth sort's first pass only: the
-    // renderer of the view sorts what it receives), colour + packed records
-    const DepthSortFirstPass dfirst = depth_sort_first_pass(row_count, ctx->sort_ws.ptr);
-    launch_cull_compact(row_count, cp, scale_modifier, nullptr, r.pos, r.scale, r.rotq, r.opacity, nullptr,
-                        ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(), dfirst, st,
-                        ctx->cull_rows() ? ctx->cull_rows() + row_first : nullptr); // (the scene's bound rows, if it has them)
-    launch_depth_sort_from_chunks(row_count, row_count, ctx->cull_slab.as<uint4>(), ctx->chunk_info.as<uint2>(),
-                                  ctx->chunk_base.as<uint32_t>(), ctx->sortk[0].as<uint32_t>(), ctx->sortk[1].as<uint32_t>(),
-                                  ctx->sortv[0].as<uint32_t>(), ctx->sortv[1].as<uint32_t>(), s.vis.as<uint32_t>(),
-                                  ctx->rects.as<uint2>(), dc, ctx->sort_ws.ptr, st, nullptr, nullptr, /*first_pass_only=*/true);
-    launch_build_records(row_count, ctx->sh_deg, cp, scale_modifier, nullptr, r.pos, r.scale, r.rotq, r.sh, r.opacity,
-                         s.vis.as<uint32_t>(), dc, reinterpret_cast<SplatRecord*>(d_records), st, nullptr,
-                         keep_state ? s.shjac.as<float4>() : nullptr);
-    s.has_jac = keep_state && build_records_writes_jacobian(ctx->sh_deg, r.sh, false);
-    launch_rows_global(s.vis.as<uint32_t>(), dc, (uint32_t)row_first, d_rows, row_count, st);
-    LCGS_HIP_CHECK(hipGetLastError());
-    s.valid          = true;
-    s.cp             = cp;
-    s.scale_modifier = scale_modifier;
-    s.num            = -1; // (on the device until read back)
-    ctx->last.valid  = false; // (the context's own frame state was overwritten)
+    LCGS_TRY(project_rows(ctx, slot, cp, scale_modifier, keep_state != 0, d_rows, d_records, nullptr));
     if (!num_rows) return LCGS_OK; // asynchronous: lcgs_owner_counts reads the count (with the other views' counts)
     return lcgs_owner_counts(ctx, slot, 1, num_rows);
+}
+
+// The N views of a step in one call: view k -> slot first_slot + k.  N independent short pipelines over the same row range;
+// they run side by side on the context's lanes (context.hpp OwnerLane) and are joined on the context's stream before the call
+// returns, so work the caller enqueues there afterwards sees every output.  Counts stay on the device (lcgs_owner_counts).
+lcgs_status lcgs_owner_project_views(lcgs_context* ctx, int first_slot, int num_views, const lcgs_camera* cameras,
+                                     float scale_modifier, int row_first, int row_count, int keep_state, uint32_t* const* d_rows,
+                                     float* const* d_records)
+{
+    LCGS_REQUIRE(ctx && cameras && d_rows && d_records, "NULL argument");
+    LCGS_REQUIRE(first_slot >= 0 && num_views >= 1 && first_slot + num_views <= LCGS_MAX_OWNER_VIEWS, "slots out of range");
+    LCGS_HIP_CHECK(hipSetDevice(ctx->device));
+    LCGS_REQUIRE(ctx->pos != nullptr && ctx->P > 0, "no scene bound");
+    LCGS_REQUIRE(row_first >= 0 && row_count >= 0 && (int64_t)row_first + row_count <= ctx->P, "row range outside the scene");
+    // TWO lanes by default: eight views of 766 K rows each, back to back without read-back, take 0.484 ms on one lane (the
+    // context's stream), 0.368 on two, 0.413 on four -- the host's forty launches and the event traffic bound it from there
+    // (tools/gpu/owner_rank_compute.py; A/B hook LCGS_OWNER_LANES=1..4)
+    static const int max_lanes = [] {
+        const char* e = getenv("LCGS_OWNER_LANES");
+        const int   v = e ? atoi(e) : 2;
+        return std::max(1, std::min(v, (int)lcgs_context::kOwnerLanes));
+    }();
+    const int lanes = std::min(max_lanes, num_views);
+    for (int k = 0; k < num_views; ++k) {
+        LCGS_TRY(check_camera(&cameras[k]));
+        LCGS_REQUIRE(row_count == 0 || (d_rows[k] && d_records[k]), "NULL output buffer");
+        LCGS_REQUIRE((reinterpret_cast<uintptr_t>(d_records[k]) & 15) == 0, "records must be 16-byte aligned");
+        auto& s     = ctx->owner[first_slot + k];
+        s.valid     = false;
+        s.row_first = row_first;
+        s.row_count = row_count;
+        s.num       = 0;
+    }
+    if (row_count == 0) return LCGS_OK;
+    LCGS_TRY(ensure_fused_workspace(ctx, make_cam_params(cameras[0]), keep_state != 0));
+    if (ctx->aux_pending) {
+        LCGS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_aux_done, 0));
+        ctx->aux_pending = false;
+    }
+    if (lanes <= 1) { // one view (or the hook): the context's own workspace and stream
+        for (int k = 0; k < num_views; ++k)
+            LCGS_TRY(project_rows(ctx, first_slot + k, make_cam_params(cameras[k]), scale_modifier, keep_state != 0, d_rows[k],
+                                  d_records[k], nullptr));
+        return LCGS_OK;
+    }
+    // lanes: scratch sized by the row range, a stream and an event each; every lane starts behind what the context's stream
+    // holds now (the caller's writes to the scene, an optimiser step) and the context's stream continues behind every lane
+    const size_t n = (size_t)row_count, chunks = (size_t)cull_chunk_count(row_count);
+    if (!ctx->ev_owner_fork) LCGS_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_owner_fork, hipEventDisableTiming));
+    LCGS_HIP_CHECK(hipEventRecord(ctx->ev_owner_fork, ctx->stream));
+    for (int l = 0; l < lanes; ++l) {
+        auto& L = ctx->owner_lane[l];
+        if (!L.stream) LCGS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        if (!L.done) LCGS_HIP_CHECK(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        LCGS_TRY(L.slab.ensure(chunks * 2048 * 16));
+        LCGS_TRY(L.chunk_info.ensure(chunks * 8));
+        LCGS_TRY(L.chunk_base.ensure(chunks * 4));
+        for (int i = 0; i < 2; ++i) {
+            LCGS_TRY(L.sortk[i].ensure(n * 4));
+            LCGS_TRY(L.sortv[i].ensure(n * 4));
+        }
+        LCGS_TRY(L.rects.ensure(n * 8));
+        LCGS_TRY(L.sort_ws.ensure(pair_sort_ws_bytes((int64_t)n)));
+        LCGS_HIP_CHECK(hipStreamWaitEvent(L.stream, ctx->ev_owner_fork, 0));
+    }
+    lcgs_status st = LCGS_OK;
+    for (int k = 0; k < num_views && st == LCGS_OK; ++k)
+        st = project_rows(ctx, first_slot + k, make_cam_params(cameras[k]), scale_modifier, keep_state != 0, d_rows[k], d_records[k],
+                          &ctx->owner_lane[k % lanes]);
+    for (int l = 0; l < lanes; ++l) { // (joined whatever happened: nothing may be left running beside the context's stream)
+        auto& L = ctx->owner_lane[l];
+        if (hipEventRecord(L.done, L.stream) != hipSuccess || hipStreamWaitEvent(ctx->stream, L.done, 0) != hipSuccess) {
+            (void)hipStreamSynchronize(L.stream);
+            if (st == LCGS_OK) st = LCGS_ERR_HIP;
+        }
+    }
+    return st;
 }
 
 lcgs_status lcgs_owner_counts(lcgs_context* ctx, int first_slot, int num_slots, int* num_rows)

@@ -240,6 +240,16 @@ struct lcgs_context {
         DeviceBuffer vis, shjac, counts;
     } owner[LCGS_MAX_OWNER_VIEWS];
     uint32_t*                h_owner_counts = nullptr; // pinned, LCGS_MAX_OWNER_VIEWS words (lcgs_owner_counts)
+    // lcgs_owner_project_views: the N views of a step are N INDEPENDENT short pipelines over the rank's P / N rows (five launches
+    // of a few hundred workgroups each); they run side by side on kOwnerLanes streams at most (two by default), each lane with its own scratch of
+    // the cull / first-sort-pass stages (sized by the row range), joined on the context's stream at the end of the call
+    static constexpr int kOwnerLanes = 4;
+    struct OwnerLane {
+        DeviceBuffer slab, chunk_info, chunk_base, sortk[2], sortv[2], rects, sort_ws;
+        hipStream_t  stream = nullptr;
+        hipEvent_t   done   = nullptr;
+    } owner_lane[kOwnerLanes];
+    hipEvent_t               ev_owner_fork = nullptr;
     const lcgs::SplatRecord* owner_recs = nullptr;
     int                      owner_rows = 0;
 

@@ -1147,13 +1147,19 @@ lcgs_status lcgs_owner_step_forward(lcgs_context* ctx, lcgs_comm* c, const lcgs_
     Wire      wire{ c };
     LoopGuard guard{ c };
 
-    // ---- 1. my rows, every view of the step (view v = rank v's): N asynchronous projections on the context's stream
+    // ---- 1. my rows, every view of the step (view v = rank v's): N asynchronous projections, side by side
     LCGS_TRY(c->own_rows.ensure((size_t)N * (size_t)count * 4 + 16));
     LCGS_TRY(c->own_recs.ensure((size_t)N * (size_t)count * kRecBytes + 16));
-    for (int v = 0; v < N; ++v)
-        LCGS_TRY(lcgs_owner_project(ctx, v, &cameras[v], scale_modifier, (int)first, (int)count, /*keep_state=*/1,
-                                    c->own_rows.as<uint32_t>() + (size_t)v * count,
-                                    c->own_recs.as<float>() + (size_t)v * count * LCGS_OWNER_RECORD_FLOATS, nullptr));
+    {
+        uint32_t* rows_v[LCGS_MAX_OWNER_VIEWS];
+        float*    recs_v[LCGS_MAX_OWNER_VIEWS];
+        for (int v = 0; v < N; ++v) {
+            rows_v[v] = c->own_rows.as<uint32_t>() + (size_t)v * count;
+            recs_v[v] = c->own_recs.as<float>() + (size_t)v * count * LCGS_OWNER_RECORD_FLOATS;
+        }
+        // (the N pipelines side by side on the context's lanes, joined on its stream: abi_owner.cpp)
+        LCGS_TRY(lcgs_owner_project_views(ctx, 0, N, cameras, scale_modifier, (int)first, (int)count, /*keep_state=*/1, rows_v, recs_v));
+    }
     // ---- 2. everybody learns everybody's counts: table[o][v] = rows of owner o on view v's screen
     LCGS_TRY(c->bounds.ensure((size_t)(N + 2) * 4));
     LCGS_TRY(c->matrix.ensure((size_t)N * N * 4));

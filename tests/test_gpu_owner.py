@@ -225,6 +225,17 @@ def test_every_view_of_a_step_with_one_read_back(lcgs):
     for (ra, qa), (rb, qb) in zip(one_by_one, together):
         assert ra.shape == rb.shape and torch.equal(ra, rb) and torch.equal(qa, qb)
     assert together[0][0].numel() > 0 and together[2][0].numel() == 0
+    # more views than the context has lanes (lcgs_owner_project_views runs them side by side, two at a time): a lane's second
+    # and third pipeline reuse its scratch behind the first
+    more = cams + [lcgs.get_lookat_cam([3.0 * np.cos(a), 3.0 * np.sin(a), 1.8], [0, 0, 0.5], [0, 0, 1], width=W, height=H)
+                   for a in np.linspace(0.3, 5.5, 8)]
+    one_by_one = [r.owner_project(v, cam, first, count) for v, cam in enumerate(more)]
+    for _ in range(2):  # (twice: the second call finds the lanes' buffers and streams in place)
+        together = r.owner_project_all(more, first, count)
+        for (ra, qa), (rb, qb) in zip(one_by_one, together):
+            assert ra.shape == rb.shape and torch.equal(ra, rb) and torch.equal(qa, qb)
+    assert sum(int(t[0].numel() > 0) for t in together) >= 8
+    together = r.owner_project_all(cams, first, count)  # (slots 0..2 as the rest of the test expects them)
     # the backward of a slot needs its count on the host
     import ctypes as C
 
