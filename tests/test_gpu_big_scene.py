@@ -1,0 +1,146 @@
+"""`-m gpu`, opt-in (LCGS_BIG_SCENE=1; ~80 GB of device memory, no large host arrays): a scene beyond 2^31 ELEMENTS per array.
+
+The library sizes its workspace for 288 GB of HBM and accepts up to 2^30 splats; BASELINE's largest scene has 6.13 M.  At 46 M
+splats the coefficient array holds 2.2e9 floats: every row index multiplied by 48 in 32-bit arithmetic would wrap.  The test
+places 150 000 real splats at the START, in the MIDDLE and at the END of 46 M rows (the last third lies beyond element 2^31 of
+`sh` and of its gradient array), fills the rest with splats behind the camera, and requires what a small scene of just those
+150 000 splats gives: the same image bit for bit (the small scene is itself held to the oracle here), the same radii, the same
+gradients at the real rows, exact zeros at every filler row, and the same optimiser step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_scene
+from gpu_util import DEV, assert_image_parity, upload_scene
+
+pytestmark = pytest.mark.gpu
+KEYS = ("pos", "scale", "rotq", "sh", "opacity")
+P_BIG = 46_000_000
+N_REAL = 150_000
+W, H = 640, 480
+POSE = ([-3, -0.5, 2.3], [0, 0, 0.5], [0, 0, 1])
+
+
+@pytest.mark.skipif(os.environ.get("LCGS_BIG_SCENE") != "1", reason="opt-in: LCGS_BIG_SCENE=1 (80 GB of device memory)")
+def test_rows_beyond_two_to_the_31_elements(lcgs, oracle):
+    rng = np.random.default_rng(4600)
+    small = make_scene(rng, N_REAL, log_scale=(-4.2, 0.6))
+    cam = lcgs.get_lookat_cam(*POSE, width=W, height=H)
+    ocam = oracle.lookat(*POSE, width=W, height=H)
+    bg = (0.05, 0.1, 0.15)
+    third = N_REAL // 3
+    # where the real rows go: the first rows, rows around the middle, the last rows (ascending: blend order of equal depths is
+    # the row order, and the small scene keeps the same relative order)
+    dst = torch.cat([torch.arange(0, third), torch.arange(P_BIG // 2, P_BIG // 2 + third),
+                     torch.arange(P_BIG - (N_REAL - 2 * third), P_BIG)]).to(DEV)
+    assert int(dst[-1]) * 48 > 2**31
+    sm = upload_scene(small)
+    # the filler: behind the camera (the reference's near test drops it), finite everywhere
+    eye = torch.tensor(POSE[0], dtype=torch.float32, device=DEV)
+    front = torch.tensor(POSE[1], dtype=torch.float32, device=DEV) - eye
+    front = front / front.norm()
+    shape = {"pos": (P_BIG, 3), "scale": (P_BIG, 3), "rotq": (P_BIG, 4), "sh": (P_BIG, 48), "opacity": (P_BIG,)}
+    big = {k: torch.empty(*shape[k], device=DEV) for k in KEYS}
+    big["pos"][:] = eye - 5.0 * front
+    big["scale"].fill_(0.01)
+    big["rotq"].zero_()
+    big["rotq"][:, 0] = 1.0
+    big["sh"].fill_(0.25)
+    big["opacity"].fill_(0.5)
+    for k in KEYS:
+        big[k][dst] = sm[k]
+
+    def frame_and_grads(arrays, P):
+        r = lcgs.Renderer(lcgs.Context(0))
+        r.bind_scene(*[arrays[k] for k in KEYS])
+        img = torch.full((3, H, W), -1.0, device=DEV)
+        radii = torch.full((P,), -7, dtype=torch.int32, device=DEV)
+        n = r.forward(cam, img, bg=bg, radii=radii, keep_state=True, sync=True)
+        g = {k: torch.full_like(arrays[k], 3.0) for k in KEYS}
+        r.backward(dL, *[g[k] for k in KEYS])
+        r.ctx.synchronize()
+        return r, img, radii, n, g
+
+    dL = torch.randn(3, H, W, device=DEV)
+    r_s, img_s, rad_s, n_s, g_s = frame_and_grads(sm, N_REAL)
+    ref = oracle.render(small, ocam, bg=bg)
+    assert n_s == ref["num_rendered"] and n_s > 100_000
+    assert_image_parity(img_s.cpu().numpy(), ref)  # (the yardstick itself: the oracle's frame)
+
+    r_b, img_b, rad_b, n_b, g_b = frame_and_grads(big, P_BIG)
+    assert n_b == n_s
+    assert torch.equal(img_b, img_s)
+    assert torch.equal(rad_b[dst], rad_s)
+    filler = torch.ones(P_BIG, dtype=torch.bool, device=DEV)
+    filler[dst] = False
+    assert int((rad_b[filler] != 0).sum()) == 0
+    st = r_b.frame_stats()
+    assert st["num_visible"] == r_s.frame_stats()["num_visible"] and st["num_pairs"] == r_s.frame_stats()["num_pairs"]
+    for k in KEYS:
+        a, b = g_b[k][dst].double(), g_s[k].double()
+        rel = float((a - b).norm() / max(float(b.norm()), 1e-30))
+        assert rel < 2e-5, (k, rel)  # (float atomics: the order of the adds differs)
+        rest = g_b[k].clone()
+        rest[dst] = 0
+        assert float(rest.abs().max()) == 0.0, k  # every filler row: an exact zero
+        del rest
+        assert float(b.abs().max()) > 0
+    # rows beyond element 2^31 of the coefficient gradients carry real values
+    assert float(g_b["sh"][dst[-1000:]].abs().max()) > 0
+
+    # the same 46 M rows as a scene the CONTEXT owns, in its default spatial order (a device-side copy + Morton sort + row gather
+    # of all five arrays, 16-byte cull rows, file-order tags of equal depths): the same image, the radii and gradients through
+    # the permutation
+    r_o = lcgs.Renderer(lcgs.Context(0))
+    r_o.bind_scene(*[big[k] for k in KEYS])
+    perm = r_o.reorder_scene_spatial().long()
+    assert int(perm.min()) == 0 and int(perm.max()) == P_BIG - 1 and int(torch.bincount(perm[:1_000_000] % 977).sum()) == 1_000_000
+    img_o = torch.full((3, H, W), -1.0, device=DEV)
+    rad_o = torch.full((P_BIG,), -7, dtype=torch.int32, device=DEV)
+    assert r_o.forward(cam, img_o, bg=bg, radii=rad_o, keep_state=True, sync=True) == n_s
+    assert torch.equal(img_o, img_s)
+    back = torch.empty_like(rad_o)
+    back[perm] = rad_o  # (per-splat outputs follow the context's order: row r = file row perm[r])
+    assert torch.equal(back, rad_b)
+    del back, rad_o
+    g_o = {k: torch.full_like(big[k], 3.0) for k in KEYS}
+    r_o.backward(dL, *[g_o[k] for k in KEYS])
+    r_o.ctx.synchronize()
+    where = torch.empty(P_BIG, dtype=torch.int64, device=DEV)
+    where[perm] = torch.arange(P_BIG, device=DEV)  # file row -> the context's row
+    for k in KEYS:
+        a, b = g_o[k][where[dst]].double(), g_s[k].double()
+        assert float((a - b).norm() / max(float(b.norm()), 1e-30)) < 2e-5, k
+        g_o[k][where[dst]] = 0
+        assert float(g_o[k].abs().max()) == 0.0, k
+    del g_o, where, perm, r_o
+
+    # the optimiser step on 46 M rows = the step on the 150 000 (zero gradients and moments leave a row where it is)
+    lr = {"pos": 1e-4, "sh_dc": 1e-3, "sh_rest": 1e-4, "opacity": 1e-2, "scale": 1e-3, "rot": 1e-3}
+
+    def adam(r, arrays, grads):
+        raw = {"pos": arrays["pos"].clone(), "scale": torch.log(arrays["scale"]), "rotq": arrays["rotq"].clone(),
+               "sh": arrays["sh"].clone(), "opacity": torch.log(arrays["opacity"] / (1 - arrays["opacity"]))}
+        m = {k: torch.zeros_like(raw[k]) for k in KEYS}
+        v = {k: torch.zeros_like(raw[k]) for k in KEYS}
+        r.adam_step(grads, raw, m, v, arrays, 1, lr)
+        r.ctx.synchronize()
+        return raw
+
+    fidx = torch.nonzero(filler)[:100_000, 0]
+    before = {k: big[k][fidx].clone() for k in KEYS}
+    for k in KEYS:  # the same gradients on both sides: this half tests the optimiser's addressing, not the atomics' order
+        g_b[k][dst] = g_s[k]
+    raw_s = adam(r_s, sm, g_s)
+    raw_b = adam(r_b, big, g_b)
+    for k in KEYS:
+        assert torch.equal(raw_b[k][dst], raw_s[k]), k
+        assert torch.equal(big[k][dst], sm[k]), k  # the refreshed activated arrays
+        assert torch.equal(big[k][fidx], before[k]), k
+    # and a frame of the updated scenes: still the same image
+    img2_s = torch.zeros(3, H, W, device=DEV)
+    img2_b = torch.zeros(3, H, W, device=DEV)
+    assert r_s.forward(cam, img2_s, bg=bg, sync=True) == r_b.forward(cam, img2_b, bg=bg, sync=True)
+    assert torch.equal(img2_b, img2_s) and not torch.equal(img2_s, img_s)
