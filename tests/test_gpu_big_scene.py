@@ -117,6 +117,35 @@ def test_rows_beyond_two_to_the_31_elements(lcgs, oracle):
         assert float(g_o[k].abs().max()) == 0.0, k
     del g_o, where, perm, r_o
 
+    # the reference's three operators on the 46 M rows (stage-level calls, every buffer of the reference produced): same image
+    L = lcgs
+    ctx_st = L.Context(0)
+    shp, prj, spl = L.SHProcessor(), L.GSProjector(), L.GSTileSplatter()
+    for op in (shp, prj, spl):
+        op.create(ctx_st)
+    z = lambda *sh_, dt=torch.float32: torch.zeros(*sh_, dtype=dt, device=DEV)
+    Lcap, G_ = 4_000_000, ((W + 15) // 16) * ((H + 15) // 16)
+    color, means, covs, depth = z(P_BIG, 3), z(P_BIG, 2), z(P_BIG, 3), z(P_BIG)
+    accel = L.GSTileSplatterAccelProxy(z(P_BIG, dt=torch.int32), z(P_BIG, dt=torch.int32), z(Lcap, dt=torch.int64),
+                                       z(Lcap, dt=torch.int32), z(Lcap, dt=torch.int64), z(Lcap, dt=torch.int32),
+                                       z(2 * G_, dt=torch.int32))
+    rad_st, img_st = z(P_BIG, dt=torch.int32), torch.full((3, H, W), -1.0, device=DEV)
+    shp.process(L.GPUPointsProxy(P_BIG, 3, big["pos"]), cam, big["sh"], color, 3, 3)
+    prj.forward(L.GSProjectorInputProxy(P_BIG, big["pos"], big["scale"], big["rotq"], 1.0),
+                L.GSProjectorOutputProxy(means, covs, depth), cam)
+    n_st = spl.forward(accel, L.GSTileSplatterInputProxy(P_BIG, bg, means, depth, covs, color, big["opacity"]),
+                       L.GSSplatForwardOutputProxy(H, W, img_st, rad_st))
+    ctx_st.synchronize()
+    assert n_st == n_s and torch.equal(img_st, img_s) and torch.equal(rad_st, rad_b)
+    # (the SH operator's colours exist for EVERY row, as in the reference: the last rows' are the small scene's last rows')
+    shp_s, ctx_s2 = L.SHProcessor(), L.Context(0)
+    shp_s.create(ctx_s2)
+    color_s = z(N_REAL, 3)
+    shp_s.process(L.GPUPointsProxy(N_REAL, 3, sm["pos"]), cam, sm["sh"], color_s, 3, 3)
+    ctx_s2.synchronize()
+    assert torch.equal(color[dst], color_s)
+    del color, means, covs, depth, accel, rad_st, img_st
+
     # the optimiser step on 46 M rows = the step on the 150 000 (zero gradients and moments leave a row where it is)
     lr = {"pos": 1e-4, "sh_dc": 1e-3, "sh_rest": 1e-4, "opacity": 1e-2, "scale": 1e-3, "rot": 1e-3}
 
@@ -144,3 +173,6 @@ def test_rows_beyond_two_to_the_31_elements(lcgs, oracle):
     img2_b = torch.zeros(3, H, W, device=DEV)
     assert r_s.forward(cam, img2_s, bg=bg, sync=True) == r_b.forward(cam, img2_b, bg=bg, sync=True)
     assert torch.equal(img2_b, img2_s) and not torch.equal(img2_s, img_s)
+    print(f"[big scene] {P_BIG} splats ({P_BIG * 48} coefficients), {N_REAL} of them real: num_rendered {n_s}, on screen "
+          f"{st['num_visible']}, sorted pairs {st['num_pairs']}; peak device memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB "
+          f"in torch tensors (+ the contexts' workspaces)")
